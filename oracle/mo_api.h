@@ -1,0 +1,125 @@
+/* ORACLE -- TEST INFRASTRUCTURE ONLY (see mo_math.h header for scope and pinning).
+ * Flat C API of the CPU restatement, loaded through ctypes by tests/, smoke()
+ * and bench.py's cpu_baseline leg.  Never linked or imported by the product. */
+#ifndef MO_API_H
+#define MO_API_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mo_scene mo_scene;
+
+/* ---- scene construction ------------------------------------------------ */
+mo_scene *mo_scene_new(void);
+void mo_scene_free(mo_scene *s);
+/* Adds one triangle mesh (Mesh buffers as in include/mitsuba/render/mesh.h:80-90).
+ * normals / texcoords may be NULL.  bsdf_kind: 0 = diffuse (src/bsdfs/diffuse.cpp).
+ * emitter_rgb == NULL: not an emitter, else an `area` emitter (src/emitters/area.cpp).
+ * returns the shape index or <0. */
+int mo_scene_add_mesh(mo_scene *s, uint32_t n_verts, const float *positions,
+                      const float *normals, const float *texcoords, uint32_t n_faces,
+                      const uint32_t *faces, int bsdf_kind, const float *reflectance_rgb,
+                      const float *emitter_rgb);
+/* Builds the oracle's own accelerator + emitter sampling tables. */
+int mo_scene_finalize(mo_scene *s);
+/* naive != 0: the render entry points answer every query by brute force. */
+void mo_scene_set_naive(mo_scene *s, int naive);
+uint32_t mo_scene_prim_count(const mo_scene *s);
+float mo_scene_emitter_area(const mo_scene *s, uint32_t emitter);
+
+/* ---- scene queries (Scene::ray_intersect / ray_intersect_naive / ray_test) ---- */
+/* SoA rays; outputs t (inf on miss), global prim index (0xffffffff on miss),
+ * shape index, barycentrics u,v.  naive != 0: brute force (kdtree.h:2303-2328). */
+void mo_ray_intersect(const mo_scene *s, uint64_t n, const float *ox, const float *oy,
+                      const float *oz, const float *dx, const float *dy, const float *dz,
+                      const float *mint, const float *maxt, int naive, float *t,
+                      uint32_t *prim, uint32_t *shape, float *u, float *v);
+void mo_ray_test(const mo_scene *s, uint64_t n, const float *ox, const float *oy,
+                 const float *oz, const float *dx, const float *dy, const float *dz,
+                 const float *mint, const float *maxt, int naive, uint8_t *hit);
+/* Full SurfaceInteraction for given hits (kdtree.h:2334-2367 + mesh.cpp:399-462).
+ * out: 24 floats per ray: p(3) n(3) uv(2) sh_s(3) sh_t(3) sh_n(3) dp_du(3) dp_dv(3) wi(3) -> 26 */
+void mo_fill_si(const mo_scene *s, uint64_t n, const float *dx, const float *dy,
+                const float *dz, const uint32_t *prim, const float *u, const float *v,
+                float *out26);
+
+/* ---- sensor / film / integrator descriptors ---------------------------- */
+typedef struct {
+    float to_world[16];         /* row-major camera-to-world matrix */
+    float fov_x_deg;            /* horizontal field of view (after parse_fov) */
+    float near_clip, far_clip;
+    int32_t film_w, film_h;     /* full film size */
+    int32_t crop_x, crop_y, crop_w, crop_h;
+    int32_t rfilter;            /* 0 = gaussian, 1 = box */
+    float rfilter_param;        /* gaussian: stddev (0.5), box: radius (0.5) */
+    int32_t spp;
+    uint64_t base_seed;         /* sampler "seed" property */
+    int32_t max_depth, rr_depth;
+    int32_t filter_analytic;    /* 0: eval_discretized (scalar_rgb), 1: eval (gpu variants) */
+} mo_render_desc;
+
+/* mode 0: scalar_rgb block mode (spiral blocks, Morton order, one PCG32 stream per block);
+ * mode 1: wavefront mode (one PCG32 stream per sample, TEA-seeded), single pass.
+ * film_xyzaw: crop_h*crop_w*5 floats, overwritten.  n_threads<=0: all cores.
+ * block_size 0: reference rule (32 halved until #blocks >= n_threads).
+ * stats (may be NULL): [0]=closest-hit queries, [1]=any-hit queries, [2]=samples. */
+int mo_render(const mo_scene *s, const mo_render_desc *d, int mode, int n_threads,
+              int block_size, float *film_xyzaw, uint64_t *stats);
+/* Per-sample radiance in wavefront mode for sample indices [first, first+count):
+ * out_rgba[4*i] = (R,G,B, valid_ray), out_pos[2*i] = film position sample. */
+int mo_sample_radiance(const mo_scene *s, const mo_render_desc *d, uint64_t first,
+                       uint64_t count, float *out_rgba, float *out_pos);
+/* Restricted wavefront render: only samples of pixels with crop-relative row in
+ * [row0,row1) are traced; splats land in the full crop-sized film (for multi-GPU tests). */
+int mo_render_rows(const mo_scene *s, const mo_render_desc *d, int row0, int row1,
+                   float *film_xyzaw);
+/* HDRFilm::bitmap(): XYZAW -> RGBA float32 (hdrfilm.cpp:249-320, struct.cpp:1761-1811) */
+void mo_film_develop(const float *xyzaw, uint64_t n_pixels, float *rgba);
+
+/* ---- camera ------------------------------------------------------------ */
+/* PerspectiveCamera::sample_ray (perspective.cpp:106-188) for n film samples in [0,1)^2 */
+void mo_camera_rays(const mo_render_desc *d, uint64_t n, const float *sx, const float *sy,
+                    float *o3, float *d3, float *mint, float *maxt);
+
+/* ---- ImageBlock (imageblock.cpp:8-172) ---------------------------------- */
+/* Splat n samples (pos 2 floats, value ch floats) into a block of size (w,h) at offset (ox,oy)
+ * with optional border; data: (h+2b)*(w+2b)*ch floats, accumulated in place.
+ * returns the border size. */
+int mo_imageblock_put(int w, int h, int ox, int oy, int ch, int rfilter, float rfilter_param,
+                      int border, int analytic, uint64_t n, const float *pos,
+                      const float *values, float *data);
+/* ReconstructionFilter::eval_discretized table (32 entries), radius and border size */
+void mo_rfilter_table(int rfilter, float param, float *table32, float *radius, int *border);
+
+/* ---- unit-level entry points for known-answer tests --------------------- */
+uint32_t mo_kat_tea32(uint32_t v0, uint32_t v1, int rounds);
+uint64_t mo_kat_tea64_u32(uint32_t v0, uint32_t v1, int rounds);
+uint64_t mo_kat_tea64_u64(uint64_t v0, uint64_t v1, int rounds);
+float mo_kat_tea_float32(uint32_t v0, uint32_t v1, int rounds);
+double mo_kat_tea_float64(uint32_t v0, uint32_t v1, int rounds);
+void mo_kat_pcg32(uint64_t initstate, uint64_t initseq, int n, uint32_t *out_u32, float *out_f32);
+void mo_kat_warp(int which, uint64_t n, const float *sx, const float *sy, float *out3);
+void mo_kat_coordinate_system(const float *n3, float *s3, float *t3);
+/* Spiral(size, offset, block_size, passes): fills up to max entries of (ox,oy,w,h,id) */
+int mo_kat_spiral(int w, int h, int off_x, int off_y, int block_size, int passes, int max_entries,
+                  int64_t *out5);
+void mo_kat_morton(uint32_t n, uint32_t *xy);
+/* DiscreteDistribution: returns sum; cdf out; sample / sample_reuse for values */
+float mo_kat_distr(uint32_t n, const float *pmf, float *cdf, uint32_t nv, const float *values,
+                   uint32_t *idx, float *reused);
+/* SmoothDiffuse::sample/eval/pdf for local wi, wo / sample2 */
+void mo_kat_diffuse(const float *reflectance, const float *wi3, const float *wo3,
+                    const float *sample2, float *eval3, float *pdf, float *s_wo3, float *s_pdf,
+                    float *s_weight3);
+/* emitter sampling from a reference point: Scene::sample_emitter_direction without the
+ * visibility test + Scene::pdf_emitter_direction evaluated on the sampled record.
+ * out: d(3) dist pdf n(3) p(3) spec(3) pdf_again = 15 floats */
+void mo_kat_sample_emitter(const mo_scene *s, const float *ref_p3, const float *sample2,
+                           float *out15);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,51 @@
+/* ORACLE -- TEST INFRASTRUCTURE ONLY (see mo_math.h header for scope and pinning). */
+#ifndef MO_INTERNAL_H
+#define MO_INTERNAL_H
+#include "mo_math.h"
+#include "mo_api.h"
+
+typedef struct { mo_v3 o, d; float mint, maxt; } mo_ray;
+typedef struct { float t; uint32_t prim; float u, v; } mo_hit;
+
+/* subset of SurfaceInteraction (include/mitsuba/render/interaction.h:102-126) used by `path` */
+typedef struct {
+    float t; uint32_t prim, shape;
+    mo_v3 p, n; mo_v2 uv; mo_frame sh; mo_v3 dp_du, dp_dv, wi;
+} mo_si;
+
+/* DirectionSample (include/mitsuba/render/records.h:121-174) */
+typedef struct { mo_v3 p, n, d; float dist, pdf; uint32_t emitter; } mo_dsample;
+
+typedef struct {
+    uint32_t n_verts, n_faces;
+    float *pos, *nrm, *uv; uint32_t *faces;
+    int bsdf_kind; float refl[3]; int emitter;
+    uint32_t prim_offset;
+    float *area_pmf, *area_cdf; float area_sum, area_norm; uint32_t valid_lo, valid_hi;
+} mo_mesh;
+
+typedef struct { uint32_t shape; float radiance[3]; } mo_emitter;
+typedef struct { double lo[3], hi[3]; uint32_t left, right, first, count; } mo_bvh_node;
+
+struct mo_scene {
+    mo_mesh *meshes; uint32_t n_meshes;
+    mo_emitter *emitters; uint32_t n_emitters;
+    uint32_t n_prims; uint32_t *prim_shape, *prim_local;
+    mo_bvh_node *bvh_nodes; uint32_t n_bvh_nodes; uint32_t *bvh_prims;
+    double scene_extent; int force_naive;
+};
+
+int mo_intersect(const mo_scene *s, const mo_ray *ray, int shadow, int naive, mo_hit *hit);
+void mo_make_si(const mo_scene *s, const mo_ray *ray, const mo_hit *hit, mo_si *si);
+void mo_sample_emitter_direction(const mo_scene *s, mo_v3 ref_p, mo_v2 sample, mo_dsample *ds, float spec[3]);
+float mo_pdf_emitter_direction(const mo_scene *s, uint32_t emitter, mo_v3 d, mo_v3 n, float dist);
+void mo_diffuse_eval_pdf(const float refl[3], mo_v3 wi, mo_v3 wo, float eval[3], float *pdf);
+int mo_diffuse_sample(const float refl[3], mo_v3 wi, mo_v2 sample2, mo_v3 *wo, float *pdf, float weight[3]);
+int mo_distr_build(uint32_t n, const float *pmf, float *cdf, float *sum_out, float *norm_out,
+                   uint32_t *valid_lo, uint32_t *valid_hi);
+uint32_t mo_distr_sample(const float *cdf, float sum, uint32_t lo, uint32_t hi, float value);
+uint32_t mo_distr_sample_reuse(const float *pmf, const float *cdf, float sum, float norm, uint32_t lo,
+                               uint32_t hi, float value, float *reused);
+void mo_scene_set_naive(mo_scene *s, int naive);
+
+#endif

@@ -1,0 +1,711 @@
+/* ORACLE -- TEST INFRASTRUCTURE ONLY (see mo_math.h header for scope and pinning).
+ *
+ * Driver, sensor, integrator and film of the hot path, restated from:
+ *   SamplingIntegrator::render/render_block/render_sample  src/librender/integrator.cpp:52-271
+ *   PathIntegrator::sample            src/integrators/path.cpp:100-227
+ *   IndependentSampler                src/samplers/independent.cpp:47-95
+ *   PerspectiveCamera                 src/sensors/perspective.cpp:106-222
+ *   Transform::perspective            include/mitsuba/core/transform.h:203-220
+ *   ReconstructionFilter              include/mitsuba/core/rfilter.h:62-65, src/libcore/rfilter.cpp:9-20
+ *   GaussianFilter / BoxFilter        src/rfilters/gaussian.cpp:33-47, src/rfilters/box.cpp:30-36
+ *   ImageBlock::put                   src/librender/imageblock.cpp:49-172
+ *   accumulate_2d                     include/mitsuba/core/bitmap.h:657-716
+ *   Spiral                            src/librender/spiral.cpp:8-74
+ *   HDRFilm::bitmap                   src/films/hdrfilm.cpp:249-320 (+ struct.cpp:1761-1811)
+ *   srgb_to_xyz                       include/mitsuba/core/spectrum.h:220-227
+ */
+#include "mo_internal.h"
+#include <stdlib.h>
+#include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ================================================================== */
+/* 4x4 matrices (row-major storage m[r][c]); products follow Enoki's
+ * column-wise fmadd order: C(r,j) = fma(A(r,3),B(3,j), fma(A(r,2),B(2,j), fma(A(r,1),B(1,j), A(r,0)*B(0,j)))) */
+typedef struct { float m[4][4]; } mat4;
+
+static mat4 mat_identity(void) {
+    mat4 r; memset(&r, 0, sizeof(r));
+    for (int i = 0; i < 4; ++i) r.m[i][i] = 1.0f;
+    return r;
+}
+static mat4 mat_mul(const mat4 *a, const mat4 *b) {
+    mat4 c;
+    for (int r = 0; r < 4; ++r)
+        for (int j = 0; j < 4; ++j) {
+            float acc = a->m[r][0] * b->m[0][j];
+            for (int i = 1; i < 4; ++i) acc = fmaf(a->m[r][i], b->m[i][j], acc);
+            c.m[r][j] = acc;
+        }
+    return c;
+}
+static mat4 mat_transpose(const mat4 *a) {
+    mat4 c;
+    for (int r = 0; r < 4; ++r) for (int j = 0; j < 4; ++j) c.m[r][j] = a->m[j][r];
+    return c;
+}
+typedef struct { mat4 matrix, inv_t; } xform;
+static xform xf_mul(const xform *a, const xform *b) {
+    xform r; r.matrix = mat_mul(&a->matrix, &b->matrix); r.inv_t = mat_mul(&a->inv_t, &b->inv_t);
+    return r;
+}
+static xform xf_scale(float x, float y, float z) {
+    xform r; r.matrix = mat_identity(); r.inv_t = mat_identity();
+    r.matrix.m[0][0] = x; r.matrix.m[1][1] = y; r.matrix.m[2][2] = z;
+    r.inv_t.m[0][0] = 1.0f / x; r.inv_t.m[1][1] = 1.0f / y; r.inv_t.m[2][2] = 1.0f / z;
+    return r;
+}
+static xform xf_translate(float x, float y, float z) {
+    xform r; r.matrix = mat_identity();
+    r.matrix.m[0][3] = x; r.matrix.m[1][3] = y; r.matrix.m[2][3] = z;
+    mat4 inv = mat_identity();
+    inv.m[0][3] = -x; inv.m[1][3] = -y; inv.m[2][3] = -z;
+    r.inv_t = mat_transpose(&inv);
+    return r;
+}
+/* transform.h:203-220 */
+static xform xf_perspective(float fov, float near_, float far_) {
+    float recip = 1.0f / (far_ - near_);
+    float tan_ = tanf((fov * 0.5f) * (MO_PI / 180.0f)), cot = 1.0f / tan_;
+    mat4 t; memset(&t, 0, sizeof(t));
+    t.m[0][0] = cot; t.m[1][1] = cot; t.m[2][2] = far_ * recip; t.m[3][3] = 0.0f;
+    t.m[2][3] = -near_ * far_ * recip; t.m[3][2] = 1.0f;
+    mat4 it; memset(&it, 0, sizeof(it));
+    it.m[0][0] = tan_; it.m[1][1] = tan_; it.m[2][2] = 0.0f; it.m[3][3] = 1.0f / near_;
+    it.m[2][3] = 1.0f; it.m[3][2] = (near_ - far_) / (far_ * near_);
+    xform r; r.matrix = t; r.inv_t = mat_transpose(&it);
+    return r;
+}
+
+typedef struct {
+    mat4 sample_to_camera, to_world;
+    float near_clip, far_clip;
+} camera;
+
+/* perspective.cpp:106-131 */
+static void camera_init(const mo_render_desc *d, camera *c) {
+    float fw = (float) d->film_w, fh = (float) d->film_h;
+    float rel_sx = (float) d->crop_w / fw, rel_sy = (float) d->crop_h / fh;
+    float rel_ox = (float) d->crop_x / fw, rel_oy = (float) d->crop_y / fh;
+    float aspect = fw / fh;
+    xform a = xf_scale(1.0f / rel_sx, 1.0f / rel_sy, 1.0f);
+    xform b = xf_translate(-rel_ox, -rel_oy, 0.0f);
+    xform e = xf_scale(-0.5f, -0.5f * aspect, 1.0f);
+    xform f = xf_translate(-1.0f, -1.0f / aspect, 0.0f);
+    xform p = xf_perspective(d->fov_x_deg, d->near_clip, d->far_clip);
+    xform c2s = xf_mul(&a, &b);
+    c2s = xf_mul(&c2s, &e); c2s = xf_mul(&c2s, &f); c2s = xf_mul(&c2s, &p);
+    /* Transform::inverse(): matrix = transpose(inverse_transpose) */
+    c->sample_to_camera = mat_transpose(&c2s.inv_t);
+    memcpy(c->to_world.m, d->to_world, sizeof(float) * 16);
+    c->near_clip = d->near_clip; c->far_clip = d->far_clip;
+}
+
+/* perspective.cpp:190-222 (ray part; differentials are unused by `path` with constant textures) */
+static void camera_sample_ray(const camera *c, float sx, float sy, mo_ray *ray) {
+    const mat4 *m = &c->sample_to_camera;
+    float r[4];
+    for (int k = 0; k < 4; ++k) {
+        float acc = m->m[k][3];
+        acc = fmaf(m->m[k][0], sx, acc);
+        acc = fmaf(m->m[k][1], sy, acc);
+        acc = fmaf(m->m[k][2], 0.0f, acc);
+        r[k] = acc;
+    }
+    float iw = mo_rcp(r[3]);
+    mo_v3 near_p = mo_v3_make(r[0] * iw, r[1] * iw, r[2] * iw);
+    mo_v3 dl = mo_normalize(near_p);
+    float inv_z = mo_rcp(dl.z);
+    ray->mint = c->near_clip * inv_z;
+    ray->maxt = c->far_clip * inv_z;
+    const mat4 *w = &c->to_world;
+    ray->o = mo_v3_make(w->m[0][3], w->m[1][3], w->m[2][3]);
+    float dd[3];
+    for (int k = 0; k < 3; ++k) {
+        float acc = w->m[k][0] * dl.x;
+        acc = fmaf(w->m[k][1], dl.y, acc);
+        acc = fmaf(w->m[k][2], dl.z, acc);
+        dd[k] = acc;
+    }
+    ray->d = mo_v3_make(dd[0], dd[1], dd[2]);
+}
+
+void mo_camera_rays(const mo_render_desc *d, uint64_t n, const float *sx, const float *sy, float *o3,
+                    float *d3, float *mint, float *maxt) {
+    camera c; camera_init(d, &c);
+    for (uint64_t i = 0; i < n; ++i) {
+        mo_ray r; camera_sample_ray(&c, sx[i], sy[i], &r);
+        o3[3 * i] = r.o.x; o3[3 * i + 1] = r.o.y; o3[3 * i + 2] = r.o.z;
+        d3[3 * i] = r.d.x; d3[3 * i + 1] = r.d.y; d3[3 * i + 2] = r.d.z;
+        mint[i] = r.mint; maxt[i] = r.maxt;
+    }
+}
+
+/* ================================================================== */
+/* reconstruction filter */
+#define MO_FILTER_RES 31
+typedef struct {
+    int kind; float radius, scale_factor; int border;
+    float alpha, bias;          /* gaussian */
+    float values[MO_FILTER_RES + 1];
+} rfilter;
+
+static float rfilter_eval(const rfilter *f, float x) {
+    if (f->kind == 0) return fmaxf(0.0f, expf(f->alpha * (x * x)) - f->bias);
+    return fabsf(x) <= f->radius ? 1.0f : 0.0f;
+}
+static void rfilter_init(rfilter *f, int kind, float param) {
+    f->kind = kind;
+    if (kind == 0) {
+        float stddev = param;
+        f->radius = 4 * stddev;
+        f->alpha = -1.0f / (2.0f * stddev * stddev);
+        f->bias = expf(f->alpha * (f->radius * f->radius));
+    } else {
+        f->radius = param + MO_RAY_EPSILON;
+        f->alpha = f->bias = 0;
+    }
+    for (int i = 0; i < MO_FILTER_RES; ++i)
+        f->values[i] = rfilter_eval(f, (f->radius * (float) i) / (float) MO_FILTER_RES);
+    f->values[MO_FILTER_RES] = 0;
+    f->scale_factor = (float) MO_FILTER_RES / f->radius;
+    f->border = (int) ceilf(f->radius - 0.5f - 2.0f * MO_RAY_EPSILON);
+}
+static inline float rfilter_eval_discretized(const rfilter *f, float x) {
+    int idx = (int) fabsf(x * f->scale_factor);
+    if (idx > MO_FILTER_RES) idx = MO_FILTER_RES;
+    return f->values[idx];
+}
+void mo_rfilter_table(int kind, float param, float *table32, float *radius, int *border) {
+    rfilter f; rfilter_init(&f, kind, param);
+    memcpy(table32, f.values, sizeof(float) * 32);
+    *radius = f.radius; *border = f.border;
+}
+
+/* ================================================================== */
+/* ImageBlock */
+typedef struct {
+    int w, h, ox, oy, ch, border;
+    const rfilter *filter; int analytic;
+    float *data;
+} iblock;
+
+static size_t iblock_floats(const iblock *b) {
+    return (size_t) b->ch * (size_t) (b->w + 2 * b->border) * (size_t) (b->h + 2 * b->border);
+}
+
+/* imageblock.cpp:80-172 (warn_negative = warn_invalid = true, normalize = false) */
+static int iblock_put(iblock *b, float px, float py, const float *value) {
+    for (int k = 0; k < b->ch; ++k)
+        if (!(value[k] >= -1e-5f) || !isfinite(value[k])) return 0;
+    const rfilter *f = b->filter;
+    float radius = f->radius;
+    int sx = b->w + 2 * b->border, sy = b->h + 2 * b->border;
+    float posx = px - ((float) (b->ox - b->border) + 0.5f), posy = py - ((float) (b->oy - b->border) + 0.5f);
+    if (radius > 1.0f) {
+        int lox = (int) ceilf(posx - radius), loy = (int) ceilf(posy - radius);
+        int hix = (int) floorf(posx + radius), hiy = (int) floorf(posy + radius);
+        if (lox < 0) lox = 0;
+        if (loy < 0) loy = 0;
+        if (hix > sx - 1) hix = sx - 1;
+        if (hiy > sy - 1) hiy = sy - 1;
+        uint32_t n = (uint32_t) ceilf((radius - 2.0f * MO_RAY_EPSILON) * 2.0f);
+        float wx[64], wy[64];
+        float basex = (float) (uint32_t) lox - posx, basey = (float) (uint32_t) loy - posy;
+        for (uint32_t i = 0; i < n && i < 64; ++i) {
+            float ppx = basex + (float) i, ppy = basey + (float) i;
+            wx[i] = b->analytic ? rfilter_eval(f, ppx) : rfilter_eval_discretized(f, ppx);
+            wy[i] = b->analytic ? rfilter_eval(f, ppy) : rfilter_eval_discretized(f, ppy);
+        }
+        for (uint32_t yr = 0; yr < n; ++yr) {
+            uint32_t y = (uint32_t) loy + yr;
+            if (!(y <= (uint32_t) hiy) || hiy < 0) continue;
+            for (uint32_t xr = 0; xr < n; ++xr) {
+                uint32_t x = (uint32_t) lox + xr;
+                if (!(x <= (uint32_t) hix) || hix < 0) break;
+                size_t off = (size_t) b->ch * ((size_t) y * (size_t) sx + x);
+                float weight = wy[yr] * wx[xr];
+                for (int k = 0; k < b->ch; ++k) b->data[off + k] += value[k] * weight;
+            }
+        }
+    } else {
+        int lox = (int) ceilf(posx - 0.5f), loy = (int) ceilf(posy - 0.5f);
+        if (lox >= 0 && loy >= 0 && lox < sx && loy < sy) {
+            size_t off = (size_t) b->ch * ((size_t) loy * (size_t) sx + (size_t) lox);
+            for (int k = 0; k < b->ch; ++k) b->data[off + k] += value[k];
+        }
+    }
+    return 1;
+}
+
+int mo_imageblock_put(int w, int h, int ox, int oy, int ch, int kind, float param, int border,
+                      int analytic, uint64_t n, const float *pos, const float *values, float *data) {
+    rfilter f; rfilter_init(&f, kind, param);
+    iblock b = { w, h, ox, oy, ch, border ? f.border : 0, &f, analytic, data };
+    for (uint64_t i = 0; i < n; ++i) iblock_put(&b, pos[2 * i], pos[2 * i + 1], values + (size_t) ch * i);
+    return b.border;
+}
+
+/* imageblock.cpp:49-77 + bitmap.h:657-716: block (with border) += into target (with its border) */
+static void iblock_put_block(iblock *target, const iblock *src) {
+    int ssx = src->w + 2 * src->border, ssy = src->h + 2 * src->border;
+    int tsx = target->w + 2 * target->border, tsy = target->h + 2 * target->border;
+    int sox = 0, soy = 0;
+    int tox = (src->ox - src->border) - (target->ox - target->border);
+    int toy = (src->oy - src->border) - (target->oy - target->border);
+    int szx = ssx, szy = ssy;
+    int shx = 0, shy = 0;
+    if (-sox > shx) shx = -sox;
+    if (-tox > shx) shx = -tox;
+    if (-soy > shy) shy = -soy;
+    if (-toy > shy) shy = -toy;
+    sox += shx; tox += shx; soy += shy; toy += shy;
+    { int a = sox + szx - ssx; if (a > 0) szx -= a; a = tox + szx - tsx; if (a > 0) szx -= a; }
+    { int a = soy + szy - ssy; if (a > 0) szy -= a; a = toy + szy - tsy; if (a > 0) szy -= a; }
+    if (szx <= 0 || szy <= 0) return;
+    int ch = src->ch;
+    for (int y = 0; y < szy; ++y) {
+        const float *sp = src->data + ((size_t) (sox) + (size_t) (soy + y) * ssx) * ch;
+        float *tp = target->data + ((size_t) (tox) + (size_t) (toy + y) * tsx) * ch;
+        for (int i = 0; i < szx * ch; ++i) tp[i] += sp[i];
+    }
+}
+
+/* ================================================================== */
+/* Spiral (spiral.cpp:8-74) */
+typedef struct {
+    int block_size, size_x, size_y, off_x, off_y, blocks_x, blocks_y;
+    size_t block_count, block_counter, remaining_passes;
+    int dir, pos_x, pos_y, steps_left, steps;
+} spiral;
+
+static void spiral_reset(spiral *s) {
+    s->block_counter = 0; s->dir = 0;
+    s->pos_x = s->blocks_x / 2; s->pos_y = s->blocks_y / 2;
+    s->steps_left = 1; s->steps = 1;
+}
+static void spiral_init(spiral *s, int w, int h, int ox, int oy, int block_size, size_t passes) {
+    s->block_size = block_size; s->size_x = w; s->size_y = h; s->off_x = ox; s->off_y = oy;
+    s->remaining_passes = passes;
+    s->blocks_x = (int) ceilf((float) w / (float) block_size);
+    s->blocks_y = (int) ceilf((float) h / (float) block_size);
+    s->block_count = (size_t) s->blocks_x * (size_t) s->blocks_y;
+    spiral_reset(s);
+}
+/* returns 0 when exhausted */
+static int spiral_next(spiral *s, int *ox, int *oy, int *w, int *h, size_t *id) {
+    if (s->block_count == s->block_counter) {
+        if (s->remaining_passes > 1) { --s->remaining_passes; spiral_reset(s); }
+        else return 0;
+    }
+    *id = s->block_counter + (s->remaining_passes - 1) * s->block_count;
+    int offx = s->pos_x * s->block_size, offy = s->pos_y * s->block_size;
+    *w = s->size_x - offx < s->block_size ? s->size_x - offx : s->block_size;
+    *h = s->size_y - offy < s->block_size ? s->size_y - offy : s->block_size;
+    *ox = offx + s->off_x; *oy = offy + s->off_y;
+    ++s->block_counter;
+    if (s->block_counter != s->block_count) {
+        do {
+            switch (s->dir) {
+                case 0: ++s->pos_x; break;   /* Right */
+                case 1: ++s->pos_y; break;   /* Down  */
+                case 2: --s->pos_x; break;   /* Left  */
+                case 3: --s->pos_y; break;   /* Up    */
+            }
+            if (--s->steps_left == 0) {
+                s->dir = (s->dir + 1) % 4;
+                if (s->dir == 2 || s->dir == 0) ++s->steps;
+                s->steps_left = s->steps;
+            }
+        } while (s->pos_x < 0 || s->pos_y < 0 || s->pos_x >= s->blocks_x || s->pos_y >= s->blocks_y);
+    }
+    return 1;
+}
+
+int mo_kat_spiral(int w, int h, int off_x, int off_y, int block_size, int passes, int max_entries,
+                  int64_t *out5) {
+    spiral s; spiral_init(&s, w, h, off_x, off_y, block_size, (size_t) passes);
+    int n = 0, ox, oy, bw, bh; size_t id;
+    while (spiral_next(&s, &ox, &oy, &bw, &bh, &id)) {
+        if (n < max_entries) {
+            out5[5 * n] = ox; out5[5 * n + 1] = oy; out5[5 * n + 2] = bw; out5[5 * n + 3] = bh;
+            out5[5 * n + 4] = (int64_t) id;
+        }
+        ++n;
+    }
+    return n;
+}
+
+/* ================================================================== */
+/* PathIntegrator::sample (path.cpp:100-211) */
+typedef struct { uint64_t closest, any; } ray_stats;
+
+static inline float mis_weight(float pdf_a, float pdf_b) {
+    pdf_a *= pdf_a; pdf_b *= pdf_b;
+    return pdf_a > 0.0f ? pdf_a / (pdf_a + pdf_b) : 0.0f;
+}
+
+static int scene_intersect(const mo_scene *s, const mo_ray *ray, mo_si *si, ray_stats *st) {
+    mo_hit h;
+    st->closest++;
+    if (mo_intersect(s, ray, 0, 0, &h)) { mo_make_si(s, ray, &h, si); return 1; }
+    si->t = INFINITY;
+    si->wi = mo_neg(ray->d);
+    return 0;
+}
+
+static void path_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, int max_depth,
+                        int rr_depth, float result[3], int *valid_ray, ray_stats *st) {
+    mo_ray ray = *ray_in;
+    float eta = 1.0f, emission_weight = 1.0f;
+    float throughput[3] = { 1.0f, 1.0f, 1.0f };
+    result[0] = result[1] = result[2] = 0.0f;
+
+    mo_si si;
+    int si_valid = scene_intersect(s, &ray, &si, st);
+    *valid_ray = si_valid;
+    int emitter = si_valid ? s->meshes[si.shape].emitter : -1;
+    int active = 1;
+
+    for (int depth = 1;; ++depth) {
+        /* ---------------- Intersection with emitters ---------------- */
+        if (emitter >= 0 && active) {
+            /* AreaLight::eval (area.cpp:71-79) */
+            if (si.wi.z > 0.0f) {
+                const float *le = s->emitters[emitter].radiance;
+                for (int k = 0; k < 3; ++k) result[k] += (emission_weight * throughput[k]) * le[k];
+            }
+        }
+        active = active && si_valid;
+
+        /* Russian roulette (path.cpp:137-141) */
+        if (depth > rr_depth) {
+            float q = fminf(fmaxf(fmaxf(throughput[0], throughput[1]), throughput[2]) * (eta * eta), 0.95f);
+            if (active) active = mo_pcg32_next_f32(rng) < q;
+            float rq = mo_rcp(q);
+            for (int k = 0; k < 3; ++k) throughput[k] *= rq;
+        }
+
+        if ((uint32_t) depth >= (uint32_t) max_depth || !active) break;
+
+        /* --------------------- Emitter sampling --------------------- */
+        const mo_mesh *mesh = &s->meshes[si.shape];
+        {   /* diffuse has BSDFFlags::Smooth -> active_e = active */
+            mo_v2 s2; s2.x = mo_pcg32_next_f32(rng); s2.y = mo_pcg32_next_f32(rng);
+            mo_dsample ds; float emitter_val[3];
+            mo_sample_emitter_direction(s, si.p, s2, &ds, emitter_val);
+            int active_e = ds.pdf != 0.0f;
+            if (active_e && s->n_emitters > 0) {
+                /* visibility test (scene.cpp:178-182) */
+                mo_ray sr;
+                sr.o = si.p; sr.d = ds.d;
+                sr.mint = MO_RAY_EPSILON * (1.0f + mo_hmax_abs(si.p));
+                sr.maxt = ds.dist * (1.0f - MO_SHADOW_EPSILON);
+                st->any++;
+                if (mo_intersect(s, &sr, 1, 0, NULL)) emitter_val[0] = emitter_val[1] = emitter_val[2] = 0.0f;
+            }
+            if (active_e) {
+                mo_v3 wo = mo_to_local(&si.sh, ds.d);
+                float bsdf_val[3], bsdf_pdf;
+                mo_diffuse_eval_pdf(mesh->refl, si.wi, wo, bsdf_val, &bsdf_pdf);
+                float mis = mis_weight(ds.pdf, bsdf_pdf);
+                for (int k = 0; k < 3; ++k)
+                    result[k] += ((mis * throughput[k]) * bsdf_val[k]) * emitter_val[k];
+            }
+        }
+
+        /* ----------------------- BSDF sampling ---------------------- */
+        float s1 = mo_pcg32_next_f32(rng); (void) s1;
+        mo_v2 s2; s2.x = mo_pcg32_next_f32(rng); s2.y = mo_pcg32_next_f32(rng);
+        mo_v3 bs_wo; float bs_pdf, bsdf_w[3];
+        mo_diffuse_sample(mesh->refl, si.wi, s2, &bs_wo, &bs_pdf, bsdf_w);
+        for (int k = 0; k < 3; ++k) throughput[k] = throughput[k] * bsdf_w[k];
+        active = active && (throughput[0] != 0.0f || throughput[1] != 0.0f || throughput[2] != 0.0f);
+        if (!active) break;
+        eta *= 1.0f; /* bs.eta == 1 for diffuse */
+
+        /* spawn_ray (interaction.h:58-61) */
+        ray.o = si.p; ray.d = mo_to_world(&si.sh, bs_wo);
+        ray.mint = (1.0f + mo_hmax_abs(si.p)) * MO_RAY_EPSILON;
+        ray.maxt = INFINITY;
+        mo_si si_bsdf;
+        int v2 = scene_intersect(s, &ray, &si_bsdf, st);
+        emitter = v2 ? s->meshes[si_bsdf.shape].emitter : -1;
+        if (emitter >= 0) {
+            /* DirectionSample(si_bsdf, si) (records.h:168-174) */
+            mo_v3 d = mo_sub(si_bsdf.p, si.p);
+            float dist = mo_norm(d);
+            d = mo_div_s(d, dist);
+            float emitter_pdf = mo_pdf_emitter_direction(s, (uint32_t) emitter, d, si_bsdf.sh.n, dist);
+            emission_weight = mis_weight(bs_pdf, emitter_pdf);
+        }
+        si = si_bsdf; si_valid = v2;
+    }
+}
+
+/* spectrum.h:220-227 (Matrix * Vector: column-wise fmadd) */
+static inline void srgb_to_xyz(const float rgb[3], float xyz[3]) {
+    static const float M[3][3] = { { 0.412453f, 0.357580f, 0.180423f },
+                                   { 0.212671f, 0.715160f, 0.072169f },
+                                   { 0.019334f, 0.119193f, 0.950227f } };
+    for (int r = 0; r < 3; ++r)
+        xyz[r] = fmaf(M[r][2], rgb[2], fmaf(M[r][1], rgb[1], M[r][0] * rgb[0]));
+}
+
+/* render_sample (integrator.cpp:224-271); pos = integer pixel position */
+static void render_sample(const mo_scene *s, const mo_render_desc *d, const camera *cam, mo_pcg32 *rng,
+                          float pos_x, float pos_y, float aovs[5], float pos_sample[2], float rgb_out[3],
+                          int *valid_out, ray_stats *st) {
+    float jx = mo_pcg32_next_f32(rng), jy = mo_pcg32_next_f32(rng);
+    float psx = pos_x + jx, psy = pos_y + jy;
+    float wavelength_sample = mo_pcg32_next_f32(rng); (void) wavelength_sample;
+    float ax = (psx - (float) d->crop_x) / (float) d->crop_w, ay = (psy - (float) d->crop_y) / (float) d->crop_h;
+    mo_ray ray; camera_sample_ray(cam, ax, ay, &ray);
+    float L[3]; int valid;
+    path_sample(s, rng, &ray, d->max_depth, d->rr_depth, L, &valid, st);
+    /* ray_weight == 1 in RGB mode (spectrum.h:304-309) */
+    float xyz[3]; srgb_to_xyz(L, xyz);
+    aovs[0] = xyz[0]; aovs[1] = xyz[1]; aovs[2] = xyz[2]; aovs[3] = valid ? 1.0f : 0.0f; aovs[4] = 1.0f;
+    pos_sample[0] = psx; pos_sample[1] = psy;
+    if (rgb_out) { rgb_out[0] = L[0]; rgb_out[1] = L[1]; rgb_out[2] = L[2]; }
+    if (valid_out) *valid_out = valid;
+}
+
+/* IndependentSampler::seed, wavefront flavour (independent.cpp:62-72) */
+static inline void seed_wavefront(mo_pcg32 *rng, uint64_t index, uint64_t base_seed) {
+    uint64_t seed_value = index + base_seed, idx = index;
+    mo_pcg32_seed(rng, mo_tea64_u64(seed_value, idx, 4), mo_tea64_u64(idx, seed_value, 4));
+}
+
+static int desc_check(const mo_render_desc *d) {
+    if (d->max_depth < 0 && d->max_depth != -1) return -1;   /* integrator.cpp:290-292 */
+    if (d->rr_depth <= 0) return -1;
+    if (d->crop_w <= 0 || d->crop_h <= 0 || d->spp <= 0) return -1;
+    return 0;
+}
+
+int mo_sample_radiance(const mo_scene *s, const mo_render_desc *d, uint64_t first, uint64_t count,
+                       float *out_rgba, float *out_pos) {
+    if (desc_check(d)) return -1;
+    camera cam; camera_init(d, &cam);
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int64_t k = 0; k < (int64_t) count; ++k) {
+        uint64_t i = first + (uint64_t) k;
+        mo_pcg32 rng; seed_wavefront(&rng, i, d->base_seed);
+        uint64_t pixel = i / (uint64_t) d->spp;
+        float px = (float) (uint32_t) (pixel % (uint64_t) d->crop_w), py = (float) (uint32_t) (pixel / (uint64_t) d->crop_w);
+        float aovs[5], ps[2], rgb[3]; int valid; ray_stats st = { 0, 0 };
+        /* GPU branch positions are crop-relative pixel indices (integrator.cpp:152-161); the
+         * sensor sees them through crop_offset, so add it to stay on the same film position. */
+        render_sample(s, d, &cam, &rng, px + (float) d->crop_x, py + (float) d->crop_y, aovs, ps, rgb, &valid, &st);
+        out_rgba[4 * k] = rgb[0]; out_rgba[4 * k + 1] = rgb[1]; out_rgba[4 * k + 2] = rgb[2];
+        out_rgba[4 * k + 3] = valid ? 1.0f : 0.0f;
+        if (out_pos) { out_pos[2 * k] = ps[0]; out_pos[2 * k + 1] = ps[1]; }
+    }
+    return 0;
+}
+
+static int render_wavefront_rows(const mo_scene *s, const mo_render_desc *d, int row0, int row1,
+                                 float *film, uint64_t *stats) {
+    camera cam; camera_init(d, &cam);
+    rfilter f; rfilter_init(&f, d->rfilter, d->rfilter_param);
+    /* ImageBlock(film_size, 5, filter, border = true) then film->put(block) (integrator.cpp:156-168) */
+    iblock blk = { d->crop_w, d->crop_h, d->crop_x, d->crop_y, 5, f.border, &f, d->filter_analytic, NULL };
+    blk.data = (float *) calloc(iblock_floats(&blk), sizeof(float));
+    uint64_t n0 = (uint64_t) row0 * d->crop_w * d->spp, n1 = (uint64_t) row1 * d->crop_w * d->spp;
+    uint64_t chunk = 1u << 16;
+    float *buf = (float *) malloc(sizeof(float) * 7 * chunk);
+    ray_stats total = { 0, 0 };
+    for (uint64_t c0 = n0; c0 < n1; c0 += chunk) {
+        uint64_t cn = n1 - c0 < chunk ? n1 - c0 : chunk;
+        uint64_t cl = 0, an = 0;
+#pragma omp parallel for schedule(dynamic, 512) reduction(+ : cl, an)
+        for (int64_t k = 0; k < (int64_t) cn; ++k) {
+            uint64_t i = c0 + (uint64_t) k;
+            mo_pcg32 rng; seed_wavefront(&rng, i, d->base_seed);
+            uint64_t pixel = i / (uint64_t) d->spp;
+            float px = (float) (uint32_t) (pixel % (uint64_t) d->crop_w), py = (float) (uint32_t) (pixel / (uint64_t) d->crop_w);
+            ray_stats st = { 0, 0 };
+            render_sample(s, d, &cam, &rng, px + (float) d->crop_x, py + (float) d->crop_y, buf + 7 * k, buf + 7 * k + 5, NULL, NULL, &st);
+            cl += st.closest; an += st.any;
+        }
+        total.closest += cl; total.any += an;
+        for (uint64_t k = 0; k < cn; ++k) iblock_put(&blk, buf[7 * k + 5], buf[7 * k + 6], buf + 7 * k);
+    }
+    free(buf);
+    memset(film, 0, sizeof(float) * 5 * (size_t) d->crop_w * d->crop_h);
+    iblock storage = { d->crop_w, d->crop_h, d->crop_x, d->crop_y, 5, 0, NULL, 0, film };
+    iblock_put_block(&storage, &blk);
+    free(blk.data);
+    if (stats) { stats[0] = total.closest; stats[1] = total.any; stats[2] = n1 - n0; }
+    return 0;
+}
+
+int mo_render_rows(const mo_scene *s, const mo_render_desc *d, int row0, int row1, float *film) {
+    if (desc_check(d) || row0 < 0 || row1 > d->crop_h || row0 > row1) return -1;
+    return render_wavefront_rows(s, d, row0, row1, film, NULL);
+}
+
+/* scalar_rgb branch of SamplingIntegrator::render (integrator.cpp:76-143) + render_block (:178-203) */
+static int render_blocks(const mo_scene *s, const mo_render_desc *d, int n_threads, int block_size,
+                         float *film, uint64_t *stats) {
+    camera cam; camera_init(d, &cam);
+    rfilter f; rfilter_init(&f, d->rfilter, d->rfilter_param);
+    if (block_size == 0) {
+        uint32_t bs = 32;
+        while (1) {
+            size_t nb = (size_t) ((d->crop_w + bs - 1) / bs) * (size_t) ((d->crop_h + bs - 1) / bs);
+            if (bs == 1 || nb >= (size_t) n_threads) break;
+            bs /= 2;
+        }
+        block_size = (int) bs;
+    }
+    spiral sp; spiral_init(&sp, d->crop_w, d->crop_h, d->crop_x, d->crop_y, block_size, 1);
+    size_t nblocks = sp.block_count;
+    int *bo = (int *) malloc(sizeof(int) * 4 * nblocks);
+    size_t *ids = (size_t *) malloc(sizeof(size_t) * nblocks);
+    for (size_t b = 0; b < nblocks; ++b)
+        spiral_next(&sp, &bo[4 * b], &bo[4 * b + 1], &bo[4 * b + 2], &bo[4 * b + 3], &ids[b]);
+    memset(film, 0, sizeof(float) * 5 * (size_t) d->crop_w * d->crop_h);
+    iblock storage = { d->crop_w, d->crop_h, d->crop_x, d->crop_y, 5, 0, NULL, 0, film };
+    int bsz = block_size + 2 * f.border;
+    size_t per_block = (size_t) 5 * bsz * bsz;
+    /* blocks are rendered in parallel into private ImageBlocks and merged in spiral order */
+    size_t batch = 256;
+    float *bufs = (float *) malloc(sizeof(float) * per_block * batch);
+    uint64_t cl = 0, an = 0;
+    for (size_t b0 = 0; b0 < nblocks; b0 += batch) {
+        size_t bn = nblocks - b0 < batch ? nblocks - b0 : batch;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : cl, an)
+        for (int64_t bi = 0; bi < (int64_t) bn; ++bi) {
+            size_t b = b0 + (size_t) bi;
+            iblock blk = { bo[4 * b + 2], bo[4 * b + 3], bo[4 * b], bo[4 * b + 1], 5, f.border, &f, d->filter_analytic,
+                           bufs + per_block * (size_t) bi };
+            memset(blk.data, 0, sizeof(float) * iblock_floats(&blk));
+            mo_pcg32 rng;  /* sampler->seed(block_id): scalar flavour (independent.cpp:73-75) */
+            mo_pcg32_seed(&rng, (uint64_t) ids[b] + d->base_seed, MO_PCG32_DEFAULT_STREAM);
+            ray_stats st = { 0, 0 };
+            uint32_t pixel_count = (uint32_t) (block_size * block_size);
+            for (uint32_t i = 0; i < pixel_count; ++i) {
+                uint32_t mx, my; mo_morton_decode2(i, &mx, &my);
+                if (mx >= (uint32_t) blk.w || my >= (uint32_t) blk.h) continue;
+                float px = (float) (mx + (uint32_t) blk.ox), py = (float) (my + (uint32_t) blk.oy);
+                for (int j = 0; j < d->spp; ++j) {
+                    float aovs[5], ps[2];
+                    render_sample(s, d, &cam, &rng, px, py, aovs, ps, NULL, NULL, &st);
+                    iblock_put(&blk, ps[0], ps[1], aovs);
+                }
+            }
+            cl += st.closest; an += st.any;
+        }
+        for (size_t bi = 0; bi < bn; ++bi) {
+            size_t b = b0 + bi;
+            iblock blk = { bo[4 * b + 2], bo[4 * b + 3], bo[4 * b], bo[4 * b + 1], 5, f.border, &f, d->filter_analytic,
+                           bufs + per_block * bi };
+            iblock_put_block(&storage, &blk);
+        }
+    }
+    free(bufs); free(bo); free(ids);
+    if (stats) { stats[0] = cl; stats[1] = an; stats[2] = (uint64_t) d->crop_w * d->crop_h * d->spp; }
+    return 0;
+}
+
+int mo_render(const mo_scene *s, const mo_render_desc *d, int mode, int n_threads, int block_size,
+              float *film, uint64_t *stats) {
+    if (desc_check(d)) return -1;
+#ifdef _OPENMP
+    int prev = omp_get_max_threads();
+    if (n_threads <= 0) n_threads = omp_get_num_procs();
+    omp_set_num_threads(n_threads);
+#else
+    n_threads = 1;
+#endif
+    int rc = mode == 0 ? render_blocks(s, d, n_threads, block_size, film, stats)
+                       : render_wavefront_rows(s, d, 0, d->crop_h, film, stats);
+#ifdef _OPENMP
+    omp_set_num_threads(prev);
+#endif
+    return rc;
+}
+
+/* HDRFilm::bitmap: (X,Y,Z,A) * (1/W), RGB = M * XYZ (hdrfilm.cpp:278-299, struct.cpp:1761-1811) */
+void mo_film_develop(const float *xyzaw, uint64_t n, float *rgba) {
+    for (uint64_t i = 0; i < n; ++i) {
+        const float *p = xyzaw + 5 * i;
+        float inv_w = 1.0f / p[4];
+        float r = 0.0f, g = 0.0f, b = 0.0f;
+        r += 3.240479f * p[0]; r += -1.537150f * p[1]; r += -0.498535f * p[2];
+        g += -0.969256f * p[0]; g += 1.875991f * p[1]; g += 0.041556f * p[2];
+        b += 0.055648f * p[0]; b += -0.204043f * p[1]; b += 1.057311f * p[2];
+        rgba[4 * i] = r * inv_w; rgba[4 * i + 1] = g * inv_w; rgba[4 * i + 2] = b * inv_w;
+        rgba[4 * i + 3] = p[3] * inv_w;
+    }
+}
+
+/* ================================================================== */
+/* known-answer entry points */
+uint32_t mo_kat_tea32(uint32_t v0, uint32_t v1, int rounds) { return mo_tea32(v0, v1, rounds); }
+uint64_t mo_kat_tea64_u32(uint32_t v0, uint32_t v1, int rounds) { return mo_tea64_u32(v0, v1, rounds); }
+uint64_t mo_kat_tea64_u64(uint64_t v0, uint64_t v1, int rounds) { return mo_tea64_u64(v0, v1, rounds); }
+float mo_kat_tea_float32(uint32_t v0, uint32_t v1, int rounds) { return mo_tea_float32(v0, v1, rounds); }
+double mo_kat_tea_float64(uint32_t v0, uint32_t v1, int rounds) { return mo_tea_float64(v0, v1, rounds); }
+
+void mo_kat_pcg32(uint64_t initstate, uint64_t initseq, int n, uint32_t *out_u32, float *out_f32) {
+    mo_pcg32 r; mo_pcg32_seed(&r, initstate, initseq);
+    mo_pcg32 r2 = r;
+    for (int i = 0; i < n; ++i) {
+        if (out_u32) out_u32[i] = mo_pcg32_next_u32(&r);
+        if (out_f32) out_f32[i] = mo_pcg32_next_f32(&r2);
+    }
+}
+
+void mo_kat_warp(int which, uint64_t n, const float *sx, const float *sy, float *out3) {
+    for (uint64_t i = 0; i < n; ++i) {
+        mo_v2 s = { sx[i], sy[i] };
+        float *o = out3 + 3 * i;
+        if (which == 0) { mo_v2 p = mo_square_to_uniform_disk_concentric(s); o[0] = p.x; o[1] = p.y; o[2] = 0; }
+        else if (which == 1) { mo_v3 p = mo_square_to_cosine_hemisphere(s); o[0] = p.x; o[1] = p.y; o[2] = p.z; }
+        else { mo_v2 p = mo_square_to_uniform_triangle(s); o[0] = p.x; o[1] = p.y; o[2] = 0; }
+    }
+}
+
+void mo_kat_coordinate_system(const float *n3, float *s3, float *t3) {
+    mo_v3 s, t; mo_coordinate_system(mo_v3_make(n3[0], n3[1], n3[2]), &s, &t);
+    s3[0] = s.x; s3[1] = s.y; s3[2] = s.z; t3[0] = t.x; t3[1] = t.y; t3[2] = t.z;
+}
+
+void mo_kat_morton(uint32_t n, uint32_t *xy) {
+    for (uint32_t i = 0; i < n; ++i) mo_morton_decode2(i, &xy[2 * i], &xy[2 * i + 1]);
+}
+
+float mo_kat_distr(uint32_t n, const float *pmf, float *cdf, uint32_t nv, const float *values,
+                   uint32_t *idx, float *reused) {
+    float sum, norm; uint32_t lo, hi;
+    if (mo_distr_build(n, pmf, cdf, &sum, &norm, &lo, &hi)) return -1.0f;
+    for (uint32_t i = 0; i < nv; ++i) {
+        idx[i] = mo_distr_sample(cdf, sum, lo, hi, values[i]);
+        if (reused) mo_distr_sample_reuse(pmf, cdf, sum, norm, lo, hi, values[i], &reused[i]);
+    }
+    return sum;
+}
+
+void mo_kat_diffuse(const float *refl, const float *wi3, const float *wo3, const float *sample2,
+                    float *eval3, float *pdf, float *s_wo3, float *s_pdf, float *s_weight3) {
+    mo_v3 wi = mo_v3_make(wi3[0], wi3[1], wi3[2]), wo = mo_v3_make(wo3[0], wo3[1], wo3[2]);
+    mo_diffuse_eval_pdf(refl, wi, wo, eval3, pdf);
+    mo_v2 s2 = { sample2[0], sample2[1] };
+    mo_v3 swo; mo_diffuse_sample(refl, wi, s2, &swo, s_pdf, s_weight3);
+    s_wo3[0] = swo.x; s_wo3[1] = swo.y; s_wo3[2] = swo.z;
+}
+
+void mo_kat_sample_emitter(const mo_scene *s, const float *ref_p3, const float *sample2, float *out) {
+    mo_dsample ds; float spec[3];
+    mo_v2 s2 = { sample2[0], sample2[1] };
+    mo_sample_emitter_direction(s, mo_v3_make(ref_p3[0], ref_p3[1], ref_p3[2]), s2, &ds, spec);
+    out[0] = ds.d.x; out[1] = ds.d.y; out[2] = ds.d.z; out[3] = ds.dist; out[4] = ds.pdf;
+    out[5] = ds.n.x; out[6] = ds.n.y; out[7] = ds.n.z; out[8] = ds.p.x; out[9] = ds.p.y; out[10] = ds.p.z;
+    out[11] = spec[0]; out[12] = spec[1]; out[13] = spec[2];
+    out[14] = s->n_emitters ? mo_pdf_emitter_direction(s, ds.emitter, ds.d, ds.n, ds.dist) : 0.0f;
+}
