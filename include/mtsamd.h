@@ -1,0 +1,222 @@
+/* mtsamd.h -- C ABI of the MI355X (gfx950) wavefront path-tracing backend.
+ *
+ * This is the drop-in boundary for Mitsuba 2's path-tracing hot path.  Every entry
+ * point names the reference interface it stands in for (paths relative to the
+ * Mitsuba 2 source tree).  Conventions:
+ *   - plain C, opaque handles, explicit sizes; no C++/torch types cross the boundary;
+ *   - "dev" pointers are device (HIP) addresses owned by the caller; "host" pointers
+ *     are ordinary host memory; the library never frees caller memory;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are
+ *     asynchronous on that stream unless stated otherwise;
+ *   - every function returns 0 on success and a negative mtsamd_status on failure;
+ *     mtsamd_last_error() returns a thread-local description (the reference throws
+ *     std::runtime_error via Throw(), include/mitsuba/core/logger.h:155-159);
+ *   - handles are externally synchronised (one render at a time per handle), except
+ *     mtsamd_cancel() which may be called from any thread
+ *     (Integrator::cancel, include/mitsuba/render/integrator.h:44-51).
+ */
+#ifndef MTSAMD_H
+#define MTSAMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTSAMD_ABI_VERSION 1
+
+typedef enum {
+    MTSAMD_OK = 0,
+    MTSAMD_ERR_INVALID = -1,   /* bad argument (the reference would Throw) */
+    MTSAMD_ERR_DEVICE = -2,    /* HIP runtime error */
+    MTSAMD_ERR_NOMEM = -3,
+    MTSAMD_ERR_CANCELLED = -4, /* render stopped by mtsamd_cancel (render() returns false) */
+    MTSAMD_ERR_UNSUPPORTED = -5
+} mtsamd_status;
+
+typedef struct mtsamd_scene mtsamd_scene;
+
+/* ---- library ------------------------------------------------------------- */
+int mtsamd_abi_version(void);
+const char *mtsamd_last_error(void);
+/* Number of HIP devices visible to this process (<0 on error). */
+int mtsamd_device_count(void);
+
+/* ---- scene description ----------------------------------------------------
+ * Mesh buffers exactly as Mesh exposes them (include/mitsuba/render/mesh.h:80-90,
+ * 328-332): packed xyz positions, optional packed normals / uv texcoords, u32 faces.
+ * Geometry must already be in world space (the OBJ/PLY loaders bake to_world at load
+ * time, src/shapes/obj.cpp:94-342). */
+typedef struct {
+    uint32_t vertex_count;
+    uint32_t face_count;
+    const float *positions;    /* host, 3 * vertex_count */
+    const float *normals;      /* host, 3 * vertex_count, or NULL */
+    const float *texcoords;    /* host, 2 * vertex_count, or NULL */
+    const uint32_t *faces;     /* host, 3 * face_count */
+    int32_t bsdf;              /* index into the bsdf table */
+    int32_t emitter;           /* index into the emitter table, or -1 */
+} mtsamd_mesh_desc;
+
+typedef enum { MTSAMD_BSDF_DIFFUSE = 0 } mtsamd_bsdf_type;
+typedef struct {
+    int32_t type;              /* mtsamd_bsdf_type; SmoothDiffuse = src/bsdfs/diffuse.cpp */
+    float reflectance[3];      /* constant `srgb` texture value in RGB mode (src/spectra/srgb.cpp:27-52) */
+    int32_t texture;           /* index into the bitmap-texture table or -1 (src/textures/bitmap.cpp) */
+} mtsamd_bsdf_desc;
+
+typedef enum { MTSAMD_EMITTER_AREA = 0 } mtsamd_emitter_type;
+typedef struct {
+    int32_t type;              /* mtsamd_emitter_type; AreaLight = src/emitters/area.cpp */
+    float radiance[3];
+} mtsamd_emitter_desc;
+
+typedef struct {
+    int32_t width, height;     /* texels; channels = 3 (RGB) */
+    const float *data;         /* host, height*width*3 */
+} mtsamd_texture_desc;
+
+typedef struct {
+    const mtsamd_mesh_desc *meshes;       uint32_t mesh_count;
+    const mtsamd_bsdf_desc *bsdfs;        uint32_t bsdf_count;
+    const mtsamd_emitter_desc *emitters;  uint32_t emitter_count;
+    const mtsamd_texture_desc *textures;  uint32_t texture_count;
+} mtsamd_scene_desc;
+
+/* Scene::Scene + accel_init (src/librender/scene.cpp:22-98): uploads the geometry to
+ * `device`, builds the BVH (replaces ShapeKDTree::build, include/mitsuba/render/kdtree.h:1710)
+ * and the emitter sampling tables (Mesh::area_distr_build, src/librender/mesh.cpp:284-307).
+ * Synchronous. */
+int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene **out);
+void mtsamd_scene_destroy(mtsamd_scene *scene);
+
+/* Scene::bbox (include/mitsuba/render/scene.h): out6 = min xyz, max xyz (host). */
+int mtsamd_scene_bbox(const mtsamd_scene *scene, float *out6);
+/* Scene info: out[0]=primitive count, [1]=BVH node count, [2]=BVH depth, [3]=shape count,
+ * [4]=emitter count, [5]=nodes resident in LDS. */
+int mtsamd_scene_info(const mtsamd_scene *scene, uint32_t *out6);
+/* parameters_changed() for constant reflectance / radiance / texture data
+ * (src/spectra/srgb.cpp:59-61, src/textures/bitmap.cpp:295-299): host data, synchronous. */
+int mtsamd_scene_set_bsdf_reflectance(mtsamd_scene *scene, uint32_t bsdf, const float *rgb);
+int mtsamd_scene_set_emitter_radiance(mtsamd_scene *scene, uint32_t emitter, const float *rgb);
+
+/* ---- scene queries on SoA ray streams --------------------------------------
+ * The stream layout follows the reference's device-stream precedent OptixParams
+ * (include/mitsuba/render/optix/common.h:15-35): one float array per component,
+ * one entry per ray, optional byte mask; inactive or missed lanes get t = +inf,
+ * prim/shape = 0xffffffff (src/librender/optix/optix_rt.cu:35-37).
+ * All array arguments are device pointers of `n` elements. */
+typedef struct {
+    const float *ox, *oy, *oz, *dx, *dy, *dz, *mint, *maxt;
+    const uint8_t *active;     /* may be NULL */
+} mtsamd_rays;
+
+/* Scene::ray_intersect (include/mitsuba/render/scene.h:36; closest hit,
+ * ShapeKDTree::ray_intersect_scalar<false>, kdtree.h:2079-2174): t, global primitive
+ * index, shape index, barycentric u,v (the kd-tree "cache", kdtree.h:2432-2452). */
+int mtsamd_ray_intersect(const mtsamd_scene *scene, uint64_t n, const mtsamd_rays *rays,
+                         float *t, uint32_t *prim, uint32_t *shape, float *u, float *v,
+                         void *stream);
+/* Same query answered by brute force over all triangles
+ * (Scene::ray_intersect_naive, scene.h:38-44 / kdtree.h:2303-2328) -- test aid. */
+int mtsamd_ray_intersect_naive(const mtsamd_scene *scene, uint64_t n, const mtsamd_rays *rays,
+                               float *t, uint32_t *prim, uint32_t *shape, float *u, float *v,
+                               void *stream);
+/* Scene::ray_test (scene.h:62; any hit, ray_intersect_scalar<true>). */
+int mtsamd_ray_test(const mtsamd_scene *scene, uint64_t n, const mtsamd_rays *rays,
+                    uint8_t *hit, void *stream);
+/* Full SurfaceInteraction SoA for the closest hit (create_surface_interaction,
+ * kdtree.h:2334-2367 + Mesh::fill_surface_interaction, src/librender/mesh.cpp:399-462;
+ * GPU twin __closesthit__mesh, src/shapes/optix/mesh.cuh:27-96).  si26 is a device array of
+ * 26 planes of n floats each: p(3) n(3) uv(2) sh_frame.s(3) sh_frame.t(3) sh_frame.n(3)
+ * dp_du(3) dp_dv(3) wi(3). */
+int mtsamd_ray_intersect_si(const mtsamd_scene *scene, uint64_t n, const mtsamd_rays *rays,
+                            float *t, uint32_t *prim, uint32_t *shape, float *si26,
+                            void *stream);
+
+/* ---- sensor / film / sampler / integrator ----------------------------------- */
+typedef enum { MTSAMD_RFILTER_GAUSSIAN = 0, MTSAMD_RFILTER_BOX = 1 } mtsamd_rfilter_type;
+
+typedef struct {
+    /* PerspectiveCamera (src/sensors/perspective.cpp): to_world is row-major 4x4 */
+    float to_world[16];
+    float fov_x_deg;           /* horizontal fov in degrees (after parse_fov, src/librender/sensor.cpp:119-169) */
+    float near_clip, far_clip; /* defaults 1e-2 / 1e4 (sensor.cpp:100-102) */
+    /* Film (src/librender/film.cpp:7-64): size and crop window */
+    int32_t film_width, film_height;
+    int32_t crop_x, crop_y, crop_width, crop_height;
+    /* ReconstructionFilter: gaussian stddev (src/rfilters/gaussian.cpp) / box radius (box.cpp) */
+    int32_t rfilter;           /* mtsamd_rfilter_type */
+    float rfilter_param;
+    int32_t rfilter_analytic;  /* 0: eval_discretized (scalar/packet variants, imageblock.cpp:131);
+                                  1: eval() as the reference's GPU variants do (:132) */
+    /* IndependentSampler (src/samplers/independent.cpp): sample_count, seed */
+    int32_t sample_count;
+    uint64_t seed;
+    /* MonteCarloIntegrator (src/librender/integrator.cpp:283-296) */
+    int32_t max_depth;         /* -1 = unbounded */
+    int32_t rr_depth;          /* default 5 */
+    /* work partition (multi-GPU): only pixels with crop-relative row in [row_begin,row_end)
+     * are sampled; splats still land in the full crop-sized film.  row_end <= 0: all rows. */
+    int32_t row_begin, row_end;
+    /* scheduler knobs (0 = library default) */
+    int32_t paths_per_wave;    /* in-flight path slots per scheduling wave */
+    int32_t pipeline;          /* 0 = fused bounce kernel, 1 = split wavefront kernels */
+} mtsamd_render_desc;
+
+/* SamplingIntegrator::render for the `path` integrator (src/librender/integrator.cpp:52-176,
+ * src/integrators/path.cpp:100-211) followed by Film::put: renders the crop window and ADDS
+ * the result into film_xyzaw_dev (crop_height*crop_width*5 floats, channels X,Y,Z,A,W as
+ * prepared at integrator.cpp:72-74; zero it first for a fresh image).
+ * Seeding follows the reference's wavefront branch (one PCG32 stream per sample index,
+ * integrator.cpp:144-169, independent.cpp:69-72) with samples_per_pass = sample_count.
+ * Synchronous on `stream` (returns when the film is complete).
+ * stats_host (may be NULL): [0] closest-hit queries, [1] any-hit queries, [2] camera samples,
+ * [3] bounce iterations launched, [4] path segments shaded. */
+int mtsamd_render(mtsamd_scene *scene, const mtsamd_render_desc *desc, float *film_xyzaw_dev,
+                  uint64_t *stats_host, void *stream);
+/* Integrator::cancel (integrator.h:51): thread-safe, makes a running mtsamd_render return
+ * MTSAMD_ERR_CANCELLED at the next scheduling step. */
+int mtsamd_cancel(mtsamd_scene *scene);
+
+/* SamplingIntegrator::sample for whole sample indices (integrator.h:114-119): per-sample radiance
+ * of samples [first, first+count) of the render described by desc, without film accumulation.
+ * rgba_dev: count*4 floats (R,G,B, valid_ray mask); pos_dev (may be NULL): count*2 floats film
+ * position sample.  Synchronous. */
+int mtsamd_sample_radiance(mtsamd_scene *scene, const mtsamd_render_desc *desc, uint64_t first,
+                           uint64_t count, float *rgba_dev, float *pos_dev, void *stream);
+
+/* PerspectiveCamera::sample_ray (perspective.cpp:153-188) for n film-plane samples in [0,1)^2
+ * (device SoA in, device SoA out). */
+int mtsamd_camera_sample_rays(const mtsamd_render_desc *desc, uint64_t n, const float *sx,
+                              const float *sy, float *ox, float *oy, float *oz, float *dx,
+                              float *dy, float *dz, float *mint, float *maxt, void *stream);
+
+/* ---- ImageBlock / Film ------------------------------------------------------- */
+/* ImageBlock::put(pos, value) (src/librender/imageblock.cpp:80-172) for n samples:
+ * block of (width,height) at (offset_x,offset_y) with `border` pixels of apron
+ * (0, or the filter's border_size); data_dev holds (height+2b)*(width+2b)*channels floats
+ * and is accumulated into (float atomics, as the reference's scatter_add).
+ * pos_dev: n*2 floats, values_dev: n*channels floats. */
+int mtsamd_imageblock_put(int32_t width, int32_t height, int32_t offset_x, int32_t offset_y,
+                          int32_t channels, int32_t rfilter, float rfilter_param,
+                          int32_t rfilter_analytic, int32_t border, uint64_t n,
+                          const float *pos_dev, const float *values_dev, float *data_dev,
+                          void *stream);
+/* ImageBlock::put(const ImageBlock*) (imageblock.cpp:49-77, accumulate_2d bitmap.h:657-716):
+ * target += source with clipping; both described by (w,h,offset,border). */
+int mtsamd_imageblock_put_block(const float *src_dev, int32_t src_w, int32_t src_h, int32_t src_ox,
+                                int32_t src_oy, int32_t src_border, float *dst_dev, int32_t dst_w,
+                                int32_t dst_h, int32_t dst_ox, int32_t dst_oy, int32_t dst_border,
+                                int32_t channels, void *stream);
+/* ReconstructionFilter discretisation (src/libcore/rfilter.cpp:9-20): host outputs. */
+int mtsamd_rfilter_info(int32_t rfilter, float rfilter_param, float *table32_host,
+                        float *radius_host, int32_t *border_host);
+/* HDRFilm::bitmap (src/films/hdrfilm.cpp:249-320): XYZAW -> RGBA float32, n pixels. */
+int mtsamd_film_develop(const float *xyzaw_dev, uint64_t n_pixels, float *rgba_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

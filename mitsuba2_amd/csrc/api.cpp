@@ -1,0 +1,649 @@
+// api.cpp -- host side of libmtsamd: scene upload, BVH build, emitter tables, sensor/film setup,
+// the wavefront scheduler and the C ABI declared in include/mtsamd.h.
+//
+// Reference call stack this replaces:
+//   Scene::Scene -> accel_init -> ShapeKDTree::build          src/librender/scene.cpp:22-98
+//   SamplingIntegrator::render (wavefront branch)              src/librender/integrator.cpp:144-169
+//   PerspectiveCamera::update_camera_transforms                src/sensors/perspective.cpp:106-151
+//   ReconstructionFilter::init_discretization                  src/libcore/rfilter.cpp:9-20
+//   HDRFilm::prepare/put                                       src/films/hdrfilm.cpp:188-209
+#include "../../include/mtsamd.h"
+#include "bvh.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace mtsamd;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(e_ == hipErrorOutOfMemory ? MTSAMD_ERR_NOMEM : MTSAMD_ERR_DEVICE, "%s: %s",    \
+                        #expr, hipGetErrorString(e_));                                                 \
+    } while (0)
+
+// ---- 4x4 float matrices with Enoki's product order (column-wise fmadd) ---------------------
+struct Mat4 {
+    float m[4][4];
+    static Mat4 identity() { Mat4 r{}; for (int i = 0; i < 4; ++i) r.m[i][i] = 1.0f; return r; }
+    Mat4 operator*(const Mat4 &b) const {
+        Mat4 c{};
+        for (int r = 0; r < 4; ++r)
+            for (int j = 0; j < 4; ++j) {
+                float acc = m[r][0] * b.m[0][j];
+                for (int i = 1; i < 4; ++i) acc = std::fma(m[r][i], b.m[i][j], acc);
+                c.m[r][j] = acc;
+            }
+        return c;
+    }
+    Mat4 transposed() const { Mat4 c{}; for (int r = 0; r < 4; ++r) for (int j = 0; j < 4; ++j) c.m[r][j] = m[j][r]; return c; }
+};
+struct Xform {   // Transform: matrix + inverse transpose (include/mitsuba/core/transform.h)
+    Mat4 matrix, inv_t;
+    Xform operator*(const Xform &o) const { return Xform{ matrix * o.matrix, inv_t * o.inv_t }; }
+    static Xform scale(float x, float y, float z) {
+        Xform r{ Mat4::identity(), Mat4::identity() };
+        r.matrix.m[0][0] = x; r.matrix.m[1][1] = y; r.matrix.m[2][2] = z;
+        r.inv_t.m[0][0] = 1.0f / x; r.inv_t.m[1][1] = 1.0f / y; r.inv_t.m[2][2] = 1.0f / z;
+        return r;
+    }
+    static Xform translate(float x, float y, float z) {
+        Xform r{ Mat4::identity(), Mat4::identity() };
+        r.matrix.m[0][3] = x; r.matrix.m[1][3] = y; r.matrix.m[2][3] = z;
+        Mat4 inv = Mat4::identity(); inv.m[0][3] = -x; inv.m[1][3] = -y; inv.m[2][3] = -z;
+        r.inv_t = inv.transposed();
+        return r;
+    }
+    static Xform perspective(float fov, float near_, float far_) {   // transform.h:203-220
+        float recip = 1.0f / (far_ - near_);
+        float tan_ = std::tan((fov * 0.5f) * (3.14159265358979323846f / 180.0f)), cot = 1.0f / tan_;
+        Mat4 t{}; t.m[0][0] = cot; t.m[1][1] = cot; t.m[2][2] = far_ * recip; t.m[2][3] = -near_ * far_ * recip; t.m[3][2] = 1.0f;
+        Mat4 it{}; it.m[0][0] = tan_; it.m[1][1] = tan_; it.m[3][3] = 1.0f / near_; it.m[2][3] = 1.0f;
+        it.m[3][2] = (near_ - far_) / (far_ * near_);
+        return Xform{ t, it.transposed() };
+    }
+};
+
+int make_camera(const mtsamd_render_desc &d, CameraView &c) {
+    if (!(d.near_clip > 0.0f)) return fail(MTSAMD_ERR_INVALID, "The 'near_clip' parameter must be greater than zero!");
+    if (!(d.near_clip < d.far_clip)) return fail(MTSAMD_ERR_INVALID, "The 'near_clip' parameter must be smaller than 'far_clip'.");
+    if (!(d.fov_x_deg > 0.0f && d.fov_x_deg < 180.0f))
+        return fail(MTSAMD_ERR_INVALID, "The horizontal field of view must be in the range [0, 180]!");
+    float fw = (float) d.film_width, fh = (float) d.film_height;
+    float rsx = (float) d.crop_width / fw, rsy = (float) d.crop_height / fh;
+    float rox = (float) d.crop_x / fw, roy = (float) d.crop_y / fh;
+    float aspect = fw / fh;
+    Xform c2s = Xform::scale(1.0f / rsx, 1.0f / rsy, 1.0f) * Xform::translate(-rox, -roy, 0.0f) *
+                Xform::scale(-0.5f, -0.5f * aspect, 1.0f) * Xform::translate(-1.0f, -1.0f / aspect, 0.0f) *
+                Xform::perspective(d.fov_x_deg, d.near_clip, d.far_clip);
+    Mat4 s2c = c2s.inv_t.transposed();              // Transform::inverse()
+    for (int r = 0; r < 4; ++r) for (int j = 0; j < 4; ++j) c.s2c[4 * r + j] = s2c.m[r][j];
+    std::memcpy(c.c2w, d.to_world, sizeof(float) * 16);
+    c.near_clip = d.near_clip; c.far_clip = d.far_clip;
+    return 0;
+}
+
+int make_filter(int32_t kind, float param, int32_t analytic, FilterView &f) {
+    std::memset(&f, 0, sizeof(f));
+    f.kind = kind; f.analytic = analytic;
+    if (kind == MTSAMD_RFILTER_GAUSSIAN) {
+        if (!(param > 0.0f)) return fail(MTSAMD_ERR_INVALID, "gaussian rfilter: stddev must be positive");
+        f.radius = 4 * param;
+        f.alpha = -1.0f / (2.0f * param * param);
+        f.bias = std::exp(f.alpha * (f.radius * f.radius));
+    } else if (kind == MTSAMD_RFILTER_BOX) {
+        if (!(param > 0.0f)) return fail(MTSAMD_ERR_INVALID, "box rfilter: radius must be positive");
+        f.radius = param + kRayEpsilon;
+    } else {
+        return fail(MTSAMD_ERR_UNSUPPORTED, "unsupported reconstruction filter %d (gaussian and box are implemented)", kind);
+    }
+    auto eval = [&](float x) -> float {
+        if (kind == MTSAMD_RFILTER_GAUSSIAN) return std::max(0.0f, std::exp(f.alpha * (x * x)) - f.bias);
+        return std::fabs(x) <= f.radius ? 1.0f : 0.0f;
+    };
+    for (int i = 0; i < 31; ++i) f.table[i] = eval((f.radius * (float) i) / 31.0f);
+    f.table[31] = 0.0f;
+    f.scale_factor = 31.0f / f.radius;
+    f.border = (int) std::ceil(f.radius - 0.5f - 2.0f * kRayEpsilon);
+    f.taps = (int) std::ceil((f.radius - 2.0f * kRayEpsilon) * 2.0f);
+    return 0;
+}
+
+template <typename T> int upload(T **dst, const std::vector<T> &src) {
+    *dst = nullptr;
+    size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+    HIP_TRY(hipMalloc((void **) dst, bytes));
+    if (!src.empty()) HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+struct Workspace {
+    uint32_t n_waves = 0, seg_cap = 0;
+    uint64_t pass_cap = 0;
+    PoolView pool[2] = {};
+    uint32_t *count[2] = { nullptr, nullptr };
+    uint64_t *cursor = nullptr, *cursor_end = nullptr, *wave_stats = nullptr;
+    float4 *out_rgba = nullptr; float2 *out_pos = nullptr;
+    uint32_t *h_counts = nullptr;        // pinned, 4 * n_waves
+    uint64_t *h_cursor = nullptr;        // pinned, 2 * n_waves
+    hipEvent_t ev[4] = {};
+    bool have_events = false;
+
+    void release() {
+        for (int k = 0; k < 2; ++k) {
+            hipFree(pool[k].ray_o); hipFree(pool[k].ray_d); hipFree(pool[k].thr); hipFree(pool[k].res);
+            hipFree(pool[k].rng); hipFree(pool[k].misc); hipFree(count[k]);
+            pool[k] = PoolView{}; count[k] = nullptr;
+        }
+        hipFree(cursor); hipFree(cursor_end); hipFree(wave_stats); hipFree(out_rgba); hipFree(out_pos);
+        cursor = cursor_end = wave_stats = nullptr; out_rgba = nullptr; out_pos = nullptr;
+        if (h_counts) hipHostFree(h_counts);
+        if (h_cursor) hipHostFree(h_cursor);
+        h_counts = nullptr; h_cursor = nullptr;
+        if (have_events) for (auto &e : ev) hipEventDestroy(e);
+        have_events = false;
+        n_waves = seg_cap = 0; pass_cap = 0;
+    }
+};
+
+} // namespace
+
+struct mtsamd_scene {
+    int device = 0;
+    int cu_count = 256;
+    BvhOutput bvh;
+    uint32_t n_prims = 0, n_shapes = 0;
+    std::vector<DevBsdf> bsdfs;
+    std::vector<DevEmitter> emitters;
+    float4 *d_nodes = nullptr, *d_tris = nullptr;
+    float *d_tri_pos = nullptr, *d_tri_nrm = nullptr, *d_tri_uv = nullptr;
+    uint32_t *d_prim_shape = nullptr;
+    DevShape *d_shapes = nullptr; DevBsdf *d_bsdfs = nullptr; DevEmitter *d_emitters = nullptr;
+    float *d_area_pmf = nullptr, *d_area_cdf = nullptr;
+    SceneView view{};
+    Workspace ws;
+    std::atomic<int> cancel{ 0 };
+};
+
+extern "C" {
+
+int mtsamd_abi_version(void) { return MTSAMD_ABI_VERSION; }
+const char *mtsamd_last_error(void) { return g_last_error.c_str(); }
+
+int mtsamd_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(MTSAMD_ERR_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+void mtsamd_scene_destroy(mtsamd_scene *s) {
+    if (!s) return;
+    hipSetDevice(s->device);
+    s->ws.release();
+    hipFree(s->d_nodes); hipFree(s->d_tris); hipFree(s->d_tri_pos); hipFree(s->d_tri_nrm); hipFree(s->d_tri_uv);
+    hipFree(s->d_prim_shape); hipFree(s->d_shapes); hipFree(s->d_bsdfs); hipFree(s->d_emitters);
+    hipFree(s->d_area_pmf); hipFree(s->d_area_cdf);
+    delete s;
+}
+
+int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene **out) {
+    if (!desc || !out) return fail(MTSAMD_ERR_INVALID, "mtsamd_scene_create: null argument");
+    *out = nullptr;
+    if (desc->mesh_count == 0 || !desc->meshes) return fail(MTSAMD_ERR_INVALID, "scene has no shapes");
+    if (desc->bsdf_count == 0 || !desc->bsdfs) return fail(MTSAMD_ERR_INVALID, "scene has no BSDFs");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(MTSAMD_ERR_INVALID, "invalid device index %d (have %d)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+
+    // ---- validate + flatten the meshes into one global primitive list ----------------------
+    uint64_t total = 0;
+    bool any_nrm = false, any_uv = false;
+    std::vector<int32_t> emitter_shape(desc->emitter_count, -1);
+    for (uint32_t i = 0; i < desc->mesh_count; ++i) {
+        const mtsamd_mesh_desc &m = desc->meshes[i];
+        if (!m.positions || !m.faces || m.face_count == 0 || m.vertex_count == 0)
+            return fail(MTSAMD_ERR_INVALID, "mesh %u: empty mesh", i);
+        if (m.bsdf < 0 || (uint32_t) m.bsdf >= desc->bsdf_count) return fail(MTSAMD_ERR_INVALID, "mesh %u: invalid bsdf index %d", i, m.bsdf);
+        if (m.emitter >= (int32_t) desc->emitter_count) return fail(MTSAMD_ERR_INVALID, "mesh %u: invalid emitter index %d", i, m.emitter);
+        if (m.emitter >= 0) {
+            // "An area emitter can be only be attached to a single shape." (area.cpp:64-66)
+            if (emitter_shape[m.emitter] >= 0) return fail(MTSAMD_ERR_INVALID, "An area emitter can be only be attached to a single shape.");
+            emitter_shape[m.emitter] = (int32_t) i;
+        }
+        for (uint64_t k = 0; k < 3ull * m.face_count; ++k)
+            if (m.faces[k] >= m.vertex_count) return fail(MTSAMD_ERR_INVALID, "mesh %u: face index out of range", i);
+        total += m.face_count;
+        any_nrm |= m.normals != nullptr; any_uv |= m.texcoords != nullptr;
+    }
+    for (uint32_t e = 0; e < desc->emitter_count; ++e) {
+        if (emitter_shape[e] < 0) return fail(MTSAMD_ERR_INVALID, "emitter %u is not attached to a shape", e);
+        if (desc->emitters[e].type != MTSAMD_EMITTER_AREA) return fail(MTSAMD_ERR_UNSUPPORTED, "emitter %u: only 'area' emitters are implemented", e);
+    }
+    for (uint32_t b = 0; b < desc->bsdf_count; ++b)
+        if (desc->bsdfs[b].type != MTSAMD_BSDF_DIFFUSE) return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u: only 'diffuse' is implemented", b);
+    if (total >= (1ull << 27)) return fail(MTSAMD_ERR_UNSUPPORTED, "too many primitives (%llu)", (unsigned long long) total);
+
+    mtsamd_scene *s = new mtsamd_scene();
+    s->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->cu_count = prop.multiProcessorCount;
+    s->n_prims = (uint32_t) total; s->n_shapes = desc->mesh_count;
+
+    std::vector<float> tri_pos(9 * total), tri_nrm(any_nrm ? 9 * total : 0), tri_uv(any_uv ? 6 * total : 0);
+    std::vector<uint32_t> prim_shape(total);
+    std::vector<DevShape> shapes(desc->mesh_count);
+    std::vector<float> area_pmf(total, 0.0f), area_cdf(total, 0.0f);
+    s->emitters.resize(desc->emitter_count);
+    uint32_t off = 0;
+    for (uint32_t i = 0; i < desc->mesh_count; ++i) {
+        const mtsamd_mesh_desc &m = desc->meshes[i];
+        shapes[i].bsdf = m.bsdf; shapes[i].emitter = m.emitter; shapes[i].first_prim = off;
+        shapes[i].flags = (m.normals ? kShapeHasNormals : 0u) | (m.texcoords ? kShapeHasUV : 0u);
+        for (uint32_t f = 0; f < m.face_count; ++f) {
+            uint32_t gp = off + f;
+            prim_shape[gp] = i;
+            for (int j = 0; j < 3; ++j) {
+                uint32_t vi = m.faces[3 * f + j];
+                for (int k = 0; k < 3; ++k) tri_pos[9 * (size_t) gp + 3 * j + k] = m.positions[3 * (size_t) vi + k];
+                if (m.normals) for (int k = 0; k < 3; ++k) tri_nrm[9 * (size_t) gp + 3 * j + k] = m.normals[3 * (size_t) vi + k];
+                if (m.texcoords) for (int k = 0; k < 2; ++k) tri_uv[6 * (size_t) gp + 2 * j + k] = m.texcoords[2 * (size_t) vi + k];
+            }
+        }
+        if (m.emitter >= 0) {
+            // Mesh::area_distr_build (mesh.cpp:284-307) + DiscreteDistribution::update (distr_1d.h:49-88)
+            double sum = 0.0; uint32_t lo = 0xffffffffu, hi = 0xffffffffu;
+            for (uint32_t f = 0; f < m.face_count; ++f) {
+                const float *tp = &tri_pos[9 * (size_t) (off + f)];
+                float e1[3] = { tp[3] - tp[0], tp[4] - tp[1], tp[5] - tp[2] }, e2[3] = { tp[6] - tp[0], tp[7] - tp[1], tp[8] - tp[2] };
+                float cx = std::fma(e1[1], e2[2], -(e1[2] * e2[1])), cy = std::fma(e1[2], e2[0], -(e1[0] * e2[2])),
+                      cz = std::fma(e1[0], e2[1], -(e1[1] * e2[0]));
+                float area = 0.5f * std::sqrt(std::fma(cz, cz, std::fma(cy, cy, cx * cx)));
+                area_pmf[off + f] = area;
+                sum += (double) area;
+                area_cdf[off + f] = (float) sum;
+                if (area > 0.0f) { if (lo == 0xffffffffu) lo = f; hi = f; }
+            }
+            if (lo == 0xffffffffu) { delete s; return fail(MTSAMD_ERR_INVALID, "DiscreteDistribution: no probability mass found!"); }
+            DevEmitter &e = s->emitters[m.emitter];
+            std::memset(&e, 0, sizeof(e));
+            const mtsamd_emitter_desc &ed = desc->emitters[m.emitter];
+            e.r = ed.radiance[0]; e.g = ed.radiance[1]; e.b = ed.radiance[2];
+            e.shape = i; e.first_prim = off; e.n_prims = m.face_count;
+            e.area_sum = (float) sum; e.area_norm = (float) (1.0 / sum);
+            e.valid_lo = lo; e.valid_hi = hi;
+        }
+        off += m.face_count;
+    }
+    s->bsdfs.resize(desc->bsdf_count);
+    for (uint32_t b = 0; b < desc->bsdf_count; ++b) {
+        DevBsdf &d = s->bsdfs[b];
+        std::memset(&d, 0, sizeof(d));
+        d.r = desc->bsdfs[b].reflectance[0]; d.g = desc->bsdfs[b].reflectance[1]; d.b = desc->bsdfs[b].reflectance[2];
+        d.type = desc->bsdfs[b].type; d.texture = -1;
+    }
+
+    // ---- accelerator -------------------------------------------------------------------------
+    build_bvh(tri_pos.data(), s->n_prims, 4, s->bvh);
+
+    std::vector<float4> nodes(4 * (size_t) s->bvh.n_nodes), tris(3 * (size_t) s->bvh.n_slots);
+    std::memcpy(nodes.data(), s->bvh.nodes.data(), s->bvh.nodes.size() * sizeof(float));
+    std::memcpy(tris.data(), s->bvh.tris.data(), s->bvh.tris.size() * sizeof(float));
+    int rc = 0;
+    if ((rc = upload(&s->d_nodes, nodes)) || (rc = upload(&s->d_tris, tris)) || (rc = upload(&s->d_tri_pos, tri_pos)) ||
+        (rc = upload(&s->d_tri_nrm, tri_nrm)) || (rc = upload(&s->d_tri_uv, tri_uv)) || (rc = upload(&s->d_prim_shape, prim_shape)) ||
+        (rc = upload(&s->d_shapes, shapes)) || (rc = upload(&s->d_bsdfs, s->bsdfs)) || (rc = upload(&s->d_emitters, s->emitters)) ||
+        (rc = upload(&s->d_area_pmf, area_pmf)) || (rc = upload(&s->d_area_cdf, area_cdf))) {
+        mtsamd_scene_destroy(s);
+        return rc;
+    }
+    SceneView &v = s->view;
+    v.nodes = s->d_nodes; v.tris = s->d_tris; v.root = s->bvh.root;
+    v.n_nodes = s->bvh.n_nodes; v.n_slots = s->bvh.n_slots; v.n_prims = s->n_prims;
+    // LDS residency: the whole accelerator when it is small (Cornell-box class scenes), else the
+    // top of the tree (nodes are stored in BFS order).
+    const size_t small_budget = 40 * 1024;
+    if ((size_t) 64 * v.n_nodes + (size_t) 48 * v.n_slots <= small_budget) { v.lds_nodes = v.n_nodes; v.lds_slots = v.n_slots; }
+    else { v.lds_nodes = std::min<uint32_t>(v.n_nodes, 384); v.lds_slots = 0; }
+    v.stack_depth = std::max<uint32_t>(s->bvh.depth, 2);
+    v.tri_pos = s->d_tri_pos; v.tri_nrm = any_nrm ? s->d_tri_nrm : nullptr; v.tri_uv = any_uv ? s->d_tri_uv : nullptr;
+    v.prim_shape = s->d_prim_shape; v.shapes = s->d_shapes; v.bsdfs = s->d_bsdfs;
+    v.emitters = s->d_emitters; v.n_emitters = desc->emitter_count;
+    v.area_pmf = s->d_area_pmf; v.area_cdf = s->d_area_cdf;
+    if (bounce_lds_bytes(v) > 150 * 1024) {
+        mtsamd_scene_destroy(s);
+        return fail(MTSAMD_ERR_UNSUPPORTED, "BVH too deep for the LDS traversal stack (depth %u)", v.stack_depth);
+    }
+    *out = s;
+    return MTSAMD_OK;
+}
+
+int mtsamd_scene_bbox(const mtsamd_scene *s, float *out6) {
+    if (!s || !out6) return fail(MTSAMD_ERR_INVALID, "null argument");
+    std::memcpy(out6, s->bvh.bbox, sizeof(float) * 6);
+    return MTSAMD_OK;
+}
+
+int mtsamd_scene_info(const mtsamd_scene *s, uint32_t *out6) {
+    if (!s || !out6) return fail(MTSAMD_ERR_INVALID, "null argument");
+    out6[0] = s->n_prims; out6[1] = s->bvh.n_nodes; out6[2] = s->bvh.depth; out6[3] = s->n_shapes;
+    out6[4] = (uint32_t) s->emitters.size(); out6[5] = s->view.lds_nodes;
+    return MTSAMD_OK;
+}
+
+int mtsamd_scene_set_bsdf_reflectance(mtsamd_scene *s, uint32_t bsdf, const float *rgb) {
+    if (!s || !rgb || bsdf >= s->bsdfs.size()) return fail(MTSAMD_ERR_INVALID, "invalid bsdf index");
+    HIP_TRY(hipSetDevice(s->device));
+    s->bsdfs[bsdf].r = rgb[0]; s->bsdfs[bsdf].g = rgb[1]; s->bsdfs[bsdf].b = rgb[2];
+    HIP_TRY(hipMemcpy(s->d_bsdfs + bsdf, &s->bsdfs[bsdf], sizeof(DevBsdf), hipMemcpyHostToDevice));
+    return MTSAMD_OK;
+}
+
+int mtsamd_scene_set_emitter_radiance(mtsamd_scene *s, uint32_t emitter, const float *rgb) {
+    if (!s || !rgb || emitter >= s->emitters.size()) return fail(MTSAMD_ERR_INVALID, "invalid emitter index");
+    HIP_TRY(hipSetDevice(s->device));
+    s->emitters[emitter].r = rgb[0]; s->emitters[emitter].g = rgb[1]; s->emitters[emitter].b = rgb[2];
+    HIP_TRY(hipMemcpy(s->d_emitters + emitter, &s->emitters[emitter], sizeof(DevEmitter), hipMemcpyHostToDevice));
+    return MTSAMD_OK;
+}
+
+// ---- scene queries -------------------------------------------------------------------------
+static int check_rays(const mtsamd_scene *s, const mtsamd_rays *r) {
+    if (!s || !r) return fail(MTSAMD_ERR_INVALID, "null argument");
+    if (!r->ox || !r->oy || !r->oz || !r->dx || !r->dy || !r->dz || !r->mint || !r->maxt)
+        return fail(MTSAMD_ERR_INVALID, "ray stream has a null component");
+    return 0;
+}
+static RayStreams to_streams(const mtsamd_rays *r) {
+    return RayStreams{ r->ox, r->oy, r->oz, r->dx, r->dy, r->dz, r->mint, r->maxt, r->active };
+}
+
+int mtsamd_ray_intersect(const mtsamd_scene *s, uint64_t n, const mtsamd_rays *rays, float *t, uint32_t *prim,
+                         uint32_t *shape, float *u, float *v, void *stream) {
+    if (int rc = check_rays(s, rays)) return rc;
+    if (!t || !prim) return fail(MTSAMD_ERR_INVALID, "t and prim outputs are required");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(launch_ray_intersect(s->view, n, to_streams(rays), 0, t, prim, shape, u, v, nullptr, (hipStream_t) stream));
+    return MTSAMD_OK;
+}
+
+int mtsamd_ray_intersect_naive(const mtsamd_scene *s, uint64_t n, const mtsamd_rays *rays, float *t, uint32_t *prim,
+                               uint32_t *shape, float *u, float *v, void *stream) {
+    if (int rc = check_rays(s, rays)) return rc;
+    if (!t || !prim) return fail(MTSAMD_ERR_INVALID, "t and prim outputs are required");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(launch_ray_intersect(s->view, n, to_streams(rays), 1, t, prim, shape, u, v, nullptr, (hipStream_t) stream));
+    return MTSAMD_OK;
+}
+
+int mtsamd_ray_intersect_si(const mtsamd_scene *s, uint64_t n, const mtsamd_rays *rays, float *t, uint32_t *prim,
+                            uint32_t *shape, float *si26, void *stream) {
+    if (int rc = check_rays(s, rays)) return rc;
+    if (!t || !prim || !si26) return fail(MTSAMD_ERR_INVALID, "t, prim and si26 outputs are required");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(launch_ray_intersect(s->view, n, to_streams(rays), 0, t, prim, shape, nullptr, nullptr, si26, (hipStream_t) stream));
+    return MTSAMD_OK;
+}
+
+int mtsamd_ray_test(const mtsamd_scene *s, uint64_t n, const mtsamd_rays *rays, uint8_t *hit, void *stream) {
+    if (int rc = check_rays(s, rays)) return rc;
+    if (!hit) return fail(MTSAMD_ERR_INVALID, "hit output is required");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(launch_ray_test(s->view, n, to_streams(rays), hit, (hipStream_t) stream));
+    return MTSAMD_OK;
+}
+
+// ---- render ----------------------------------------------------------------------------------
+static int check_desc(const mtsamd_render_desc *d) {
+    if (!d) return fail(MTSAMD_ERR_INVALID, "null render descriptor");
+    // MonteCarloIntegrator (integrator.cpp:288-295)
+    if (d->max_depth < 0 && d->max_depth != -1)
+        return fail(MTSAMD_ERR_INVALID, "\"max_depth\" must be set to -1 (infinite) or a value >= 0");
+    if (d->rr_depth <= 0) return fail(MTSAMD_ERR_INVALID, "\"rr_depth\" must be set to a value greater than zero!");
+    if (d->film_width <= 0 || d->film_height <= 0 || d->crop_width <= 0 || d->crop_height <= 0 || d->crop_x < 0 || d->crop_y < 0 ||
+        d->crop_x + d->crop_width > d->film_width || d->crop_y + d->crop_height > d->film_height)
+        return fail(MTSAMD_ERR_INVALID, "Invalid crop window specification!");      // film.cpp:24-32
+    if (d->sample_count <= 0) return fail(MTSAMD_ERR_INVALID, "sample_count must be positive");
+    if (d->pipeline != 0) return fail(MTSAMD_ERR_UNSUPPORTED, "pipeline %d is not available in this build", d->pipeline);
+    return 0;
+}
+
+static int ensure_workspace(mtsamd_scene *s, uint32_t n_waves, uint32_t seg_cap, uint64_t pass_cap) {
+    Workspace &w = s->ws;
+    if (w.n_waves == n_waves && w.seg_cap == seg_cap && w.pass_cap >= pass_cap) return 0;
+    w.release();
+    size_t slots = (size_t) n_waves * seg_cap;
+    for (int k = 0; k < 2; ++k) {
+        HIP_TRY(hipMalloc((void **) &w.pool[k].ray_o, slots * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **) &w.pool[k].ray_d, slots * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **) &w.pool[k].thr, slots * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **) &w.pool[k].res, slots * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **) &w.pool[k].rng, slots * sizeof(uint4)));
+        HIP_TRY(hipMalloc((void **) &w.pool[k].misc, slots * sizeof(uint2)));
+        HIP_TRY(hipMalloc((void **) &w.count[k], n_waves * sizeof(uint32_t)));
+    }
+    HIP_TRY(hipMalloc((void **) &w.cursor, n_waves * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc((void **) &w.cursor_end, n_waves * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc((void **) &w.wave_stats, 4 * (size_t) n_waves * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc((void **) &w.out_rgba, pass_cap * sizeof(float4)));
+    HIP_TRY(hipMalloc((void **) &w.out_pos, pass_cap * sizeof(float2)));
+    HIP_TRY(hipHostMalloc((void **) &w.h_counts, 4 * (size_t) n_waves * sizeof(uint32_t), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **) &w.h_cursor, 2 * (size_t) n_waves * sizeof(uint64_t), hipHostMallocDefault));
+    for (auto &e : w.ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    w.have_events = true;
+    w.n_waves = n_waves; w.seg_cap = seg_cap; w.pass_cap = pass_cap;
+    return 0;
+}
+
+namespace {
+struct Job {
+    mtsamd_scene *s; const mtsamd_render_desc *d; hipStream_t stream;
+    CameraView cam; FilterView filter;
+    uint32_t n_waves, target; uint64_t pass_cap;
+    uint64_t iterations = 0;
+};
+
+// Traces sample indices [first, first+n) to completion; results land in ws.out_rgba / out_pos.
+int trace_pass(Job &j, uint64_t first, uint64_t n) {
+    Workspace &w = j.s->ws;
+    const uint32_t nw = j.n_waves;
+    for (uint32_t k = 0; k < nw; ++k) {
+        w.h_cursor[k] = (uint64_t) (((unsigned __int128) n * k) / nw);
+        w.h_cursor[nw + k] = (uint64_t) (((unsigned __int128) n * (k + 1)) / nw);
+    }
+    HIP_TRY(hipMemcpyAsync(w.cursor, w.h_cursor, nw * sizeof(uint64_t), hipMemcpyHostToDevice, j.stream));
+    HIP_TRY(hipMemcpyAsync(w.cursor_end, w.h_cursor + nw, nw * sizeof(uint64_t), hipMemcpyHostToDevice, j.stream));
+    HIP_TRY(hipMemsetAsync(w.count[0], 0, nw * sizeof(uint32_t), j.stream));
+    HIP_TRY(hipMemsetAsync(w.count[1], 0, nw * sizeof(uint32_t), j.stream));
+
+    RenderParams p{};
+    p.sv = j.s->view; p.cam = j.cam;
+    p.cursor = w.cursor; p.cursor_end = w.cursor_end; p.wave_stats = w.wave_stats;
+    p.out_rgba = w.out_rgba; p.out_pos = w.out_pos;
+    p.first_sample = first; p.base_seed = j.d->seed;
+    p.n_waves = nw; p.seg_cap = w.seg_cap; p.target = j.target;
+    p.spp = j.d->sample_count; p.crop_x = j.d->crop_x; p.crop_y = j.d->crop_y; p.crop_w = j.d->crop_width; p.crop_h = j.d->crop_height;
+    p.max_depth = j.d->max_depth; p.rr_depth = j.d->rr_depth;
+
+    // the sample cursors cannot run dry before this many launches
+    const uint64_t min_iters = (n + (uint64_t) nw * j.target - 1) / ((uint64_t) nw * j.target);
+    uint64_t it = 0;
+    int cur = 0;
+    const int lag = 2;
+    while (true) {
+        if (j.s->cancel.load(std::memory_order_relaxed)) {
+            hipStreamSynchronize(j.stream);
+            return fail(MTSAMD_ERR_CANCELLED, "render cancelled");
+        }
+        p.in = w.pool[cur]; p.out = w.pool[cur ^ 1];
+        p.count_in = w.count[cur]; p.count_out = w.count[cur ^ 1];
+        HIP_TRY(launch_bounce(p, j.stream));
+        cur ^= 1; ++it;
+        if (it >= min_iters) {
+            int slot = (int) (it % 4);
+            HIP_TRY(hipMemcpyAsync(w.h_counts + (size_t) slot * nw, w.count[cur], nw * sizeof(uint32_t), hipMemcpyDeviceToHost, j.stream));
+            HIP_TRY(hipEventRecord(w.ev[slot], j.stream));
+            if (it >= min_iters + lag) {
+                int old = (int) ((it - lag) % 4);
+                HIP_TRY(hipEventSynchronize(w.ev[old]));
+                uint64_t alive = 0;
+                const uint32_t *hc = w.h_counts + (size_t) old * nw;
+                for (uint32_t k = 0; k < nw; ++k) alive += hc[k];
+                if (alive == 0) break;
+            }
+        }
+        if (it > (1ull << 24)) return fail(MTSAMD_ERR_DEVICE, "wavefront scheduler did not converge");
+    }
+    j.iterations += it;
+    return 0;
+}
+
+int setup_job(Job &j, mtsamd_scene *s, const mtsamd_render_desc *d, hipStream_t stream, uint64_t max_pass) {
+    j.s = s; j.d = d; j.stream = stream;
+    if (int rc = make_camera(*d, j.cam)) return rc;
+    if (int rc = make_filter(d->rfilter, d->rfilter_param, d->rfilter_analytic, j.filter)) return rc;
+    j.target = d->paths_per_wave > 0 ? (uint32_t) d->paths_per_wave : 256u;
+    j.target = std::min<uint32_t>(std::max<uint32_t>(j.target, 64u), 4096u);
+    j.n_waves = (uint32_t) s->cu_count * 16u;
+    j.pass_cap = std::max<uint64_t>(std::min<uint64_t>(max_pass, 1ull << 26), 1);
+    if (int rc = ensure_workspace(s, j.n_waves, j.target, j.pass_cap)) return rc;
+    j.pass_cap = s->ws.pass_cap;
+    HIP_TRY(hipMemsetAsync(s->ws.wave_stats, 0, 4 * (size_t) j.n_waves * sizeof(uint64_t), stream));
+    s->cancel.store(0);
+    return 0;
+}
+
+int collect_stats(Job &j, uint64_t samples, uint64_t *stats_host) {
+    if (!stats_host) return 0;
+    std::vector<uint64_t> ws(4 * (size_t) j.n_waves);
+    HIP_TRY(hipMemcpyAsync(ws.data(), j.s->ws.wave_stats, ws.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, j.stream));
+    HIP_TRY(hipStreamSynchronize(j.stream));
+    uint64_t tot[4] = { 0, 0, 0, 0 };
+    for (uint32_t k = 0; k < j.n_waves; ++k) for (int q = 0; q < 4; ++q) tot[q] += ws[4 * (size_t) k + q];
+    stats_host[0] = tot[0]; stats_host[1] = tot[1]; stats_host[2] = samples; stats_host[3] = j.iterations; stats_host[4] = tot[2];
+    return 0;
+}
+} // namespace
+
+int mtsamd_render(mtsamd_scene *s, const mtsamd_render_desc *d, float *film, uint64_t *stats_host, void *stream_) {
+    if (!s || !film) return fail(MTSAMD_ERR_INVALID, "null argument");
+    if (int rc = check_desc(d)) return rc;
+    HIP_TRY(hipSetDevice(s->device));
+    hipStream_t stream = (hipStream_t) stream_;
+    int row0 = d->row_begin, row1 = d->row_end <= 0 ? d->crop_height : d->row_end;
+    if (row0 < 0 || row1 > d->crop_height || row0 > row1) return fail(MTSAMD_ERR_INVALID, "invalid row range [%d,%d)", row0, row1);
+    const uint64_t per_row = (uint64_t) d->crop_width * (uint64_t) d->sample_count;
+    const uint64_t s0 = per_row * (uint64_t) row0, s1 = per_row * (uint64_t) row1;
+    Job j;
+    if (int rc = setup_job(j, s, d, stream, s1 - s0)) return rc;
+    const int R = (int) std::ceil(j.filter.radius);
+    for (uint64_t a = s0; a < s1; a += j.pass_cap) {
+        uint64_t n = std::min<uint64_t>(j.pass_cap, s1 - a);
+        if (int rc = trace_pass(j, a, n)) return rc;
+        // Film::put: splat this pass into the rows its samples can reach
+        FilmParams f{};
+        f.out_rgba = s->ws.out_rgba; f.out_pos = s->ws.out_pos; f.film = film; f.filter = j.filter;
+        f.first_sample = a; f.n_samples = n; f.spp = d->sample_count;
+        f.crop_x = d->crop_x; f.crop_y = d->crop_y; f.crop_w = d->crop_width; f.crop_h = d->crop_height;
+        int64_t py0 = (int64_t) ((a / (uint64_t) d->sample_count) / (uint64_t) d->crop_width);
+        int64_t py1 = (int64_t) (((a + n - 1) / (uint64_t) d->sample_count) / (uint64_t) d->crop_width);
+        f.row0 = (int32_t) std::max<int64_t>(0, py0 - R); f.row1 = (int32_t) std::min<int64_t>(d->crop_height, py1 + R + 1);
+        HIP_TRY(launch_film_gather(f, stream));
+    }
+    if (int rc = collect_stats(j, s1 - s0, stats_host)) return rc;
+    HIP_TRY(hipStreamSynchronize(stream));
+    return MTSAMD_OK;
+}
+
+int mtsamd_cancel(mtsamd_scene *s) {
+    if (!s) return fail(MTSAMD_ERR_INVALID, "null argument");
+    s->cancel.store(1);
+    return MTSAMD_OK;
+}
+
+int mtsamd_sample_radiance(mtsamd_scene *s, const mtsamd_render_desc *d, uint64_t first, uint64_t count, float *rgba,
+                           float *pos, void *stream_) {
+    if (!s || !rgba) return fail(MTSAMD_ERR_INVALID, "null argument");
+    if (int rc = check_desc(d)) return rc;
+    HIP_TRY(hipSetDevice(s->device));
+    hipStream_t stream = (hipStream_t) stream_;
+    const uint64_t total = (uint64_t) d->crop_width * d->crop_height * (uint64_t) d->sample_count;
+    if (first + count > total) return fail(MTSAMD_ERR_INVALID, "sample range exceeds W*H*sample_count");
+    if (count == 0) return MTSAMD_OK;
+    Job j;
+    if (int rc = setup_job(j, s, d, stream, count)) return rc;
+    for (uint64_t a = 0; a < count; a += j.pass_cap) {
+        uint64_t n = std::min<uint64_t>(j.pass_cap, count - a);
+        if (int rc = trace_pass(j, first + a, n)) return rc;
+        HIP_TRY(hipMemcpyAsync(rgba + 4 * a, s->ws.out_rgba, n * sizeof(float4), hipMemcpyDeviceToDevice, stream));
+        if (pos) HIP_TRY(hipMemcpyAsync(pos + 2 * a, s->ws.out_pos, n * sizeof(float2), hipMemcpyDeviceToDevice, stream));
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    return MTSAMD_OK;
+}
+
+int mtsamd_camera_sample_rays(const mtsamd_render_desc *d, uint64_t n, const float *sx, const float *sy, float *ox, float *oy,
+                              float *oz, float *dx, float *dy, float *dz, float *mint, float *maxt, void *stream) {
+    if (!d || !sx || !sy || !ox || !oy || !oz || !dx || !dy || !dz || !mint || !maxt) return fail(MTSAMD_ERR_INVALID, "null argument");
+    CameraView cam;
+    if (int rc = make_camera(*d, cam)) return rc;
+    HIP_TRY(launch_camera_rays(cam, n, sx, sy, ox, oy, oz, dx, dy, dz, mint, maxt, (hipStream_t) stream));
+    return MTSAMD_OK;
+}
+
+// ---- ImageBlock / Film ------------------------------------------------------------------------
+int mtsamd_imageblock_put(int32_t width, int32_t height, int32_t offset_x, int32_t offset_y, int32_t channels, int32_t rfilter,
+                          float rfilter_param, int32_t analytic, int32_t border, uint64_t n, const float *pos, const float *values,
+                          float *data, void *stream) {
+    if (width <= 0 || height <= 0 || channels <= 0 || channels > 16 || !pos || !values || !data) return fail(MTSAMD_ERR_INVALID, "invalid ImageBlock arguments");
+    FilterView f;
+    if (int rc = make_filter(rfilter, rfilter_param, analytic, f)) return rc;
+    if (border != 0 && border != f.border) return fail(MTSAMD_ERR_INVALID, "border must be 0 or the filter's border_size (%d)", f.border);
+    HIP_TRY(launch_imageblock_put(f, width, height, offset_x, offset_y, channels, border, n, pos, values, data, (hipStream_t) stream));
+    return MTSAMD_OK;
+}
+
+int mtsamd_imageblock_put_block(const float *src, int32_t sw, int32_t sh, int32_t sox, int32_t soy, int32_t sb, float *dst, int32_t dw,
+                                int32_t dh, int32_t dox, int32_t doy, int32_t db, int32_t channels, void *stream) {
+    if (!src || !dst || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || channels <= 0 || sb < 0 || db < 0)
+        return fail(MTSAMD_ERR_INVALID, "invalid ImageBlock arguments");
+    HIP_TRY(launch_put_block(src, sw, sh, sox, soy, sb, dst, dw, dh, dox, doy, db, channels, (hipStream_t) stream));
+    return MTSAMD_OK;
+}
+
+int mtsamd_rfilter_info(int32_t rfilter, float param, float *table32, float *radius, int32_t *border) {
+    FilterView f;
+    if (int rc = make_filter(rfilter, param, 0, f)) return rc;
+    if (table32) std::memcpy(table32, f.table, sizeof(float) * 32);
+    if (radius) *radius = f.radius;
+    if (border) *border = f.border;
+    return MTSAMD_OK;
+}
+
+int mtsamd_film_develop(const float *xyzaw, uint64_t n, float *rgba, void *stream) {
+    if (!xyzaw || !rgba) return fail(MTSAMD_ERR_INVALID, "null argument");
+    HIP_TRY(launch_film_develop(xyzaw, n, rgba, (hipStream_t) stream));
+    return MTSAMD_OK;
+}
+
+} // extern "C"

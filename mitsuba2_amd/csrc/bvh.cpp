@@ -1,0 +1,214 @@
+// bvh.cpp -- binned-SAH BVH2 builder (host).  See bvh.h.
+#include "bvh.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <queue>
+
+namespace mtsamd {
+namespace {
+
+constexpr uint32_t kLeafFlag = 0x80000000u;
+constexpr uint32_t kLeafCountShift = 27;
+constexpr int kBins = 16;
+constexpr double kTraversalCost = 1.0, kIntersectCost = 1.5;
+
+struct Box {
+    double lo[3], hi[3];
+    void reset() { for (int k = 0; k < 3; ++k) { lo[k] = DBL_MAX; hi[k] = -DBL_MAX; } }
+    void grow(const Box &b) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], b.lo[k]); hi[k] = std::max(hi[k], b.hi[k]); } }
+    void grow(const double *p) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); } }
+    double area() const {
+        double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (dx < 0) return 0.0;
+        return 2.0 * (dx * dy + dy * dz + dz * dx);
+    }
+};
+
+struct TmpNode {
+    Box box;
+    int32_t left = -1, right = -1;   // children (TmpNode indices) or -1
+    uint32_t first = 0, count = 0;   // leaf range in the permuted primitive list
+    uint32_t depth = 0;
+};
+
+struct Builder {
+    const float *tri_pos;
+    uint32_t n_prims, max_leaf;
+    std::vector<Box> prim_box;
+    std::vector<double> centroid;    // 3 per prim
+    std::vector<uint32_t> perm;
+    std::vector<TmpNode> nodes;
+    uint32_t max_depth = 0;
+
+    int32_t build(uint32_t first, uint32_t count, uint32_t depth) {
+        int32_t idx = (int32_t) nodes.size();
+        nodes.emplace_back();
+        TmpNode n;
+        n.depth = depth;
+        n.box.reset();
+        Box cb; cb.reset();
+        for (uint32_t i = 0; i < count; ++i) {
+            uint32_t p = perm[first + i];
+            n.box.grow(prim_box[p]);
+            cb.grow(&centroid[3 * p]);
+        }
+        max_depth = std::max(max_depth, depth);
+        auto make_leaf = [&]() { n.first = first; n.count = count; nodes[idx] = n; return idx; };
+        if (count <= 1) return make_leaf();
+
+        // binned SAH over the three axes
+        double best_cost = DBL_MAX; int best_axis = -1, best_bin = -1;
+        double parent_area = std::max(n.box.area(), 1e-300);
+        for (int axis = 0; axis < 3; ++axis) {
+            double lo = cb.lo[axis], ext = cb.hi[axis] - cb.lo[axis];
+            if (!(ext > 0.0)) continue;
+            Box bin_box[kBins]; uint32_t bin_cnt[kBins];
+            for (int b = 0; b < kBins; ++b) { bin_box[b].reset(); bin_cnt[b] = 0; }
+            double scale = kBins / ext;
+            for (uint32_t i = 0; i < count; ++i) {
+                uint32_t p = perm[first + i];
+                int b = std::min(kBins - 1, std::max(0, (int) ((centroid[3 * p + axis] - lo) * scale)));
+                bin_box[b].grow(prim_box[p]); bin_cnt[b]++;
+            }
+            double right_area[kBins]; uint32_t right_cnt[kBins];
+            Box acc; acc.reset(); uint32_t cnt = 0;
+            for (int b = kBins - 1; b > 0; --b) {
+                if (bin_cnt[b]) acc.grow(bin_box[b]);
+                cnt += bin_cnt[b];
+                right_area[b] = cnt ? acc.area() : 0.0; right_cnt[b] = cnt;
+            }
+            acc.reset(); cnt = 0;
+            for (int b = 0; b < kBins - 1; ++b) {
+                if (bin_cnt[b]) acc.grow(bin_box[b]);
+                cnt += bin_cnt[b];
+                if (cnt == 0 || right_cnt[b + 1] == 0) continue;
+                double cost = kTraversalCost +
+                              kIntersectCost * (acc.area() * cnt + right_area[b + 1] * right_cnt[b + 1]) / parent_area;
+                if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+            }
+        }
+        double leaf_cost = kIntersectCost * count;
+        if (count <= max_leaf && (best_axis < 0 || leaf_cost <= best_cost)) return make_leaf();
+
+        uint32_t mid;
+        if (best_axis >= 0) {
+            double lo = cb.lo[best_axis], ext = cb.hi[best_axis] - cb.lo[best_axis];
+            double scale = kBins / ext;
+            auto it = std::partition(perm.begin() + first, perm.begin() + first + count, [&](uint32_t p) {
+                int b = std::min(kBins - 1, std::max(0, (int) ((centroid[3 * p + best_axis] - lo) * scale)));
+                return b <= best_bin;
+            });
+            mid = (uint32_t) (it - perm.begin());
+        } else {
+            // all centroids coincide: split by index
+            std::sort(perm.begin() + first, perm.begin() + first + count);
+            mid = first + count / 2;
+        }
+        if (mid == first || mid == first + count) mid = first + count / 2;
+        nodes[idx] = n;
+        int32_t l = build(first, mid - first, depth + 1);
+        int32_t r = build(mid, first + count - mid, depth + 1);
+        nodes[idx].left = l; nodes[idx].right = r;
+        return idx;
+    }
+};
+
+// outward-rounded, padded float bounds: the slab test must never cull a triangle that the fp32
+// Moeller-Trumbore test (mesh.h:195-221) would accept.
+inline void padded(const Box &b, double scene_extent, float lo[3], float hi[3]) {
+    for (int k = 0; k < 3; ++k) {
+        double pad = 1e-5 * std::max({ std::fabs(b.lo[k]), std::fabs(b.hi[k]), b.hi[k] - b.lo[k] }) +
+                     1e-7 * scene_extent + 1e-30;
+        lo[k] = std::nextafter((float) (b.lo[k] - pad), -INFINITY);
+        hi[k] = std::nextafter((float) (b.hi[k] + pad), INFINITY);
+    }
+}
+
+inline float bits(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+} // namespace
+
+void build_bvh(const float *tri_pos, uint32_t n_prims, uint32_t max_leaf, BvhOutput &out) {
+    Builder b;
+    b.tri_pos = tri_pos; b.n_prims = n_prims; b.max_leaf = std::min<uint32_t>(std::max<uint32_t>(max_leaf, 1), 15);
+    b.prim_box.resize(n_prims); b.centroid.resize(3 * (size_t) n_prims); b.perm.resize(n_prims);
+    Box scene; scene.reset();
+    for (uint32_t p = 0; p < n_prims; ++p) {
+        Box bx; bx.reset();
+        for (int j = 0; j < 3; ++j) {
+            double v[3] = { tri_pos[9 * (size_t) p + 3 * j], tri_pos[9 * (size_t) p + 3 * j + 1], tri_pos[9 * (size_t) p + 3 * j + 2] };
+            bx.grow(v);
+        }
+        b.prim_box[p] = bx;
+        for (int k = 0; k < 3; ++k) b.centroid[3 * (size_t) p + k] = 0.5 * (bx.lo[k] + bx.hi[k]);
+        b.perm[p] = p;
+        scene.grow(bx);
+    }
+    double extent = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        extent = std::max({ extent, std::fabs(scene.lo[k]), std::fabs(scene.hi[k]), scene.hi[k] - scene.lo[k] });
+        out.bbox[k] = (float) scene.lo[k]; out.bbox[3 + k] = (float) scene.hi[k];
+    }
+    b.nodes.reserve(2 * (size_t) n_prims);
+    int32_t root = b.build(0, n_prims, 0);
+
+    // emit: inner nodes in BFS order (the top of the tree comes first, so a prefix of the node
+    // array is what gets staged in LDS), triangle slots in the order their leaves are reached.
+    std::vector<int32_t> inner_index(b.nodes.size(), -1);
+    std::vector<int32_t> bfs;
+    {
+        std::queue<int32_t> q;
+        if (b.nodes[root].left >= 0) q.push(root);
+        while (!q.empty()) {
+            int32_t t = q.front(); q.pop();
+            inner_index[t] = (int32_t) bfs.size(); bfs.push_back(t);
+            const TmpNode &n = b.nodes[t];
+            if (b.nodes[n.left].left >= 0) q.push(n.left);
+            if (b.nodes[n.right].left >= 0) q.push(n.right);
+        }
+    }
+    out.nodes.assign(16 * bfs.size(), 0.0f);
+    out.tris.clear(); out.tris.reserve(12 * (size_t) n_prims);
+    uint32_t slot = 0;
+    auto emit_leaf = [&](const TmpNode &n) -> uint32_t {
+        uint32_t start = slot;
+        for (uint32_t i = 0; i < n.count; ++i) {
+            uint32_t p = b.perm[n.first + i];
+            const float *tp = tri_pos + 9 * (size_t) p;
+            float p0[3] = { tp[0], tp[1], tp[2] };
+            float e1[3] = { tp[3] - tp[0], tp[4] - tp[1], tp[5] - tp[2] };
+            float e2[3] = { tp[6] - tp[0], tp[7] - tp[1], tp[8] - tp[2] };
+            float rec[12] = { p0[0], p0[1], p0[2], e1[0], e1[1], e1[2], e2[0], e2[1], e2[2], bits(p), 0.0f, 0.0f };
+            out.tris.insert(out.tris.end(), rec, rec + 12);
+            ++slot;
+        }
+        return kLeafFlag | (n.count << kLeafCountShift) | start;
+    };
+    auto child_ref = [&](int32_t t) -> uint32_t {
+        const TmpNode &n = b.nodes[t];
+        if (n.left >= 0) return (uint32_t) inner_index[t];
+        return emit_leaf(n);
+    };
+    for (size_t i = 0; i < bfs.size(); ++i) {
+        const TmpNode &n = b.nodes[bfs[i]];
+        float llo[3], lhi[3], rlo[3], rhi[3];
+        padded(b.nodes[n.left].box, extent, llo, lhi);
+        padded(b.nodes[n.right].box, extent, rlo, rhi);
+        uint32_t cl = child_ref(n.left), cr = child_ref(n.right);
+        float *q = out.nodes.data() + 16 * i;
+        q[0] = llo[0]; q[1] = llo[1]; q[2] = llo[2]; q[3] = lhi[0];
+        q[4] = lhi[1]; q[5] = lhi[2]; q[6] = rlo[0]; q[7] = rlo[1];
+        q[8] = rlo[2]; q[9] = rhi[0]; q[10] = rhi[1]; q[11] = rhi[2];
+        q[12] = bits(cl); q[13] = bits(cr); q[14] = 0.0f; q[15] = 0.0f;
+    }
+    if (bfs.empty()) out.root = emit_leaf(b.nodes[root]);   // whole scene is one leaf
+    else out.root = 0;
+    out.n_nodes = (uint32_t) bfs.size();
+    out.n_slots = slot;
+    out.depth = b.max_depth + 1;
+}
+
+} // namespace mtsamd

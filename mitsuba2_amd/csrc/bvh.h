@@ -1,0 +1,25 @@
+// bvh.h -- host-side binned-SAH BVH2 builder for the gfx950 traversal kernels.
+//
+// Replaces the reference's SAH kd-tree builder (include/mitsuba/render/kdtree.h:676-1881):
+// only the *query result* of the accelerator is part of the contract (closest t / any hit,
+// kdtree.h:2079-2174), so the structure is chosen for the GPU: 64-byte two-child nodes that a
+// lane fetches with four 16-byte loads (LDS or L2), leaves of at most 4 triangles stored as
+// 48-byte pre-subtracted (p0, e1, e2) records in leaf order.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace mtsamd {
+
+struct BvhOutput {
+    std::vector<float> nodes;      // 16 floats per node (see device_scene.h for the layout)
+    std::vector<float> tris;       // 12 floats per triangle slot
+    uint32_t root = 0;             // child reference of the root
+    uint32_t n_nodes = 0, n_slots = 0, depth = 0;
+    float bbox[6] = { 0, 0, 0, 0, 0, 0 };
+};
+
+// positions: 9 floats per primitive (p0, p1, p2), n_prims >= 1
+void build_bvh(const float *tri_pos, uint32_t n_prims, uint32_t max_leaf, BvhOutput &out);
+
+} // namespace mtsamd

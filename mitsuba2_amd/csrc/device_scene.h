@@ -1,0 +1,394 @@
+// device_scene.h -- device-side scene view, BVH traversal, surface interaction and the
+// light-transport stages of the `path` integrator, as inline device functions so that the
+// fused and the split wavefront kernels are built from the same code.
+//
+// Reference semantics followed (paths relative to the Mitsuba 2 tree):
+//   Mesh::ray_intersect_triangle           include/mitsuba/render/mesh.h:195-221
+//   query contract of the kd-tree walk     include/mitsuba/render/kdtree.h:2079-2174
+//   create_surface_interaction             include/mitsuba/render/kdtree.h:2334-2367
+//   Mesh::fill_surface_interaction         src/librender/mesh.cpp:399-462
+//   Mesh::sample_position                  src/librender/mesh.cpp:320-365
+//   DiscreteDistribution::sample_reuse     include/mitsuba/core/distr_1d.h:144-203
+//   Shape::sample_direction/pdf_direction  src/librender/shape.cpp:252-283
+//   AreaLight                              src/emitters/area.cpp:71-125
+//   Scene::sample_emitter_direction        src/librender/scene.cpp:141-206
+//   SmoothDiffuse                          src/bsdfs/diffuse.cpp:78-135
+#pragma once
+#include "device_math.h"
+
+namespace mtsamd {
+
+constexpr uint32_t kLeafFlag = 0x80000000u;
+constexpr uint32_t kLeafCountShift = 27;
+constexpr uint32_t kLeafStartMask = (1u << kLeafCountShift) - 1u;
+constexpr uint32_t kNoPrim = 0xffffffffu;
+
+// BVH2 node, 64 B: both child boxes + child references.
+//   q0 = (l.min.x, l.min.y, l.min.z, l.max.x)   q1 = (l.max.y, l.max.z, r.min.x, r.min.y)
+//   q2 = (r.min.z, r.max.x, r.max.y, r.max.z)   q3 = (left ref, right ref, -, -) as bits
+// child ref: inner node index, or kLeafFlag | count << 27 | first triangle slot.
+// Triangle slot, 48 B: t0 = (p0.xyz, e1.x) t1 = (e1.y, e1.z, e2.x, e2.y) t2 = (e2.z, prim id bits, -, -)
+
+struct DevShape { int32_t bsdf; int32_t emitter; uint32_t flags; uint32_t first_prim; };
+constexpr uint32_t kShapeHasNormals = 1u, kShapeHasUV = 2u;
+struct DevBsdf { float r, g, b; int32_t type; int32_t texture; int32_t pad0, pad1, pad2; };
+struct DevEmitter {
+    float r, g, b; uint32_t shape;
+    uint32_t first_prim, n_prims; float area_sum, area_norm;
+    uint32_t valid_lo, valid_hi; uint32_t pad0, pad1;
+};
+
+struct SceneView {
+    const float4 *nodes;       // 4 per node
+    const float4 *tris;        // 3 per slot (leaf order)
+    uint32_t root;             // child ref of the root
+    uint32_t n_nodes, n_slots, n_prims;
+    uint32_t lds_nodes;        // nodes [0, lds_nodes) are staged in LDS
+    uint32_t lds_slots;        // triangle slots [0, lds_slots) are staged in LDS
+    uint32_t stack_depth;      // entries per lane
+    const float *tri_pos;      // 9 per prim (p0,p1,p2)
+    const float *tri_nrm;      // 9 per prim or nullptr
+    const float *tri_uv;       // 6 per prim or nullptr
+    const uint32_t *prim_shape;
+    const DevShape *shapes;
+    const DevBsdf *bsdfs;
+    const DevEmitter *emitters; uint32_t n_emitters;
+    const float *area_pmf, *area_cdf;   // per prim (global index), valid inside emitter ranges
+};
+
+// LDS carve-up of one workgroup: [nodes][tris][stack]
+struct LdsView {
+    const float4 *nodes;
+    const float4 *tris;
+    uint32_t *stack;           // [depth][blockDim]
+    uint32_t stride;           // blockDim.x
+};
+
+MTS_DEV LdsView lds_stage(const SceneView &sv, float4 *smem) {
+    LdsView l;
+    float4 *n = smem;
+    float4 *t = n + 4u * sv.lds_nodes;
+    for (uint32_t i = threadIdx.x; i < 4u * sv.lds_nodes; i += blockDim.x) n[i] = sv.nodes[i];
+    for (uint32_t i = threadIdx.x; i < 3u * sv.lds_slots; i += blockDim.x) t[i] = sv.tris[i];
+    l.nodes = n; l.tris = t;
+    l.stack = reinterpret_cast<uint32_t *>(t + 3u * sv.lds_slots);
+    l.stride = blockDim.x;
+    __syncthreads();
+    return l;
+}
+inline size_t lds_bytes(uint32_t lds_nodes, uint32_t lds_slots, uint32_t stack_depth, uint32_t block) {
+    return (size_t) 64 * lds_nodes + (size_t) 48 * lds_slots + (size_t) 4 * stack_depth * block;
+}
+
+struct Hit { float t; uint32_t prim; float u, v; };
+
+// Moeller-Trumbore exactly as mesh.h:195-221 (no culling, closed intervals).
+MTS_DEV bool tri_test(float4 t0, float4 t1, float4 t2, f3 o, f3 d, float mint, float maxt,
+                      float &u, float &v, float &t) {
+    f3 p0 = mk3(t0.x, t0.y, t0.z), e1 = mk3(t0.w, t1.x, t1.y), e2 = mk3(t1.z, t1.w, t2.x);
+    f3 pvec = cross(d, e2);
+    float inv_det = rcp(dot(e1, pvec));
+    f3 tvec = o - p0;
+    u = dot(tvec, pvec) * inv_det;
+    bool ok = (u >= 0.0f) && (u <= 1.0f);
+    f3 qvec = cross(tvec, e1);
+    v = dot(d, qvec) * inv_det;
+    ok = ok && (v >= 0.0f) && (u + v <= 1.0f);
+    t = dot(e2, qvec) * inv_det;
+    return ok && (t >= mint) && (t <= maxt);
+}
+
+MTS_DEV float clamp_inv(float d) {
+    float r = 1.0f / d;
+    // zero / denormal components: keep the slab test NaN-free (0 * huge = 0, never inf * 0)
+    return fabsf(r) <= 3.0e38f ? r : copysignf(3.0e38f, d);
+}
+
+// Closest-hit (ANY=false) or any-hit (ANY=true) query.  Among hits with exactly equal t the
+// highest primitive index wins (what the brute-force loop of ray_intersect_naive produces).
+template <bool ANY>
+MTS_DEV bool traverse(const SceneView &sv, const LdsView &lds, f3 o, f3 d, float mint, float maxt,
+                      Hit &hit, uint32_t &tri_tests) {
+    const f3 inv = mk3(clamp_inv(d.x), clamp_inv(d.y), clamp_inv(d.z));
+    uint32_t *stack = lds.stack + threadIdx.x;
+    const uint32_t stride = lds.stride;
+    uint32_t sp = 0;
+    uint32_t cur = sv.root;
+    float best = maxt;
+    uint32_t best_prim = kNoPrim;
+    bool found = false;
+
+    while (true) {
+        if (!(cur & kLeafFlag)) {
+            float4 q0, q1, q2, q3;
+            if (cur < sv.lds_nodes) {
+                const float4 *p = lds.nodes + 4u * cur;
+                q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+            } else {
+                const float4 *p = sv.nodes + 4u * cur;
+                q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+            }
+            // left box
+            float ax = (q0.x - o.x) * inv.x, bx = (q0.w - o.x) * inv.x;
+            float ay = (q0.y - o.y) * inv.y, by = (q1.x - o.y) * inv.y;
+            float az = (q0.z - o.z) * inv.z, bz = (q1.y - o.z) * inv.z;
+            float nearL = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), mint));
+            float farL = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best));
+            // right box
+            ax = (q1.z - o.x) * inv.x; bx = (q2.y - o.x) * inv.x;
+            ay = (q1.w - o.y) * inv.y; by = (q2.z - o.y) * inv.y;
+            az = (q2.x - o.z) * inv.z; bz = (q2.w - o.z) * inv.z;
+            float nearR = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), mint));
+            float farR = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best));
+            bool hl = nearL <= farL, hr = nearR <= farR;
+            uint32_t cl = __float_as_uint(q3.x), cr = __float_as_uint(q3.y);
+            if (hl && hr) {
+                bool lf = nearL <= nearR;
+                stack[sp * stride] = lf ? cr : cl;
+                ++sp;
+                cur = lf ? cl : cr;
+                continue;
+            } else if (hl) { cur = cl; continue; }
+            else if (hr) { cur = cr; continue; }
+        } else {
+            uint32_t start = cur & kLeafStartMask, count = (cur >> kLeafCountShift) & 0xfu;
+            for (uint32_t i = 0; i < count; ++i) {
+                uint32_t s = start + i;
+                float4 t0, t1, t2;
+                if (s < sv.lds_slots) {
+                    const float4 *p = lds.tris + 3u * s;
+                    t0 = p[0]; t1 = p[1]; t2 = p[2];
+                } else {
+                    const float4 *p = sv.tris + 3u * s;
+                    t0 = p[0]; t1 = p[1]; t2 = p[2];
+                }
+                float u, v, t;
+                ++tri_tests;
+                if (tri_test(t0, t1, t2, o, d, mint, maxt, u, v, t)) {
+                    if (ANY) return true;
+                    uint32_t prim = __float_as_uint(t2.y);
+                    if (!found || t < best || (t == best && prim > best_prim)) {
+                        found = true; best = t; best_prim = prim;
+                        hit.t = t; hit.prim = prim; hit.u = u; hit.v = v;
+                    }
+                }
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        cur = stack[sp * stride];
+    }
+    return found;
+}
+
+// Brute force over every triangle slot (ray_intersect_naive, kdtree.h:2303-2328).
+template <bool ANY>
+MTS_DEV bool traverse_naive(const SceneView &sv, f3 o, f3 d, float mint, float maxt, Hit &hit) {
+    bool found = false; float best = maxt; uint32_t best_prim = kNoPrim;
+    for (uint32_t s = 0; s < sv.n_slots; ++s) {
+        const float4 *p = sv.tris + 3u * s;
+        float u, v, t;
+        if (tri_test(p[0], p[1], p[2], o, d, mint, maxt, u, v, t)) {
+            if (ANY) return true;
+            uint32_t prim = __float_as_uint(p[2].y);
+            if (!found || t < best || (t == best && prim > best_prim)) {
+                found = true; best = t; best_prim = prim;
+                hit.t = t; hit.prim = prim; hit.u = u; hit.v = v;
+            }
+        }
+    }
+    return found;
+}
+
+// ---------------------------------------------------------------------------
+struct SurfaceInteraction {
+    f3 p, n; f2 uv; Frame sh; f3 dp_du, dp_dv, wi; uint32_t shape;
+};
+
+MTS_DEV void fill_si(const SceneView &sv, f3 ray_d, uint32_t prim, float b1, float b2, SurfaceInteraction &si) {
+    const float *tp = sv.tri_pos + 9u * prim;
+    f3 p0 = mk3(tp[0], tp[1], tp[2]), p1 = mk3(tp[3], tp[4], tp[5]), p2 = mk3(tp[6], tp[7], tp[8]);
+    float b0 = 1.0f - b1 - b2;
+    f3 dp0 = p1 - p0, dp1 = p2 - p0;
+    si.p = (p0 * b0 + p1 * b1) + p2 * b2;
+    f3 n = normalize(cross(dp0, dp1));
+    si.n = n;
+    uint32_t shape = sv.prim_shape[prim];
+    si.shape = shape;
+    uint32_t flags = sv.shapes[shape].flags;
+    f3 dp_du, dp_dv;
+    coordinate_system(n, dp_du, dp_dv);
+    si.uv.x = b1; si.uv.y = b2;
+    if (flags & kShapeHasUV) {
+        const float *tu = sv.tri_uv + 6u * prim;
+        f2 uv0 = { tu[0], tu[1] }, uv1 = { tu[2], tu[3] }, uv2 = { tu[4], tu[5] };
+        si.uv.x = (uv0.x * b0 + uv1.x * b1) + uv2.x * b2;
+        si.uv.y = (uv0.y * b0 + uv1.y * b1) + uv2.y * b2;
+        f2 duv0 = { uv1.x - uv0.x, uv1.y - uv0.y }, duv1 = { uv2.x - uv0.x, uv2.y - uv0.y };
+        float det = fmaf(duv0.x, duv1.y, -(duv0.y * duv1.x));
+        float inv_det = rcp(det);
+        if (det != 0.0f) {
+            dp_du = mk3(fmaf(duv1.y, dp0.x, -(duv0.y * dp1.x)) * inv_det,
+                        fmaf(duv1.y, dp0.y, -(duv0.y * dp1.y)) * inv_det,
+                        fmaf(duv1.y, dp0.z, -(duv0.y * dp1.z)) * inv_det);
+            dp_dv = mk3(fmaf(-duv1.x, dp0.x, duv0.x * dp1.x) * inv_det,
+                        fmaf(-duv1.x, dp0.y, duv0.x * dp1.y) * inv_det,
+                        fmaf(-duv1.x, dp0.z, duv0.x * dp1.z) * inv_det);
+        }
+    }
+    if (flags & kShapeHasNormals) {
+        const float *tn = sv.tri_nrm + 9u * prim;
+        f3 n0 = mk3(tn[0], tn[1], tn[2]), n1 = mk3(tn[3], tn[4], tn[5]), n2 = mk3(tn[6], tn[7], tn[8]);
+        n = normalize((n0 * b0 + n1 * b1) + n2 * b2);
+    }
+    si.sh.n = n;
+    si.dp_du = dp_du; si.dp_dv = dp_dv;
+    float dd = dot(n, dp_du);
+    si.sh.s = normalize(mk3(fmaf(-n.x, dd, dp_du.x), fmaf(-n.y, dd, dp_du.y), fmaf(-n.z, dd, dp_du.z)));
+    si.sh.t = cross(n, si.sh.s);
+    si.wi = to_local(si.sh, -ray_d);
+}
+
+// ---------------------------------------------------------------------------
+struct DirectionSample { f3 p, n, d; float dist, pdf; uint32_t emitter; };
+
+MTS_DEV uint32_t distr_sample_reuse(const float *pmf, const float *cdf, float sum, float norm,
+                                    uint32_t lo, uint32_t hi, float value, float &reused) {
+    float scaled = value * sum;
+    uint32_t start = lo, end = hi;
+    while (start < end) {
+        uint32_t middle = (start + end) >> 1;
+        if (cdf[middle] < scaled) { start = middle + 1; if (start > end) start = end; }
+        else end = middle;
+    }
+    float p = pmf[start] * norm;
+    float c = start > 0 ? cdf[start - 1] * norm : 0.0f;
+    reused = (value - c) / p;
+    return start;
+}
+
+// Scene::sample_emitter_direction without the visibility test; spec = radiance / pdf (masked).
+MTS_DEV void sample_emitter_direction(const SceneView &sv, f3 ref_p, f2 sample, DirectionSample &ds, f3 &spec) {
+    ds.pdf = 0.0f; ds.dist = 0.0f; ds.emitter = 0;
+    ds.p = ds.n = ds.d = mk3(0, 0, 0);
+    spec = mk3(0, 0, 0);
+    if (sv.n_emitters == 0) return;
+    uint32_t index = 0;
+    float emitter_pdf = 1.0f;
+    if (sv.n_emitters > 1) {
+        float nf = (float) sv.n_emitters;
+        emitter_pdf = 1.0f / nf;
+        uint32_t idx = (uint32_t) (sample.x * nf);
+        index = min(idx, sv.n_emitters - 1u);
+        sample.x = (sample.x - (float) index * emitter_pdf) * nf;
+    }
+    const DevEmitter e = sv.emitters[index];
+    // Mesh::sample_position
+    float reused;
+    uint32_t f = distr_sample_reuse(sv.area_pmf + e.first_prim, sv.area_cdf + e.first_prim, e.area_sum,
+                                    e.area_norm, e.valid_lo, e.valid_hi, sample.y, reused);
+    sample.y = reused;
+    uint32_t prim = e.first_prim + f;
+    const float *tp = sv.tri_pos + 9u * prim;
+    f3 p0 = mk3(tp[0], tp[1], tp[2]), p1 = mk3(tp[3], tp[4], tp[5]), p2 = mk3(tp[6], tp[7], tp[8]);
+    f3 e0 = p1 - p0, e1 = p2 - p0;
+    f2 b = square_to_uniform_triangle(sample);
+    ds.p = (p0 + e0 * b.x) + e1 * b.y;
+    ds.pdf = e.area_norm;
+    if (sv.shapes[e.shape].flags & kShapeHasNormals) {
+        const float *tn = sv.tri_nrm + 9u * prim;
+        f3 n0 = mk3(tn[0], tn[1], tn[2]), n1 = mk3(tn[3], tn[4], tn[5]), n2 = mk3(tn[6], tn[7], tn[8]);
+        float b0 = 1.0f - b.x - b.y;
+        ds.n = normalize((n0 * b0 + n1 * b.x) + n2 * b.y);
+    } else {
+        ds.n = normalize(cross(e0, e1));
+    }
+    // Shape::sample_direction
+    ds.d = ds.p - ref_p;
+    float dist_squared = sqnorm(ds.d);
+    ds.dist = sqrtf(dist_squared);
+    ds.d = div_s(ds.d, ds.dist);
+    float dp = fabsf(dot(ds.d, ds.n));
+    ds.pdf *= (dp != 0.0f) ? dist_squared / dp : 0.0f;
+    ds.emitter = index;
+    // AreaLight::sample_direction
+    bool active = (dot(ds.d, ds.n) < 0.0f) && (ds.pdf != 0.0f);
+    if (active) {
+        float r = rcp(ds.pdf);
+        spec = mk3(e.r * r, e.g * r, e.b * r);
+    }
+    if (sv.n_emitters > 1) {
+        ds.pdf *= emitter_pdf;
+        float r = rcp(emitter_pdf);
+        spec = spec * r;
+    }
+}
+
+MTS_DEV float pdf_emitter_direction(const SceneView &sv, uint32_t emitter, f3 d, f3 n, float dist) {
+    float pdf = 0.0f;
+    if (dot(d, n) < 0.0f) {
+        pdf = sv.emitters[emitter].area_norm;
+        float dp = fabsf(dot(d, n));
+        pdf *= (dp != 0.0f) ? (dist * dist) / dp : 0.0f;
+    }
+    if (sv.n_emitters > 1) pdf *= 1.0f / (float) sv.n_emitters;
+    return pdf;
+}
+
+// SmoothDiffuse
+MTS_DEV void diffuse_eval_pdf(f3 refl, f3 wi, f3 wo, f3 &value, float &pdf) {
+    bool active = wi.z > 0.0f && wo.z > 0.0f;
+    value = active ? mk3((refl.x * kInvPi) * wo.z, (refl.y * kInvPi) * wo.z, (refl.z * kInvPi) * wo.z)
+                   : mk3(0, 0, 0);
+    pdf = active ? kInvPi * wo.z : 0.0f;
+}
+MTS_DEV void diffuse_sample(f3 refl, f3 wi, f2 sample2, f3 &wo, float &pdf, f3 &weight) {
+    wo = mk3(0, 0, 0); pdf = 0.0f; weight = mk3(0, 0, 0);
+    if (!(wi.z > 0.0f)) return;
+    wo = square_to_cosine_hemisphere(sample2);
+    pdf = kInvPi * wo.z;
+    if (pdf > 0.0f) weight = refl;
+}
+
+// srgb_to_xyz (include/mitsuba/core/spectrum.h:220-227)
+MTS_DEV f3 srgb_to_xyz(f3 c) {
+    return mk3(fmaf(0.180423f, c.z, fmaf(0.357580f, c.y, 0.412453f * c.x)),
+               fmaf(0.072169f, c.z, fmaf(0.715160f, c.y, 0.212671f * c.x)),
+               fmaf(0.950227f, c.z, fmaf(0.119193f, c.y, 0.019334f * c.x)));
+}
+
+// ---------------------------------------------------------------------------
+// PerspectiveCamera::sample_ray_differential (perspective.cpp:190-222), ray part.
+struct CameraView {
+    float s2c[16];      // sample_to_camera, row-major
+    float c2w[16];      // to_world, row-major
+    float near_clip, far_clip;
+};
+MTS_DEV void camera_ray(const CameraView &c, float sx, float sy, f3 &o, f3 &d, float &mint, float &maxt) {
+    float r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float acc = c.s2c[4 * k + 3];
+        acc = fmaf(c.s2c[4 * k + 0], sx, acc);
+        acc = fmaf(c.s2c[4 * k + 1], sy, acc);
+        acc = fmaf(c.s2c[4 * k + 2], 0.0f, acc);
+        r[k] = acc;
+    }
+    float iw = rcp(r[3]);
+    f3 dl = normalize(mk3(r[0] * iw, r[1] * iw, r[2] * iw));
+    float inv_z = rcp(dl.z);
+    mint = c.near_clip * inv_z;
+    maxt = c.far_clip * inv_z;
+    o = mk3(c.c2w[3], c.c2w[7], c.c2w[11]);
+    float dd[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float acc = c.c2w[4 * k + 0] * dl.x;
+        acc = fmaf(c.c2w[4 * k + 1], dl.y, acc);
+        acc = fmaf(c.c2w[4 * k + 2], dl.z, acc);
+        dd[k] = acc;
+    }
+    d = mk3(dd[0], dd[1], dd[2]);
+}
+
+} // namespace mtsamd

@@ -1,0 +1,75 @@
+// kernels.h -- host-visible launch interface of the gfx950 kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "device_scene.h"
+
+namespace mtsamd {
+
+// Path-state streams: SoA of 16-byte vectors, one slot per in-flight path (88 B per path).
+//   ray_o = (o.xyz, mint)  ray_d = (d.xyz, maxt)  thr = (throughput rgb, bs_pdf)
+//   res = (radiance rgb, eta)  rng = PCG32 (state, inc)  misc = (sample ordinal, depth | flags << 16)
+struct PoolView {
+    float4 *ray_o, *ray_d, *thr, *res;
+    uint4 *rng;
+    uint2 *misc;
+};
+
+struct FilterView {
+    float table[32];
+    float radius, scale_factor, alpha, bias;
+    int32_t kind, analytic, border, taps;   // taps = n in imageblock.cpp:123
+};
+
+struct RenderParams {
+    SceneView sv;
+    CameraView cam;
+    PoolView in, out;
+    const uint32_t *count_in;   // per scheduling wave
+    uint32_t *count_out;
+    uint64_t *cursor;           // per wave: next sample ordinal to generate
+    const uint64_t *cursor_end;
+    uint64_t *wave_stats;       // per wave: closest, any, segments, tri tests
+    float4 *out_rgba;           // per sample ordinal: radiance rgb + valid_ray
+    float2 *out_pos;            // per sample ordinal: film position sample
+    uint64_t first_sample;      // global index of ordinal 0
+    uint64_t base_seed;
+    uint32_t n_waves, seg_cap, target;
+    int32_t spp, crop_x, crop_y, crop_w, crop_h;
+    int32_t max_depth, rr_depth;
+};
+
+struct FilmParams {
+    const float4 *out_rgba;
+    const float2 *out_pos;
+    float *film;                // crop_h * crop_w * 5
+    FilterView filter;
+    uint64_t first_sample, n_samples;
+    int32_t spp, crop_x, crop_y, crop_w, crop_h;
+    int32_t row0, row1;         // target rows [row0,row1)
+};
+
+struct RayStreams {
+    const float *ox, *oy, *oz, *dx, *dy, *dz, *mint, *maxt;
+    const uint8_t *active;
+};
+
+size_t bounce_lds_bytes(const SceneView &sv);
+hipError_t launch_bounce(const RenderParams &p, hipStream_t s);
+hipError_t launch_film_gather(const FilmParams &p, hipStream_t s);
+// mode 0: closest (BVH), 1: closest (brute force)
+hipError_t launch_ray_intersect(const SceneView &sv, uint64_t n, const RayStreams &r, int mode, float *t,
+                                uint32_t *prim, uint32_t *shape, float *u, float *v, float *si26,
+                                hipStream_t s);
+hipError_t launch_ray_test(const SceneView &sv, uint64_t n, const RayStreams &r, uint8_t *hit, hipStream_t s);
+hipError_t launch_camera_rays(const CameraView &cam, uint64_t n, const float *sx, const float *sy, float *ox,
+                              float *oy, float *oz, float *dx, float *dy, float *dz, float *mint, float *maxt,
+                              hipStream_t s);
+hipError_t launch_imageblock_put(const FilterView &f, int32_t w, int32_t h, int32_t ox, int32_t oy, int32_t ch,
+                                 int32_t border, uint64_t n, const float *pos, const float *values, float *data,
+                                 hipStream_t s);
+hipError_t launch_put_block(const float *src, int32_t sw, int32_t sh, int32_t sox, int32_t soy, int32_t sb,
+                            float *dst, int32_t dw, int32_t dh, int32_t dox, int32_t doy, int32_t db, int32_t ch,
+                            hipStream_t s);
+hipError_t launch_film_develop(const float *xyzaw, uint64_t n, float *rgba, hipStream_t s);
+
+} // namespace mtsamd

@@ -1,0 +1,490 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the wavefront path tracer.
+//
+//   k_bounce        one path segment per in-flight path: BVH closest hit, surface interaction,
+//                   emitter hit + MIS, Russian roulette, emitter sampling + BVH any hit, BSDF
+//                   sampling, then ballot/prefix-sum compaction of the surviving paths into the
+//                   wave's output segment and regeneration of camera paths into the free slots
+//                   (PathIntegrator::sample, src/integrators/path.cpp:100-211; render_sample,
+//                   src/librender/integrator.cpp:224-271)
+//   k_film_gather   ImageBlock::put as a deterministic per-pixel gather over the per-sample
+//                   radiance stream (src/librender/imageblock.cpp:80-172)
+//   k_ray_intersect / k_ray_test   Scene::ray_intersect / ray_test on SoA ray streams
+//   k_camera_rays, k_imageblock_put, k_put_block, k_film_develop
+//
+// Scheduling: the in-flight paths live in per-wave segments of the SoA pool.  A scheduling wave
+// owns `seg_cap` slots and a private range of sample ordinals; no atomics and no inter-workgroup
+// traffic are needed, so the result is independent of dispatch order.
+#include "kernels.h"
+
+namespace mtsamd {
+
+constexpr int kBlock = 256;
+
+// ---------------------------------------------------------------------------------------------
+struct PathState {
+    f3 o, d; float mint, maxt;
+    f3 thr; float bs_pdf;
+    f3 res; float eta;
+    Pcg32 rng;
+    uint32_t ordinal, depth, flags;
+};
+
+MTS_DEV void load_state(const PoolView &p, size_t i, PathState &s) {
+    float4 a = p.ray_o[i], b = p.ray_d[i], c = p.thr[i], e = p.res[i];
+    uint4 r = p.rng[i]; uint2 m = p.misc[i];
+    s.o = mk3(a.x, a.y, a.z); s.mint = a.w;
+    s.d = mk3(b.x, b.y, b.z); s.maxt = b.w;
+    s.thr = mk3(c.x, c.y, c.z); s.bs_pdf = c.w;
+    s.res = mk3(e.x, e.y, e.z); s.eta = e.w;
+    s.rng.state = (uint64_t) r.x | ((uint64_t) r.y << 32);
+    s.rng.inc = (uint64_t) r.z | ((uint64_t) r.w << 32);
+    s.ordinal = m.x; s.depth = m.y & 0xffffu; s.flags = m.y >> 16;
+}
+MTS_DEV void store_state(const PoolView &p, size_t i, const PathState &s) {
+    p.ray_o[i] = make_float4(s.o.x, s.o.y, s.o.z, s.mint);
+    p.ray_d[i] = make_float4(s.d.x, s.d.y, s.d.z, s.maxt);
+    p.thr[i] = make_float4(s.thr.x, s.thr.y, s.thr.z, s.bs_pdf);
+    p.res[i] = make_float4(s.res.x, s.res.y, s.res.z, s.eta);
+    p.rng[i] = make_uint4((uint32_t) s.rng.state, (uint32_t) (s.rng.state >> 32), (uint32_t) s.rng.inc,
+                          (uint32_t) (s.rng.inc >> 32));
+    p.misc[i] = make_uint2(s.ordinal, (s.depth & 0xffffu) | (s.flags << 16));
+}
+
+struct Counters { uint32_t closest, any, segments, tri_tests; };
+
+// One iteration of the path.cpp loop, rotated so that it starts with the intersection of the
+// ray spawned by the previous iteration (or by the sensor).  Returns true if the path survives.
+MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s, Counters &c) {
+    const SceneView &sv = P.sv;
+    Hit hit;
+    ++c.closest; ++c.segments;
+    bool found = traverse<false>(sv, lds, s.o, s.d, s.mint, s.maxt, hit, c.tri_tests);
+    if (s.depth == 1u) s.flags = found ? 1u : 0u;          // valid_ray (path.cpp:121)
+
+    SurfaceInteraction si;
+    if (found) {
+        fill_si(sv, s.d, hit.prim, hit.u, hit.v, si);
+        int32_t emitter = sv.shapes[si.shape].emitter;
+        if (emitter >= 0) {
+            // emission_weight of the previous iteration (path.cpp:194-205); 1 for camera rays
+            float ew = 1.0f;
+            if (s.depth > 1u) {
+                f3 dd = si.p - s.o;                         // DirectionSample(si_bsdf, si), records.h:168-174
+                float dist = sqrtf(sqnorm(dd));
+                dd = div_s(dd, dist);
+                ew = mis_weight(s.bs_pdf, pdf_emitter_direction(sv, (uint32_t) emitter, dd, si.sh.n, dist));
+            }
+            if (si.wi.z > 0.0f) {                           // AreaLight::eval (area.cpp:71-79)
+                const DevEmitter e = sv.emitters[emitter];
+                s.res.x += (ew * s.thr.x) * e.r; s.res.y += (ew * s.thr.y) * e.g; s.res.z += (ew * s.thr.z) * e.b;
+            }
+        }
+    }
+    bool active = found;
+
+    // Russian roulette (path.cpp:137-141)
+    if ((int32_t) s.depth > P.rr_depth) {
+        float q = fminf(fmaxf(fmaxf(s.thr.x, s.thr.y), s.thr.z) * (s.eta * s.eta), 0.95f);
+        if (active) active = pcg_next_f32(s.rng) < q;
+        float rq = rcp(q);
+        s.thr = s.thr * rq;
+    }
+    if (s.depth >= (uint32_t) P.max_depth || !active) return false;
+
+    const DevBsdf bsdf = sv.bsdfs[sv.shapes[si.shape].bsdf];
+    const f3 refl = mk3(bsdf.r, bsdf.g, bsdf.b);
+
+    // --------------------- Emitter sampling (path.cpp:153-172) ---------------------
+    {
+        f2 s2; s2.x = pcg_next_f32(s.rng); s2.y = pcg_next_f32(s.rng);
+        DirectionSample ds; f3 spec;
+        sample_emitter_direction(sv, si.p, s2, ds, spec);
+        if (ds.pdf != 0.0f) {
+            f3 wo = to_local(si.sh, ds.d);
+            f3 bv; float bp;
+            diffuse_eval_pdf(refl, si.wi, wo, bv, bp);
+            float mis = mis_weight(ds.pdf, bp);
+            f3 contrib = mk3(((mis * s.thr.x) * bv.x) * spec.x, ((mis * s.thr.y) * bv.y) * spec.y,
+                             ((mis * s.thr.z) * bv.z) * spec.z);
+            // The visibility test only ever zeroes `spec` (scene.cpp:178-182): trace the shadow
+            // ray only if an unoccluded sample would contribute.
+            if (contrib.x != 0.0f || contrib.y != 0.0f || contrib.z != 0.0f) {
+                Hit sh;
+                ++c.any;
+                bool occluded = traverse<true>(sv, lds, si.p, ds.d, kRayEpsilon * (1.0f + hmax_abs(si.p)),
+                                               ds.dist * (1.0f - kShadowEpsilon), sh, c.tri_tests);
+                if (!occluded) s.res = s.res + contrib;
+            }
+        }
+    }
+
+    // ----------------------- BSDF sampling (path.cpp:177-190) ----------------------
+    (void) pcg_next_f32(s.rng);                              // sample1, unused by SmoothDiffuse
+    f2 s2; s2.x = pcg_next_f32(s.rng); s2.y = pcg_next_f32(s.rng);
+    f3 wo, weight; float pdf;
+    diffuse_sample(refl, si.wi, s2, wo, pdf, weight);
+    s.thr = mk3(s.thr.x * weight.x, s.thr.y * weight.y, s.thr.z * weight.z);
+    if (!(s.thr.x != 0.0f || s.thr.y != 0.0f || s.thr.z != 0.0f)) return false;
+    // eta *= bs.eta (== 1)
+    s.o = si.p;                                              // spawn_ray (interaction.h:58-61)
+    s.d = to_world(si.sh, wo);
+    s.mint = (1.0f + hmax_abs(si.p)) * kRayEpsilon;
+    s.maxt = __builtin_inff();
+    s.bs_pdf = pdf;
+    s.depth += 1u;
+    return true;
+}
+
+// render_sample up to the camera ray (integrator.cpp:224-246)
+MTS_DEV void generate_path(const RenderParams &P, uint64_t ordinal, PathState &s) {
+    uint64_t index = P.first_sample + ordinal;
+    seed_sample(s.rng, index, P.base_seed);
+    uint64_t pixel = index / (uint64_t) P.spp;
+    uint32_t px = (uint32_t) (pixel % (uint64_t) P.crop_w), py = (uint32_t) (pixel / (uint64_t) P.crop_w);
+    float jx = pcg_next_f32(s.rng), jy = pcg_next_f32(s.rng);
+    float psx = ((float) px + (float) P.crop_x) + jx, psy = ((float) py + (float) P.crop_y) + jy;
+    (void) pcg_next_f32(s.rng);                              // wavelength sample (drawn even in RGB mode)
+    float ax = (psx - (float) P.crop_x) / (float) P.crop_w, ay = (psy - (float) P.crop_y) / (float) P.crop_h;
+    camera_ray(P.cam, ax, ay, s.o, s.d, s.mint, s.maxt);
+    s.thr = mk3(1.0f, 1.0f, 1.0f); s.bs_pdf = 0.0f;
+    s.res = mk3(0.0f, 0.0f, 0.0f); s.eta = 1.0f;
+    s.ordinal = (uint32_t) ordinal; s.depth = 1u; s.flags = 0u;
+    P.out_pos[ordinal] = make_float2(psx, psy);
+}
+
+__global__ __launch_bounds__(kBlock) void k_bounce(const RenderParams P) {
+    extern __shared__ float4 smem[];
+    const LdsView lds = lds_stage(P.sv, smem);
+    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    if (wave >= P.n_waves) return;
+    const uint32_t lane = lane_id();
+    const uint32_t n_in = __builtin_amdgcn_readfirstlane(P.count_in[wave]);
+    const size_t base = (size_t) wave * P.seg_cap;
+    uint32_t n_out = 0;
+    Counters c = { 0u, 0u, 0u, 0u };
+
+    for (uint32_t i0 = 0; i0 < n_in; i0 += 64u) {
+        PathState s;
+        bool alive = false;
+        if (i0 + lane < n_in) {
+            load_state(P.in, base + i0 + lane, s);
+            alive = bounce_step(P, lds, s, c);
+            if (!alive) P.out_rgba[s.ordinal] = make_float4(s.res.x, s.res.y, s.res.z, (s.flags & 1u) ? 1.0f : 0.0f);
+        }
+        // wavefront ballot + prefix rank: compact the survivors to the front of the output segment
+        const uint64_t m = __ballot(alive);
+        if (alive) store_state(P.out, base + n_out + mask_rank(m), s);
+        n_out += (uint32_t) __popcll(m);
+    }
+
+    // regenerate camera paths into the free slots of this wave's segment
+    uint64_t cursor = P.cursor[wave];
+    const uint64_t end = P.cursor_end[wave];
+    while (n_out < P.target && cursor < end) {
+        uint64_t left = end - cursor;
+        uint32_t n_new = min(64u, P.target - n_out);
+        if ((uint64_t) n_new > left) n_new = (uint32_t) left;
+        if (lane < n_new) {
+            PathState s;
+            generate_path(P, cursor + lane, s);
+            store_state(P.out, base + n_out + lane, s);
+        }
+        n_out += n_new; cursor += n_new;
+    }
+
+    // per-wave bookkeeping (each wave owns its slots: no atomics)
+    uint32_t tot[4] = { c.closest, c.any, c.segments, c.tri_tests };
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        for (int off = 32; off > 0; off >>= 1) tot[k] += __shfl_xor(tot[k], off);
+    if (lane == 0) {
+        P.count_out[wave] = n_out;
+        P.cursor[wave] = cursor;
+        uint64_t *ws = P.wave_stats + 4u * (size_t) wave;
+        ws[0] += tot[0]; ws[1] += tot[1]; ws[2] += tot[2]; ws[3] += tot[3];
+    }
+}
+
+size_t bounce_lds_bytes(const SceneView &sv) { return lds_bytes(sv.lds_nodes, sv.lds_slots, sv.stack_depth, kBlock); }
+
+hipError_t launch_bounce(const RenderParams &p, hipStream_t s) {
+    uint32_t blocks = (p.n_waves * 64u + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(k_bounce, dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// ImageBlock::put as a gather: one wave per film pixel, lanes stride over the samples of the
+// (2R+1)^2 neighbouring pixels, fixed-order butterfly reduction -> bitwise reproducible film.
+MTS_DEV float filter_eval(const FilterView &f, float x) {
+    if (f.kind == 0) return fmaxf(0.0f, expf(f.alpha * (x * x)) - f.bias);
+    return fabsf(x) <= f.radius ? 1.0f : 0.0f;
+}
+MTS_DEV float filter_weight(const FilterView &f, float x) {
+    if (f.analytic) return filter_eval(f, x);
+    int idx = min((int) fabsf(x * f.scale_factor), 31);
+    return f.table[idx];
+}
+
+// weight of the sample at block-relative position `pos` for block pixel `t` along one axis
+// (imageblock.cpp:117-161); `size` = block extent incl. border
+MTS_DEV float axis_weight(const FilterView &f, float pos, int t, int size) {
+    if (f.radius > 1.0f) {
+        int lo = max((int) ceilf(pos - f.radius), 0);
+        int hi = min((int) floorf(pos + f.radius), size - 1);
+        int i = t - lo;
+        if (i < 0 || i >= f.taps || t > hi) return 0.0f;
+        float base = (float) (uint32_t) lo - pos;
+        return filter_weight(f, base + (float) i);
+    } else {
+        int lo = (int) ceilf(pos - 0.5f);
+        return (lo == t && lo >= 0 && lo < size) ? 1.0f : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_film_gather(const FilmParams F) {
+    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const uint32_t lane = lane_id();
+    const uint32_t n_rows = (uint32_t) (F.row1 - F.row0);
+    if (wave >= n_rows * (uint32_t) F.crop_w) return;
+    const int x = (int) (wave % (uint32_t) F.crop_w), y = F.row0 + (int) (wave / (uint32_t) F.crop_w);
+    const FilterView &f = F.filter;
+    const int b = f.border;
+    const int R = (int) ceilf(f.radius);
+    const int sx = F.crop_w + 2 * b, sy = F.crop_h + 2 * b;
+    // block offset = crop offset, with border: pos = pos_ - (offset - border + 0.5)
+    const float offx = (float) (F.crop_x - b) + 0.5f, offy = (float) (F.crop_y - b) + 0.5f;
+    const uint64_t i0 = F.first_sample, i1 = F.first_sample + F.n_samples;
+    float acc[5] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+    for (int qy = y - R; qy <= y + R; ++qy) {
+        if (qy < 0 || qy >= F.crop_h) continue;
+        for (int qx = x - R; qx <= x + R; ++qx) {
+            if (qx < 0 || qx >= F.crop_w) continue;
+            uint64_t q = (uint64_t) qy * (uint64_t) F.crop_w + (uint64_t) qx;
+            uint64_t s_lo = q * (uint64_t) F.spp, s_hi = s_lo + (uint64_t) F.spp;
+            if (s_lo < i0) s_lo = i0;
+            if (s_hi > i1) s_hi = i1;
+            for (uint64_t sidx = s_lo + lane; sidx < s_hi; sidx += 64u) {
+                const float2 pp = F.out_pos[sidx - i0];
+                const float4 val = F.out_rgba[sidx - i0];
+                float wx = axis_weight(f, pp.x - offx, x + b, sx);
+                float wy = axis_weight(f, pp.y - offy, y + b, sy);
+                float w = wy * wx;                        // box filter: exactly 1 or 0
+                if (w == 0.0f) continue;                  // outside the footprint (or a zero tap: adds nothing)
+                f3 xyz = srgb_to_xyz(mk3(val.x, val.y, val.z));
+                float v[5] = { xyz.x, xyz.y, xyz.z, val.w, 1.0f };
+                bool valid = true;                        // imageblock.cpp:85-109: invalid samples are dropped
+#pragma unroll
+                for (int k = 0; k < 5; ++k) valid = valid && (v[k] >= -1e-5f) && isfinite(v[k]);
+                if (!valid) continue;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) acc[k] += v[k] * w;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+        for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_xor(acc[k], off);
+    if (lane == 0) {
+        float *dst = F.film + 5u * ((size_t) y * (size_t) F.crop_w + (size_t) x);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) dst[k] += acc[k];
+    }
+}
+
+hipError_t launch_film_gather(const FilmParams &p, hipStream_t s) {
+    uint64_t waves = (uint64_t) (p.row1 - p.row0) * (uint64_t) p.crop_w;
+    if (waves == 0) return hipSuccess;
+    uint64_t blocks = (waves * 64u + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(k_film_gather, dim3((uint32_t) blocks), dim3(kBlock), 0, s, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scene::ray_intersect / ray_intersect_naive / ray_test on SoA ray streams
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_ray_intersect(const SceneView sv, uint64_t n, const RayStreams r,
+                                                          float *t, uint32_t *prim, uint32_t *shape, float *u,
+                                                          float *v, float *si26) {
+    extern __shared__ float4 smem[];
+    const LdsView lds = lds_stage(sv, smem);
+    for (uint64_t i = (uint64_t) blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t) gridDim.x * kBlock) {
+        bool active = r.active ? r.active[i] != 0 : true;
+        Hit hit; bool found = false;
+        f3 o = mk3(r.ox[i], r.oy[i], r.oz[i]), d = mk3(r.dx[i], r.dy[i], r.dz[i]);
+        if (active) {
+            uint32_t tt = 0;
+            if (MODE == 0) found = traverse<false>(sv, lds, o, d, r.mint[i], r.maxt[i], hit, tt);
+            else found = traverse_naive<false>(sv, o, d, r.mint[i], r.maxt[i], hit);
+        }
+        t[i] = found ? hit.t : __builtin_inff();
+        prim[i] = found ? hit.prim : kNoPrim;
+        if (shape) shape[i] = found ? sv.prim_shape[hit.prim] : kNoPrim;
+        if (u) u[i] = found ? hit.u : 0.0f;
+        if (v) v[i] = found ? hit.v : 0.0f;
+        if (si26) {
+            float o26[26];
+#pragma unroll
+            for (int k = 0; k < 26; ++k) o26[k] = 0.0f;
+            if (found) {
+                SurfaceInteraction si;
+                fill_si(sv, d, hit.prim, hit.u, hit.v, si);
+                o26[0] = si.p.x; o26[1] = si.p.y; o26[2] = si.p.z; o26[3] = si.n.x; o26[4] = si.n.y; o26[5] = si.n.z;
+                o26[6] = si.uv.x; o26[7] = si.uv.y;
+                o26[8] = si.sh.s.x; o26[9] = si.sh.s.y; o26[10] = si.sh.s.z;
+                o26[11] = si.sh.t.x; o26[12] = si.sh.t.y; o26[13] = si.sh.t.z;
+                o26[14] = si.sh.n.x; o26[15] = si.sh.n.y; o26[16] = si.sh.n.z;
+                o26[17] = si.dp_du.x; o26[18] = si.dp_du.y; o26[19] = si.dp_du.z;
+                o26[20] = si.dp_dv.x; o26[21] = si.dp_dv.y; o26[22] = si.dp_dv.z;
+                o26[23] = si.wi.x; o26[24] = si.wi.y; o26[25] = si.wi.z;
+            } else {
+                o26[23] = -d.x; o26[24] = -d.y; o26[25] = -d.z;   // scene_native.inl:28-31
+            }
+#pragma unroll
+            for (int k = 0; k < 26; ++k) si26[(size_t) k * n + i] = o26[k];
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_ray_test(const SceneView sv, uint64_t n, const RayStreams r, uint8_t *hit_out) {
+    extern __shared__ float4 smem[];
+    const LdsView lds = lds_stage(sv, smem);
+    for (uint64_t i = (uint64_t) blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t) gridDim.x * kBlock) {
+        bool active = r.active ? r.active[i] != 0 : true;
+        bool found = false;
+        if (active) {
+            Hit hit; uint32_t tt = 0;
+            found = traverse<true>(sv, lds, mk3(r.ox[i], r.oy[i], r.oz[i]), mk3(r.dx[i], r.dy[i], r.dz[i]), r.mint[i],
+                                   r.maxt[i], hit, tt);
+        }
+        hit_out[i] = found ? 1 : 0;
+    }
+}
+
+static uint32_t stream_grid(uint64_t n) {
+    uint64_t blocks = (n + kBlock - 1) / kBlock;
+    return (uint32_t) (blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks));
+}
+
+hipError_t launch_ray_intersect(const SceneView &sv, uint64_t n, const RayStreams &r, int mode, float *t,
+                                uint32_t *prim, uint32_t *shape, float *u, float *v, float *si26, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    size_t lds = bounce_lds_bytes(sv);
+    if (mode == 0)
+        hipLaunchKernelGGL(k_ray_intersect<0>, dim3(stream_grid(n)), dim3(kBlock), lds, s, sv, n, r, t, prim, shape, u, v, si26);
+    else
+        hipLaunchKernelGGL(k_ray_intersect<1>, dim3(stream_grid(n)), dim3(kBlock), lds, s, sv, n, r, t, prim, shape, u, v, si26);
+    return hipGetLastError();
+}
+
+hipError_t launch_ray_test(const SceneView &sv, uint64_t n, const RayStreams &r, uint8_t *hit, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_ray_test, dim3(stream_grid(n)), dim3(kBlock), bounce_lds_bytes(sv), s, sv, n, r, hit);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_camera_rays(const CameraView cam, uint64_t n, const float *sx, const float *sy,
+                                                        float *ox, float *oy, float *oz, float *dx, float *dy, float *dz,
+                                                        float *mint, float *maxt) {
+    for (uint64_t i = (uint64_t) blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t) gridDim.x * kBlock) {
+        f3 o, d; float t0, t1;
+        camera_ray(cam, sx[i], sy[i], o, d, t0, t1);
+        ox[i] = o.x; oy[i] = o.y; oz[i] = o.z; dx[i] = d.x; dy[i] = d.y; dz[i] = d.z; mint[i] = t0; maxt[i] = t1;
+    }
+}
+hipError_t launch_camera_rays(const CameraView &cam, uint64_t n, const float *sx, const float *sy, float *ox, float *oy,
+                              float *oz, float *dx, float *dy, float *dz, float *mint, float *maxt, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_camera_rays, dim3(stream_grid(n)), dim3(kBlock), 0, s, cam, n, sx, sy, ox, oy, oz, dx, dy, dz, mint, maxt);
+    return hipGetLastError();
+}
+
+// ImageBlock::put(pos, value) as a scatter with float atomics (the reference's scatter_add)
+__global__ __launch_bounds__(kBlock) void k_imageblock_put(const FilterView f, int32_t w, int32_t h, int32_t ox, int32_t oy,
+                                                           int32_t ch, int32_t border, uint64_t n, const float *pos,
+                                                           const float *values, float *data) {
+    const int sx = w + 2 * border, sy = h + 2 * border;
+    for (uint64_t i = (uint64_t) blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t) gridDim.x * kBlock) {
+        const float *val = values + (size_t) ch * i;
+        bool valid = true;
+        for (int k = 0; k < ch; ++k) valid = valid && (val[k] >= -1e-5f) && isfinite(val[k]);
+        if (!valid) continue;
+        float px = pos[2 * i] - ((float) (ox - border) + 0.5f), py = pos[2 * i + 1] - ((float) (oy - border) + 0.5f);
+        if (f.radius > 1.0f) {
+            int lox = max((int) ceilf(px - f.radius), 0), loy = max((int) ceilf(py - f.radius), 0);
+            int hix = min((int) floorf(px + f.radius), sx - 1), hiy = min((int) floorf(py + f.radius), sy - 1);
+            float bx = (float) (uint32_t) lox - px, by = (float) (uint32_t) loy - py;
+            for (int yr = 0; yr < f.taps; ++yr) {
+                int y = loy + yr;
+                if (y > hiy) break;
+                float wy = filter_weight(f, by + (float) yr);
+                for (int xr = 0; xr < f.taps; ++xr) {
+                    int x = lox + xr;
+                    if (x > hix) break;
+                    float wgt = wy * filter_weight(f, bx + (float) xr);
+                    float *dst = data + (size_t) ch * ((size_t) y * sx + x);
+                    for (int k = 0; k < ch; ++k) atomicAdd(dst + k, val[k] * wgt);
+                }
+            }
+        } else {
+            int lox = (int) ceilf(px - 0.5f), loy = (int) ceilf(py - 0.5f);
+            if (lox >= 0 && loy >= 0 && lox < sx && loy < sy) {
+                float *dst = data + (size_t) ch * ((size_t) loy * sx + lox);
+                for (int k = 0; k < ch; ++k) atomicAdd(dst + k, val[k]);
+            }
+        }
+    }
+}
+hipError_t launch_imageblock_put(const FilterView &f, int32_t w, int32_t h, int32_t ox, int32_t oy, int32_t ch,
+                                 int32_t border, uint64_t n, const float *pos, const float *values, float *data,
+                                 hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_imageblock_put, dim3(stream_grid(n)), dim3(kBlock), 0, s, f, w, h, ox, oy, ch, border, n, pos, values, data);
+    return hipGetLastError();
+}
+
+// ImageBlock::put(block): clipped rectangular += (accumulate_2d, bitmap.h:657-716)
+__global__ __launch_bounds__(kBlock) void k_put_block(const float *src, int ssx, int sox, int soy, float *dst, int tsx, int tox,
+                                                      int toy, int szx, int szy, int ch) {
+    uint64_t total = (uint64_t) szx * szy * ch;
+    for (uint64_t i = (uint64_t) blockIdx.x * kBlock + threadIdx.x; i < total; i += (uint64_t) gridDim.x * kBlock) {
+        int row_elems = szx * ch;
+        int y = (int) (i / row_elems), c = (int) (i % row_elems);
+        dst[((size_t) (toy + y) * tsx + tox) * ch + c] += src[((size_t) (soy + y) * ssx + sox) * ch + c];
+    }
+}
+hipError_t launch_put_block(const float *src, int32_t sw, int32_t sh, int32_t sox_, int32_t soy_, int32_t sb, float *dst,
+                            int32_t dw, int32_t dh, int32_t dox, int32_t doy, int32_t db, int32_t ch, hipStream_t s) {
+    int ssx = sw + 2 * sb, ssy = sh + 2 * sb, tsx = dw + 2 * db, tsy = dh + 2 * db;
+    int sox = 0, soy = 0, tox = (sox_ - sb) - (dox - db), toy = (soy_ - sb) - (doy - db);
+    int szx = ssx, szy = ssy;
+    int shx = std::max(0, std::max(-sox, -tox)), shy = std::max(0, std::max(-soy, -toy));
+    sox += shx; tox += shx; soy += shy; toy += shy;
+    szx -= std::max(sox + szx - ssx, 0); szx -= std::max(tox + szx - tsx, 0);
+    szy -= std::max(soy + szy - ssy, 0); szy -= std::max(toy + szy - tsy, 0);
+    if (szx <= 0 || szy <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_put_block, dim3(stream_grid((uint64_t) szx * szy * ch)), dim3(kBlock), 0, s, src, ssx, sox, soy, dst,
+                       tsx, tox, toy, szx, szy, ch);
+    return hipGetLastError();
+}
+
+// HDRFilm::bitmap: (X,Y,Z,A) / W, RGB = M * XYZ (hdrfilm.cpp:278-299, struct.cpp:1761-1811)
+__global__ __launch_bounds__(kBlock) void k_film_develop(const float *xyzaw, uint64_t n, float *rgba) {
+    for (uint64_t i = (uint64_t) blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t) gridDim.x * kBlock) {
+        const float *p = xyzaw + 5 * i;
+        float inv_w = 1.0f / p[4];
+        float r = 0.0f, g = 0.0f, b = 0.0f;
+        r += 3.240479f * p[0]; r += -1.537150f * p[1]; r += -0.498535f * p[2];
+        g += -0.969256f * p[0]; g += 1.875991f * p[1]; g += 0.041556f * p[2];
+        b += 0.055648f * p[0]; b += -0.204043f * p[1]; b += 1.057311f * p[2];
+        rgba[4 * i] = r * inv_w; rgba[4 * i + 1] = g * inv_w; rgba[4 * i + 2] = b * inv_w; rgba[4 * i + 3] = p[3] * inv_w;
+    }
+}
+hipError_t launch_film_develop(const float *xyzaw, uint64_t n, float *rgba, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_film_develop, dim3(stream_grid(n)), dim3(kBlock), 0, s, xyzaw, n, rgba);
+    return hipGetLastError();
+}
+
+} // namespace mtsamd

@@ -1,0 +1,494 @@
+"""Host-side mirror of the reference's Python surface for the path-tracing hot path.
+
+Class and method names follow the pybind11 bindings of Mitsuba 2 (``src/librender/python/scene_v.cpp:37-86``,
+``integrator_v.cpp:61-170``, ``imageblock_v.cpp:5-40``, ``src/films/hdrfilm.cpp``) for the supported subset;
+every compute call goes through the C ABI of ``libmtsamd.so`` (``include/mtsamd.h``).  PyTorch is used only
+to own device memory and streams.
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+RayEpsilon = float(np.float32(np.finfo(np.float32).eps / 2 * 1500))
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# --------------------------------------------------------------------------------------------
+# records (include/mitsuba/core/ray.h:21-62, include/mitsuba/render/interaction.h:33-126)
+@dataclass
+class Ray3f:
+    o: torch.Tensor                     # (N,3)
+    d: torch.Tensor                     # (N,3)
+    mint: Optional[torch.Tensor] = None  # (N,), default RayEpsilon (ray.h:33)
+    maxt: Optional[torch.Tensor] = None  # (N,), default +inf (ray.h:34)
+    time: float = 0.0
+
+    def __post_init__(self):
+        n = self.o.shape[0]
+        dev = self.o.device
+        if self.mint is None:
+            self.mint = torch.full((n,), RayEpsilon, dtype=torch.float32, device=dev)
+        if self.maxt is None:
+            self.maxt = torch.full((n,), float("inf"), dtype=torch.float32, device=dev)
+
+
+@dataclass
+class SurfaceInteraction3f:
+    t: torch.Tensor
+    prim_index: torch.Tensor
+    shape_index: torch.Tensor
+    p: Optional[torch.Tensor] = None
+    n: Optional[torch.Tensor] = None
+    uv: Optional[torch.Tensor] = None
+    sh_frame_s: Optional[torch.Tensor] = None
+    sh_frame_t: Optional[torch.Tensor] = None
+    sh_frame_n: Optional[torch.Tensor] = None
+    dp_du: Optional[torch.Tensor] = None
+    dp_dv: Optional[torch.Tensor] = None
+    wi: Optional[torch.Tensor] = None
+    prim_uv: Optional[torch.Tensor] = None   # barycentric (u,v): the kd-tree "cache" (kdtree.h:2432-2452)
+
+    def is_valid(self):
+        """interaction.h:53-55"""
+        return self.t != float("inf")
+
+
+# --------------------------------------------------------------------------------------------
+class ReconstructionFilter:
+    """include/mitsuba/core/rfilter.h; discretisation from src/libcore/rfilter.cpp:9-20 via the C ABI."""
+    kind = -1
+
+    def __init__(self, param):
+        self.param = float(param)
+        table = (C.c_float * 32)()
+        radius = C.c_float()
+        border = C.c_int32()
+        L.check(L.lib().mtsamd_rfilter_info(self.kind, self.param, table, C.byref(radius), C.byref(border)))
+        self._table = np.array(table, dtype=np.float32)
+        self._radius = radius.value
+        self._border = border.value
+
+    def radius(self):
+        return self._radius
+
+    def border_size(self):
+        return self._border
+
+    def eval_discretized(self, x):
+        idx = min(int(abs(np.float32(x) * np.float32(31.0 / self._radius))), 31)
+        return float(self._table[idx])
+
+
+class GaussianFilter(ReconstructionFilter):
+    """src/rfilters/gaussian.cpp"""
+    kind = 0
+
+    def __init__(self, stddev=0.5):
+        super().__init__(stddev)
+
+
+class BoxFilter(ReconstructionFilter):
+    """src/rfilters/box.cpp"""
+    kind = 1
+
+    def __init__(self, radius=0.5):
+        super().__init__(radius)
+
+
+class ImageBlock:
+    """src/librender/imageblock.cpp.  ``data()`` is a (H+2b, W+2b, C) float32 CUDA tensor."""
+
+    def __init__(self, size, channel_count, filter=None, warn_negative=True, warn_invalid=True, border=True,
+                 normalize=False, device="cuda"):
+        if normalize:
+            raise RuntimeError("ImageBlock: normalize=True is not supported by this backend")
+        self._size = (int(size[0]), int(size[1]))
+        self._offset = (0, 0)
+        self._channels = int(channel_count)
+        self._filter = filter
+        self._border = filter.border_size() if (filter is not None and border) else 0
+        self._device = torch.device(device)
+        self._data = torch.zeros((self._size[1] + 2 * self._border, self._size[0] + 2 * self._border, self._channels),
+                                 dtype=torch.float32, device=self._device)
+
+    def size(self): return self._size
+    def width(self): return self._size[0]
+    def height(self): return self._size[1]
+    def offset(self): return self._offset
+    def set_offset(self, o): self._offset = (int(o[0]), int(o[1]))
+    def channel_count(self): return self._channels
+    def border_size(self): return self._border
+    def data(self): return self._data
+    def clear(self): self._data.zero_()
+
+    def put(self, pos, values=None, active=None):
+        """put(block) or put(pos, values): imageblock.cpp:49-77 / :80-172."""
+        lib = L.lib()
+        if isinstance(pos, ImageBlock):
+            src = pos
+            if src.channel_count() != self.channel_count():
+                raise RuntimeError("ImageBlock::put(): mismatched channel counts!")
+            L.check(lib.mtsamd_imageblock_put_block(_ptr(src._data), src._size[0], src._size[1], src._offset[0], src._offset[1],
+                                                    src._border, _ptr(self._data), self._size[0], self._size[1], self._offset[0],
+                                                    self._offset[1], self._border, self._channels, _stream()))
+            return
+        if self._filter is None:
+            raise RuntimeError("ImageBlock::put(): a reconstruction filter is required")
+        pos = torch.as_tensor(pos, dtype=torch.float32, device=self._device).reshape(-1, 2).contiguous()
+        values = torch.as_tensor(values, dtype=torch.float32, device=self._device).reshape(-1, self._channels).contiguous()
+        if active is not None:
+            keep = torch.as_tensor(active, device=self._device).bool().reshape(-1)
+            pos, values = pos[keep].contiguous(), values[keep].contiguous()
+        f = self._filter
+        L.check(lib.mtsamd_imageblock_put(self._size[0], self._size[1], self._offset[0], self._offset[1], self._channels, f.kind,
+                                          f.param, 0, self._border, pos.shape[0], _ptr(pos), _ptr(values), _ptr(self._data),
+                                          _stream()))
+
+
+# --------------------------------------------------------------------------------------------
+class IndependentSampler:
+    """src/samplers/independent.cpp (sample_count default 4, seed 0: src/librender/sampler.cpp:7-8)"""
+
+    def __init__(self, sample_count=4, seed=0):
+        self._sample_count = int(sample_count)
+        self._seed = int(seed)
+
+    def sample_count(self): return self._sample_count
+    def seed_value(self): return self._seed
+
+
+class HDRFilm:
+    """src/films/hdrfilm.cpp + src/librender/film.cpp (defaults 768x576, gaussian filter)."""
+
+    def __init__(self, width=768, height=576, crop_offset=None, crop_size=None, rfilter=None):
+        self._size = (int(width), int(height))
+        co = (0, 0) if crop_offset is None else (int(crop_offset[0]), int(crop_offset[1]))
+        cs = self._size if crop_size is None else (int(crop_size[0]), int(crop_size[1]))
+        self.set_crop_window(co, cs)
+        self._filter = rfilter if rfilter is not None else GaussianFilter()
+        self._storage = None
+
+    def size(self): return self._size
+    def crop_size(self): return self._crop_size
+    def crop_offset(self): return self._crop_offset
+    def reconstruction_filter(self): return self._filter
+
+    def set_crop_window(self, crop_offset, crop_size):
+        """film.cpp:55-64"""
+        if (crop_offset[0] < 0 or crop_offset[1] < 0 or crop_size[0] <= 0 or crop_size[1] <= 0 or
+                crop_offset[0] + crop_size[0] > self._size[0] or crop_offset[1] + crop_size[1] > self._size[1]):
+            raise RuntimeError("Invalid crop window specification!")
+        self._crop_offset = (int(crop_offset[0]), int(crop_offset[1]))
+        self._crop_size = (int(crop_size[0]), int(crop_size[1]))
+
+    def prepare(self, channels=("X", "Y", "Z", "A", "W"), device="cuda"):
+        """hdrfilm.cpp:188-203: storage ImageBlock(crop_size, n_channels), no filter / border."""
+        if len(set(channels)) != len(channels):
+            raise RuntimeError("Film::prepare(): duplicate channel name")
+        self._storage = ImageBlock(self._crop_size, len(channels), device=device)
+        self._storage.set_offset(self._crop_offset)
+
+    def put(self, block):
+        self._storage.put(block)
+
+    def bitmap(self, raw=False):
+        """hdrfilm.cpp:249-320: raw=True -> XYZAW storage, else RGBA float32 (H, W, 4)."""
+        if self._storage is None:
+            raise RuntimeError("HDRFilm::bitmap(): no storage (render first)")
+        data = self._storage.data()
+        if raw:
+            return data
+        out = torch.empty((data.shape[0], data.shape[1], 4), dtype=torch.float32, device=data.device)
+        L.check(L.lib().mtsamd_film_develop(_ptr(data), data.shape[0] * data.shape[1], _ptr(out), _stream()))
+        return out
+
+
+def parse_fov(fov=None, focal_length=None, fov_axis="x", aspect=1.0):
+    """src/librender/sensor.cpp:119-169"""
+    if fov is not None and focal_length is not None:
+        raise RuntimeError("Please specify either a focal length ('focal_length') or a field of view ('fov')!")
+    f32 = np.float32
+    if fov is not None:
+        fov = f32(fov)
+        fov_axis = fov_axis.lower()
+        if fov_axis == "smaller":
+            fov_axis = "y" if aspect > 1 else "x"
+        elif fov_axis == "larger":
+            fov_axis = "x" if aspect > 1 else "y"
+    else:
+        f = "50mm" if focal_length is None else str(focal_length)
+        if f.endswith("mm"):
+            f = f[:-2]
+        try:
+            value = f32(float(f))
+        except ValueError:
+            raise RuntimeError("Could not parse the focal length (must be of the form <x>mm, where <x> is a positive integer)!")
+        fov = f32(2.0) * f32(np.degrees(np.arctan(f32(np.sqrt(f32(36 * 36 + 24 * 24))) / (f32(2.0) * value))))
+        fov_axis = "diagonal"
+    if fov_axis == "x":
+        result = fov
+    elif fov_axis == "y":
+        result = f32(np.degrees(f32(2.0) * np.arctan(np.tan(f32(0.5) * f32(np.radians(fov))) * f32(aspect))))
+    elif fov_axis == "diagonal":
+        diagonal = f32(2.0) * np.tan(f32(0.5) * f32(np.radians(fov)))
+        width = diagonal / f32(np.sqrt(f32(1.0) + f32(1.0) / f32(aspect * aspect)))
+        result = f32(np.degrees(f32(2.0) * np.arctan(width * f32(0.5))))
+    else:
+        raise RuntimeError("The 'fov_axis' parameter must be set to one of 'smaller', 'larger', 'diagonal', 'x', or 'y'!")
+    if result <= 0.0 or result >= 180.0:
+        raise RuntimeError("The horizontal field of view must be in the range [0, 180]!")
+    return float(result)
+
+
+class PerspectiveCamera:
+    """src/sensors/perspective.cpp"""
+
+    def __init__(self, to_world=None, fov=None, focal_length=None, fov_axis="x", near_clip=1e-2, far_clip=1e4, film=None,
+                 sampler=None):
+        self._film = film if film is not None else HDRFilm()
+        self._sampler = sampler if sampler is not None else IndependentSampler()
+        self._to_world = np.eye(4, dtype=np.float32) if to_world is None else _f32(to_world).reshape(4, 4)
+        if near_clip <= 0:
+            raise RuntimeError("The 'near_clip' parameter must be greater than zero!")
+        if near_clip >= far_clip:
+            raise RuntimeError("The 'near_clip' parameter must be smaller than 'far_clip'.")
+        self._near, self._far = float(near_clip), float(far_clip)
+        w, h = self._film.size()
+        self._x_fov = parse_fov(fov, focal_length, fov_axis, w / h)
+
+    def film(self): return self._film
+    def sampler(self): return self._sampler
+    def x_fov(self): return self._x_fov
+    def near_clip(self): return self._near
+    def far_clip(self): return self._far
+    def world_transform(self): return self._to_world
+
+    def _fill_desc(self, d):
+        d.to_world = (C.c_float * 16)(*self._to_world.reshape(-1).tolist())
+        d.fov_x_deg = self._x_fov
+        d.near_clip, d.far_clip = self._near, self._far
+        f = self._film
+        d.film_width, d.film_height = f.size()
+        d.crop_x, d.crop_y = f.crop_offset()
+        d.crop_width, d.crop_height = f.crop_size()
+        d.rfilter = f.reconstruction_filter().kind
+        d.rfilter_param = f.reconstruction_filter().param
+        d.rfilter_analytic = 0
+        d.sample_count = self._sampler.sample_count()
+        d.seed = self._sampler.seed_value()
+
+    def sample_ray(self, position_sample):
+        """perspective.cpp:153-188 for (N,2) film-plane samples in [0,1)^2 -> Ray3f."""
+        ps = torch.as_tensor(position_sample, dtype=torch.float32, device="cuda").reshape(-1, 2)
+        n = ps.shape[0]
+        sx, sy = ps[:, 0].contiguous(), ps[:, 1].contiguous()
+        out = torch.empty((8, n), dtype=torch.float32, device="cuda")
+        d = L.RenderDesc()
+        self._fill_desc(d)
+        d.max_depth, d.rr_depth = -1, 5
+        L.check(L.lib().mtsamd_camera_sample_rays(C.byref(d), n, _ptr(sx), _ptr(sy), *[_ptr(out[k]) for k in range(8)], _stream()))
+        return Ray3f(o=out[0:3].t().contiguous(), d=out[3:6].t().contiguous(), mint=out[6].clone(), maxt=out[7].clone())
+
+
+# --------------------------------------------------------------------------------------------
+class Scene:
+    """src/librender/scene.cpp: shapes + BSDFs + emitters uploaded to one GPU, BVH built by the library."""
+
+    def __init__(self, scene_dict, device=0, sensor=None, integrator=None):
+        lib = L.lib()
+        if not torch.cuda.is_available():
+            raise RuntimeError("mitsuba2_amd requires a HIP device (torch.cuda.is_available() is False)")
+        self._device_index = int(device)
+        self._dict = scene_dict
+        self._sensors = [sensor] if sensor is not None else []
+        self._integrator = integrator
+        meshes, bsdfs, emitters = scene_dict["meshes"], scene_dict["bsdfs"], scene_dict.get("emitters", [])
+        keep = []
+        md = (L.MeshDesc * len(meshes))()
+        for i, m in enumerate(meshes):
+            pos, faces = _f32(m["positions"]).reshape(-1, 3), np.ascontiguousarray(m["faces"], dtype=np.uint32).reshape(-1, 3)
+            nrm = _f32(m["normals"]).reshape(-1, 3) if m.get("normals") is not None else None
+            uv = _f32(m["texcoords"]).reshape(-1, 2) if m.get("texcoords") is not None else None
+            keep += [pos, faces, nrm, uv]
+            md[i].vertex_count, md[i].face_count = pos.shape[0], faces.shape[0]
+            md[i].positions = pos.ctypes.data_as(L.f32p)
+            md[i].faces = faces.ctypes.data_as(L.u32p)
+            md[i].normals = nrm.ctypes.data_as(L.f32p) if nrm is not None else None
+            md[i].texcoords = uv.ctypes.data_as(L.f32p) if uv is not None else None
+            md[i].bsdf, md[i].emitter = int(m["bsdf"]), int(m.get("emitter", -1))
+        bd = (L.BsdfDesc * max(len(bsdfs), 1))()
+        for i, b in enumerate(bsdfs):
+            if b.get("type", "diffuse") != "diffuse":
+                raise RuntimeError("BSDF plugin '%s' is not supported by this backend (diffuse only)" % b.get("type"))
+            bd[i].type = 0
+            bd[i].reflectance = (C.c_float * 3)(*[float(x) for x in b["reflectance"]])
+            bd[i].texture = -1
+        ed = (L.EmitterDesc * max(len(emitters), 1))()
+        for i, e in enumerate(emitters):
+            if e.get("type", "area") != "area":
+                raise RuntimeError("Emitter plugin '%s' is not supported by this backend (area only)" % e.get("type"))
+            ed[i].type = 0
+            ed[i].radiance = (C.c_float * 3)(*[float(x) for x in e["radiance"]])
+        sd = L.SceneDesc(md, len(meshes), bd, len(bsdfs), ed, len(emitters), None, 0)
+        handle = C.c_void_p()
+        L.check(lib.mtsamd_scene_create(C.byref(sd), self._device_index, C.byref(handle)))
+        self._handle = handle
+        self._shape_count = len(meshes)
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h:
+            try:
+                L.lib().mtsamd_scene_destroy(h)
+            except Exception:
+                pass
+            self._handle = None
+
+    # -- accessors (scene_v.cpp:37-86)
+    def sensors(self): return self._sensors
+    def integrator(self): return self._integrator
+    def shape_count(self): return self._shape_count
+
+    def bbox(self):
+        out = (C.c_float * 6)()
+        L.check(L.lib().mtsamd_scene_bbox(self._handle, out))
+        return np.array(out[:3], dtype=np.float32), np.array(out[3:], dtype=np.float32)
+
+    def info(self):
+        out = (C.c_uint32 * 6)()
+        L.check(L.lib().mtsamd_scene_info(self._handle, out))
+        return dict(zip(("primitives", "bvh_nodes", "bvh_depth", "shapes", "emitters", "lds_nodes"), [int(x) for x in out]))
+
+    def set_bsdf_reflectance(self, index, rgb):
+        L.check(L.lib().mtsamd_scene_set_bsdf_reflectance(self._handle, int(index), (C.c_float * 3)(*[float(x) for x in rgb])))
+
+    def set_emitter_radiance(self, index, rgb):
+        L.check(L.lib().mtsamd_scene_set_emitter_radiance(self._handle, int(index), (C.c_float * 3)(*[float(x) for x in rgb])))
+
+    # -- queries
+    def _soa(self, ray, active):
+        dev = torch.device("cuda", self._device_index)
+        o = ray.o.to(dev, torch.float32).t().contiguous()
+        d = ray.d.to(dev, torch.float32).t().contiguous()
+        mint = ray.mint.to(dev, torch.float32).contiguous()
+        maxt = ray.maxt.to(dev, torch.float32).contiguous()
+        act = None
+        if active is not None and active is not True:
+            act = torch.as_tensor(active, device=dev).to(torch.uint8).contiguous()
+        r = L.Rays(_ptr(o[0]), _ptr(o[1]), _ptr(o[2]), _ptr(d[0]), _ptr(d[1]), _ptr(d[2]), _ptr(mint), _ptr(maxt), _ptr(act))
+        return r, (o, d, mint, maxt, act), o.shape[1], dev
+
+    def ray_intersect(self, ray, active=True, full=True):
+        """Scene::ray_intersect (scene.h:36).  full=False skips the SurfaceInteraction fill."""
+        r, keep, n, dev = self._soa(ray, active)
+        t = torch.empty(n, dtype=torch.float32, device=dev)
+        prim = torch.empty(n, dtype=torch.int32, device=dev)
+        shape = torch.empty(n, dtype=torch.int32, device=dev)
+        if not full:
+            u = torch.empty(n, dtype=torch.float32, device=dev)
+            v = torch.empty(n, dtype=torch.float32, device=dev)
+            L.check(L.lib().mtsamd_ray_intersect(self._handle, n, C.byref(r), _ptr(t), _ptr(prim), _ptr(shape), _ptr(u), _ptr(v), _stream()))
+            return SurfaceInteraction3f(t=t, prim_index=prim, shape_index=shape, prim_uv=torch.stack([u, v], dim=1))
+        si = torch.empty((26, n), dtype=torch.float32, device=dev)
+        L.check(L.lib().mtsamd_ray_intersect_si(self._handle, n, C.byref(r), _ptr(t), _ptr(prim), _ptr(shape), _ptr(si), _stream()))
+        g = lambda a, b: si[a:b].t().contiguous()
+        return SurfaceInteraction3f(t=t, prim_index=prim, shape_index=shape, p=g(0, 3), n=g(3, 6), uv=g(6, 8), sh_frame_s=g(8, 11),
+                                    sh_frame_t=g(11, 14), sh_frame_n=g(14, 17), dp_du=g(17, 20), dp_dv=g(20, 23), wi=g(23, 26))
+
+    def ray_intersect_naive(self, ray, active=True):
+        """Scene::ray_intersect_naive (scene.h:38-44): brute force, for tests."""
+        r, keep, n, dev = self._soa(ray, active)
+        t = torch.empty(n, dtype=torch.float32, device=dev)
+        prim = torch.empty(n, dtype=torch.int32, device=dev)
+        shape = torch.empty(n, dtype=torch.int32, device=dev)
+        u = torch.empty(n, dtype=torch.float32, device=dev)
+        v = torch.empty(n, dtype=torch.float32, device=dev)
+        L.check(L.lib().mtsamd_ray_intersect_naive(self._handle, n, C.byref(r), _ptr(t), _ptr(prim), _ptr(shape), _ptr(u), _ptr(v), _stream()))
+        return SurfaceInteraction3f(t=t, prim_index=prim, shape_index=shape, prim_uv=torch.stack([u, v], dim=1))
+
+    def ray_test(self, ray, active=True):
+        """Scene::ray_test (scene.h:62)"""
+        r, keep, n, dev = self._soa(ray, active)
+        hit = torch.empty(n, dtype=torch.uint8, device=dev)
+        L.check(L.lib().mtsamd_ray_test(self._handle, n, C.byref(r), _ptr(hit), _stream()))
+        return hit.bool()
+
+
+# --------------------------------------------------------------------------------------------
+class PathIntegrator:
+    """src/integrators/path.cpp + MonteCarloIntegrator (src/librender/integrator.cpp:283-296)."""
+
+    def __init__(self, max_depth=-1, rr_depth=5, paths_per_wave=0):
+        if max_depth < 0 and max_depth != -1:
+            raise RuntimeError("\"max_depth\" must be set to -1 (infinite) or a value >= 0")
+        if rr_depth <= 0:
+            raise RuntimeError("\"rr_depth\" must be set to a value greater than zero!")
+        self.max_depth, self.rr_depth = int(max_depth), int(rr_depth)
+        self.paths_per_wave = int(paths_per_wave)
+        self._scene = None
+        self.stats = None
+
+    def _desc(self, sensor, rows=None):
+        d = L.RenderDesc()
+        sensor._fill_desc(d)
+        d.max_depth, d.rr_depth = self.max_depth, self.rr_depth
+        d.row_begin, d.row_end = (0, 0) if rows is None else (int(rows[0]), int(rows[1]))
+        d.paths_per_wave = self.paths_per_wave
+        d.pipeline = 0
+        return d
+
+    def render(self, scene, sensor=None, rows=None):
+        """Integrator::render (integrator.h:42): renders into sensor.film(); returns False if cancelled."""
+        sensor = sensor if sensor is not None else scene.sensors()[0]
+        film = sensor.film()
+        film.prepare(("X", "Y", "Z", "A", "W"), device="cuda:%d" % scene._device_index)
+        d = self._desc(sensor, rows)
+        stats = (C.c_uint64 * 5)()
+        self._scene = scene
+        rc = L.lib().mtsamd_render(scene._handle, C.byref(d), _ptr(film._storage.data()), stats, _stream())
+        self._scene = None
+        if rc == -4:                     # MTSAMD_ERR_CANCELLED: render() returns false (integrator.cpp:175)
+            return False
+        L.check(rc)
+        self.stats = dict(zip(("closest_hit_rays", "any_hit_rays", "samples", "iterations", "segments"), [int(x) for x in stats]))
+        return True
+
+    def cancel(self):
+        if self._scene is not None:
+            L.lib().mtsamd_cancel(self._scene._handle)
+
+    def sample(self, scene, sensor, first, count):
+        """SamplingIntegrator::sample for whole sample indices: returns (rgb (N,3), mask (N,), position (N,2))."""
+        d = self._desc(sensor)
+        dev = torch.device("cuda", scene._device_index)
+        rgba = torch.empty((count, 4), dtype=torch.float32, device=dev)
+        pos = torch.empty((count, 2), dtype=torch.float32, device=dev)
+        L.check(L.lib().mtsamd_sample_radiance(scene._handle, C.byref(d), int(first), int(count), _ptr(rgba), _ptr(pos), _stream()))
+        return rgba[:, :3], rgba[:, 3] > 0.5, pos
+
+
+def make_sensor(params):
+    """Build PerspectiveCamera/HDRFilm/IndependentSampler from a scenes.*_sensor() dict."""
+    flt = GaussianFilter(params["rfilter_param"]) if params["rfilter"] == "gaussian" else BoxFilter(params["rfilter_param"])
+    cx, cy, cw, ch = params["crop"]
+    film = HDRFilm(params["width"], params["height"], (cx, cy), (cw, ch), flt)
+    sampler = IndependentSampler(params["sample_count"], params["seed"])
+    return PerspectiveCamera(to_world=params["to_world"], fov=params["fov"], near_clip=params["near_clip"],
+                             far_clip=params["far_clip"], film=film, sampler=sampler)

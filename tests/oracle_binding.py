@@ -1,0 +1,210 @@
+"""ctypes binding of the CPU oracle (oracle/libmts_oracle.so).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "libmts_oracle.so")
+
+f32p = C.POINTER(C.c_float)
+u32p = C.POINTER(C.c_uint32)
+
+
+class RenderDesc(C.Structure):
+    _fields_ = [("to_world", C.c_float * 16), ("fov_x_deg", C.c_float), ("near_clip", C.c_float), ("far_clip", C.c_float),
+                ("film_w", C.c_int32), ("film_h", C.c_int32), ("crop_x", C.c_int32), ("crop_y", C.c_int32), ("crop_w", C.c_int32),
+                ("crop_h", C.c_int32), ("rfilter", C.c_int32), ("rfilter_param", C.c_float), ("spp", C.c_int32),
+                ("base_seed", C.c_uint64), ("max_depth", C.c_int32), ("rr_depth", C.c_int32), ("filter_analytic", C.c_int32)]
+
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-C", ORACLE_DIR, "libmts_oracle.so"], stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        L.mo_scene_new.restype = C.c_void_p
+        L.mo_scene_free.argtypes = [C.c_void_p]
+        L.mo_scene_add_mesh.argtypes = [C.c_void_p, C.c_uint32, f32p, f32p, f32p, C.c_uint32, u32p, C.c_int, f32p, f32p]
+        L.mo_scene_finalize.argtypes = [C.c_void_p]
+        L.mo_scene_set_naive.argtypes = [C.c_void_p, C.c_int]
+        L.mo_scene_prim_count.argtypes = [C.c_void_p]
+        L.mo_scene_prim_count.restype = C.c_uint32
+        L.mo_scene_emitter_area.argtypes = [C.c_void_p, C.c_uint32]
+        L.mo_scene_emitter_area.restype = C.c_float
+        vp = C.c_void_p
+        L.mo_ray_intersect.argtypes = [vp, C.c_uint64] + [vp] * 8 + [C.c_int] + [vp] * 5
+        L.mo_ray_test.argtypes = [vp, C.c_uint64] + [vp] * 8 + [C.c_int, vp]
+        L.mo_fill_si.argtypes = [vp, C.c_uint64] + [vp] * 7
+        L.mo_render.argtypes = [vp, C.POINTER(RenderDesc), C.c_int, C.c_int, C.c_int, vp, vp]
+        L.mo_sample_radiance.argtypes = [vp, C.POINTER(RenderDesc), C.c_uint64, C.c_uint64, vp, vp]
+        L.mo_render_rows.argtypes = [vp, C.POINTER(RenderDesc), C.c_int, C.c_int, vp]
+        L.mo_film_develop.argtypes = [vp, C.c_uint64, vp]
+        L.mo_camera_rays.argtypes = [C.POINTER(RenderDesc), C.c_uint64] + [vp] * 6
+        L.mo_imageblock_put.argtypes = [C.c_int] * 6 + [C.c_float, C.c_int, C.c_int, C.c_uint64, vp, vp, vp]
+        L.mo_rfilter_table.argtypes = [C.c_int, C.c_float, vp, f32p, C.POINTER(C.c_int)]
+        L.mo_kat_tea32.restype = C.c_uint32
+        L.mo_kat_tea32.argtypes = [C.c_uint32, C.c_uint32, C.c_int]
+        L.mo_kat_tea64_u32.restype = C.c_uint64
+        L.mo_kat_tea64_u32.argtypes = [C.c_uint32, C.c_uint32, C.c_int]
+        L.mo_kat_tea64_u64.restype = C.c_uint64
+        L.mo_kat_tea64_u64.argtypes = [C.c_uint64, C.c_uint64, C.c_int]
+        L.mo_kat_tea_float32.restype = C.c_float
+        L.mo_kat_tea_float32.argtypes = [C.c_uint32, C.c_uint32, C.c_int]
+        L.mo_kat_tea_float64.restype = C.c_double
+        L.mo_kat_tea_float64.argtypes = [C.c_uint32, C.c_uint32, C.c_int]
+        L.mo_kat_pcg32.argtypes = [C.c_uint64, C.c_uint64, C.c_int, vp, vp]
+        L.mo_kat_warp.argtypes = [C.c_int, C.c_uint64, vp, vp, vp]
+        L.mo_kat_coordinate_system.argtypes = [vp, vp, vp]
+        L.mo_kat_spiral.argtypes = [C.c_int] * 7 + [vp]
+        L.mo_kat_morton.argtypes = [C.c_uint32, vp]
+        L.mo_kat_distr.restype = C.c_float
+        L.mo_kat_distr.argtypes = [C.c_uint32, vp, vp, C.c_uint32, vp, vp, vp]
+        L.mo_kat_diffuse.argtypes = [vp] * 9
+        L.mo_kat_sample_emitter.argtypes = [vp] * 4
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class OracleScene:
+    def __init__(self, scene_dict, naive=False):
+        L = lib()
+        self.h = C.c_void_p(L.mo_scene_new())
+        for m in scene_dict["meshes"]:
+            pos = _f(m["positions"]).reshape(-1, 3)
+            faces = np.ascontiguousarray(m["faces"], dtype=np.uint32).reshape(-1, 3)
+            nrm = _f(m["normals"]) if m.get("normals") is not None else None
+            uv = _f(m["texcoords"]) if m.get("texcoords") is not None else None
+            refl = _f(scene_dict["bsdfs"][m["bsdf"]]["reflectance"])
+            em = _f(scene_dict["emitters"][m["emitter"]]["radiance"]) if m.get("emitter", -1) >= 0 else None
+            rc = L.mo_scene_add_mesh(self.h, pos.shape[0], pos.ctypes.data_as(f32p), nrm.ctypes.data_as(f32p) if nrm is not None else None,
+                                     uv.ctypes.data_as(f32p) if uv is not None else None, faces.shape[0], faces.ctypes.data_as(u32p), 0,
+                                     refl.ctypes.data_as(f32p), em.ctypes.data_as(f32p) if em is not None else None)
+            assert rc >= 0, rc
+        assert L.mo_scene_finalize(self.h) == 0
+        L.mo_scene_set_naive(self.h, 1 if naive else 0)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().mo_scene_free(self.h)
+            self.h = None
+
+    def set_naive(self, naive):
+        lib().mo_scene_set_naive(self.h, 1 if naive else 0)
+
+    def ray_intersect(self, o, d, mint, maxt, naive=True):
+        o, d, mint, maxt = _f(o), _f(d), _f(mint), _f(maxt)
+        n = o.shape[0]
+        cols = [np.ascontiguousarray(o[:, k]) for k in range(3)] + [np.ascontiguousarray(d[:, k]) for k in range(3)]
+        t = np.empty(n, np.float32); prim = np.empty(n, np.uint32); shape = np.empty(n, np.uint32)
+        u = np.empty(n, np.float32); v = np.empty(n, np.float32)
+        lib().mo_ray_intersect(self.h, n, *[_p(c) for c in cols], _p(mint), _p(maxt), 1 if naive else 0, _p(t), _p(prim), _p(shape), _p(u), _p(v))
+        return t, prim, shape, u, v
+
+    def ray_test(self, o, d, mint, maxt, naive=True):
+        o, d, mint, maxt = _f(o), _f(d), _f(mint), _f(maxt)
+        n = o.shape[0]
+        cols = [np.ascontiguousarray(o[:, k]) for k in range(3)] + [np.ascontiguousarray(d[:, k]) for k in range(3)]
+        hit = np.empty(n, np.uint8)
+        lib().mo_ray_test(self.h, n, *[_p(c) for c in cols], _p(mint), _p(maxt), 1 if naive else 0, _p(hit))
+        return hit.astype(bool)
+
+    def fill_si(self, d, prim, u, v):
+        d = _f(d); n = d.shape[0]
+        cols = [np.ascontiguousarray(d[:, k]) for k in range(3)]
+        prim = np.ascontiguousarray(prim, dtype=np.uint32); u = _f(u); v = _f(v)
+        out = np.empty((n, 26), np.float32)
+        lib().mo_fill_si(self.h, n, *[_p(c) for c in cols], _p(prim), _p(u), _p(v), _p(out))
+        return out
+
+    def render(self, desc, mode=1, n_threads=0, block_size=0):
+        film = np.empty((desc.crop_h, desc.crop_w, 5), np.float32)
+        stats = np.zeros(3, np.uint64)
+        rc = lib().mo_render(self.h, C.byref(desc), mode, n_threads, block_size, _p(film), _p(stats))
+        if rc != 0:
+            raise RuntimeError("oracle render failed (%d)" % rc)
+        return film, stats
+
+    def render_rows(self, desc, row0, row1):
+        film = np.empty((desc.crop_h, desc.crop_w, 5), np.float32)
+        assert lib().mo_render_rows(self.h, C.byref(desc), row0, row1, _p(film)) == 0
+        return film
+
+    def sample_radiance(self, desc, first, count):
+        rgba = np.empty((count, 4), np.float32); pos = np.empty((count, 2), np.float32)
+        assert lib().mo_sample_radiance(self.h, C.byref(desc), first, count, _p(rgba), _p(pos)) == 0
+        return rgba, pos
+
+    def sample_emitter(self, ref_p, sample2):
+        out = np.empty(15, np.float32)
+        lib().mo_kat_sample_emitter(self.h, _p(_f(ref_p)), _p(_f(sample2)), _p(out))
+        return out
+
+
+def make_desc(params, analytic=False):
+    """scenes.*_sensor() dict -> oracle RenderDesc (fov must already be the horizontal fov)."""
+    d = RenderDesc()
+    d.to_world = (C.c_float * 16)(*np.asarray(params["to_world"], dtype=np.float32).reshape(-1).tolist())
+    d.fov_x_deg = params["fov"]
+    d.near_clip, d.far_clip = params["near_clip"], params["far_clip"]
+    d.film_w, d.film_h = params["width"], params["height"]
+    d.crop_x, d.crop_y, d.crop_w, d.crop_h = params["crop"]
+    d.rfilter = 0 if params["rfilter"] == "gaussian" else 1
+    d.rfilter_param = params["rfilter_param"]
+    d.spp = params["sample_count"]
+    d.base_seed = params["seed"]
+    d.max_depth, d.rr_depth = params["max_depth"], params["rr_depth"]
+    d.filter_analytic = 1 if analytic else 0
+    return d
+
+
+def film_develop(xyzaw):
+    xyzaw = _f(xyzaw)
+    n = xyzaw.size // 5
+    out = np.empty(xyzaw.shape[:-1] + (4,), np.float32)
+    lib().mo_film_develop(_p(xyzaw), n, _p(out))
+    return out
+
+
+def camera_rays(desc, sx, sy):
+    sx, sy = _f(sx), _f(sy)
+    n = sx.shape[0]
+    o = np.empty((n, 3), np.float32); d = np.empty((n, 3), np.float32)
+    mint = np.empty(n, np.float32); maxt = np.empty(n, np.float32)
+    lib().mo_camera_rays(C.byref(desc), n, _p(sx), _p(sy), _p(o), _p(d), _p(mint), _p(maxt))
+    return o, d, mint, maxt
+
+
+def imageblock_put(w, h, ox, oy, ch, rfilter, param, border, pos, values, analytic=False):
+    pos, values = _f(pos).reshape(-1, 2), _f(values).reshape(-1, ch)
+    tbl = np.empty(32, np.float32); radius = C.c_float(); b = C.c_int()
+    lib().mo_rfilter_table(rfilter, param, _p(tbl), C.byref(radius), C.byref(b))
+    bs = b.value if border else 0
+    data = np.zeros((h + 2 * bs, w + 2 * bs, ch), np.float32)
+    lib().mo_imageblock_put(w, h, ox, oy, ch, rfilter, param, 1 if border else 0, 1 if analytic else 0, pos.shape[0], _p(pos), _p(values), _p(data))
+    return data
+
+
+def rfilter_table(rfilter, param):
+    tbl = np.empty(32, np.float32); radius = C.c_float(); b = C.c_int()
+    lib().mo_rfilter_table(rfilter, param, _p(tbl), C.byref(radius), C.byref(b))
+    return tbl, radius.value, b.value
