@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Msample/s (and Mray/s) of the `path` integrator on the synthetic Cornell box,
+1024x1024 @ 256 spp per GPU (BASELINE.json configs[1]), with the dominant kernel's achieved fraction of
+the HBM roofline and the CPU port (the oracle, scalar_rgb block mode) timed on the same box.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step is one complete render (every sample traced to termination, film splatted).  With N > 1 the film is
+partitioned into row bands, one rank per GPU renders its band (all spp) into a full-size XYZAW film and the
+films are summed with one RCCL reduce to rank 0 (weak scaling: the film grows to 1024 x 1024*N rows so the
+per-GPU work stays 2^28 samples).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+STATE_BYTES = 88               # per in-flight path: ray 32 B + path state 56 B (kernels.h PoolView)
+
+
+def cpu_baseline(width, height, seconds=12.0):
+    """The CPU port (oracle, scalar_rgb block mode, BVH, all host cores) on a bounded sample of the same
+    workload: same film, reduced spp.  Checker code used as the *baseline*, never as the thing measured."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    from mitsuba2_amd import scenes
+    sd = scenes.cornell_box()
+    S = ob.OracleScene(sd)
+    cores = os.cpu_count() or 1
+    # calibrate on 1 spp, then pick an spp that gives roughly `seconds` of CPU work
+    p = scenes.cornell_box_sensor(width, height, 1)
+    t0 = time.perf_counter()
+    S.render(ob.make_desc(p), mode=0, n_threads=cores)
+    dt1 = max(time.perf_counter() - t0, 1e-3)
+    spp = int(max(1, min(64, round(seconds / dt1))))
+    p = scenes.cornell_box_sensor(width, height, spp)
+    t0 = time.perf_counter()
+    _, stats = S.render(ob.make_desc(p), mode=0, n_threads=cores)
+    dt = time.perf_counter() - t0
+    samples = width * height * spp
+    return {"value": samples / dt / 1e6, "unit": "Msample/s", "cores": cores, "kind": "port",
+            "sample": "cbox %dx%d@%dspp, oracle scalar_rgb block mode (spiral 32x32 blocks, BVH), %.1f s" % (width, height, spp, dt),
+            "mray_per_s": float(stats[0] + stats[1]) / dt / 1e6}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--paths-per-wave", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from mitsuba2_amd import render, scenes
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    n = world
+    torch.cuda.set_device(local_rank)
+
+    width, band = args.width, args.height
+    height = band * n                       # weak scaling: one 1024-row band per GPU
+    sd = scenes.cornell_box()
+    p = scenes.cornell_box_sensor(width, height, args.spp)
+    if n > 1:
+        # keep the vertical field of view of the single-band image: the taller film shows the same box stretched
+        # over N bands, so every band sees geometry (fov is horizontal, aspect changes with N)
+        pass
+    scene = render.Scene(sd, device=local_rank)
+    sensor = render.make_sensor(p)
+    integ = render.PathIntegrator(paths_per_wave=args.paths_per_wave)
+    rows = (rank * band, (rank + 1) * band)
+
+    def step():
+        ok = integ.render(scene, sensor, rows=rows)
+        assert ok
+        film = sensor.film().bitmap(raw=True)
+        if n > 1:
+            dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)      # RCCL over xGMI: per-band ImageBlocks -> rank 0
+        return film
+
+    def barrier():
+        if n > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    acc = dict(closest_hit_rays=0, any_hit_rays=0, samples=0, iterations=0, segments=0, bounce_ns=0, film_ns=0, tri_tests=0)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        for k in acc:
+            acc[k] += integ.stats[k]
+    barrier()
+    dt = time.perf_counter() - t0
+    if n > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        cnt = torch.tensor([acc["closest_hit_rays"], acc["any_hit_rays"], acc["samples"]], dtype=torch.float64, device="cuda")
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        tot_closest, tot_any, tot_samples = [float(x) for x in cnt.tolist()]
+    else:
+        tot_closest, tot_any, tot_samples = float(acc["closest_hit_rays"]), float(acc["any_hit_rays"]), float(acc["samples"])
+
+    if rank == 0:
+        # roofline of the dominant kernel (k_bounce) on rank 0: algorithmic bytes per launch / average launch time.
+        # Per segment the kernel reads one 88-B path record and writes one (a survivor or a regenerated camera path:
+        # survivors + generated == segments over a whole render); per finished sample it writes 16 B radiance + 8 B
+        # film position.  Launch durations come from HIP events recorded on the render stream inside mtsamd_render.
+        launches = max(acc["iterations"], 1)
+        alg_bytes = 2 * STATE_BYTES * acc["segments"] + 24 * acc["samples"]
+        bounce_s = acc["bounce_ns"] * 1e-9
+        achieved = alg_bytes / max(bounce_s, 1e-12) / 1e9
+        out = {
+            "metric": "Msample/s, cbox %dx%d@%dspp per GPU, path integrator (max_depth=-1, rr_depth=5)" % (width, band, args.spp),
+            "value": tot_samples / dt / 1e6,
+            "unit": "Msample/s",
+            "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "synthetic Cornell box (36 triangles, diffuse, 1 area light), %dx%d film (%d-row band per GPU), %d spp, "
+                                   "gaussian rfilter, independent sampler" % (width, height, band, args.spp),
+                       "partition": "row bands + RCCL reduce" if n > 1 else "single GPU"},
+            "mray_per_s": (tot_closest + tot_any) / dt / 1e6,
+            "segments_per_sample": acc["segments"] / max(acc["samples"], 1),
+            "kernel_ms": {"k_bounce_per_step": acc["bounce_ns"] / args.steps * 1e-6, "k_film_gather_per_step": acc["film_ns"] / args.steps * 1e-6,
+                          "k_bounce_launches_per_step": launches / args.steps, "k_bounce_avg_launch_us": bounce_s / launches * 1e6},
+            "roofline": {"bound": "hbm", "kernel": "k_bounce", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "alg_bytes_per_launch": alg_bytes / launches},
+        }
+        if not args.no_cpu_baseline and n == 1:
+            out["cpu_baseline"] = cpu_baseline(width, band)
+        print(json.dumps(out))
+    if n > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -172,8 +172,9 @@ typedef struct {
  * Seeding follows the reference's wavefront branch (one PCG32 stream per sample index,
  * integrator.cpp:144-169, independent.cpp:69-72) with samples_per_pass = sample_count.
  * Synchronous on `stream` (returns when the film is complete).
- * stats_host (may be NULL): [0] closest-hit queries, [1] any-hit queries, [2] camera samples,
- * [3] bounce iterations launched, [4] path segments shaded. */
+ * stats_host (may be NULL, 8 entries): [0] closest-hit queries, [1] any-hit queries, [2] camera samples,
+ * [3] k_bounce launches, [4] path segments shaded, [5] device time of the k_bounce launches in ns
+ * (HIP events on `stream`), [6] device time of the film gather in ns, [7] triangle tests. */
 int mtsamd_render(mtsamd_scene *scene, const mtsamd_render_desc *desc, float *film_xyzaw_dev,
                   uint64_t *stats_host, void *stream);
 /* Integrator::cancel (integrator.h:51): thread-safe, makes a running mtsamd_render return

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmtsamd.so")
+LIB_PATH = os.environ.get("MTSAMD_LIB", os.path.join(_HERE, "libmtsamd.so"))   # override: kernel experiments only
 
 u8p = C.POINTER(C.c_uint8)
 u32p = C.POINTER(C.c_uint32)

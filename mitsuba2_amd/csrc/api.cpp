@@ -146,20 +146,21 @@ struct Workspace {
     uint32_t *h_counts = nullptr;        // pinned, 4 * n_waves
     uint64_t *h_cursor = nullptr;        // pinned, 2 * n_waves
     hipEvent_t ev[4] = {};
+    hipEvent_t tev[3] = {};              // timing: bounce loop begin / end, film end
     bool have_events = false;
 
     void release() {
         for (int k = 0; k < 2; ++k) {
-            hipFree(pool[k].ray_o); hipFree(pool[k].ray_d); hipFree(pool[k].thr); hipFree(pool[k].res);
-            hipFree(pool[k].rng); hipFree(pool[k].misc); hipFree(count[k]);
+            (void) hipFree(pool[k].ray_o); (void) hipFree(pool[k].ray_d); (void) hipFree(pool[k].thr); (void) hipFree(pool[k].res);
+            (void) hipFree(pool[k].rng); (void) hipFree(pool[k].misc); (void) hipFree(count[k]);
             pool[k] = PoolView{}; count[k] = nullptr;
         }
-        hipFree(cursor); hipFree(cursor_end); hipFree(wave_stats); hipFree(out_rgba); hipFree(out_pos);
+        (void) hipFree(cursor); (void) hipFree(cursor_end); (void) hipFree(wave_stats); (void) hipFree(out_rgba); (void) hipFree(out_pos);
         cursor = cursor_end = wave_stats = nullptr; out_rgba = nullptr; out_pos = nullptr;
-        if (h_counts) hipHostFree(h_counts);
-        if (h_cursor) hipHostFree(h_cursor);
+        if (h_counts) (void) hipHostFree(h_counts);
+        if (h_cursor) (void) hipHostFree(h_cursor);
         h_counts = nullptr; h_cursor = nullptr;
-        if (have_events) for (auto &e : ev) hipEventDestroy(e);
+        if (have_events) for (auto &e : ev) (void) hipEventDestroy(e);
         have_events = false;
         n_waves = seg_cap = 0; pass_cap = 0;
     }
@@ -179,6 +180,7 @@ struct mtsamd_scene {
     uint32_t *d_prim_shape = nullptr;
     DevShape *d_shapes = nullptr; DevBsdf *d_bsdfs = nullptr; DevEmitter *d_emitters = nullptr;
     float *d_area_pmf = nullptr, *d_area_cdf = nullptr;
+    float4 *d_flat = nullptr;
     SceneView view{};
     Workspace ws;
     std::atomic<int> cancel{ 0 };
@@ -198,11 +200,11 @@ int mtsamd_device_count(void) {
 
 void mtsamd_scene_destroy(mtsamd_scene *s) {
     if (!s) return;
-    hipSetDevice(s->device);
+    (void) hipSetDevice(s->device);
     s->ws.release();
-    hipFree(s->d_nodes); hipFree(s->d_tris); hipFree(s->d_tri_pos); hipFree(s->d_tri_nrm); hipFree(s->d_tri_uv);
-    hipFree(s->d_prim_shape); hipFree(s->d_shapes); hipFree(s->d_bsdfs); hipFree(s->d_emitters);
-    hipFree(s->d_area_pmf); hipFree(s->d_area_cdf);
+    (void) hipFree(s->d_nodes); (void) hipFree(s->d_tris); (void) hipFree(s->d_tri_pos); (void) hipFree(s->d_tri_nrm); (void) hipFree(s->d_tri_uv);
+    (void) hipFree(s->d_prim_shape); (void) hipFree(s->d_shapes); (void) hipFree(s->d_bsdfs); (void) hipFree(s->d_emitters);
+    (void) hipFree(s->d_area_pmf); (void) hipFree(s->d_area_cdf); (void) hipFree(s->d_flat);
     delete s;
 }
 
@@ -309,8 +311,19 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     std::vector<float4> nodes(4 * (size_t) s->bvh.n_nodes), tris(3 * (size_t) s->bvh.n_slots);
     std::memcpy(nodes.data(), s->bvh.nodes.data(), s->bvh.nodes.size() * sizeof(float));
     std::memcpy(tris.data(), s->bvh.tris.data(), s->bvh.tris.size() * sizeof(float));
+    // flat scenes: 64-byte records in primitive order (device_scene.h)
+    const bool flat = s->n_prims <= kFlatMaxPrims;
+    std::vector<float4> flat_recs(flat ? 4 * (size_t) s->n_prims : 0);
+    for (uint32_t gp = 0; flat && gp < s->n_prims; ++gp) {
+        const float *tp = &tri_pos[9 * (size_t) gp];
+        uint32_t sh = prim_shape[gp]; float shf; std::memcpy(&shf, &sh, 4);
+        flat_recs[4 * gp + 0] = make_float4(tp[0], tp[1], tp[2], tp[3] - tp[0]);
+        flat_recs[4 * gp + 1] = make_float4(tp[4] - tp[1], tp[5] - tp[2], tp[6] - tp[0], tp[7] - tp[1]);
+        flat_recs[4 * gp + 2] = make_float4(tp[8] - tp[2], tp[3], tp[4], tp[5]);
+        flat_recs[4 * gp + 3] = make_float4(tp[6], tp[7], tp[8], shf);
+    }
     int rc = 0;
-    if ((rc = upload(&s->d_nodes, nodes)) || (rc = upload(&s->d_tris, tris)) || (rc = upload(&s->d_tri_pos, tri_pos)) ||
+    if ((rc = upload(&s->d_flat, flat_recs)) || (rc = upload(&s->d_nodes, nodes)) || (rc = upload(&s->d_tris, tris)) || (rc = upload(&s->d_tri_pos, tri_pos)) ||
         (rc = upload(&s->d_tri_nrm, tri_nrm)) || (rc = upload(&s->d_tri_uv, tri_uv)) || (rc = upload(&s->d_prim_shape, prim_shape)) ||
         (rc = upload(&s->d_shapes, shapes)) || (rc = upload(&s->d_bsdfs, s->bsdfs)) || (rc = upload(&s->d_emitters, s->emitters)) ||
         (rc = upload(&s->d_area_pmf, area_pmf)) || (rc = upload(&s->d_area_cdf, area_cdf))) {
@@ -330,6 +343,8 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     v.prim_shape = s->d_prim_shape; v.shapes = s->d_shapes; v.bsdfs = s->d_bsdfs;
     v.emitters = s->d_emitters; v.n_emitters = desc->emitter_count;
     v.area_pmf = s->d_area_pmf; v.area_cdf = s->d_area_cdf;
+    v.n_shapes = desc->mesh_count; v.n_bsdfs = desc->bsdf_count;
+    v.flat_recs = s->d_flat; v.flat = flat ? 1u : 0u;
     if (bounce_lds_bytes(v) > 150 * 1024) {
         mtsamd_scene_destroy(s);
         return fail(MTSAMD_ERR_UNSUPPORTED, "BVH too deep for the LDS traversal stack (depth %u)", v.stack_depth);
@@ -450,6 +465,7 @@ static int ensure_workspace(mtsamd_scene *s, uint32_t n_waves, uint32_t seg_cap,
     HIP_TRY(hipHostMalloc((void **) &w.h_counts, 4 * (size_t) n_waves * sizeof(uint32_t), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **) &w.h_cursor, 2 * (size_t) n_waves * sizeof(uint64_t), hipHostMallocDefault));
     for (auto &e : w.ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : w.tev) HIP_TRY(hipEventCreate(&e));
     w.have_events = true;
     w.n_waves = n_waves; w.seg_cap = seg_cap; w.pass_cap = pass_cap;
     return 0;
@@ -461,6 +477,7 @@ struct Job {
     CameraView cam; FilterView filter;
     uint32_t n_waves, target; uint64_t pass_cap;
     uint64_t iterations = 0;
+    double bounce_ms = 0.0, film_ms = 0.0;
 };
 
 // Traces sample indices [first, first+n) to completion; results land in ws.out_rgba / out_pos.
@@ -490,9 +507,10 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     uint64_t it = 0;
     int cur = 0;
     const int lag = 2;
+    HIP_TRY(hipEventRecord(w.tev[0], j.stream));
     while (true) {
         if (j.s->cancel.load(std::memory_order_relaxed)) {
-            hipStreamSynchronize(j.stream);
+            (void) hipStreamSynchronize(j.stream);
             return fail(MTSAMD_ERR_CANCELLED, "render cancelled");
         }
         p.in = w.pool[cur]; p.out = w.pool[cur ^ 1];
@@ -514,6 +532,11 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
         }
         if (it > (1ull << 24)) return fail(MTSAMD_ERR_DEVICE, "wavefront scheduler did not converge");
     }
+    HIP_TRY(hipEventRecord(w.tev[1], j.stream));
+    HIP_TRY(hipEventSynchronize(w.tev[1]));
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, w.tev[0], w.tev[1]));
+    j.bounce_ms += ms;
     j.iterations += it;
     return 0;
 }
@@ -541,6 +564,7 @@ int collect_stats(Job &j, uint64_t samples, uint64_t *stats_host) {
     uint64_t tot[4] = { 0, 0, 0, 0 };
     for (uint32_t k = 0; k < j.n_waves; ++k) for (int q = 0; q < 4; ++q) tot[q] += ws[4 * (size_t) k + q];
     stats_host[0] = tot[0]; stats_host[1] = tot[1]; stats_host[2] = samples; stats_host[3] = j.iterations; stats_host[4] = tot[2];
+    stats_host[5] = (uint64_t) (j.bounce_ms * 1e6); stats_host[6] = (uint64_t) (j.film_ms * 1e6); stats_host[7] = tot[3];
     return 0;
 }
 } // namespace
@@ -569,6 +593,11 @@ int mtsamd_render(mtsamd_scene *s, const mtsamd_render_desc *d, float *film, uin
         int64_t py1 = (int64_t) (((a + n - 1) / (uint64_t) d->sample_count) / (uint64_t) d->crop_width);
         f.row0 = (int32_t) std::max<int64_t>(0, py0 - R); f.row1 = (int32_t) std::min<int64_t>(d->crop_height, py1 + R + 1);
         HIP_TRY(launch_film_gather(f, stream));
+        HIP_TRY(hipEventRecord(s->ws.tev[2], stream));
+        HIP_TRY(hipEventSynchronize(s->ws.tev[2]));
+        float fms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&fms, s->ws.tev[1], s->ws.tev[2]));
+        j.film_ms += fms;
     }
     if (int rc = collect_stats(j, s1 - s0, stats_host)) return rc;
     HIP_TRY(hipStreamSynchronize(stream));

@@ -53,39 +53,77 @@ struct SceneView {
     const DevShape *shapes;
     const DevBsdf *bsdfs;
     const DevEmitter *emitters; uint32_t n_emitters;
+    uint32_t n_shapes, n_bsdfs;
     const float *area_pmf, *area_cdf;   // per prim (global index), valid inside emitter ranges
+    // "flat" scenes (n_prims <= kFlatMaxPrims): no hierarchy pays off; the whole scene is kept in LDS
+    // as 64-byte records in primitive order and every query is a wave-uniform loop over them.
+    //   r0 = (p0.xyz, e1.x) r1 = (e1.y, e1.z, e2.x, e2.y) r2 = (e2.z, p1.xyz) r3 = (p2.xyz, shape bits)
+    const float4 *flat_recs;
+    uint32_t flat;
 };
+constexpr uint32_t kFlatMaxPrims = 64;
 
-// LDS carve-up of one workgroup: [nodes][tris][stack]
+// LDS carve-up of one workgroup.
+//   hierarchy scenes: [BVH nodes (top of the tree)][triangle slots][traversal stack]
+//   flat scenes:      [flat records][shapes][bsdfs][emitters][area pmf][area cdf]
 struct LdsView {
     const float4 *nodes;
     const float4 *tris;
     uint32_t *stack;           // [depth][blockDim]
     uint32_t stride;           // blockDim.x
+    const float4 *flat;        // 4 per prim
+    const DevShape *shapes;
+    const DevBsdf *bsdfs;
+    const DevEmitter *emitters;
+    const float *pmf, *cdf;
 };
 
+inline uint32_t flat_shape_count(const SceneView &sv) { return sv.n_shapes; }
+
+template <bool FLAT>
 MTS_DEV LdsView lds_stage(const SceneView &sv, float4 *smem) {
-    LdsView l;
-    float4 *n = smem;
-    float4 *t = n + 4u * sv.lds_nodes;
-    for (uint32_t i = threadIdx.x; i < 4u * sv.lds_nodes; i += blockDim.x) n[i] = sv.nodes[i];
-    for (uint32_t i = threadIdx.x; i < 3u * sv.lds_slots; i += blockDim.x) t[i] = sv.tris[i];
-    l.nodes = n; l.tris = t;
-    l.stack = reinterpret_cast<uint32_t *>(t + 3u * sv.lds_slots);
+    LdsView l = {};
     l.stride = blockDim.x;
+    if (FLAT) {
+        float4 *f = smem;
+        for (uint32_t i = threadIdx.x; i < 4u * sv.n_prims; i += blockDim.x) f[i] = sv.flat_recs[i];
+        l.flat = f;
+        uint32_t *w = reinterpret_cast<uint32_t *>(f + 4u * sv.n_prims);
+        const uint32_t n_sh = (sizeof(DevShape) / 4u) * sv.n_shapes, n_bs = (sizeof(DevBsdf) / 4u) * sv.n_bsdfs,
+                       n_em = (sizeof(DevEmitter) / 4u) * sv.n_emitters;
+        const uint32_t *g_sh = reinterpret_cast<const uint32_t *>(sv.shapes), *g_bs = reinterpret_cast<const uint32_t *>(sv.bsdfs),
+                       *g_em = reinterpret_cast<const uint32_t *>(sv.emitters);
+        for (uint32_t i = threadIdx.x; i < n_sh; i += blockDim.x) w[i] = g_sh[i];
+        l.shapes = reinterpret_cast<const DevShape *>(w); w += n_sh;
+        for (uint32_t i = threadIdx.x; i < n_bs; i += blockDim.x) w[i] = g_bs[i];
+        l.bsdfs = reinterpret_cast<const DevBsdf *>(w); w += n_bs;
+        for (uint32_t i = threadIdx.x; i < n_em; i += blockDim.x) w[i] = g_em[i];
+        l.emitters = reinterpret_cast<const DevEmitter *>(w); w += n_em;
+        float *fw = reinterpret_cast<float *>(w);
+        for (uint32_t i = threadIdx.x; i < sv.n_prims; i += blockDim.x) { fw[i] = sv.area_pmf[i]; fw[sv.n_prims + i] = sv.area_cdf[i]; }
+        l.pmf = fw; l.cdf = fw + sv.n_prims;
+    } else {
+        float4 *n = smem;
+        float4 *t = n + 4u * sv.lds_nodes;
+        for (uint32_t i = threadIdx.x; i < 4u * sv.lds_nodes; i += blockDim.x) n[i] = sv.nodes[i];
+        for (uint32_t i = threadIdx.x; i < 3u * sv.lds_slots; i += blockDim.x) t[i] = sv.tris[i];
+        l.nodes = n; l.tris = t;
+        l.stack = reinterpret_cast<uint32_t *>(t + 3u * sv.lds_slots);
+    }
     __syncthreads();
     return l;
 }
-inline size_t lds_bytes(uint32_t lds_nodes, uint32_t lds_slots, uint32_t stack_depth, uint32_t block) {
-    return (size_t) 64 * lds_nodes + (size_t) 48 * lds_slots + (size_t) 4 * stack_depth * block;
+inline size_t lds_bytes(const SceneView &sv, uint32_t block) {
+    if (sv.flat)
+        return (size_t) 64 * sv.n_prims + sizeof(DevShape) * sv.n_shapes + sizeof(DevBsdf) * sv.n_bsdfs +
+               sizeof(DevEmitter) * sv.n_emitters + (size_t) 8 * sv.n_prims;
+    return (size_t) 64 * sv.lds_nodes + (size_t) 48 * sv.lds_slots + (size_t) 4 * sv.stack_depth * block;
 }
 
 struct Hit { float t; uint32_t prim; float u, v; };
 
 // Moeller-Trumbore exactly as mesh.h:195-221 (no culling, closed intervals).
-MTS_DEV bool tri_test(float4 t0, float4 t1, float4 t2, f3 o, f3 d, float mint, float maxt,
-                      float &u, float &v, float &t) {
-    f3 p0 = mk3(t0.x, t0.y, t0.z), e1 = mk3(t0.w, t1.x, t1.y), e2 = mk3(t1.z, t1.w, t2.x);
+MTS_DEV bool tri_test(f3 p0, f3 e1, f3 e2, f3 o, f3 d, float mint, float maxt, float &u, float &v, float &t) {
     f3 pvec = cross(d, e2);
     float inv_det = rcp(dot(e1, pvec));
     f3 tvec = o - p0;
@@ -104,11 +142,13 @@ MTS_DEV float clamp_inv(float d) {
     return fabsf(r) <= 3.0e38f ? r : copysignf(3.0e38f, d);
 }
 
-// Closest-hit (ANY=false) or any-hit (ANY=true) query.  Among hits with exactly equal t the
-// highest primitive index wins (what the brute-force loop of ray_intersect_naive produces).
+// Hierarchy scenes.  Closest-hit (ANY=false) or any-hit (ANY=true) query with a per-lane stack in LDS.
+// Among hits with exactly equal t the highest primitive index wins (what the brute-force loop of
+// ray_intersect_naive produces).  The slab test only culls; boxes are padded on the host so that it never
+// rejects a triangle the fp32 Moeller-Trumbore test would accept.
 template <bool ANY>
-MTS_DEV bool traverse(const SceneView &sv, const LdsView &lds, f3 o, f3 d, float mint, float maxt,
-                      Hit &hit, uint32_t &tri_tests) {
+MTS_DEV bool traverse_bvh(const SceneView &sv, const LdsView &lds, f3 o, f3 d, float mint, float maxt,
+                          Hit &hit, uint32_t &tri_tests) {
     const f3 inv = mk3(clamp_inv(d.x), clamp_inv(d.y), clamp_inv(d.z));
     uint32_t *stack = lds.stack + threadIdx.x;
     const uint32_t stride = lds.stride;
@@ -128,13 +168,11 @@ MTS_DEV bool traverse(const SceneView &sv, const LdsView &lds, f3 o, f3 d, float
                 const float4 *p = sv.nodes + 4u * cur;
                 q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
             }
-            // left box
             float ax = (q0.x - o.x) * inv.x, bx = (q0.w - o.x) * inv.x;
             float ay = (q0.y - o.y) * inv.y, by = (q1.x - o.y) * inv.y;
             float az = (q0.z - o.z) * inv.z, bz = (q1.y - o.z) * inv.z;
             float nearL = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), mint));
             float farL = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best));
-            // right box
             ax = (q1.z - o.x) * inv.x; bx = (q2.y - o.x) * inv.x;
             ay = (q1.w - o.y) * inv.y; by = (q2.z - o.y) * inv.y;
             az = (q2.x - o.z) * inv.z; bz = (q2.w - o.z) * inv.z;
@@ -164,7 +202,7 @@ MTS_DEV bool traverse(const SceneView &sv, const LdsView &lds, f3 o, f3 d, float
                 }
                 float u, v, t;
                 ++tri_tests;
-                if (tri_test(t0, t1, t2, o, d, mint, maxt, u, v, t)) {
+                if (tri_test(mk3(t0.x, t0.y, t0.z), mk3(t0.w, t1.x, t1.y), mk3(t1.z, t1.w, t2.x), o, d, mint, maxt, u, v, t)) {
                     if (ANY) return true;
                     uint32_t prim = __float_as_uint(t2.y);
                     if (!found || t < best || (t == best && prim > best_prim)) {
@@ -181,16 +219,53 @@ MTS_DEV bool traverse(const SceneView &sv, const LdsView &lds, f3 o, f3 d, float
     return found;
 }
 
-// Brute force over every triangle slot (ray_intersect_naive, kdtree.h:2303-2328).
+// Flat scenes: a wave-uniform loop over every primitive record in LDS (broadcast reads, no stack,
+// no divergence).  Primitive order + "t <= best" reproduces the brute-force loop of
+// ray_intersect_naive (kdtree.h:2303-2328) literally: later primitives win ties.
+template <bool ANY>
+MTS_DEV bool traverse_flat(const SceneView &sv, const LdsView &lds, f3 o, f3 d, float mint, float maxt,
+                           Hit &hit, uint32_t &tri_tests) {
+    float best = maxt, bu = 0.0f, bv = 0.0f;
+    uint32_t best_prim = kNoPrim;
+    bool any = false;
+    const uint32_t n = sv.n_prims;
+    tri_tests += n;
+#ifndef MTS_FLAT_UNROLL
+#define MTS_FLAT_UNROLL 2
+#endif
+#pragma unroll MTS_FLAT_UNROLL
+    for (uint32_t s = 0; s < n; ++s) {
+        const float4 r0 = lds.flat[4u * s], r1 = lds.flat[4u * s + 1u], r2 = lds.flat[4u * s + 2u];
+        float u, v, t;
+        bool ok = tri_test(mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), mk3(r1.z, r1.w, r2.x), o, d, mint, ANY ? maxt : best, u, v, t);
+        if (ANY) {
+            any = any || ok;
+        } else {
+            best = ok ? t : best; best_prim = ok ? s : best_prim; bu = ok ? u : bu; bv = ok ? v : bv;
+        }
+    }
+    if (ANY) return any;
+    hit.t = best; hit.prim = best_prim; hit.u = bu; hit.v = bv;
+    return best_prim != kNoPrim;
+}
+
+template <bool FLAT, bool ANY>
+MTS_DEV bool traverse(const SceneView &sv, const LdsView &lds, f3 o, f3 d, float mint, float maxt, Hit &hit, uint32_t &tri_tests) {
+    if (FLAT) return traverse_flat<ANY>(sv, lds, o, d, mint, maxt, hit, tri_tests);
+    return traverse_bvh<ANY>(sv, lds, o, d, mint, maxt, hit, tri_tests);
+}
+
+// Brute force over every triangle slot from global memory (ray_intersect_naive, kdtree.h:2303-2328).
 template <bool ANY>
 MTS_DEV bool traverse_naive(const SceneView &sv, f3 o, f3 d, float mint, float maxt, Hit &hit) {
     bool found = false; float best = maxt; uint32_t best_prim = kNoPrim;
     for (uint32_t s = 0; s < sv.n_slots; ++s) {
         const float4 *p = sv.tris + 3u * s;
+        const float4 t0 = p[0], t1 = p[1], t2 = p[2];
         float u, v, t;
-        if (tri_test(p[0], p[1], p[2], o, d, mint, maxt, u, v, t)) {
+        if (tri_test(mk3(t0.x, t0.y, t0.z), mk3(t0.w, t1.x, t1.y), mk3(t1.z, t1.w, t2.x), o, d, mint, maxt, u, v, t)) {
             if (ANY) return true;
-            uint32_t prim = __float_as_uint(p[2].y);
+            uint32_t prim = __float_as_uint(t2.y);
             if (!found || t < best || (t == best && prim > best_prim)) {
                 found = true; best = t; best_prim = prim;
                 hit.t = t; hit.prim = prim; hit.u = u; hit.v = v;
@@ -201,21 +276,46 @@ MTS_DEV bool traverse_naive(const SceneView &sv, f3 o, f3 d, float mint, float m
 }
 
 // ---------------------------------------------------------------------------
-struct SurfaceInteraction {
-    f3 p, n; f2 uv; Frame sh; f3 dp_du, dp_dv, wi; uint32_t shape;
+// Scene data access: LDS for flat scenes, global memory (L2) otherwise.
+template <bool FLAT> struct Geo {
+    const SceneView &sv; const LdsView &lds;
+    MTS_DEV void tri_positions(uint32_t prim, f3 &p0, f3 &p1, f3 &p2) const {
+        if (FLAT) {
+            const float4 r0 = lds.flat[4u * prim], r2 = lds.flat[4u * prim + 2u], r3 = lds.flat[4u * prim + 3u];
+            p0 = mk3(r0.x, r0.y, r0.z); p1 = mk3(r2.y, r2.z, r2.w); p2 = mk3(r3.x, r3.y, r3.z);
+        } else {
+            const float *tp = sv.tri_pos + 9u * prim;
+            p0 = mk3(tp[0], tp[1], tp[2]); p1 = mk3(tp[3], tp[4], tp[5]); p2 = mk3(tp[6], tp[7], tp[8]);
+        }
+    }
+    MTS_DEV uint32_t prim_shape(uint32_t prim) const {
+        return FLAT ? __float_as_uint(lds.flat[4u * prim + 3u].w) : sv.prim_shape[prim];
+    }
+    MTS_DEV DevShape shape(uint32_t i) const { return FLAT ? lds.shapes[i] : sv.shapes[i]; }
+    MTS_DEV DevBsdf bsdf(uint32_t i) const { return FLAT ? lds.bsdfs[i] : sv.bsdfs[i]; }
+    MTS_DEV DevEmitter emitter(uint32_t i) const { return FLAT ? lds.emitters[i] : sv.emitters[i]; }
+    MTS_DEV float pmf(uint32_t i) const { return FLAT ? lds.pmf[i] : sv.area_pmf[i]; }
+    MTS_DEV float cdf(uint32_t i) const { return FLAT ? lds.cdf[i] : sv.area_cdf[i]; }
 };
 
-MTS_DEV void fill_si(const SceneView &sv, f3 ray_d, uint32_t prim, float b1, float b2, SurfaceInteraction &si) {
-    const float *tp = sv.tri_pos + 9u * prim;
-    f3 p0 = mk3(tp[0], tp[1], tp[2]), p1 = mk3(tp[3], tp[4], tp[5]), p2 = mk3(tp[6], tp[7], tp[8]);
+struct SurfaceInteraction {
+    f3 p, n; f2 uv; Frame sh; f3 dp_du, dp_dv, wi; uint32_t shape; DevShape shape_rec;
+};
+
+template <bool FLAT>
+MTS_DEV void fill_si(const Geo<FLAT> &g, f3 ray_d, uint32_t prim, float b1, float b2, SurfaceInteraction &si) {
+    const SceneView &sv = g.sv;
+    f3 p0, p1, p2;
+    g.tri_positions(prim, p0, p1, p2);
     float b0 = 1.0f - b1 - b2;
     f3 dp0 = p1 - p0, dp1 = p2 - p0;
     si.p = (p0 * b0 + p1 * b1) + p2 * b2;
     f3 n = normalize(cross(dp0, dp1));
     si.n = n;
-    uint32_t shape = sv.prim_shape[prim];
+    uint32_t shape = g.prim_shape(prim);
     si.shape = shape;
-    uint32_t flags = sv.shapes[shape].flags;
+    si.shape_rec = g.shape(shape);
+    uint32_t flags = si.shape_rec.flags;
     f3 dp_du, dp_dv;
     coordinate_system(n, dp_du, dp_dv);
     si.uv.x = b1; si.uv.y = b2;
@@ -252,23 +352,10 @@ MTS_DEV void fill_si(const SceneView &sv, f3 ray_d, uint32_t prim, float b1, flo
 // ---------------------------------------------------------------------------
 struct DirectionSample { f3 p, n, d; float dist, pdf; uint32_t emitter; };
 
-MTS_DEV uint32_t distr_sample_reuse(const float *pmf, const float *cdf, float sum, float norm,
-                                    uint32_t lo, uint32_t hi, float value, float &reused) {
-    float scaled = value * sum;
-    uint32_t start = lo, end = hi;
-    while (start < end) {
-        uint32_t middle = (start + end) >> 1;
-        if (cdf[middle] < scaled) { start = middle + 1; if (start > end) start = end; }
-        else end = middle;
-    }
-    float p = pmf[start] * norm;
-    float c = start > 0 ? cdf[start - 1] * norm : 0.0f;
-    reused = (value - c) / p;
-    return start;
-}
-
 // Scene::sample_emitter_direction without the visibility test; spec = radiance / pdf (masked).
-MTS_DEV void sample_emitter_direction(const SceneView &sv, f3 ref_p, f2 sample, DirectionSample &ds, f3 &spec) {
+template <bool FLAT>
+MTS_DEV void sample_emitter_direction(const Geo<FLAT> &g, f3 ref_p, f2 sample, DirectionSample &ds, f3 &spec) {
+    const SceneView &sv = g.sv;
     ds.pdf = 0.0f; ds.dist = 0.0f; ds.emitter = 0;
     ds.p = ds.n = ds.d = mk3(0, 0, 0);
     spec = mk3(0, 0, 0);
@@ -282,20 +369,30 @@ MTS_DEV void sample_emitter_direction(const SceneView &sv, f3 ref_p, f2 sample, 
         index = min(idx, sv.n_emitters - 1u);
         sample.x = (sample.x - (float) index * emitter_pdf) * nf;
     }
-    const DevEmitter e = sv.emitters[index];
-    // Mesh::sample_position
-    float reused;
-    uint32_t f = distr_sample_reuse(sv.area_pmf + e.first_prim, sv.area_cdf + e.first_prim, e.area_sum,
-                                    e.area_norm, e.valid_lo, e.valid_hi, sample.y, reused);
-    sample.y = reused;
+    const DevEmitter e = g.emitter(index);
+    // Mesh::sample_position: DiscreteDistribution::sample_reuse (distr_1d.h:144-203)
+    uint32_t f;
+    {
+        float scaled = sample.y * e.area_sum;
+        uint32_t start = e.valid_lo, end = e.valid_hi;
+        while (start < end) {
+            uint32_t middle = (start + end) >> 1;
+            if (g.cdf(e.first_prim + middle) < scaled) { start = middle + 1; if (start > end) start = end; }
+            else end = middle;
+        }
+        float p = g.pmf(e.first_prim + start) * e.area_norm;
+        float c = start > 0 ? g.cdf(e.first_prim + start - 1) * e.area_norm : 0.0f;
+        sample.y = (sample.y - c) / p;
+        f = start;
+    }
     uint32_t prim = e.first_prim + f;
-    const float *tp = sv.tri_pos + 9u * prim;
-    f3 p0 = mk3(tp[0], tp[1], tp[2]), p1 = mk3(tp[3], tp[4], tp[5]), p2 = mk3(tp[6], tp[7], tp[8]);
+    f3 p0, p1, p2;
+    g.tri_positions(prim, p0, p1, p2);
     f3 e0 = p1 - p0, e1 = p2 - p0;
     f2 b = square_to_uniform_triangle(sample);
     ds.p = (p0 + e0 * b.x) + e1 * b.y;
     ds.pdf = e.area_norm;
-    if (sv.shapes[e.shape].flags & kShapeHasNormals) {
+    if (g.shape(e.shape).flags & kShapeHasNormals) {
         const float *tn = sv.tri_nrm + 9u * prim;
         f3 n0 = mk3(tn[0], tn[1], tn[2]), n1 = mk3(tn[3], tn[4], tn[5]), n2 = mk3(tn[6], tn[7], tn[8]);
         float b0 = 1.0f - b.x - b.y;
@@ -324,14 +421,14 @@ MTS_DEV void sample_emitter_direction(const SceneView &sv, f3 ref_p, f2 sample, 
     }
 }
 
-MTS_DEV float pdf_emitter_direction(const SceneView &sv, uint32_t emitter, f3 d, f3 n, float dist) {
+MTS_DEV float pdf_emitter_direction(uint32_t n_emitters, float area_norm, f3 d, f3 n, float dist) {
     float pdf = 0.0f;
     if (dot(d, n) < 0.0f) {
-        pdf = sv.emitters[emitter].area_norm;
+        pdf = area_norm;
         float dp = fabsf(dot(d, n));
         pdf *= (dp != 0.0f) ? (dist * dist) / dp : 0.0f;
     }
-    if (sv.n_emitters > 1) pdf *= 1.0f / (float) sv.n_emitters;
+    if (n_emitters > 1) pdf *= 1.0f / (float) n_emitters;
     return pdf;
 }
 

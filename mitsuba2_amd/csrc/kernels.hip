@@ -54,28 +54,30 @@ struct Counters { uint32_t closest, any, segments, tri_tests; };
 
 // One iteration of the path.cpp loop, rotated so that it starts with the intersection of the
 // ray spawned by the previous iteration (or by the sensor).  Returns true if the path survives.
+template <bool FLAT>
 MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s, Counters &c) {
     const SceneView &sv = P.sv;
+    const Geo<FLAT> geo{ sv, lds };
     Hit hit;
     ++c.closest; ++c.segments;
-    bool found = traverse<false>(sv, lds, s.o, s.d, s.mint, s.maxt, hit, c.tri_tests);
+    bool found = traverse<FLAT, false>(sv, lds, s.o, s.d, s.mint, s.maxt, hit, c.tri_tests);
     if (s.depth == 1u) s.flags = found ? 1u : 0u;          // valid_ray (path.cpp:121)
 
     SurfaceInteraction si;
     if (found) {
-        fill_si(sv, s.d, hit.prim, hit.u, hit.v, si);
-        int32_t emitter = sv.shapes[si.shape].emitter;
+        fill_si(geo, s.d, hit.prim, hit.u, hit.v, si);
+        int32_t emitter = si.shape_rec.emitter;
         if (emitter >= 0) {
+            const DevEmitter e = geo.emitter((uint32_t) emitter);
             // emission_weight of the previous iteration (path.cpp:194-205); 1 for camera rays
             float ew = 1.0f;
             if (s.depth > 1u) {
                 f3 dd = si.p - s.o;                         // DirectionSample(si_bsdf, si), records.h:168-174
                 float dist = sqrtf(sqnorm(dd));
                 dd = div_s(dd, dist);
-                ew = mis_weight(s.bs_pdf, pdf_emitter_direction(sv, (uint32_t) emitter, dd, si.sh.n, dist));
+                ew = mis_weight(s.bs_pdf, pdf_emitter_direction(sv.n_emitters, e.area_norm, dd, si.sh.n, dist));
             }
             if (si.wi.z > 0.0f) {                           // AreaLight::eval (area.cpp:71-79)
-                const DevEmitter e = sv.emitters[emitter];
                 s.res.x += (ew * s.thr.x) * e.r; s.res.y += (ew * s.thr.y) * e.g; s.res.z += (ew * s.thr.z) * e.b;
             }
         }
@@ -91,14 +93,14 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
     }
     if (s.depth >= (uint32_t) P.max_depth || !active) return false;
 
-    const DevBsdf bsdf = sv.bsdfs[sv.shapes[si.shape].bsdf];
+    const DevBsdf bsdf = geo.bsdf((uint32_t) si.shape_rec.bsdf);
     const f3 refl = mk3(bsdf.r, bsdf.g, bsdf.b);
 
     // --------------------- Emitter sampling (path.cpp:153-172) ---------------------
     {
         f2 s2; s2.x = pcg_next_f32(s.rng); s2.y = pcg_next_f32(s.rng);
         DirectionSample ds; f3 spec;
-        sample_emitter_direction(sv, si.p, s2, ds, spec);
+        sample_emitter_direction(geo, si.p, s2, ds, spec);
         if (ds.pdf != 0.0f) {
             f3 wo = to_local(si.sh, ds.d);
             f3 bv; float bp;
@@ -111,7 +113,7 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
             if (contrib.x != 0.0f || contrib.y != 0.0f || contrib.z != 0.0f) {
                 Hit sh;
                 ++c.any;
-                bool occluded = traverse<true>(sv, lds, si.p, ds.d, kRayEpsilon * (1.0f + hmax_abs(si.p)),
+                bool occluded = traverse<FLAT, true>(sv, lds, si.p, ds.d, kRayEpsilon * (1.0f + hmax_abs(si.p)),
                                                ds.dist * (1.0f - kShadowEpsilon), sh, c.tri_tests);
                 if (!occluded) s.res = s.res + contrib;
             }
@@ -152,9 +154,10 @@ MTS_DEV void generate_path(const RenderParams &P, uint64_t ordinal, PathState &s
     P.out_pos[ordinal] = make_float2(psx, psy);
 }
 
+template <bool FLAT>
 __global__ __launch_bounds__(kBlock) void k_bounce(const RenderParams P) {
     extern __shared__ float4 smem[];
-    const LdsView lds = lds_stage(P.sv, smem);
+    const LdsView lds = lds_stage<FLAT>(P.sv, smem);
     const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
     if (wave >= P.n_waves) return;
     const uint32_t lane = lane_id();
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const RenderParams P) {
         bool alive = false;
         if (i0 + lane < n_in) {
             load_state(P.in, base + i0 + lane, s);
-            alive = bounce_step(P, lds, s, c);
+            alive = bounce_step<FLAT>(P, lds, s, c);
             if (!alive) P.out_rgba[s.ordinal] = make_float4(s.res.x, s.res.y, s.res.z, (s.flags & 1u) ? 1.0f : 0.0f);
         }
         // wavefront ballot + prefix rank: compact the survivors to the front of the output segment
@@ -205,11 +208,12 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const RenderParams P) {
     }
 }
 
-size_t bounce_lds_bytes(const SceneView &sv) { return lds_bytes(sv.lds_nodes, sv.lds_slots, sv.stack_depth, kBlock); }
+size_t bounce_lds_bytes(const SceneView &sv) { return lds_bytes(sv, kBlock); }
 
 hipError_t launch_bounce(const RenderParams &p, hipStream_t s) {
     uint32_t blocks = (p.n_waves * 64u + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(k_bounce, dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);
+    if (p.sv.flat) hipLaunchKernelGGL(k_bounce<true>, dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);
+    else hipLaunchKernelGGL(k_bounce<false>, dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);
     return hipGetLastError();
 }
 
@@ -302,24 +306,25 @@ hipError_t launch_film_gather(const FilmParams &p, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------------
 // Scene::ray_intersect / ray_intersect_naive / ray_test on SoA ray streams
-template <int MODE>
+template <int MODE, bool FLAT>
 __global__ __launch_bounds__(kBlock) void k_ray_intersect(const SceneView sv, uint64_t n, const RayStreams r,
                                                           float *t, uint32_t *prim, uint32_t *shape, float *u,
                                                           float *v, float *si26) {
     extern __shared__ float4 smem[];
-    const LdsView lds = lds_stage(sv, smem);
+    const LdsView lds = lds_stage<FLAT>(sv, smem);
+    const Geo<FLAT> geo{ sv, lds };
     for (uint64_t i = (uint64_t) blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t) gridDim.x * kBlock) {
         bool active = r.active ? r.active[i] != 0 : true;
         Hit hit; bool found = false;
         f3 o = mk3(r.ox[i], r.oy[i], r.oz[i]), d = mk3(r.dx[i], r.dy[i], r.dz[i]);
         if (active) {
             uint32_t tt = 0;
-            if (MODE == 0) found = traverse<false>(sv, lds, o, d, r.mint[i], r.maxt[i], hit, tt);
+            if (MODE == 0) found = traverse<FLAT, false>(sv, lds, o, d, r.mint[i], r.maxt[i], hit, tt);
             else found = traverse_naive<false>(sv, o, d, r.mint[i], r.maxt[i], hit);
         }
         t[i] = found ? hit.t : __builtin_inff();
         prim[i] = found ? hit.prim : kNoPrim;
-        if (shape) shape[i] = found ? sv.prim_shape[hit.prim] : kNoPrim;
+        if (shape) shape[i] = found ? geo.prim_shape(hit.prim) : kNoPrim;
         if (u) u[i] = found ? hit.u : 0.0f;
         if (v) v[i] = found ? hit.v : 0.0f;
         if (si26) {
@@ -328,7 +333,7 @@ __global__ __launch_bounds__(kBlock) void k_ray_intersect(const SceneView sv, ui
             for (int k = 0; k < 26; ++k) o26[k] = 0.0f;
             if (found) {
                 SurfaceInteraction si;
-                fill_si(sv, d, hit.prim, hit.u, hit.v, si);
+                fill_si(geo, d, hit.prim, hit.u, hit.v, si);
                 o26[0] = si.p.x; o26[1] = si.p.y; o26[2] = si.p.z; o26[3] = si.n.x; o26[4] = si.n.y; o26[5] = si.n.z;
                 o26[6] = si.uv.x; o26[7] = si.uv.y;
                 o26[8] = si.sh.s.x; o26[9] = si.sh.s.y; o26[10] = si.sh.s.z;
@@ -346,15 +351,16 @@ __global__ __launch_bounds__(kBlock) void k_ray_intersect(const SceneView sv, ui
     }
 }
 
+template <bool FLAT>
 __global__ __launch_bounds__(kBlock) void k_ray_test(const SceneView sv, uint64_t n, const RayStreams r, uint8_t *hit_out) {
     extern __shared__ float4 smem[];
-    const LdsView lds = lds_stage(sv, smem);
+    const LdsView lds = lds_stage<FLAT>(sv, smem);
     for (uint64_t i = (uint64_t) blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t) gridDim.x * kBlock) {
         bool active = r.active ? r.active[i] != 0 : true;
         bool found = false;
         if (active) {
             Hit hit; uint32_t tt = 0;
-            found = traverse<true>(sv, lds, mk3(r.ox[i], r.oy[i], r.oz[i]), mk3(r.dx[i], r.dy[i], r.dz[i]), r.mint[i],
+            found = traverse<FLAT, true>(sv, lds, mk3(r.ox[i], r.oy[i], r.oz[i]), mk3(r.dx[i], r.dy[i], r.dz[i]), r.mint[i],
                                    r.maxt[i], hit, tt);
         }
         hit_out[i] = found ? 1 : 0;
@@ -370,16 +376,21 @@ hipError_t launch_ray_intersect(const SceneView &sv, uint64_t n, const RayStream
                                 uint32_t *prim, uint32_t *shape, float *u, float *v, float *si26, hipStream_t s) {
     if (n == 0) return hipSuccess;
     size_t lds = bounce_lds_bytes(sv);
-    if (mode == 0)
-        hipLaunchKernelGGL(k_ray_intersect<0>, dim3(stream_grid(n)), dim3(kBlock), lds, s, sv, n, r, t, prim, shape, u, v, si26);
+    if (mode == 0 && sv.flat)
+        hipLaunchKernelGGL((k_ray_intersect<0, true>), dim3(stream_grid(n)), dim3(kBlock), lds, s, sv, n, r, t, prim, shape, u, v, si26);
+    else if (mode == 0)
+        hipLaunchKernelGGL((k_ray_intersect<0, false>), dim3(stream_grid(n)), dim3(kBlock), lds, s, sv, n, r, t, prim, shape, u, v, si26);
+    else if (sv.flat)
+        hipLaunchKernelGGL((k_ray_intersect<1, true>), dim3(stream_grid(n)), dim3(kBlock), lds, s, sv, n, r, t, prim, shape, u, v, si26);
     else
-        hipLaunchKernelGGL(k_ray_intersect<1>, dim3(stream_grid(n)), dim3(kBlock), lds, s, sv, n, r, t, prim, shape, u, v, si26);
+        hipLaunchKernelGGL((k_ray_intersect<1, false>), dim3(stream_grid(n)), dim3(kBlock), lds, s, sv, n, r, t, prim, shape, u, v, si26);
     return hipGetLastError();
 }
 
 hipError_t launch_ray_test(const SceneView &sv, uint64_t n, const RayStreams &r, uint8_t *hit, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_ray_test, dim3(stream_grid(n)), dim3(kBlock), bounce_lds_bytes(sv), s, sv, n, r, hit);
+    if (sv.flat) hipLaunchKernelGGL(k_ray_test<true>, dim3(stream_grid(n)), dim3(kBlock), bounce_lds_bytes(sv), s, sv, n, r, hit);
+    else hipLaunchKernelGGL(k_ray_test<false>, dim3(stream_grid(n)), dim3(kBlock), bounce_lds_bytes(sv), s, sv, n, r, hit);
     return hipGetLastError();
 }
 

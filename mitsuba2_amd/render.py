@@ -460,14 +460,15 @@ class PathIntegrator:
         film = sensor.film()
         film.prepare(("X", "Y", "Z", "A", "W"), device="cuda:%d" % scene._device_index)
         d = self._desc(sensor, rows)
-        stats = (C.c_uint64 * 5)()
+        stats = (C.c_uint64 * 8)()
         self._scene = scene
         rc = L.lib().mtsamd_render(scene._handle, C.byref(d), _ptr(film._storage.data()), stats, _stream())
         self._scene = None
         if rc == -4:                     # MTSAMD_ERR_CANCELLED: render() returns false (integrator.cpp:175)
             return False
         L.check(rc)
-        self.stats = dict(zip(("closest_hit_rays", "any_hit_rays", "samples", "iterations", "segments"), [int(x) for x in stats]))
+        self.stats = dict(zip(("closest_hit_rays", "any_hit_rays", "samples", "iterations", "segments", "bounce_ns", "film_ns", "tri_tests"),
+                              [int(x) for x in stats]))
         return True
 
     def cancel(self):
