@@ -180,7 +180,7 @@ struct mtsamd_scene {
     uint32_t *d_prim_shape = nullptr;
     DevShape *d_shapes = nullptr; DevBsdf *d_bsdfs = nullptr; DevEmitter *d_emitters = nullptr;
     float *d_area_pmf = nullptr, *d_area_cdf = nullptr;
-    float4 *d_flat = nullptr;
+    float4 *d_flat = nullptr, *d_pairs = nullptr;
     SceneView view{};
     Workspace ws;
     std::atomic<int> cancel{ 0 };
@@ -204,7 +204,7 @@ void mtsamd_scene_destroy(mtsamd_scene *s) {
     s->ws.release();
     (void) hipFree(s->d_nodes); (void) hipFree(s->d_tris); (void) hipFree(s->d_tri_pos); (void) hipFree(s->d_tri_nrm); (void) hipFree(s->d_tri_uv);
     (void) hipFree(s->d_prim_shape); (void) hipFree(s->d_shapes); (void) hipFree(s->d_bsdfs); (void) hipFree(s->d_emitters);
-    (void) hipFree(s->d_area_pmf); (void) hipFree(s->d_area_cdf); (void) hipFree(s->d_flat);
+    (void) hipFree(s->d_area_pmf); (void) hipFree(s->d_area_cdf); (void) hipFree(s->d_flat); (void) hipFree(s->d_pairs);
     delete s;
 }
 
@@ -322,8 +322,27 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         flat_recs[4 * gp + 2] = make_float4(tp[8] - tp[2], tp[3], tp[4], tp[5]);
         flat_recs[4 * gp + 3] = make_float4(tp[6], tp[7], tp[8], shf);
     }
+    const uint32_t n_pairs = flat ? (s->n_prims + 1) / 2 : 0;
+    std::vector<float4> pair_recs(5 * (size_t) n_pairs, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    for (uint32_t k = 0; k < n_pairs; ++k) {
+        float a[9] = { 0 }, b[9] = { 0 };       // p0, e1, e2 of primitives 2k and 2k+1 (zero = never hit)
+        for (int which = 0; which < 2; ++which) {
+            uint32_t gp = 2 * k + which;
+            if (gp >= s->n_prims) continue;
+            const float *tp = &tri_pos[9 * (size_t) gp];
+            float *r = which ? b : a;
+            r[0] = tp[0]; r[1] = tp[1]; r[2] = tp[2];
+            r[3] = tp[3] - tp[0]; r[4] = tp[4] - tp[1]; r[5] = tp[5] - tp[2];
+            r[6] = tp[6] - tp[0]; r[7] = tp[7] - tp[1]; r[8] = tp[8] - tp[2];
+        }
+        pair_recs[5 * k + 0] = make_float4(a[0], b[0], a[1], b[1]);
+        pair_recs[5 * k + 1] = make_float4(a[2], b[2], a[3], b[3]);
+        pair_recs[5 * k + 2] = make_float4(a[4], b[4], a[5], b[5]);
+        pair_recs[5 * k + 3] = make_float4(a[6], b[6], a[7], b[7]);
+        pair_recs[5 * k + 4] = make_float4(a[8], b[8], 0.0f, 0.0f);
+    }
     int rc = 0;
-    if ((rc = upload(&s->d_flat, flat_recs)) || (rc = upload(&s->d_nodes, nodes)) || (rc = upload(&s->d_tris, tris)) || (rc = upload(&s->d_tri_pos, tri_pos)) ||
+    if ((rc = upload(&s->d_flat, flat_recs)) || (rc = upload(&s->d_pairs, pair_recs)) || (rc = upload(&s->d_nodes, nodes)) || (rc = upload(&s->d_tris, tris)) || (rc = upload(&s->d_tri_pos, tri_pos)) ||
         (rc = upload(&s->d_tri_nrm, tri_nrm)) || (rc = upload(&s->d_tri_uv, tri_uv)) || (rc = upload(&s->d_prim_shape, prim_shape)) ||
         (rc = upload(&s->d_shapes, shapes)) || (rc = upload(&s->d_bsdfs, s->bsdfs)) || (rc = upload(&s->d_emitters, s->emitters)) ||
         (rc = upload(&s->d_area_pmf, area_pmf)) || (rc = upload(&s->d_area_cdf, area_cdf))) {
@@ -345,6 +364,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     v.area_pmf = s->d_area_pmf; v.area_cdf = s->d_area_cdf;
     v.n_shapes = desc->mesh_count; v.n_bsdfs = desc->bsdf_count;
     v.flat_recs = s->d_flat; v.flat = flat ? 1u : 0u;
+    v.flat_pairs = s->d_pairs; v.n_pairs = n_pairs;
     if (bounce_lds_bytes(v) > 150 * 1024) {
         mtsamd_scene_destroy(s);
         return fail(MTSAMD_ERR_UNSUPPORTED, "BVH too deep for the LDS traversal stack (depth %u)", v.stack_depth);

@@ -58,8 +58,11 @@ struct SceneView {
     // "flat" scenes (n_prims <= kFlatMaxPrims): no hierarchy pays off; the whole scene is kept in LDS
     // as 64-byte records in primitive order and every query is a wave-uniform loop over them.
     //   r0 = (p0.xyz, e1.x) r1 = (e1.y, e1.z, e2.x, e2.y) r2 = (e2.z, p1.xyz) r3 = (p2.xyz, shape bits)
+    // plus 80-byte intersection records for primitive pairs (A = 2k, B = 2k+1), laid out for packed fp32 math:
+    //   (p0x.ab, p0y.ab) (p0z.ab, e1x.ab) (e1y.ab, e1z.ab) (e2x.ab, e2y.ab) (e2z.ab, -, -)
     const float4 *flat_recs;
-    uint32_t flat;
+    const float4 *flat_pairs;
+    uint32_t flat, n_pairs;
 };
 constexpr uint32_t kFlatMaxPrims = 64;
 
@@ -71,7 +74,8 @@ struct LdsView {
     const float4 *tris;
     uint32_t *stack;           // [depth][blockDim]
     uint32_t stride;           // blockDim.x
-    const float4 *flat;        // 4 per prim
+    const float4 *flat;        // 4 per prim (shading records)
+    const float4 *pairs;       // 5 per primitive pair (intersection records), + 1 all-zero pair
     const DevShape *shapes;
     const DevBsdf *bsdfs;
     const DevEmitter *emitters;
@@ -88,7 +92,11 @@ MTS_DEV LdsView lds_stage(const SceneView &sv, float4 *smem) {
         float4 *f = smem;
         for (uint32_t i = threadIdx.x; i < 4u * sv.n_prims; i += blockDim.x) f[i] = sv.flat_recs[i];
         l.flat = f;
-        uint32_t *w = reinterpret_cast<uint32_t *>(f + 4u * sv.n_prims);
+        float4 *pr = f + 4u * sv.n_prims;
+        for (uint32_t i = threadIdx.x; i < 5u * sv.n_pairs; i += blockDim.x) pr[i] = sv.flat_pairs[i];
+        if (threadIdx.x < 5u) pr[5u * sv.n_pairs + threadIdx.x] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        l.pairs = pr;
+        uint32_t *w = reinterpret_cast<uint32_t *>(pr + 5u * sv.n_pairs + 5u);
         const uint32_t n_sh = (sizeof(DevShape) / 4u) * sv.n_shapes, n_bs = (sizeof(DevBsdf) / 4u) * sv.n_bsdfs,
                        n_em = (sizeof(DevEmitter) / 4u) * sv.n_emitters;
         const uint32_t *g_sh = reinterpret_cast<const uint32_t *>(sv.shapes), *g_bs = reinterpret_cast<const uint32_t *>(sv.bsdfs),
@@ -115,10 +123,14 @@ MTS_DEV LdsView lds_stage(const SceneView &sv, float4 *smem) {
 }
 inline size_t lds_bytes(const SceneView &sv, uint32_t block) {
     if (sv.flat)
-        return (size_t) 64 * sv.n_prims + sizeof(DevShape) * sv.n_shapes + sizeof(DevBsdf) * sv.n_bsdfs +
+        return (size_t) 64 * sv.n_prims + (size_t) 80 * (sv.n_pairs + 1) + sizeof(DevShape) * sv.n_shapes + sizeof(DevBsdf) * sv.n_bsdfs +
                sizeof(DevEmitter) * sv.n_emitters + (size_t) 8 * sv.n_prims;
     return (size_t) 64 * sv.lds_nodes + (size_t) 48 * sv.lds_slots + (size_t) 4 * sv.stack_depth * block;
 }
+
+#ifndef MTS_FLAT_UNROLL
+#define MTS_FLAT_UNROLL 2
+#endif
 
 struct Hit { float t; uint32_t prim; float u, v; };
 
@@ -222,26 +234,68 @@ MTS_DEV bool traverse_bvh(const SceneView &sv, const LdsView &lds, f3 o, f3 d, f
 // Flat scenes: a wave-uniform loop over every primitive record in LDS (broadcast reads, no stack,
 // no divergence).  Primitive order + "t <= best" reproduces the brute-force loop of
 // ray_intersect_naive (kdtree.h:2303-2328) literally: later primitives win ties.
+typedef float v2f __attribute__((ext_vector_type(2)));
+MTS_DEV v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+MTS_DEV v2f splat(float x) { v2f r = { x, x }; return r; }
+
+// Correctly rounded 1/x for normal-range x: v_rcp_f32 (<= 1 ulp) followed by two Newton-Raphson steps with
+// exact fma residuals.  x == 0 gives NaN instead of inf; every comparison of the triangle test still fails.
+MTS_DEV v2f rcp_nr2(v2f x) {
+    v2f r = { __builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y) };
+    const v2f one = { 1.0f, 1.0f };
+    v2f e = vfma(-x, r, one);
+    r = vfma(e, r, r);
+    e = vfma(-x, r, one);
+    return vfma(e, r, r);
+}
+
+// Flat scenes: a wave-uniform loop over every primitive, two per iteration on the packed-fp32 pipe
+// (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32), operands broadcast from LDS (no stack, no divergence).
+// Primitive order + "t <= best" reproduces the brute-force loop of ray_intersect_naive
+// (kdtree.h:2303-2328) literally: later primitives win ties.  Per element the arithmetic is exactly
+// Mesh::ray_intersect_triangle (mesh.h:195-221).
 template <bool ANY>
 MTS_DEV bool traverse_flat(const SceneView &sv, const LdsView &lds, f3 o, f3 d, float mint, float maxt,
                            Hit &hit, uint32_t &tri_tests) {
     float best = maxt, bu = 0.0f, bv = 0.0f;
     uint32_t best_prim = kNoPrim;
     bool any = false;
-    const uint32_t n = sv.n_prims;
-    tri_tests += n;
-#ifndef MTS_FLAT_UNROLL
-#define MTS_FLAT_UNROLL 2
-#endif
-#pragma unroll MTS_FLAT_UNROLL
-    for (uint32_t s = 0; s < n; ++s) {
-        const float4 r0 = lds.flat[4u * s], r1 = lds.flat[4u * s + 1u], r2 = lds.flat[4u * s + 2u];
-        float u, v, t;
-        bool ok = tri_test(mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), mk3(r1.z, r1.w, r2.x), o, d, mint, ANY ? maxt : best, u, v, t);
+    const uint32_t np = sv.n_pairs;
+    tri_tests += sv.n_prims;
+    const v2f ox = splat(o.x), oy = splat(o.y), oz = splat(o.z), dx = splat(d.x), dy = splat(d.y), dz = splat(d.z);
+    // software pipeline: the next pair is fetched while the current one is tested (the staged array ends
+    // with an all-zero pair, which can never be hit: det == 0)
+    const float4 *rec = lds.pairs;
+    float4 n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3], n4 = rec[4];
+#pragma unroll 1
+    for (uint32_t k = 0; k < np; ++k) {
+        const float4 q0 = n0, q1 = n1, q2 = n2, q3 = n3, q4 = n4;
+        rec += 5;
+        n0 = rec[0]; n1 = rec[1]; n2 = rec[2]; n3 = rec[3]; n4 = rec[4];
+        const v2f p0x = { q0.x, q0.y }, p0y = { q0.z, q0.w }, p0z = { q1.x, q1.y };
+        const v2f e1x = { q1.z, q1.w }, e1y = { q2.x, q2.y }, e1z = { q2.z, q2.w };
+        const v2f e2x = { q3.x, q3.y }, e2y = { q3.z, q3.w }, e2z = { q4.x, q4.y };
+        // pvec = cross(d, e2)
+        const v2f pvx = vfma(dy, e2z, -(dz * e2y)), pvy = vfma(dz, e2x, -(dx * e2z)), pvz = vfma(dx, e2y, -(dy * e2x));
+        const v2f det = vfma(e1z, pvz, vfma(e1y, pvy, e1x * pvx));
+        const v2f inv = rcp_nr2(det);
+        const v2f tx = ox - p0x, ty = oy - p0y, tz = oz - p0z;
+        const v2f u = vfma(tz, pvz, vfma(ty, pvy, tx * pvx)) * inv;
+        // qvec = cross(tvec, e1)
+        const v2f qx = vfma(ty, e1z, -(tz * e1y)), qy = vfma(tz, e1x, -(tx * e1z)), qz = vfma(tx, e1y, -(ty * e1x));
+        const v2f v = vfma(dz, qz, vfma(dy, qy, dx * qx)) * inv;
+        const v2f t = vfma(e2z, qz, vfma(e2y, qy, e2x * qx)) * inv;
+        const v2f uv = u + v;
+        // u <= 1 is implied by v >= 0 && u + v <= 1 (rounded addition is monotone); NaNs fail u >= 0 or u + v <= 1
         if (ANY) {
-            any = any || ok;
+            bool ok_a = (u.x >= 0.0f) && (v.x >= 0.0f) && (uv.x <= 1.0f) && (t.x >= mint) && (t.x <= maxt);
+            bool ok_b = (u.y >= 0.0f) && (v.y >= 0.0f) && (uv.y <= 1.0f) && (t.y >= mint) && (t.y <= maxt);
+            any = any || ok_a || ok_b;
         } else {
-            best = ok ? t : best; best_prim = ok ? s : best_prim; bu = ok ? u : bu; bv = ok ? v : bv;
+            bool ok_a = (u.x >= 0.0f) && (v.x >= 0.0f) && (uv.x <= 1.0f) && (t.x >= mint) && (t.x <= best);
+            best = ok_a ? t.x : best; best_prim = ok_a ? 2u * k : best_prim; bu = ok_a ? u.x : bu; bv = ok_a ? v.x : bv;
+            bool ok_b = (u.y >= 0.0f) && (v.y >= 0.0f) && (uv.y <= 1.0f) && (t.y >= mint) && (t.y <= best);
+            best = ok_b ? t.y : best; best_prim = ok_b ? 2u * k + 1u : best_prim; bu = ok_b ? u.y : bu; bv = ok_b ? v.y : bv;
         }
     }
     if (ANY) return any;

@@ -113,8 +113,12 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
             if (contrib.x != 0.0f || contrib.y != 0.0f || contrib.z != 0.0f) {
                 Hit sh;
                 ++c.any;
+#if defined(MTS_ABLATE_SHADOW)   // diagnostic build only: wrong image, used to price the any-hit loop in situ
+                bool occluded = false;
+#else
                 bool occluded = traverse<FLAT, true>(sv, lds, si.p, ds.d, kRayEpsilon * (1.0f + hmax_abs(si.p)),
                                                ds.dist * (1.0f - kShadowEpsilon), sh, c.tri_tests);
+#endif
                 if (!occluded) s.res = s.res + contrib;
             }
         }
@@ -154,8 +158,12 @@ MTS_DEV void generate_path(const RenderParams &P, uint64_t ordinal, PathState &s
     P.out_pos[ordinal] = make_float2(psx, psy);
 }
 
+#ifndef MTS_BOUNCE_WAVES
+#define MTS_BOUNCE_WAVES 4
+#endif
 template <bool FLAT>
-__global__ __launch_bounds__(kBlock) void k_bounce(const RenderParams P) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MTS_BOUNCE_WAVES, MTS_BOUNCE_WAVES)))
+void k_bounce(const RenderParams P) {
     extern __shared__ float4 smem[];
     const LdsView lds = lds_stage<FLAT>(P.sv, smem);
     const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
