@@ -7,9 +7,9 @@ the HBM roofline and the CPU port (the oracle, scalar_rgb block mode) timed on t
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step is one complete render (every sample traced to termination, film splatted).  With N > 1 the film is
-partitioned into row bands, one rank per GPU renders its band (all spp) into a full-size XYZAW film and the
-films are summed with one RCCL reduce to rank 0 (weak scaling: the film grows to 1024 x 1024*N rows so the
-per-GPU work stays 2^28 samples).
+partitioned into interleaved 32-row tiles (mitsuba2_amd/dist.py), one rank per GPU renders its tiles into a
+full-size XYZAW film and the films are summed with one RCCL reduce to rank 0.  Weak scaling: the sample count
+grows to 256*N spp so that every GPU keeps tracing 1024*1024*256 = 2^28 camera samples per step.
 """
 import argparse
 import json
@@ -24,6 +24,18 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 STATE_BYTES = 88               # per in-flight path: ray 32 B + path state 56 B (kernels.h PoolView)
 
 
+def host_cores():
+    """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(width, height, seconds=12.0):
     """The CPU port (oracle, scalar_rgb block mode, BVH, all host cores) on a bounded sample of the same
     workload: same film, reduced spp.  Checker code used as the *baseline*, never as the thing measured."""
@@ -32,7 +44,7 @@ def cpu_baseline(width, height, seconds=12.0):
     from mitsuba2_amd import scenes
     sd = scenes.cornell_box()
     S = ob.OracleScene(sd)
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     # calibrate on 1 spp, then pick an spp that gives roughly `seconds` of CPU work
     p = scenes.cornell_box_sensor(width, height, 1)
     t0 = time.perf_counter()
@@ -59,6 +71,7 @@ def main():
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--paths-per-wave", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real path) or gloo (rehearsal of N ranks on fewer GPUs)")
     args = ap.parse_args()
 
     import torch
@@ -70,31 +83,29 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     n = world
+    local_rank = local_rank % torch.cuda.device_count()      # rehearsal: several ranks may share a card
     torch.cuda.set_device(local_rank)
 
-    width, band = args.width, args.height
-    height = band * n                       # weak scaling: one 1024-row band per GPU
+    from mitsuba2_amd import dist as mdist
+    width, height = args.width, args.height
+    spp_total = args.spp * n                # weak scaling: 2^28 camera samples per GPU and step
     sd = scenes.cornell_box()
-    p = scenes.cornell_box_sensor(width, height, args.spp)
-    if n > 1:
-        # keep the vertical field of view of the single-band image: the taller film shows the same box stretched
-        # over N bands, so every band sees geometry (fov is horizontal, aspect changes with N)
-        pass
+    p = scenes.cornell_box_sensor(width, height, spp_total)
     scene = render.Scene(sd, device=local_rank)
     sensor = render.make_sensor(p)
     integ = render.PathIntegrator(paths_per_wave=args.paths_per_wave)
-    rows = (rank * band, (rank + 1) * band)
+    partition = mdist.film_partition(rank, n)
 
     def step():
-        ok = integ.render(scene, sensor, rows=rows)
+        ok = integ.render(scene, sensor, partition=partition)
         assert ok
-        film = sensor.film().bitmap(raw=True)
-        if n > 1:
-            dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)      # RCCL over xGMI: per-band ImageBlocks -> rank 0
-        return film
+        return mdist.reduce_film(sensor.film().bitmap(raw=True))   # RCCL over xGMI: per-rank ImageBlocks -> rank 0
 
     def barrier():
         if n > 1:
@@ -113,10 +124,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if n > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        cdev = "cuda" if args.backend == "nccl" else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        cnt = torch.tensor([acc["closest_hit_rays"], acc["any_hit_rays"], acc["samples"]], dtype=torch.float64, device="cuda")
+        cnt = torch.tensor([acc["closest_hit_rays"], acc["any_hit_rays"], acc["samples"]], dtype=torch.float64, device=cdev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         tot_closest, tot_any, tot_samples = [float(x) for x in cnt.tolist()]
     else:
@@ -132,7 +144,7 @@ def main():
         bounce_s = acc["bounce_ns"] * 1e-9
         achieved = alg_bytes / max(bounce_s, 1e-12) / 1e9
         out = {
-            "metric": "Msample/s, cbox %dx%d@%dspp per GPU, path integrator (max_depth=-1, rr_depth=5)" % (width, band, args.spp),
+            "metric": "Msample/s, cbox %dx%d@%dspp per GPU, path integrator (max_depth=-1, rr_depth=5)" % (width, height, args.spp),
             "value": tot_samples / dt / 1e6,
             "unit": "Msample/s",
             "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
@@ -142,9 +154,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "synthetic Cornell box (36 triangles, diffuse, 1 area light), %dx%d film (%d-row band per GPU), %d spp, "
-                                   "gaussian rfilter, independent sampler" % (width, height, band, args.spp),
-                       "partition": "row bands + RCCL reduce" if n > 1 else "single GPU"},
+            "config": {"workload": "synthetic Cornell box (36 triangles, diffuse, 1 area light), %dx%d film, %d spp total (%d per GPU), "
+                                   "gaussian rfilter, independent sampler" % (width, height, spp_total, args.spp),
+                       "partition": "interleaved 32-row film tiles + RCCL reduce" if n > 1 else "single GPU"},
             "mray_per_s": (tot_closest + tot_any) / dt / 1e6,
             "segments_per_sample": acc["segments"] / max(acc["samples"], 1),
             "kernel_ms": {"k_bounce_per_step": acc["bounce_ns"] / args.steps * 1e-6, "k_film_gather_per_step": acc["film_ns"] / args.steps * 1e-6,
@@ -154,7 +166,7 @@ def main():
                          "alg_bytes_per_launch": alg_bytes / launches},
         }
         if not args.no_cpu_baseline and n == 1:
-            out["cpu_baseline"] = cpu_baseline(width, band)
+            out["cpu_baseline"] = cpu_baseline(width, height)
         print(json.dumps(out))
     if n > 1:
         dist.destroy_process_group()

@@ -157,9 +157,13 @@ typedef struct {
     /* MonteCarloIntegrator (src/librender/integrator.cpp:283-296) */
     int32_t max_depth;         /* -1 = unbounded */
     int32_t rr_depth;          /* default 5 */
-    /* work partition (multi-GPU): only pixels with crop-relative row in [row_begin,row_end)
-     * are sampled; splats still land in the full crop-sized film.  row_end <= 0: all rows. */
+    /* work partition (multi-GPU film partition): only pixels of the rows this call owns are sampled;
+     * their splats still land in the full crop-sized film, so the per-GPU films simply add up.
+     * Either a window of crop-relative rows [row_begin,row_end) (row_end <= 0: all rows), or -- with
+     * part_count > 1 -- tiles of part_tile_rows rows (32 = MTS_BLOCK_SIZE, include/mitsuba/render/spiral.h:10)
+     * dealt round-robin: this call owns tiles t with t % part_count == part_index. */
     int32_t row_begin, row_end;
+    int32_t part_index, part_count, part_tile_rows;
     /* scheduler knobs (0 = library default) */
     int32_t paths_per_wave;    /* in-flight path slots per scheduling wave */
     int32_t pipeline;          /* 0 = fused bounce kernel, 1 = split wavefront kernels */

@@ -49,7 +49,8 @@ class RenderDesc(C.Structure):
                 ("film_width", C.c_int32), ("film_height", C.c_int32), ("crop_x", C.c_int32), ("crop_y", C.c_int32),
                 ("crop_width", C.c_int32), ("crop_height", C.c_int32), ("rfilter", C.c_int32), ("rfilter_param", C.c_float),
                 ("rfilter_analytic", C.c_int32), ("sample_count", C.c_int32), ("seed", C.c_uint64), ("max_depth", C.c_int32),
-                ("rr_depth", C.c_int32), ("row_begin", C.c_int32), ("row_end", C.c_int32), ("paths_per_wave", C.c_int32),
+                ("rr_depth", C.c_int32), ("row_begin", C.c_int32), ("row_end", C.c_int32), ("part_index", C.c_int32),
+                ("part_count", C.c_int32), ("part_tile_rows", C.c_int32), ("paths_per_wave", C.c_int32),
                 ("pipeline", C.c_int32)]
 
 

@@ -142,6 +142,7 @@ struct Workspace {
     PoolView pool[2] = {};
     uint32_t *count[2] = { nullptr, nullptr };
     uint64_t *cursor = nullptr, *cursor_end = nullptr, *wave_stats = nullptr;
+    uint32_t *cursor_pix = nullptr, *cursor_rem = nullptr;
     float4 *out_rgba = nullptr; float2 *out_pos = nullptr;
     uint32_t *h_counts = nullptr;        // pinned, 4 * n_waves
     uint64_t *h_cursor = nullptr;        // pinned, 2 * n_waves
@@ -155,7 +156,8 @@ struct Workspace {
             (void) hipFree(pool[k].rng); (void) hipFree(pool[k].misc); (void) hipFree(count[k]);
             pool[k] = PoolView{}; count[k] = nullptr;
         }
-        (void) hipFree(cursor); (void) hipFree(cursor_end); (void) hipFree(wave_stats); (void) hipFree(out_rgba); (void) hipFree(out_pos);
+        (void) hipFree(cursor); (void) hipFree(cursor_end); (void) hipFree(wave_stats); (void) hipFree(cursor_pix); (void) hipFree(cursor_rem);
+        cursor_pix = cursor_rem = nullptr; (void) hipFree(out_rgba); (void) hipFree(out_pos);
         cursor = cursor_end = wave_stats = nullptr; out_rgba = nullptr; out_pos = nullptr;
         if (h_counts) (void) hipHostFree(h_counts);
         if (h_cursor) (void) hipHostFree(h_cursor);
@@ -480,10 +482,12 @@ static int ensure_workspace(mtsamd_scene *s, uint32_t n_waves, uint32_t seg_cap,
     HIP_TRY(hipMalloc((void **) &w.cursor, n_waves * sizeof(uint64_t)));
     HIP_TRY(hipMalloc((void **) &w.cursor_end, n_waves * sizeof(uint64_t)));
     HIP_TRY(hipMalloc((void **) &w.wave_stats, 4 * (size_t) n_waves * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc((void **) &w.cursor_pix, n_waves * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **) &w.cursor_rem, n_waves * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **) &w.out_rgba, pass_cap * sizeof(float4)));
     HIP_TRY(hipMalloc((void **) &w.out_pos, pass_cap * sizeof(float2)));
     HIP_TRY(hipHostMalloc((void **) &w.h_counts, 4 * (size_t) n_waves * sizeof(uint32_t), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void **) &w.h_cursor, 2 * (size_t) n_waves * sizeof(uint64_t), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **) &w.h_cursor, 3 * (size_t) n_waves * sizeof(uint64_t), hipHostMallocDefault));
     for (auto &e : w.ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : w.tev) HIP_TRY(hipEventCreate(&e));
     w.have_events = true;
@@ -498,18 +502,26 @@ struct Job {
     uint32_t n_waves, target; uint64_t pass_cap;
     uint64_t iterations = 0;
     double bounce_ms = 0.0, film_ms = 0.0;
+    RowMap rows{};
+    int store_xyz = 1;
 };
 
-// Traces sample indices [first, first+n) to completion; results land in ws.out_rgba / out_pos.
+// Traces the local sample ordinals [first, first+n) of this render's rows to completion; results land in
+// ws.out_rgba / out_pos (slot = ordinal - first).
 int trace_pass(Job &j, uint64_t first, uint64_t n) {
     Workspace &w = j.s->ws;
     const uint32_t nw = j.n_waves;
+    const uint64_t spp = (uint64_t) j.d->sample_count;
+    uint32_t *h_pix = reinterpret_cast<uint32_t *>(w.h_cursor + 2 * (size_t) nw), *h_rem = h_pix + nw;
     for (uint32_t k = 0; k < nw; ++k) {
-        w.h_cursor[k] = (uint64_t) (((unsigned __int128) n * k) / nw);
-        w.h_cursor[nw + k] = (uint64_t) (((unsigned __int128) n * (k + 1)) / nw);
+        uint64_t c0 = first + (uint64_t) (((unsigned __int128) n * k) / nw), c1 = first + (uint64_t) (((unsigned __int128) n * (k + 1)) / nw);
+        w.h_cursor[k] = c0; w.h_cursor[nw + k] = c1;
+        h_pix[k] = (uint32_t) (c0 / spp); h_rem[k] = (uint32_t) (c0 % spp);
     }
     HIP_TRY(hipMemcpyAsync(w.cursor, w.h_cursor, nw * sizeof(uint64_t), hipMemcpyHostToDevice, j.stream));
     HIP_TRY(hipMemcpyAsync(w.cursor_end, w.h_cursor + nw, nw * sizeof(uint64_t), hipMemcpyHostToDevice, j.stream));
+    HIP_TRY(hipMemcpyAsync(w.cursor_pix, h_pix, nw * sizeof(uint32_t), hipMemcpyHostToDevice, j.stream));
+    HIP_TRY(hipMemcpyAsync(w.cursor_rem, h_rem, nw * sizeof(uint32_t), hipMemcpyHostToDevice, j.stream));
     HIP_TRY(hipMemsetAsync(w.count[0], 0, nw * sizeof(uint32_t), j.stream));
     HIP_TRY(hipMemsetAsync(w.count[1], 0, nw * sizeof(uint32_t), j.stream));
 
@@ -517,7 +529,9 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     p.sv = j.s->view; p.cam = j.cam;
     p.cursor = w.cursor; p.cursor_end = w.cursor_end; p.wave_stats = w.wave_stats;
     p.out_rgba = w.out_rgba; p.out_pos = w.out_pos;
-    p.first_sample = first; p.base_seed = j.d->seed;
+    p.cursor_pix = w.cursor_pix; p.cursor_rem = w.cursor_rem;
+    p.first_ordinal = first; p.base_seed = j.d->seed;
+    p.rows = j.rows; p.store_xyz = j.store_xyz;
     p.n_waves = nw; p.seg_cap = w.seg_cap; p.target = j.target;
     p.spp = j.d->sample_count; p.crop_x = j.d->crop_x; p.crop_y = j.d->crop_y; p.crop_w = j.d->crop_width; p.crop_h = j.d->crop_height;
     p.max_depth = j.d->max_depth; p.rr_depth = j.d->rr_depth;
@@ -526,7 +540,10 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     const uint64_t min_iters = (n + (uint64_t) nw * j.target - 1) / ((uint64_t) nw * j.target);
     uint64_t it = 0;
     int cur = 0;
-    const int lag = 2;
+    // Termination test without stalling the device: every `stride` launches the per-wave path counts are copied to
+    // pinned memory; the copy issued at the previous checkpoint (long complete) is inspected before issuing a new one.
+    const uint64_t stride = 4;
+    int pending = -1, slot = 0;
     HIP_TRY(hipEventRecord(w.tev[0], j.stream));
     while (true) {
         if (j.s->cancel.load(std::memory_order_relaxed)) {
@@ -537,18 +554,17 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
         p.count_in = w.count[cur]; p.count_out = w.count[cur ^ 1];
         HIP_TRY(launch_bounce(p, j.stream));
         cur ^= 1; ++it;
-        if (it >= min_iters) {
-            int slot = (int) (it % 4);
-            HIP_TRY(hipMemcpyAsync(w.h_counts + (size_t) slot * nw, w.count[cur], nw * sizeof(uint32_t), hipMemcpyDeviceToHost, j.stream));
-            HIP_TRY(hipEventRecord(w.ev[slot], j.stream));
-            if (it >= min_iters + lag) {
-                int old = (int) ((it - lag) % 4);
-                HIP_TRY(hipEventSynchronize(w.ev[old]));
+        if (it >= min_iters && (it - min_iters) % stride == 0) {
+            if (pending >= 0) {
+                HIP_TRY(hipEventSynchronize(w.ev[pending]));
                 uint64_t alive = 0;
-                const uint32_t *hc = w.h_counts + (size_t) old * nw;
+                const uint32_t *hc = w.h_counts + (size_t) pending * nw;
                 for (uint32_t k = 0; k < nw; ++k) alive += hc[k];
                 if (alive == 0) break;
             }
+            HIP_TRY(hipMemcpyAsync(w.h_counts + (size_t) slot * nw, w.count[cur], nw * sizeof(uint32_t), hipMemcpyDeviceToHost, j.stream));
+            HIP_TRY(hipEventRecord(w.ev[slot], j.stream));
+            pending = slot; slot ^= 1;
         }
         if (it > (1ull << 24)) return fail(MTSAMD_ERR_DEVICE, "wavefront scheduler did not converge");
     }
@@ -589,29 +605,55 @@ int collect_stats(Job &j, uint64_t samples, uint64_t *stats_host) {
 }
 } // namespace
 
+// Film rows owned by this call (include/mtsamd.h: row_begin/row_end window, or interleaved tiles).
+static int make_rows(const mtsamd_render_desc *d, RowMap &m) {
+    if (d->part_count > 1) {
+        if (d->part_index < 0 || d->part_index >= d->part_count || d->part_tile_rows <= 0)
+            return fail(MTSAMD_ERR_INVALID, "invalid film partition (index %d of %d, %d rows per tile)", d->part_index, d->part_count, d->part_tile_rows);
+        if (d->row_begin != 0 || d->row_end > 0) return fail(MTSAMD_ERR_INVALID, "row window and tile partition are mutually exclusive");
+        m.row0 = 0; m.tile_rows = d->part_tile_rows; m.part = d->part_index; m.count = d->part_count;
+        int32_t rows = 0;
+        for (int32_t t = d->part_index; t * d->part_tile_rows < d->crop_height; t += d->part_count)
+            rows += std::min(d->part_tile_rows, d->crop_height - t * d->part_tile_rows);
+        m.local_rows = rows;
+        return 0;
+    }
+    int row0 = d->row_begin, row1 = d->row_end <= 0 ? d->crop_height : d->row_end;
+    if (row0 < 0 || row1 > d->crop_height || row0 > row1) return fail(MTSAMD_ERR_INVALID, "invalid row range [%d,%d)", row0, row1);
+    m.row0 = row0; m.local_rows = row1 - row0; m.tile_rows = std::max(d->crop_height, 1); m.part = 0; m.count = 1;
+    return 0;
+}
+
 int mtsamd_render(mtsamd_scene *s, const mtsamd_render_desc *d, float *film, uint64_t *stats_host, void *stream_) {
     if (!s || !film) return fail(MTSAMD_ERR_INVALID, "null argument");
     if (int rc = check_desc(d)) return rc;
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t stream = (hipStream_t) stream_;
-    int row0 = d->row_begin, row1 = d->row_end <= 0 ? d->crop_height : d->row_end;
-    if (row0 < 0 || row1 > d->crop_height || row0 > row1) return fail(MTSAMD_ERR_INVALID, "invalid row range [%d,%d)", row0, row1);
+    RowMap rows{};
+    if (int rc = make_rows(d, rows)) return rc;
     const uint64_t per_row = (uint64_t) d->crop_width * (uint64_t) d->sample_count;
-    const uint64_t s0 = per_row * (uint64_t) row0, s1 = per_row * (uint64_t) row1;
+    const uint64_t total = per_row * (uint64_t) rows.local_rows;       // local sample ordinals [0, total)
     Job j;
-    if (int rc = setup_job(j, s, d, stream, s1 - s0)) return rc;
+    if (int rc = setup_job(j, s, d, stream, total)) return rc;
+    j.rows = rows; j.store_xyz = 1;
     const int R = (int) std::ceil(j.filter.radius);
-    for (uint64_t a = s0; a < s1; a += j.pass_cap) {
-        uint64_t n = std::min<uint64_t>(j.pass_cap, s1 - a);
+    for (uint64_t a = 0; a < total; a += j.pass_cap) {
+        uint64_t n = std::min<uint64_t>(j.pass_cap, total - a);
         if (int rc = trace_pass(j, a, n)) return rc;
-        // Film::put: splat this pass into the rows its samples can reach
+        // Film::put: splat this pass into the film rows its samples can reach
         FilmParams f{};
         f.out_rgba = s->ws.out_rgba; f.out_pos = s->ws.out_pos; f.film = film; f.filter = j.filter;
-        f.first_sample = a; f.n_samples = n; f.spp = d->sample_count;
+        f.first_ordinal = a; f.n_samples = n; f.spp = d->sample_count; f.rows = rows;
         f.crop_x = d->crop_x; f.crop_y = d->crop_y; f.crop_w = d->crop_width; f.crop_h = d->crop_height;
-        int64_t py0 = (int64_t) ((a / (uint64_t) d->sample_count) / (uint64_t) d->crop_width);
-        int64_t py1 = (int64_t) (((a + n - 1) / (uint64_t) d->sample_count) / (uint64_t) d->crop_width);
-        f.row0 = (int32_t) std::max<int64_t>(0, py0 - R); f.row1 = (int32_t) std::min<int64_t>(d->crop_height, py1 + R + 1);
+        int32_t lr0 = (int32_t) (a / per_row), lr1 = (int32_t) ((a + n - 1) / per_row);
+        int32_t g0, g1;
+        if (rows.count <= 1) { g0 = rows.row0 + lr0; g1 = rows.row0 + lr1; }
+        else {   // global rows are monotone in the local row index
+            int32_t t0 = lr0 / rows.tile_rows, t1 = lr1 / rows.tile_rows;
+            g0 = (t0 * rows.count + rows.part) * rows.tile_rows + (lr0 - t0 * rows.tile_rows);
+            g1 = (t1 * rows.count + rows.part) * rows.tile_rows + (lr1 - t1 * rows.tile_rows);
+        }
+        f.row0 = std::max<int32_t>(0, g0 - R); f.row1 = std::min<int32_t>(d->crop_height, g1 + R + 1);
         HIP_TRY(launch_film_gather(f, stream));
         HIP_TRY(hipEventRecord(s->ws.tev[2], stream));
         HIP_TRY(hipEventSynchronize(s->ws.tev[2]));
@@ -619,7 +661,7 @@ int mtsamd_render(mtsamd_scene *s, const mtsamd_render_desc *d, float *film, uin
         HIP_TRY(hipEventElapsedTime(&fms, s->ws.tev[1], s->ws.tev[2]));
         j.film_ms += fms;
     }
-    if (int rc = collect_stats(j, s1 - s0, stats_host)) return rc;
+    if (int rc = collect_stats(j, total, stats_host)) return rc;
     HIP_TRY(hipStreamSynchronize(stream));
     return MTSAMD_OK;
 }
@@ -641,6 +683,8 @@ int mtsamd_sample_radiance(mtsamd_scene *s, const mtsamd_render_desc *d, uint64_
     if (count == 0) return MTSAMD_OK;
     Job j;
     if (int rc = setup_job(j, s, d, stream, count)) return rc;
+    j.rows = RowMap{ 0, d->crop_height, std::max(d->crop_height, 1), 0, 1 };
+    j.store_xyz = 0;
     for (uint64_t a = 0; a < count; a += j.pass_cap) {
         uint64_t n = std::min<uint64_t>(j.pass_cap, count - a);
         if (int rc = trace_pass(j, first + a, n)) return rc;

@@ -129,7 +129,10 @@ inline size_t lds_bytes(const SceneView &sv, uint32_t block) {
 }
 
 #ifndef MTS_FLAT_UNROLL
-#define MTS_FLAT_UNROLL 2
+#define MTS_FLAT_UNROLL 1
+#endif
+#ifndef MTS_FLAT_PREFETCH
+#define MTS_FLAT_PREFETCH 1
 #endif
 
 struct Hit { float t; uint32_t prim; float u, v; };
@@ -266,12 +269,19 @@ MTS_DEV bool traverse_flat(const SceneView &sv, const LdsView &lds, f3 o, f3 d, 
     // software pipeline: the next pair is fetched while the current one is tested (the staged array ends
     // with an all-zero pair, which can never be hit: det == 0)
     const float4 *rec = lds.pairs;
+#if MTS_FLAT_PREFETCH
     float4 n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3], n4 = rec[4];
-#pragma unroll 1
+#endif
+#pragma unroll MTS_FLAT_UNROLL
     for (uint32_t k = 0; k < np; ++k) {
+#if MTS_FLAT_PREFETCH
         const float4 q0 = n0, q1 = n1, q2 = n2, q3 = n3, q4 = n4;
         rec += 5;
         n0 = rec[0]; n1 = rec[1]; n2 = rec[2]; n3 = rec[3]; n4 = rec[4];
+#else
+        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4];
+        rec += 5;
+#endif
         const v2f p0x = { q0.x, q0.y }, p0y = { q0.z, q0.w }, p0z = { q1.x, q1.y };
         const v2f e1x = { q1.z, q1.w }, e1y = { q2.x, q2.y }, e1z = { q2.z, q2.w };
         const v2f e2x = { q3.x, q3.y }, e2y = { q3.z, q3.w }, e2z = { q4.x, q4.y };

@@ -14,6 +14,21 @@ struct PoolView {
     uint2 *misc;
 };
 
+// Film rows owned by one render call.  count <= 1: the contiguous window [row0, row0 + local_rows);
+// count > 1: the film is cut into tiles of tile_rows rows dealt round-robin, this call owns tiles t % count == part.
+struct RowMap { int32_t row0, local_rows, tile_rows, part, count; };
+MTS_DEV int32_t row_to_global(const RowMap &m, int32_t lr) {
+    if (m.count <= 1) return m.row0 + lr;
+    int32_t t = lr / m.tile_rows;
+    return (t * m.count + m.part) * m.tile_rows + (lr - t * m.tile_rows);
+}
+MTS_DEV int32_t row_to_local(const RowMap &m, int32_t gr) {     // -1: not owned
+    if (m.count <= 1) { int32_t lr = gr - m.row0; return (lr >= 0 && lr < m.local_rows) ? lr : -1; }
+    int32_t t = gr / m.tile_rows;
+    if (t % m.count != m.part) return -1;
+    return (t / m.count) * m.tile_rows + (gr - t * m.tile_rows);
+}
+
 struct FilterView {
     float table[32];
     float radius, scale_factor, alpha, bias;
@@ -31,8 +46,11 @@ struct RenderParams {
     uint64_t *wave_stats;       // per wave: closest, any, segments, tri tests
     float4 *out_rgba;           // per sample ordinal: radiance rgb + valid_ray
     float2 *out_pos;            // per sample ordinal: film position sample
-    uint64_t first_sample;      // global index of ordinal 0
+    uint32_t *cursor_pix, *cursor_rem;   // per wave: local pixel of the cursor and its remainder (cursor == pix * spp + rem)
+    uint64_t first_ordinal;     // local sample ordinal of slot 0 of out_rgba / out_pos
     uint64_t base_seed;
+    RowMap rows;                // which film rows this render owns (multi-GPU film partition)
+    int32_t store_xyz;          // 1: out_rgba holds (X,Y,Z,alpha | -1 if the sample is invalid) for the film, 0: (R,G,B,alpha)
     uint32_t n_waves, seg_cap, target;
     int32_t spp, crop_x, crop_y, crop_w, crop_h;
     int32_t max_depth, rr_depth;
@@ -43,9 +61,10 @@ struct FilmParams {
     const float2 *out_pos;
     float *film;                // crop_h * crop_w * 5
     FilterView filter;
-    uint64_t first_sample, n_samples;
+    uint64_t first_ordinal, n_samples;   // local sample ordinals held by out_rgba / out_pos
+    RowMap rows;
     int32_t spp, crop_x, crop_y, crop_w, crop_h;
-    int32_t row0, row1;         // target rows [row0,row1)
+    int32_t row0, row1;         // target (global) rows [row0,row1)
 };
 
 struct RayStreams {

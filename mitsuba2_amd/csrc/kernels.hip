@@ -141,12 +141,15 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
     return true;
 }
 
-// render_sample up to the camera ray (integrator.cpp:224-246)
-MTS_DEV void generate_path(const RenderParams &P, uint64_t ordinal, PathState &s) {
-    uint64_t index = P.first_sample + ordinal;
+// render_sample up to the camera ray (integrator.cpp:224-246).  `lp` = local pixel index (row-major over the rows
+// this render owns), `j` = sample number inside the pixel; the RNG stream is seeded with the GLOBAL sample index
+// pixel * spp + j, so the image does not depend on how the film is partitioned.
+MTS_DEV void generate_path(const RenderParams &P, uint64_t ordinal, uint32_t lp, uint32_t j, PathState &s) {
+    const uint32_t w = (uint32_t) P.crop_w;
+    const uint32_t lr = lp / w, px = lp - lr * w;
+    const uint32_t py = (uint32_t) row_to_global(P.rows, (int32_t) lr);
+    const uint64_t index = ((uint64_t) py * w + px) * (uint64_t) P.spp + j;
     seed_sample(s.rng, index, P.base_seed);
-    uint64_t pixel = index / (uint64_t) P.spp;
-    uint32_t px = (uint32_t) (pixel % (uint64_t) P.crop_w), py = (uint32_t) (pixel / (uint64_t) P.crop_w);
     float jx = pcg_next_f32(s.rng), jy = pcg_next_f32(s.rng);
     float psx = ((float) px + (float) P.crop_x) + jx, psy = ((float) py + (float) P.crop_y) + jy;
     (void) pcg_next_f32(s.rng);                              // wavelength sample (drawn even in RGB mode)
@@ -154,8 +157,21 @@ MTS_DEV void generate_path(const RenderParams &P, uint64_t ordinal, PathState &s
     camera_ray(P.cam, ax, ay, s.o, s.d, s.mint, s.maxt);
     s.thr = mk3(1.0f, 1.0f, 1.0f); s.bs_pdf = 0.0f;
     s.res = mk3(0.0f, 0.0f, 0.0f); s.eta = 1.0f;
-    s.ordinal = (uint32_t) ordinal; s.depth = 1u; s.flags = 0u;
-    P.out_pos[ordinal] = make_float2(psx, psy);
+    s.ordinal = (uint32_t) (ordinal - P.first_ordinal); s.depth = 1u; s.flags = 0u;
+    P.out_pos[s.ordinal] = make_float2(psx, psy);
+}
+
+// final radiance of a terminated path -> per-sample stream
+MTS_DEV void store_result(const RenderParams &P, const PathState &s) {
+    float alpha = (s.flags & 1u) ? 1.0f : 0.0f;
+    if (P.store_xyz) {
+        f3 xyz = srgb_to_xyz(s.res);                        // integrator.cpp:254-262
+        bool valid = (xyz.x >= -1e-5f) && (xyz.y >= -1e-5f) && (xyz.z >= -1e-5f) && isfinite(xyz.x) && isfinite(xyz.y) &&
+                     isfinite(xyz.z);                       // ImageBlock::put drops invalid samples (imageblock.cpp:85-109)
+        P.out_rgba[s.ordinal] = make_float4(xyz.x, xyz.y, xyz.z, valid ? alpha : -1.0f);
+    } else {
+        P.out_rgba[s.ordinal] = make_float4(s.res.x, s.res.y, s.res.z, alpha);
+    }
 }
 
 #ifndef MTS_BOUNCE_WAVES
@@ -180,7 +196,7 @@ void k_bounce(const RenderParams P) {
         if (i0 + lane < n_in) {
             load_state(P.in, base + i0 + lane, s);
             alive = bounce_step<FLAT>(P, lds, s, c);
-            if (!alive) P.out_rgba[s.ordinal] = make_float4(s.res.x, s.res.y, s.res.z, (s.flags & 1u) ? 1.0f : 0.0f);
+            if (!alive) store_result(P, s);
         }
         // wavefront ballot + prefix rank: compact the survivors to the front of the output segment
         const uint64_t m = __ballot(alive);
@@ -188,19 +204,25 @@ void k_bounce(const RenderParams P) {
         n_out += (uint32_t) __popcll(m);
     }
 
-    // regenerate camera paths into the free slots of this wave's segment
+    // regenerate camera paths into the free slots of this wave's segment.  The cursor is kept decomposed as
+    // (local pixel, sample-in-pixel) so that no 64-bit division is needed per generated path.
     uint64_t cursor = P.cursor[wave];
     const uint64_t end = P.cursor_end[wave];
+    uint32_t cpix = P.cursor_pix[wave], crem = P.cursor_rem[wave];
+    const uint32_t spp = (uint32_t) P.spp;
     while (n_out < P.target && cursor < end) {
         uint64_t left = end - cursor;
         uint32_t n_new = min(64u, P.target - n_out);
         if ((uint64_t) n_new > left) n_new = (uint32_t) left;
         if (lane < n_new) {
             PathState s;
-            generate_path(P, cursor + lane, s);
+            uint32_t r = crem + lane, q = r / spp;
+            generate_path(P, cursor + lane, cpix + q, r - q * spp, s);
             store_state(P.out, base + n_out + lane, s);
         }
         n_out += n_new; cursor += n_new;
+        uint32_t r = crem + n_new, q = r / spp;
+        cpix += q; crem = r - q * spp;
     }
 
     // per-wave bookkeeping (each wave owns its slots: no atomics)
@@ -210,7 +232,7 @@ void k_bounce(const RenderParams P) {
         for (int off = 32; off > 0; off >>= 1) tot[k] += __shfl_xor(tot[k], off);
     if (lane == 0) {
         P.count_out[wave] = n_out;
-        P.cursor[wave] = cursor;
+        P.cursor[wave] = cursor; P.cursor_pix[wave] = cpix; P.cursor_rem[wave] = crem;
         uint64_t *ws = P.wave_stats + 4u * (size_t) wave;
         ws[0] += tot[0]; ws[1] += tot[1]; ws[2] += tot[2]; ws[3] += tot[3];
     }
@@ -266,31 +288,28 @@ __global__ __launch_bounds__(kBlock) void k_film_gather(const FilmParams F) {
     const int sx = F.crop_w + 2 * b, sy = F.crop_h + 2 * b;
     // block offset = crop offset, with border: pos = pos_ - (offset - border + 0.5)
     const float offx = (float) (F.crop_x - b) + 0.5f, offy = (float) (F.crop_y - b) + 0.5f;
-    const uint64_t i0 = F.first_sample, i1 = F.first_sample + F.n_samples;
+    const uint64_t i0 = F.first_ordinal, i1 = F.first_ordinal + F.n_samples;
     float acc[5] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
     for (int qy = y - R; qy <= y + R; ++qy) {
         if (qy < 0 || qy >= F.crop_h) continue;
+        const int lr = row_to_local(F.rows, qy);
+        if (lr < 0) continue;
         for (int qx = x - R; qx <= x + R; ++qx) {
             if (qx < 0 || qx >= F.crop_w) continue;
-            uint64_t q = (uint64_t) qy * (uint64_t) F.crop_w + (uint64_t) qx;
+            uint64_t q = (uint64_t) lr * (uint64_t) F.crop_w + (uint64_t) qx;
             uint64_t s_lo = q * (uint64_t) F.spp, s_hi = s_lo + (uint64_t) F.spp;
             if (s_lo < i0) s_lo = i0;
             if (s_hi > i1) s_hi = i1;
             for (uint64_t sidx = s_lo + lane; sidx < s_hi; sidx += 64u) {
+                const float4 val = F.out_rgba[sidx - i0];    // (X, Y, Z, alpha), alpha < 0: invalid sample
+                if (val.w < 0.0f) continue;
                 const float2 pp = F.out_pos[sidx - i0];
-                const float4 val = F.out_rgba[sidx - i0];
                 float wx = axis_weight(f, pp.x - offx, x + b, sx);
+                if (wx == 0.0f) continue;                 // outside the footprint (or a zero tap: adds nothing)
                 float wy = axis_weight(f, pp.y - offy, y + b, sy);
                 float w = wy * wx;                        // box filter: exactly 1 or 0
-                if (w == 0.0f) continue;                  // outside the footprint (or a zero tap: adds nothing)
-                f3 xyz = srgb_to_xyz(mk3(val.x, val.y, val.z));
-                float v[5] = { xyz.x, xyz.y, xyz.z, val.w, 1.0f };
-                bool valid = true;                        // imageblock.cpp:85-109: invalid samples are dropped
-#pragma unroll
-                for (int k = 0; k < 5; ++k) valid = valid && (v[k] >= -1e-5f) && isfinite(v[k]);
-                if (!valid) continue;
-#pragma unroll
-                for (int k = 0; k < 5; ++k) acc[k] += v[k] * w;
+                if (w == 0.0f) continue;
+                acc[0] += val.x * w; acc[1] += val.y * w; acc[2] += val.z * w; acc[3] += val.w * w; acc[4] += 1.0f * w;
             }
         }
     }

@@ -445,21 +445,25 @@ class PathIntegrator:
         self._scene = None
         self.stats = None
 
-    def _desc(self, sensor, rows=None):
+    def _desc(self, sensor, rows=None, partition=None):
         d = L.RenderDesc()
         sensor._fill_desc(d)
         d.max_depth, d.rr_depth = self.max_depth, self.rr_depth
         d.row_begin, d.row_end = (0, 0) if rows is None else (int(rows[0]), int(rows[1]))
+        if partition is not None:       # (index, count, tile_rows): interleaved row tiles of the film
+            d.part_index, d.part_count, d.part_tile_rows = (int(x) for x in partition)
         d.paths_per_wave = self.paths_per_wave
         d.pipeline = 0
         return d
 
-    def render(self, scene, sensor=None, rows=None):
-        """Integrator::render (integrator.h:42): renders into sensor.film(); returns False if cancelled."""
+    def render(self, scene, sensor=None, rows=None, partition=None):
+        """Integrator::render (integrator.h:42): renders into sensor.film(); returns False if cancelled.
+        rows=(begin, end) / partition=(index, count, tile_rows) restrict the call to a part of the film
+        (multi-GPU film partition); the film then holds that part's contribution only."""
         sensor = sensor if sensor is not None else scene.sensors()[0]
         film = sensor.film()
         film.prepare(("X", "Y", "Z", "A", "W"), device="cuda:%d" % scene._device_index)
-        d = self._desc(sensor, rows)
+        d = self._desc(sensor, rows, partition)
         stats = (C.c_uint64 * 8)()
         self._scene = scene
         rc = L.lib().mtsamd_render(scene._handle, C.byref(d), _ptr(film._storage.data()), stats, _stream())

@@ -212,6 +212,18 @@ def test_render_is_deterministic_and_row_partition_adds_up(gpu, oracle):
         assert np.allclose(parts[-1].cpu().numpy()[..., 4], ref[..., 4], rtol=1e-5, atol=1e-6)
         assert np.allclose(parts[-1].cpu().numpy(), ref, rtol=2e-2, atol=2e-3)
     assert torch.allclose(parts[0] + parts[1], films[0], rtol=1e-5, atol=1e-6)
+    # interleaved row tiles (the multi-GPU film partition): parts add up to the full film, each part matches the oracle
+    tiles = []
+    for part in range(3):
+        sensor = gpu.make_sensor(p)
+        assert integ.render(scene, sensor, partition=(part, 3, 8))
+        tiles.append(sensor.film().bitmap(raw=True).clone())
+        ref = sum(oracle.OracleScene(sd, naive=True).render_rows(oracle.make_desc(p), r0, min(r0 + 8, 40)) for r0 in range(8 * part, 40, 24))
+        assert np.allclose(tiles[-1].cpu().numpy()[..., 4], ref[..., 4], rtol=1e-5, atol=1e-6)
+        assert np.allclose(tiles[-1].cpu().numpy(), ref, rtol=2e-2, atol=2e-3)
+    assert torch.allclose(tiles[0] + tiles[1] + tiles[2], films[0], rtol=1e-5, atol=1e-6)
+    with pytest.raises(RuntimeError):
+        integ.render(scene, gpu.make_sensor(p), partition=(3, 3, 8))
     # a different scheduler geometry does not change the image (each sample owns its RNG stream)
     sensor = gpu.make_sensor(p)
     assert gpu.PathIntegrator(paths_per_wave=64).render(scene, sensor)
