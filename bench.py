@@ -143,6 +143,17 @@ def main():
         alg_bytes = 2 * STATE_BYTES * acc["segments"] + 24 * acc["samples"]
         bounce_s = acc["bounce_ns"] * 1e-9
         achieved = alg_bytes / max(bounce_s, 1e-12) / 1e9
+        # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3 passes):
+        # measured offline with scripts/collect_profiles.sh and committed under profiles/.
+        traffic, traffic_src = None, None
+        import glob
+        pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_k_bounce.json")))
+        if pmc:
+            try:
+                traffic = json.load(open(pmc[-1]))["hbm_bytes_per_launch"]
+                traffic_src = os.path.relpath(pmc[-1], ROOT)
+            except (OSError, ValueError, KeyError):
+                pass
         out = {
             "metric": "Msample/s, cbox %dx%d@%dspp per GPU, path integrator (max_depth=-1, rr_depth=5)" % (width, height, args.spp),
             "value": tot_samples / dt / 1e6,
@@ -162,7 +173,7 @@ def main():
             "kernel_ms": {"k_bounce_per_step": acc["bounce_ns"] / args.steps * 1e-6, "k_film_gather_per_step": acc["film_ns"] / args.steps * 1e-6,
                           "k_bounce_launches_per_step": launches / args.steps, "k_bounce_avg_launch_us": bounce_s / launches * 1e6},
             "roofline": {"bound": "hbm", "kernel": "k_bounce", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "alg_bytes_per_launch": alg_bytes / launches},
         }
         if not args.no_cpu_baseline and n == 1:
