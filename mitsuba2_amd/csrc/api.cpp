@@ -17,6 +17,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -504,6 +505,7 @@ struct Job {
     double bounce_ms = 0.0, film_ms = 0.0;
     RowMap rows{};
     int store_xyz = 1;
+    uint32_t plane_pix0 = 0, plane_pixels = 0;
 };
 
 // Traces the local sample ordinals [first, first+n) of this render's rows to completion; results land in
@@ -532,6 +534,7 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     p.cursor_pix = w.cursor_pix; p.cursor_rem = w.cursor_rem;
     p.first_ordinal = first; p.base_seed = j.d->seed;
     p.rows = j.rows; p.store_xyz = j.store_xyz;
+    p.plane_pix0 = j.plane_pix0; p.plane_pixels = j.plane_pixels;
     p.n_waves = nw; p.seg_cap = w.seg_cap; p.target = j.target;
     p.spp = j.d->sample_count; p.crop_x = j.d->crop_x; p.crop_y = j.d->crop_y; p.crop_w = j.d->crop_width; p.crop_h = j.d->crop_height;
     p.max_depth = j.d->max_depth; p.rr_depth = j.d->rr_depth;
@@ -637,24 +640,36 @@ int mtsamd_render(mtsamd_scene *s, const mtsamd_render_desc *d, float *film, uin
     if (int rc = setup_job(j, s, d, stream, total)) return rc;
     j.rows = rows; j.store_xyz = 1;
     const int R = (int) std::ceil(j.filter.radius);
-    for (uint64_t a = 0; a < total; a += j.pass_cap) {
-        uint64_t n = std::min<uint64_t>(j.pass_cap, total - a);
+    // passes hold whole local rows so that the sample stream can be stored as one plane per sample number
+    if (per_row > j.pass_cap) return fail(MTSAMD_ERR_UNSUPPORTED, "one film row (%llu samples) exceeds the pass capacity", (unsigned long long) per_row);
+    const uint64_t rows_per_pass = std::max<uint64_t>(1, j.pass_cap / per_row);
+    const bool tiled = film_tiles_supported(j.filter);
+    for (uint64_t lr0 = 0; lr0 < (uint64_t) rows.local_rows; lr0 += rows_per_pass) {
+        const uint64_t nrows = std::min<uint64_t>(rows_per_pass, (uint64_t) rows.local_rows - lr0);
+        const uint64_t a = lr0 * per_row, n = nrows * per_row;
+        j.plane_pix0 = (uint32_t) (lr0 * (uint64_t) d->crop_width);
+        // sample-stream layout: pixel-major measured faster overall than one plane per sample number
+        // (k_bounce's scattered 16-B result writes cost more than the film tiles' strided reads gain)
+        constexpr bool kPlaneLayout = false;
+        j.plane_pixels = (tiled && kPlaneLayout) ? (uint32_t) (nrows * (uint64_t) d->crop_width) : 0u;
         if (int rc = trace_pass(j, a, n)) return rc;
         // Film::put: splat this pass into the film rows its samples can reach
         FilmParams f{};
         f.out_rgba = s->ws.out_rgba; f.out_pos = s->ws.out_pos; f.film = film; f.filter = j.filter;
         f.first_ordinal = a; f.n_samples = n; f.spp = d->sample_count; f.rows = rows;
+        f.plane_pix0 = j.plane_pix0; f.plane_pixels = j.plane_pixels;
         f.crop_x = d->crop_x; f.crop_y = d->crop_y; f.crop_w = d->crop_width; f.crop_h = d->crop_height;
-        int32_t lr0 = (int32_t) (a / per_row), lr1 = (int32_t) ((a + n - 1) / per_row);
+        const int32_t l0 = (int32_t) lr0, l1 = (int32_t) (lr0 + nrows - 1);
         int32_t g0, g1;
-        if (rows.count <= 1) { g0 = rows.row0 + lr0; g1 = rows.row0 + lr1; }
+        if (rows.count <= 1) { g0 = rows.row0 + l0; g1 = rows.row0 + l1; }
         else {   // global rows are monotone in the local row index
-            int32_t t0 = lr0 / rows.tile_rows, t1 = lr1 / rows.tile_rows;
-            g0 = (t0 * rows.count + rows.part) * rows.tile_rows + (lr0 - t0 * rows.tile_rows);
-            g1 = (t1 * rows.count + rows.part) * rows.tile_rows + (lr1 - t1 * rows.tile_rows);
+            int32_t t0 = l0 / rows.tile_rows, t1 = l1 / rows.tile_rows;
+            g0 = (t0 * rows.count + rows.part) * rows.tile_rows + (l0 - t0 * rows.tile_rows);
+            g1 = (t1 * rows.count + rows.part) * rows.tile_rows + (l1 - t1 * rows.tile_rows);
         }
         f.row0 = std::max<int32_t>(0, g0 - R); f.row1 = std::min<int32_t>(d->crop_height, g1 + R + 1);
-        HIP_TRY(launch_film_gather(f, stream));
+        if (tiled) HIP_TRY(launch_film_tiles(f, stream));
+        else HIP_TRY(launch_film_gather(f, stream));
         HIP_TRY(hipEventRecord(s->ws.tev[2], stream));
         HIP_TRY(hipEventSynchronize(s->ws.tev[2]));
         float fms = 0.0f;

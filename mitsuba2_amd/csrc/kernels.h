@@ -51,6 +51,9 @@ struct RenderParams {
     uint64_t base_seed;
     RowMap rows;                // which film rows this render owns (multi-GPU film partition)
     int32_t store_xyz;          // 1: out_rgba holds (X,Y,Z,alpha | -1 if the sample is invalid) for the film, 0: (R,G,B,alpha)
+    // sample-stream slot of (local pixel lp, sample j): plane_pixels == 0: ordinal - first_ordinal (pixel-major);
+    // else j * plane_pixels + (lp - plane_pix0): one plane per sample number, so that a film tile reads contiguous pixels
+    uint32_t plane_pix0, plane_pixels;
     uint32_t n_waves, seg_cap, target;
     int32_t spp, crop_x, crop_y, crop_w, crop_h;
     int32_t max_depth, rr_depth;
@@ -61,7 +64,8 @@ struct FilmParams {
     const float2 *out_pos;
     float *film;                // crop_h * crop_w * 5
     FilterView filter;
-    uint64_t first_ordinal, n_samples;   // local sample ordinals held by out_rgba / out_pos
+    uint64_t first_ordinal, n_samples;   // local sample ordinals held by out_rgba / out_pos (pixel-major layout)
+    uint32_t plane_pix0, plane_pixels;   // plane layout (see RenderParams): the pass holds whole local rows
     RowMap rows;
     int32_t spp, crop_x, crop_y, crop_w, crop_h;
     int32_t row0, row1;         // target (global) rows [row0,row1)
@@ -75,6 +79,9 @@ struct RayStreams {
 size_t bounce_lds_bytes(const SceneView &sv);
 hipError_t launch_bounce(const RenderParams &p, hipStream_t s);
 hipError_t launch_film_gather(const FilmParams &p, hipStream_t s);
+// tiled variant for the plane layout and filters with <= 4 taps (gaussian stddev 0.5, box)
+hipError_t launch_film_tiles(const FilmParams &p, hipStream_t s);
+bool film_tiles_supported(const FilterView &f);
 // mode 0: closest (BVH), 1: closest (brute force)
 hipError_t launch_ray_intersect(const SceneView &sv, uint64_t n, const RayStreams &r, int mode, float *t,
                                 uint32_t *prim, uint32_t *shape, float *u, float *v, float *si26,

@@ -157,7 +157,8 @@ MTS_DEV void generate_path(const RenderParams &P, uint64_t ordinal, uint32_t lp,
     camera_ray(P.cam, ax, ay, s.o, s.d, s.mint, s.maxt);
     s.thr = mk3(1.0f, 1.0f, 1.0f); s.bs_pdf = 0.0f;
     s.res = mk3(0.0f, 0.0f, 0.0f); s.eta = 1.0f;
-    s.ordinal = (uint32_t) (ordinal - P.first_ordinal); s.depth = 1u; s.flags = 0u;
+    s.ordinal = P.plane_pixels ? j * P.plane_pixels + (lp - P.plane_pix0) : (uint32_t) (ordinal - P.first_ordinal);
+    s.depth = 1u; s.flags = 0u;
     P.out_pos[s.ordinal] = make_float2(psx, psy);
 }
 
@@ -321,6 +322,117 @@ __global__ __launch_bounds__(kBlock) void k_film_gather(const FilmParams F) {
 #pragma unroll
         for (int k = 0; k < 5; ++k) dst[k] += acc[k];
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ImageBlock::put, tiled: a workgroup owns a 16x16 tile of film pixels.  For a chunk of kFilmChunk sample
+// planes it first turns every sample of the (16+2R)^2 source pixels into a record in LDS -- value (X,Y,Z,A),
+// the first footprint pixel (lo) and the <= 4 filter taps per axis, exactly as imageblock.cpp:117-147 computes
+// them -- and then every thread gathers its pixel's taps from those records, branch-free.  Each film pixel is
+// accumulated by one thread in a fixed order: bitwise reproducible, no atomics.
+constexpr int kFilmTile = 16, kFilmChunk = 2, kFilmTaps = 5;      // taps per axis seen from the source pixel: 2R+1 <= 5
+
+// Filter weights of one sample along one axis for the 2R+1 film pixels q-R .. q+R around its source pixel q
+// (block coordinates t = q + border + k - R), exactly as imageblock.cpp:117-147 evaluates them: 0 outside [lo, hi]
+// and beyond the n = `taps` entries starting at lo.
+MTS_DEV void axis_taps(const FilterView &f, const float *table, float pos, int size, int t0, int R, float w[kFilmTaps]) {
+#pragma unroll
+    for (int k = 0; k < kFilmTaps; ++k) w[k] = 0.0f;
+    if (f.radius > 1.0f) {
+        const int lo = max((int) ceilf(pos - f.radius), 0);
+        const int hi = min((int) floorf(pos + f.radius), size - 1);
+        const float base = (float) (uint32_t) lo - pos;
+#pragma unroll
+        for (int k = 0; k < kFilmTaps; ++k) {
+            const int t = t0 + k, i = t - lo;
+            if (k <= 2 * R && i >= 0 && i < f.taps && t <= hi) {
+                const float xx = base + (float) i;
+                w[k] = f.analytic ? filter_eval(f, xx) : table[min((int) fabsf(xx * f.scale_factor), 31)];
+            }
+        }
+    } else {
+        const int lo = (int) ceilf(pos - 0.5f);
+        const int k = lo - t0;
+        if (lo >= 0 && lo < size && k >= 0 && k <= 2 * R) w[k] = 1.0f;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_film_tiles(const FilmParams F) {
+    extern __shared__ float4 smem[];
+    const FilterView &f = F.filter;
+    const int b = f.border, R = (int) ceilf(f.radius), SW = kFilmTile + 2 * R, NS = SW * SW;
+    float4 *V = smem;
+    float *WX = reinterpret_cast<float *>(V + kFilmChunk * NS), *WY = WX + kFilmTaps * kFilmChunk * NS;
+    float *table = WY + kFilmTaps * kFilmChunk * NS;
+    if (threadIdx.x < 32) table[threadIdx.x] = f.table[threadIdx.x];
+    const int tiles_x = (F.crop_w + kFilmTile - 1) / kFilmTile;
+    const int tx0 = (int) (blockIdx.x % (uint32_t) tiles_x) * kFilmTile, ty0 = F.row0 + (int) (blockIdx.x / (uint32_t) tiles_x) * kFilmTile;
+    const int lx = (int) threadIdx.x % kFilmTile, ly = (int) threadIdx.x / kFilmTile;
+    const int x = tx0 + lx, y = ty0 + ly;
+    const int sx = F.crop_w + 2 * b, sy = F.crop_h + 2 * b;
+    const float offx = (float) (F.crop_x - b) + 0.5f, offy = (float) (F.crop_y - b) + 0.5f;
+    const uint32_t pix0 = F.plane_pix0, npix = F.plane_pixels;
+    float acc[5] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+    __syncthreads();
+    for (int s0 = 0; s0 < F.spp; s0 += kFilmChunk) {
+        // ---- stage: one record per (sample plane, source pixel): value + 2R+1 taps per axis
+        for (int e = (int) threadIdx.x; e < kFilmChunk * NS; e += kBlock) {
+            const int c = e / NS, sp = e - c * NS;
+            const int qx = tx0 - R + sp % SW, qy = ty0 - R + sp / SW;
+            float4 val = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            float wxs[kFilmTaps], wys[kFilmTaps];
+#pragma unroll
+            for (int k = 0; k < kFilmTaps; ++k) wxs[k] = wys[k] = 0.0f;
+            const int lr = (qx >= 0 && qx < F.crop_w && qy >= 0 && qy < F.crop_h && s0 + c < F.spp) ? row_to_local(F.rows, qy) : -1;
+            if (lr >= 0) {
+                const uint32_t lp = (uint32_t) lr * (uint32_t) F.crop_w + (uint32_t) qx;
+                const uint64_t ord = (uint64_t) lp * (uint64_t) F.spp + (uint64_t) (s0 + c);
+                const bool have = npix ? (lp >= pix0 && lp - pix0 < npix) : (ord >= F.first_ordinal && ord - F.first_ordinal < F.n_samples);
+                if (have) {
+                    const size_t slot = npix ? (size_t) (s0 + c) * npix + (lp - pix0) : (size_t) (ord - F.first_ordinal);
+                    const float4 v = F.out_rgba[slot];          // (X, Y, Z, alpha), alpha < 0: invalid sample (dropped)
+                    if (v.w >= 0.0f) {
+                        const float2 pp = F.out_pos[slot];
+                        val = v;
+                        axis_taps(f, table, pp.x - offx, sx, qx + b - R, R, wxs);
+                        axis_taps(f, table, pp.y - offy, sy, qy + b - R, R, wys);
+                    }
+                }
+            }
+            V[e] = val;
+#pragma unroll
+            for (int k = 0; k < kFilmTaps; ++k) { WX[kFilmTaps * e + k] = wxs[k]; WY[kFilmTaps * e + k] = wys[k]; }
+        }
+        __syncthreads();
+        // ---- gather: film pixel (x, y) <- samples of the (2R+1)^2 neighbouring pixels, fixed order.  The source
+        // pixel at offset (dx, dy) of the tile origin sees this film pixel as its tap (2R - dx, 2R - dy).
+        for (int c = 0; c < kFilmChunk; ++c)
+            for (int dy = 0; dy <= 2 * R; ++dy)
+                for (int dx = 0; dx <= 2 * R; ++dx) {
+                    const int e = c * NS + (ly + dy) * SW + (lx + dx);
+                    const float w = WY[kFilmTaps * e + (2 * R - dy)] * WX[kFilmTaps * e + (2 * R - dx)];
+                    if (w == 0.0f) continue;               // a skipped tap adds nothing (imageblock.cpp:148-161)
+                    const float4 v = V[e];
+                    acc[0] += v.x * w; acc[1] += v.y * w; acc[2] += v.z * w; acc[3] += v.w * w; acc[4] += 1.0f * w;
+                }
+        __syncthreads();
+    }
+    if (x < F.crop_w && y < F.row1) {
+        float *dst = F.film + 5u * ((size_t) y * (size_t) F.crop_w + (size_t) x);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) dst[k] += acc[k];
+    }
+}
+
+bool film_tiles_supported(const FilterView &f) { return f.taps <= 4 && (int) ceilf(f.radius) <= 2; }
+
+hipError_t launch_film_tiles(const FilmParams &p, hipStream_t s) {
+    if (p.row1 <= p.row0) return hipSuccess;
+    const int R = (int) std::ceil(p.filter.radius), SW = kFilmTile + 2 * R;
+    const int tiles_x = (p.crop_w + kFilmTile - 1) / kFilmTile, tiles_y = (p.row1 - p.row0 + kFilmTile - 1) / kFilmTile;
+    const size_t lds = (size_t) kFilmChunk * SW * SW * (sizeof(float4) + 2 * kFilmTaps * sizeof(float)) + 32 * sizeof(float);
+    hipLaunchKernelGGL(k_film_tiles, dim3((uint32_t) (tiles_x * tiles_y)), dim3(kBlock), lds, s, p);
+    return hipGetLastError();
 }
 
 hipError_t launch_film_gather(const FilmParams &p, hipStream_t s) {
