@@ -100,6 +100,9 @@ int mtsamd_scene_info(const mtsamd_scene *scene, uint32_t *out6);
  * (src/spectra/srgb.cpp:59-61, src/textures/bitmap.cpp:295-299): host data, synchronous. */
 int mtsamd_scene_set_bsdf_reflectance(mtsamd_scene *scene, uint32_t bsdf, const float *rgb);
 int mtsamd_scene_set_emitter_radiance(mtsamd_scene *scene, uint32_t emitter, const float *rgb);
+/* BitmapTexture `data` parameter (bitmap.cpp:295-299): rgb is a host OR device pointer to height*width*3 floats;
+ * asynchronous on `stream`. */
+int mtsamd_scene_update_texture(mtsamd_scene *scene, uint32_t texture, const float *rgb, void *stream);
 
 /* ---- scene queries on SoA ray streams --------------------------------------
  * The stream layout follows the reference's device-stream precedent OptixParams
@@ -166,7 +169,9 @@ typedef struct {
     int32_t part_index, part_count, part_tile_rows;
     /* scheduler knobs (0 = library default) */
     int32_t paths_per_wave;    /* in-flight path slots per scheduling wave */
-    int32_t pipeline;          /* 0 = fused bounce kernel, 1 = split wavefront kernels */
+    int32_t pipeline;          /* 0 = fused bounce kernel (the only pipeline in this build) */
+    int32_t film_rgb;          /* 0: film channels X,Y,Z,A,W (integrator.cpp:72-74, 254-268);
+                                  1: R,G,B,A,W -- linear RGB as mitsuba.python.autodiff._render_helper accumulates (autodiff.py:53-72) */
 } mtsamd_render_desc;
 
 /* SamplingIntegrator::render for the `path` integrator (src/librender/integrator.cpp:52-176,
@@ -191,6 +196,19 @@ int mtsamd_cancel(mtsamd_scene *scene);
  * position sample.  Synchronous. */
 int mtsamd_sample_radiance(mtsamd_scene *scene, const mtsamd_render_desc *desc, uint64_t first,
                            uint64_t count, float *rgba_dev, float *pos_dev, void *stream);
+
+/* Reverse-mode derivative of mitsuba.python.autodiff.render (src/python/python/autodiff.py:6-91,121-194) with respect
+ * to diffuse reflectances -- what `ek.backward()` propagates into 'bsdf.reflectance.value' (src/spectra/srgb.cpp:59-61)
+ * and 'bsdf.reflectance.data' (src/textures/bitmap.cpp:295-299).  The image is values / (weight + 1e-8) of a film
+ * rendered with `desc` and desc->film_rgb = 1 (channels R,G,B,A,W); dloss_dimage_dev holds dLoss/dImage
+ * (crop_height*crop_width*3), film_dev that primal film.  Paths are replayed with the same per-sample PCG32 streams.
+ * grad_bsdf_dev (bsdf_count*3) and grad_textures_dev (all textures concatenated in index order, see
+ * mtsamd_scene_texture_info) are ACCUMULATED into; either may be NULL.  Needs 0 <= max_depth <= 16. */
+int mtsamd_render_adjoint(mtsamd_scene *scene, const mtsamd_render_desc *desc, const float *dloss_dimage_dev,
+                          const float *film_dev, float *grad_bsdf_dev, float *grad_textures_dev, void *stream);
+/* Size of a bitmap texture and its float offset inside the concatenated texture-gradient buffer. */
+int mtsamd_scene_texture_info(const mtsamd_scene *scene, uint32_t texture, int32_t *width, int32_t *height,
+                              uint64_t *grad_offset);
 
 /* PerspectiveCamera::sample_ray (perspective.cpp:153-188) for n film-plane samples in [0,1)^2
  * (device SoA in, device SoA out). */

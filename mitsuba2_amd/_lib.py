@@ -51,7 +51,7 @@ class RenderDesc(C.Structure):
                 ("rfilter_analytic", C.c_int32), ("sample_count", C.c_int32), ("seed", C.c_uint64), ("max_depth", C.c_int32),
                 ("rr_depth", C.c_int32), ("row_begin", C.c_int32), ("row_end", C.c_int32), ("part_index", C.c_int32),
                 ("part_count", C.c_int32), ("part_tile_rows", C.c_int32), ("paths_per_wave", C.c_int32),
-                ("pipeline", C.c_int32)]
+                ("pipeline", C.c_int32), ("film_rgb", C.c_int32)]
 
 
 # every symbol include/mtsamd.h declares: name -> (restype, argtypes)
@@ -65,12 +65,15 @@ SYMBOLS = {
     "mtsamd_scene_info": (C.c_int, [vp, u32p]),
     "mtsamd_scene_set_bsdf_reflectance": (C.c_int, [vp, C.c_uint32, f32p]),
     "mtsamd_scene_set_emitter_radiance": (C.c_int, [vp, C.c_uint32, f32p]),
+    "mtsamd_scene_update_texture": (C.c_int, [vp, C.c_uint32, vp, vp]),
     "mtsamd_ray_intersect": (C.c_int, [vp, C.c_uint64, C.POINTER(Rays), vp, vp, vp, vp, vp, vp]),
     "mtsamd_ray_intersect_naive": (C.c_int, [vp, C.c_uint64, C.POINTER(Rays), vp, vp, vp, vp, vp, vp]),
     "mtsamd_ray_test": (C.c_int, [vp, C.c_uint64, C.POINTER(Rays), vp, vp]),
     "mtsamd_ray_intersect_si": (C.c_int, [vp, C.c_uint64, C.POINTER(Rays), vp, vp, vp, vp, vp]),
     "mtsamd_render": (C.c_int, [vp, C.POINTER(RenderDesc), vp, u64p, vp]),
     "mtsamd_cancel": (C.c_int, [vp]),
+    "mtsamd_render_adjoint": (C.c_int, [vp, C.POINTER(RenderDesc), vp, vp, vp, vp, vp]),
+    "mtsamd_scene_texture_info": (C.c_int, [vp, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), u64p]),
     "mtsamd_sample_radiance": (C.c_int, [vp, C.POINTER(RenderDesc), C.c_uint64, C.c_uint64, vp, vp, vp]),
     "mtsamd_camera_sample_rays": (C.c_int, [C.POINTER(RenderDesc), C.c_uint64] + [vp] * 11),
     "mtsamd_imageblock_put": (C.c_int, [C.c_int32] * 6 + [C.c_float, C.c_int32, C.c_int32, C.c_uint64, vp, vp, vp, vp]),

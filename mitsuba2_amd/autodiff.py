@@ -1,0 +1,275 @@
+"""Differentiable rendering: the counterpart of ``mitsuba.python.autodiff`` / ``mitsuba.python.util.traverse``
+(``src/python/python/autodiff.py:6-91,121-194,200-377``, ``util.py:16-179``) for the parameters this backend supports --
+diffuse reflectances, constant (``'<bsdf>.reflectance.value'``, ``src/spectra/srgb.cpp:59-61``) or bitmap
+(``'<bsdf>.reflectance.data'``, ``src/textures/bitmap.cpp:295-299``).
+
+The reference records the whole render in Enoki's autodiff graph and calls ``ek.backward``.  Here the forward pass is
+the ordinary wavefront render into an R,G,B,A,W film, and the backward pass is ``mtsamd_render_adjoint``: every camera
+sample is replayed with the same PCG32 stream and its vertices are swept backwards (``k_adjoint`` in
+``csrc/kernels.hip``).  PyTorch only provides the autograd plumbing (as ``render_torch`` does in the reference,
+``autodiff.py:380-482``).
+"""
+import ctypes as C
+import math
+from contextlib import contextmanager
+
+import torch
+
+from . import _lib as L
+from .render import PathIntegrator, _ptr, _stream
+
+_DERIV_SEED_OFFSET = 0x9E3779B97F4A7C15      # decorrelates the derivative pass from the primal pass (unbiased=True)
+
+
+class ParameterMap:
+    """Dictionary-like view of the differentiable scene parameters (util.py:16-130): torch tensors on the scene's GPU.
+    Writes take effect in the scene after :meth:`update` (``parameters_changed``)."""
+
+    def __init__(self, scene):
+        self._scene = scene
+        self.properties = {}
+        self._kind = {}
+        dev = torch.device("cuda", scene._device_index)
+        for i, b in enumerate(scene._dict["bsdfs"]):
+            name = b.get("id", "bsdf_%d" % i)
+            refl = b["reflectance"]
+            if isinstance(refl, dict):
+                key = name + ".reflectance.data"
+                self.properties[key] = torch.as_tensor(refl["data"], dtype=torch.float32, device=dev).clone()
+                self._kind[key] = ("texture", scene.texture_index(i), i)
+            else:
+                key = name + ".reflectance.value"
+                self.properties[key] = torch.as_tensor([float(x) for x in refl], dtype=torch.float32, device=dev)
+                self._kind[key] = ("bsdf", i, i)
+
+    def __getitem__(self, k): return self.properties[k]
+    def __contains__(self, k): return k in self.properties
+    def __len__(self): return len(self.properties)
+    def keys(self): return self.properties.keys()
+    def items(self): return self.properties.items()
+
+    def __setitem__(self, k, value):
+        if k not in self.properties:
+            raise KeyError(k)
+        old = self.properties[k]
+        new = torch.as_tensor(value, dtype=torch.float32, device=old.device).reshape(old.shape).clone()
+        new.requires_grad_(old.requires_grad)
+        self.properties[k] = new
+
+    def keep(self, keys):
+        """util.py:120-129"""
+        keys = set(keys)
+        self.properties = {k: v for k, v in self.properties.items() if k in keys}
+
+    def all_differentiable(self):
+        return True
+
+    def update(self):
+        """util.py:103-118: push the current values into the scene (parameters_changed)."""
+        for k, v in self.properties.items():
+            kind, idx, _ = self._kind[k]
+            if kind == "texture":
+                self._scene.update_texture(idx, v)
+            else:
+                self._scene.set_bsdf_reflectance(idx, v.detach().cpu().tolist())
+
+
+def traverse(scene):
+    """mitsuba.python.util.traverse (util.py:132-179) for the supported parameters."""
+    return ParameterMap(scene)
+
+
+def _desc(scene, sensor, integrator, spp, seed):
+    d = integrator._desc(sensor)
+    if spp is not None:
+        d.sample_count = int(spp)
+    d.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    d.film_rgb = 1
+    d.rfilter_analytic = 1          # CUDA variants evaluate the filter analytically (imageblock.cpp:131-132)
+    return d
+
+
+def _render_film(scene, d):
+    dev = torch.device("cuda", scene._device_index)
+    film = torch.zeros((d.crop_height, d.crop_width, 5), dtype=torch.float32, device=dev)
+    L.check(L.lib().mtsamd_render(scene._handle, C.byref(d), _ptr(film), None, _stream()))
+    return film
+
+
+def _image_of(film):
+    """autodiff.py:80-91: values / (weight + 1e-8), flattened RGB."""
+    return (film[..., :3] / (film[..., 4:5] + 1e-8)).reshape(-1)
+
+
+class _Render(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scene, d, pmap, keys, *values):
+        pmap.update()                 # parameters_changed(): the scene sees the current values
+        film = _render_film(scene, d)
+        ctx.scene, ctx.d, ctx.pmap, ctx.keys = scene, d, pmap, keys
+        ctx.save_for_backward(film)
+        return _image_of(film)
+
+    @staticmethod
+    def backward(ctx, grad_image):
+        (film,) = ctx.saved_tensors
+        scene, d, pmap, keys = ctx.scene, ctx.d, ctx.pmap, ctx.keys
+        dev = film.device
+        n_bsdf = len(scene._dict["bsdfs"])
+        tex_floats = sum(h * w * 3 for (h, w, _) in scene._texture_shapes)
+        g_bsdf = torch.zeros((n_bsdf, 3), dtype=torch.float32, device=dev)
+        g_tex = torch.zeros(max(tex_floats, 1), dtype=torch.float32, device=dev)
+        gi = grad_image.to(dev, torch.float32).contiguous()
+        L.check(L.lib().mtsamd_render_adjoint(scene._handle, C.byref(d), _ptr(gi), _ptr(film), _ptr(g_bsdf), _ptr(g_tex), _stream()))
+        grads = []
+        for k in keys:
+            kind, idx, _ = pmap._kind[k]
+            if kind == "bsdf":
+                grads.append(g_bsdf[idx].clone())
+            else:
+                off, w, h = C.c_uint64(), C.c_int32(), C.c_int32()
+                L.check(L.lib().mtsamd_scene_texture_info(scene._handle, idx, C.byref(w), C.byref(h), C.byref(off)))
+                grads.append(g_tex[off.value: off.value + 3 * w.value * h.value].reshape(h.value, w.value, 3).clone())
+        return (None, None, None, None) + tuple(grads)
+
+
+_render_counter = {}
+
+
+def render(scene, spp=None, unbiased=False, optimizer=None, sensor_index=0, params=None):
+    """mitsuba.python.autodiff.render (autodiff.py:121-194): differentiable render returning the flattened RGB image
+    (``len == H*W*3``).  ``params`` (or ``optimizer.params``) is the :class:`ParameterMap` whose tensors with
+    ``requires_grad`` receive gradients; without one the call is a plain render.  Every call draws new random numbers
+    (the reference's sampler keeps advancing its streams between calls; here the call counter is folded into the seed).
+    """
+    sensor = scene.sensors()[sensor_index]
+    integrator = scene.integrator() if scene.integrator() is not None else PathIntegrator()
+    if optimizer is not None and params is None:
+        params = optimizer.params
+    if unbiased:
+        if optimizer is None and params is None:
+            raise Exception("render(): unbiased=True requires that an optimizer is specified!")
+        if not isinstance(spp, tuple):
+            spp = (spp, spp)
+    elif isinstance(spp, tuple):
+        raise Exception("render(): unbiased=False requires that spp is either an integer or None!")
+    call = _render_counter.get(id(scene), 0)
+    _render_counter[id(scene)] = call + 1
+    base = sensor.sampler().seed_value() + call * 0xD1B54A32D192ED03
+
+    def differentiable(spp_, seed):
+        d = _desc(scene, sensor, integrator, spp_, seed)
+        keys = [k for k, v in params.items() if v.requires_grad] if params is not None else []
+        if not keys:
+            if params is not None:
+                params.update()
+            return _image_of(_render_film(scene, d))
+        return _Render.apply(scene, d, params, keys, *[params[k] for k in keys])
+
+    if not unbiased:
+        return differentiable(spp, base)
+    with torch.no_grad():
+        if params is not None:
+            params.update()
+        image = _image_of(_render_film(scene, _desc(scene, sensor, integrator, spp[0], base)))
+    image_diff = differentiable(spp[1], base + _DERIV_SEED_OFFSET)
+    return image_diff + (image - image_diff).detach()        # ek.reattach(image, image_diff), autodiff.py:185-187
+
+
+def render_torch(scene, params=None, **kwargs):
+    """autodiff.py:380-482: the image as a torch tensor whose autograd graph reaches ``params``."""
+    return render(scene, params=params, **kwargs)
+
+
+class Optimizer:
+    """autodiff.py:200-243"""
+
+    def __init__(self, params, lr):
+        self.set_learning_rate(lr)
+        self.params = params
+        if not params.all_differentiable():
+            raise Exception("Optimizer.__init__(): all parameters should be differentiable!")
+        self.state = {}
+        for k, p in self.params.items():
+            p.requires_grad_(True)
+            self._reset(k)
+
+    def set_learning_rate(self, lr):
+        self.lr = lr
+
+    @contextmanager
+    def disable_gradients(self):
+        for _, p in self.params.items():
+            p.requires_grad_(False)
+        try:
+            yield
+        finally:
+            for _, p in self.params.items():
+                p.requires_grad_(True)
+
+    def _replace(self, key, value):
+        value = value.detach().clone()
+        value.requires_grad_(True)
+        self.params.properties[key] = value
+
+
+class SGD(Optimizer):
+    """autodiff.py:246-306: v <- mu v + g ; p <- p - lr v"""
+
+    def __init__(self, params, lr, momentum=0):
+        assert momentum >= 0 and momentum < 1
+        assert lr > 0
+        self.momentum = momentum
+        super().__init__(params, lr)
+
+    def step(self):
+        for k, p in list(self.params.items()):
+            g = p.grad
+            if g is None:
+                continue
+            if self.momentum != 0:
+                self.state[k] = self.momentum * self.state[k] + g
+                value = p.detach() - self.lr * self.state[k]
+            else:
+                value = p.detach() - self.lr * g
+            self._replace(k, value)
+        self.params.update()
+
+    def _reset(self, key):
+        if self.momentum == 0:
+            return
+        self.state[key] = torch.zeros_like(self.params[key])
+
+    def __repr__(self):
+        return "SGD[\n  lr = %.2g,\n  momentum = %.2g\n]" % (self.lr, self.momentum)
+
+
+class Adam(Optimizer):
+    """autodiff.py:309-377"""
+
+    def __init__(self, params, lr, beta_1=0.9, beta_2=0.999, epsilon=1e-8):
+        super().__init__(params, lr)
+        assert 0 <= beta_1 < 1 and 0 <= beta_2 < 1 and lr > 0 and epsilon > 0
+        self.beta_1, self.beta_2, self.epsilon = beta_1, beta_2, epsilon
+        self.t = 0
+
+    def step(self):
+        self.t += 1
+        lr_t = self.lr * math.sqrt(1 - self.beta_2 ** self.t) / (1 - self.beta_1 ** self.t)
+        for k, p in list(self.params.items()):
+            g = p.grad
+            if g is None:
+                continue
+            m_tp, v_tp = self.state[k]
+            m_t = self.beta_1 * m_tp + (1 - self.beta_1) * g
+            v_t = self.beta_2 * v_tp + (1 - self.beta_2) * g * g
+            self.state[k] = (m_t, v_t)
+            self._replace(k, p.detach() - lr_t * m_t / (torch.sqrt(v_t) + self.epsilon))
+        self.params.update()      # the reference leaves this to the next render's parameters_changed(); explicit here
+
+    def _reset(self, key):
+        p = self.params[key]
+        self.state[key] = (torch.zeros_like(p), torch.zeros_like(p))
+
+    def __repr__(self):
+        return "Adam[\n  lr = %g,\n  betas = (%g, %g),\n  eps = %g\n]" % (self.lr, self.beta_1, self.beta_2, self.epsilon)

@@ -184,6 +184,8 @@ struct mtsamd_scene {
     DevShape *d_shapes = nullptr; DevBsdf *d_bsdfs = nullptr; DevEmitter *d_emitters = nullptr;
     float *d_area_pmf = nullptr, *d_area_cdf = nullptr;
     float4 *d_flat = nullptr, *d_pairs = nullptr;
+    std::vector<DevTexture> textures;       // device data pointers, owned
+    DevTexture *d_textures = nullptr;
     SceneView view{};
     Workspace ws;
     std::atomic<int> cancel{ 0 };
@@ -208,6 +210,8 @@ void mtsamd_scene_destroy(mtsamd_scene *s) {
     (void) hipFree(s->d_nodes); (void) hipFree(s->d_tris); (void) hipFree(s->d_tri_pos); (void) hipFree(s->d_tri_nrm); (void) hipFree(s->d_tri_uv);
     (void) hipFree(s->d_prim_shape); (void) hipFree(s->d_shapes); (void) hipFree(s->d_bsdfs); (void) hipFree(s->d_emitters);
     (void) hipFree(s->d_area_pmf); (void) hipFree(s->d_area_cdf); (void) hipFree(s->d_flat); (void) hipFree(s->d_pairs);
+    for (auto &t : s->textures) (void) hipFree((void *) t.data);
+    (void) hipFree(s->d_textures);
     delete s;
 }
 
@@ -245,8 +249,13 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         if (emitter_shape[e] < 0) return fail(MTSAMD_ERR_INVALID, "emitter %u is not attached to a shape", e);
         if (desc->emitters[e].type != MTSAMD_EMITTER_AREA) return fail(MTSAMD_ERR_UNSUPPORTED, "emitter %u: only 'area' emitters are implemented", e);
     }
-    for (uint32_t b = 0; b < desc->bsdf_count; ++b)
+    for (uint32_t b = 0; b < desc->bsdf_count; ++b) {
         if (desc->bsdfs[b].type != MTSAMD_BSDF_DIFFUSE) return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u: only 'diffuse' is implemented", b);
+        if (desc->bsdfs[b].texture >= (int32_t) desc->texture_count) return fail(MTSAMD_ERR_INVALID, "bsdf %u: invalid texture index %d", b, desc->bsdfs[b].texture);
+    }
+    for (uint32_t t = 0; t < desc->texture_count; ++t)
+        if (!desc->textures || !desc->textures[t].data || desc->textures[t].width < 2 || desc->textures[t].height < 2)
+            return fail(MTSAMD_ERR_INVALID, "texture %u: image must be at least 2x2 pixels in size", t);      // bitmap.cpp:101-107
     if (total >= (1ull << 27)) return fail(MTSAMD_ERR_UNSUPPORTED, "too many primitives (%llu)", (unsigned long long) total);
 
     mtsamd_scene *s = new mtsamd_scene();
@@ -305,7 +314,21 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         DevBsdf &d = s->bsdfs[b];
         std::memset(&d, 0, sizeof(d));
         d.r = desc->bsdfs[b].reflectance[0]; d.g = desc->bsdfs[b].reflectance[1]; d.b = desc->bsdfs[b].reflectance[2];
-        d.type = desc->bsdfs[b].type; d.texture = -1;
+        d.type = desc->bsdfs[b].type; d.texture = desc->bsdfs[b].texture < 0 ? -1 : desc->bsdfs[b].texture;
+    }
+
+    for (uint32_t t = 0; t < desc->texture_count; ++t) {
+        const mtsamd_texture_desc &td = desc->textures[t];
+        DevTexture dt{ nullptr, td.width, td.height, 0u, 0u };
+        dt.grad_offset = s->textures.empty() ? 0u : s->textures.back().grad_offset + 3u * (uint32_t) s->textures.back().w * (uint32_t) s->textures.back().h;
+        size_t bytes = sizeof(float) * 3 * (size_t) td.width * td.height;
+        float *ptr = nullptr;
+        if (hipMalloc((void **) &ptr, bytes) != hipSuccess || hipMemcpy(ptr, td.data, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+            mtsamd_scene_destroy(s);
+            return fail(MTSAMD_ERR_NOMEM, "texture %u: upload failed", t);
+        }
+        dt.data = ptr;
+        s->textures.push_back(dt);
     }
 
     // ---- accelerator -------------------------------------------------------------------------
@@ -345,7 +368,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         pair_recs[5 * k + 4] = make_float4(a[8], b[8], 0.0f, 0.0f);
     }
     int rc = 0;
-    if ((rc = upload(&s->d_flat, flat_recs)) || (rc = upload(&s->d_pairs, pair_recs)) || (rc = upload(&s->d_nodes, nodes)) || (rc = upload(&s->d_tris, tris)) || (rc = upload(&s->d_tri_pos, tri_pos)) ||
+    if ((rc = upload(&s->d_textures, s->textures)) || (rc = upload(&s->d_flat, flat_recs)) || (rc = upload(&s->d_pairs, pair_recs)) || (rc = upload(&s->d_nodes, nodes)) || (rc = upload(&s->d_tris, tris)) || (rc = upload(&s->d_tri_pos, tri_pos)) ||
         (rc = upload(&s->d_tri_nrm, tri_nrm)) || (rc = upload(&s->d_tri_uv, tri_uv)) || (rc = upload(&s->d_prim_shape, prim_shape)) ||
         (rc = upload(&s->d_shapes, shapes)) || (rc = upload(&s->d_bsdfs, s->bsdfs)) || (rc = upload(&s->d_emitters, s->emitters)) ||
         (rc = upload(&s->d_area_pmf, area_pmf)) || (rc = upload(&s->d_area_cdf, area_cdf))) {
@@ -366,6 +389,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     v.emitters = s->d_emitters; v.n_emitters = desc->emitter_count;
     v.area_pmf = s->d_area_pmf; v.area_cdf = s->d_area_cdf;
     v.n_shapes = desc->mesh_count; v.n_bsdfs = desc->bsdf_count;
+    v.textures = s->d_textures; v.n_textures = desc->texture_count;
     v.flat_recs = s->d_flat; v.flat = flat ? 1u : 0u;
     v.flat_pairs = s->d_pairs; v.n_pairs = n_pairs;
     if (bounce_lds_bytes(v) > 150 * 1024) {
@@ -394,6 +418,14 @@ int mtsamd_scene_set_bsdf_reflectance(mtsamd_scene *s, uint32_t bsdf, const floa
     HIP_TRY(hipSetDevice(s->device));
     s->bsdfs[bsdf].r = rgb[0]; s->bsdfs[bsdf].g = rgb[1]; s->bsdfs[bsdf].b = rgb[2];
     HIP_TRY(hipMemcpy(s->d_bsdfs + bsdf, &s->bsdfs[bsdf], sizeof(DevBsdf), hipMemcpyHostToDevice));
+    return MTSAMD_OK;
+}
+
+int mtsamd_scene_update_texture(mtsamd_scene *s, uint32_t texture, const float *rgb, void *stream) {
+    if (!s || !rgb || texture >= s->textures.size()) return fail(MTSAMD_ERR_INVALID, "invalid texture index");
+    HIP_TRY(hipSetDevice(s->device));
+    const DevTexture &t = s->textures[texture];
+    HIP_TRY(hipMemcpyAsync((void *) t.data, rgb, sizeof(float) * 3 * (size_t) t.w * t.h, hipMemcpyDefault, (hipStream_t) stream));
     return MTSAMD_OK;
 }
 
@@ -638,7 +670,7 @@ int mtsamd_render(mtsamd_scene *s, const mtsamd_render_desc *d, float *film, uin
     const uint64_t total = per_row * (uint64_t) rows.local_rows;       // local sample ordinals [0, total)
     Job j;
     if (int rc = setup_job(j, s, d, stream, total)) return rc;
-    j.rows = rows; j.store_xyz = 1;
+    j.rows = rows; j.store_xyz = d->film_rgb ? 2 : 1;
     const int R = (int) std::ceil(j.filter.radius);
     // passes hold whole local rows so that the sample stream can be stored as one plane per sample number
     if (per_row > j.pass_cap) return fail(MTSAMD_ERR_UNSUPPORTED, "one film row (%llu samples) exceeds the pass capacity", (unsigned long long) per_row);
@@ -678,6 +710,39 @@ int mtsamd_render(mtsamd_scene *s, const mtsamd_render_desc *d, float *film, uin
     }
     if (int rc = collect_stats(j, total, stats_host)) return rc;
     HIP_TRY(hipStreamSynchronize(stream));
+    return MTSAMD_OK;
+}
+
+int mtsamd_render_adjoint(mtsamd_scene *s, const mtsamd_render_desc *d, const float *dimage, const float *film, float *grad_bsdf,
+                          float *grad_tex, void *stream_) {
+    if (!s || !dimage || !film) return fail(MTSAMD_ERR_INVALID, "null argument");
+    if (int rc = check_desc(d)) return rc;
+    if (d->max_depth < 0 || d->max_depth > 16)
+        return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass needs a finite max_depth <= 16 (got %d)", d->max_depth);
+    if (d->part_count > 1 || d->row_begin != 0 || d->row_end > 0) return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass renders the whole crop window");
+    if (s->bsdfs.size() > 32 && grad_bsdf) return fail(MTSAMD_ERR_UNSUPPORTED, "at most 32 BSDFs with constant-reflectance gradients");
+    HIP_TRY(hipSetDevice(s->device));
+    AdjointParams a{};
+    if (int rc = make_camera(*d, a.rp.cam)) return rc;
+    if (int rc = make_filter(d->rfilter, d->rfilter_param, d->rfilter_analytic, a.filter)) return rc;
+    if (a.filter.taps > 8) return fail(MTSAMD_ERR_UNSUPPORTED, "reconstruction filter too wide for the adjoint pass");
+    a.rp.sv = s->view;
+    a.rp.base_seed = d->seed; a.rp.spp = d->sample_count;
+    a.rp.crop_x = d->crop_x; a.rp.crop_y = d->crop_y; a.rp.crop_w = d->crop_width; a.rp.crop_h = d->crop_height;
+    a.rp.max_depth = d->max_depth; a.rp.rr_depth = d->rr_depth;
+    a.rp.rows = RowMap{ 0, d->crop_height, std::max(d->crop_height, 1), 0, 1 };
+    a.rp.store_xyz = 0; a.rp.out_pos = nullptr; a.rp.out_rgba = nullptr;
+    a.n_samples = (uint64_t) d->crop_width * d->crop_height * (uint64_t) d->sample_count;
+    a.dimage = dimage; a.film = film; a.grad_bsdf = grad_bsdf; a.grad_tex = grad_tex;
+    HIP_TRY(launch_adjoint(a, (hipStream_t) stream_));
+    return MTSAMD_OK;
+}
+
+int mtsamd_scene_texture_info(const mtsamd_scene *s, uint32_t texture, int32_t *width, int32_t *height, uint64_t *grad_offset) {
+    if (!s || texture >= s->textures.size()) return fail(MTSAMD_ERR_INVALID, "invalid texture index");
+    if (width) *width = s->textures[texture].w;
+    if (height) *height = s->textures[texture].h;
+    if (grad_offset) *grad_offset = s->textures[texture].grad_offset;
     return MTSAMD_OK;
 }
 

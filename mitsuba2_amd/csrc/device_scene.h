@@ -32,6 +32,7 @@ constexpr uint32_t kNoPrim = 0xffffffffu;
 struct DevShape { int32_t bsdf; int32_t emitter; uint32_t flags; uint32_t first_prim; };
 constexpr uint32_t kShapeHasNormals = 1u, kShapeHasUV = 2u;
 struct DevBsdf { float r, g, b; int32_t type; int32_t texture; int32_t pad0, pad1, pad2; };
+struct DevTexture { const float *data; int32_t w, h; uint32_t grad_offset, pad; };   // grad_offset: float offset in the concatenated gradient buffer       // linear RGB bitmap (src/textures/bitmap.cpp), identity to_uv
 struct DevEmitter {
     float r, g, b; uint32_t shape;
     uint32_t first_prim, n_prims; float area_sum, area_norm;
@@ -54,6 +55,7 @@ struct SceneView {
     const DevBsdf *bsdfs;
     const DevEmitter *emitters; uint32_t n_emitters;
     uint32_t n_shapes, n_bsdfs;
+    const DevTexture *textures; uint32_t n_textures;
     const float *area_pmf, *area_cdf;   // per prim (global index), valid inside emitter ranges
     // "flat" scenes (n_prims <= kFlatMaxPrims): no hierarchy pays off; the whole scene is kept in LDS
     // as 64-byte records in primitive order and every query is a wave-uniform loop over them.
@@ -494,6 +496,27 @@ MTS_DEV float pdf_emitter_direction(uint32_t n_emitters, float area_norm, f3 d, 
     }
     if (n_emitters > 1) pdf *= 1.0f / (float) n_emitters;
     return pdf;
+}
+
+// Diffuse reflectance at a surface interaction: the constant `srgb` colour (src/spectra/srgb.cpp:27-52) or
+// BitmapTextureImpl::interpolate (src/textures/bitmap.cpp:250-293, identity to_uv).  `texel` / `w1` return the bilinear
+// footprint (index of v00, weights towards +x / +y) for the adjoint; texel = kNoPrim for constant reflectance.
+MTS_DEV f3 eval_reflectance(const SceneView &sv, const DevBsdf &b, f2 uv, uint32_t &texel, f2 &w1) {
+    texel = kNoPrim; w1.x = w1.y = 0.0f;
+    if (b.texture < 0) return mk3(b.r, b.g, b.b);
+    const DevTexture t = sv.textures[b.texture];
+    float ux = uv.x - floorf(uv.x), uy = uv.y - floorf(uv.y);
+    ux *= (float) (uint32_t) (t.w - 1); uy *= (float) (uint32_t) (t.h - 1);
+    uint32_t px = min((uint32_t) ux, (uint32_t) (t.w - 2)), py = min((uint32_t) uy, (uint32_t) (t.h - 2));
+    w1.x = ux - (float) px; w1.y = uy - (float) py;
+    const float w0x = 1.0f - w1.x, w0y = 1.0f - w1.y;
+    texel = px + py * (uint32_t) t.w;
+    const float *v00 = t.data + 3u * (size_t) texel, *v01 = v00 + 3u * (size_t) t.w;
+    f3 r;
+    { float v0 = fmaf(w0x, v00[0], w1.x * v00[3]), v1 = fmaf(w0x, v01[0], w1.x * v01[3]); r.x = fmaf(w0y, v0, w1.y * v1); }
+    { float v0 = fmaf(w0x, v00[1], w1.x * v00[4]), v1 = fmaf(w0x, v01[1], w1.x * v01[4]); r.y = fmaf(w0y, v0, w1.y * v1); }
+    { float v0 = fmaf(w0x, v00[2], w1.x * v00[5]), v1 = fmaf(w0x, v01[2], w1.x * v01[5]); r.z = fmaf(w0y, v0, w1.y * v1); }
+    return r;
 }
 
 // SmoothDiffuse

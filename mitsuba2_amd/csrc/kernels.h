@@ -50,7 +50,8 @@ struct RenderParams {
     uint64_t first_ordinal;     // local sample ordinal of slot 0 of out_rgba / out_pos
     uint64_t base_seed;
     RowMap rows;                // which film rows this render owns (multi-GPU film partition)
-    int32_t store_xyz;          // 1: out_rgba holds (X,Y,Z,alpha | -1 if the sample is invalid) for the film, 0: (R,G,B,alpha)
+    int32_t store_xyz;          // 1: out_rgba holds (X,Y,Z,alpha | -1 if the sample is invalid) for the film, 2: same with
+                                // linear RGB instead of XYZ, 0: (R,G,B,alpha) for the per-sample API
     // sample-stream slot of (local pixel lp, sample j): plane_pixels == 0: ordinal - first_ordinal (pixel-major);
     // else j * plane_pixels + (lp - plane_pix0): one plane per sample number, so that a film tile reads contiguous pixels
     uint32_t plane_pix0, plane_pixels;
@@ -71,6 +72,16 @@ struct FilmParams {
     int32_t row0, row1;         // target (global) rows [row0,row1)
 };
 
+struct AdjointParams {
+    RenderParams rp;            // scene, sensor, sampler, integrator of the primal render (rows = the whole crop)
+    FilterView filter;
+    uint64_t n_samples;         // crop_w * crop_h * spp
+    const float *dimage;        // dLoss/dImage, crop_h * crop_w * 3
+    const float *film;          // primal film (5 channels; only the weight channel is read)
+    float *grad_bsdf;           // n_bsdfs * 3, accumulated (may be null)
+    float *grad_tex;            // all textures concatenated in index order, accumulated (may be null)
+};
+
 struct RayStreams {
     const float *ox, *oy, *oz, *dx, *dy, *dz, *mint, *maxt;
     const uint8_t *active;
@@ -78,6 +89,7 @@ struct RayStreams {
 
 size_t bounce_lds_bytes(const SceneView &sv);
 hipError_t launch_bounce(const RenderParams &p, hipStream_t s);
+hipError_t launch_adjoint(const AdjointParams &a, hipStream_t s);
 hipError_t launch_film_gather(const FilmParams &p, hipStream_t s);
 // tiled variant for the plane layout and filters with <= 4 taps (gaussian stddev 0.5, box)
 hipError_t launch_film_tiles(const FilmParams &p, hipStream_t s);

@@ -52,11 +52,24 @@ MTS_DEV void store_state(const PoolView &p, size_t i, const PathState &s) {
 
 struct Counters { uint32_t closest, any, segments, tri_tests; };
 
+// What the adjoint pass remembers about one path vertex k.  With T_k the throughput arriving at the vertex,
+//   radiance += T_k * E_k;  T'_k = T_k * invq_k (Russian roulette);  radiance += T'_k * rho_k * Nc_k (next-event
+//   estimation);  T_{k+1} = T'_k * rho_k (diffuse BSDF sample weight).
+struct VertexRec {
+    f3 E, Nc, Tp, rho; float invq;
+    f3 T; int32_t rr_channel;       // throughput before Russian roulette; channel that sets q (-1: none / q clamped)
+    uint32_t texel; f2 w1; int32_t bsdf; uint32_t has_bsdf;
+};
+
 // One iteration of the path.cpp loop, rotated so that it starts with the intersection of the
 // ray spawned by the previous iteration (or by the sensor).  Returns true if the path survives.
-template <bool FLAT>
-MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s, Counters &c) {
+template <bool FLAT, bool REC = false>
+MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s, Counters &c, VertexRec *rec = nullptr) {
     const SceneView &sv = P.sv;
+    if (REC) {
+        rec->E = rec->Nc = rec->Tp = rec->rho = mk3(0.0f, 0.0f, 0.0f);
+        rec->invq = 1.0f; rec->rr_channel = -1; rec->T = mk3(0.0f, 0.0f, 0.0f); rec->texel = kNoPrim; rec->w1.x = rec->w1.y = 0.0f; rec->bsdf = -1; rec->has_bsdf = 0u;
+    }
     const Geo<FLAT> geo{ sv, lds };
     Hit hit;
     ++c.closest; ++c.segments;
@@ -79,6 +92,7 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
             }
             if (si.wi.z > 0.0f) {                           // AreaLight::eval (area.cpp:71-79)
                 s.res.x += (ew * s.thr.x) * e.r; s.res.y += (ew * s.thr.y) * e.g; s.res.z += (ew * s.thr.z) * e.b;
+                if (REC) rec->E = mk3(ew * e.r, ew * e.g, ew * e.b);
             }
         }
     }
@@ -86,15 +100,22 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
 
     // Russian roulette (path.cpp:137-141)
     if ((int32_t) s.depth > P.rr_depth) {
-        float q = fminf(fmaxf(fmaxf(s.thr.x, s.thr.y), s.thr.z) * (s.eta * s.eta), 0.95f);
+        float hm = fmaxf(fmaxf(s.thr.x, s.thr.y), s.thr.z);
+        float q = fminf(hm * (s.eta * s.eta), 0.95f);
         if (active) active = pcg_next_f32(s.rng) < q;
         float rq = rcp(q);
+        if (REC) {
+            rec->invq = rq; rec->T = s.thr;
+            if (hm * (s.eta * s.eta) < 0.95f) rec->rr_channel = s.thr.x == hm ? 0 : (s.thr.y == hm ? 1 : 2);
+        }
         s.thr = s.thr * rq;
     }
     if (s.depth >= (uint32_t) P.max_depth || !active) return false;
 
     const DevBsdf bsdf = geo.bsdf((uint32_t) si.shape_rec.bsdf);
-    const f3 refl = mk3(bsdf.r, bsdf.g, bsdf.b);
+    uint32_t texel; f2 tw1;
+    const f3 refl = eval_reflectance(sv, bsdf, si.uv, texel, tw1);
+    if (REC) { rec->Tp = s.thr; rec->rho = refl; rec->texel = texel; rec->w1 = tw1; rec->bsdf = si.shape_rec.bsdf; rec->has_bsdf = 1u; }
 
     // --------------------- Emitter sampling (path.cpp:153-172) ---------------------
     {
@@ -119,7 +140,13 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
                 bool occluded = traverse<FLAT, true>(sv, lds, si.p, ds.d, kRayEpsilon * (1.0f + hmax_abs(si.p)),
                                                ds.dist * (1.0f - kShadowEpsilon), sh, c.tri_tests);
 #endif
-                if (!occluded) s.res = s.res + contrib;
+                if (!occluded) {
+                    s.res = s.res + contrib;
+                    if (REC && si.wi.z > 0.0f && wo.z > 0.0f) {     // d(contrib)/d(rho) / T'_k
+                        float k = mis * (kInvPi * wo.z);
+                        rec->Nc = mk3(k * spec.x, k * spec.y, k * spec.z);
+                    }
+                }
             }
         }
     }
@@ -144,7 +171,7 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
 // render_sample up to the camera ray (integrator.cpp:224-246).  `lp` = local pixel index (row-major over the rows
 // this render owns), `j` = sample number inside the pixel; the RNG stream is seeded with the GLOBAL sample index
 // pixel * spp + j, so the image does not depend on how the film is partitioned.
-MTS_DEV void generate_path(const RenderParams &P, uint64_t ordinal, uint32_t lp, uint32_t j, PathState &s) {
+MTS_DEV void generate_path(const RenderParams &P, uint64_t ordinal, uint32_t lp, uint32_t j, PathState &s, float2 *pos_out = nullptr) {
     const uint32_t w = (uint32_t) P.crop_w;
     const uint32_t lr = lp / w, px = lp - lr * w;
     const uint32_t py = (uint32_t) row_to_global(P.rows, (int32_t) lr);
@@ -159,16 +186,19 @@ MTS_DEV void generate_path(const RenderParams &P, uint64_t ordinal, uint32_t lp,
     s.res = mk3(0.0f, 0.0f, 0.0f); s.eta = 1.0f;
     s.ordinal = P.plane_pixels ? j * P.plane_pixels + (lp - P.plane_pix0) : (uint32_t) (ordinal - P.first_ordinal);
     s.depth = 1u; s.flags = 0u;
-    P.out_pos[s.ordinal] = make_float2(psx, psy);
+    if (P.out_pos) P.out_pos[s.ordinal] = make_float2(psx, psy);
+    if (pos_out) *pos_out = make_float2(psx, psy);
 }
 
 // final radiance of a terminated path -> per-sample stream
 MTS_DEV void store_result(const RenderParams &P, const PathState &s) {
     float alpha = (s.flags & 1u) ? 1.0f : 0.0f;
     if (P.store_xyz) {
-        f3 xyz = srgb_to_xyz(s.res);                        // integrator.cpp:254-262
-        bool valid = (xyz.x >= -1e-5f) && (xyz.y >= -1e-5f) && (xyz.z >= -1e-5f) && isfinite(xyz.x) && isfinite(xyz.y) &&
-                     isfinite(xyz.z);                       // ImageBlock::put drops invalid samples (imageblock.cpp:85-109)
+        f3 xyz = P.store_xyz == 1 ? srgb_to_xyz(s.res) : s.res;   // integrator.cpp:254-262; 2: linear RGB film (autodiff.py:53-57)
+        // ImageBlock::put drops invalid samples (imageblock.cpp:85-109); the autodiff film is created with
+        // warn_negative = False (autodiff.py:60-67), so there only non-finite values are dropped
+        const float lo = P.store_xyz == 1 ? -1e-5f : -__builtin_inff();
+        bool valid = (xyz.x >= lo) && (xyz.y >= lo) && (xyz.z >= lo) && isfinite(xyz.x) && isfinite(xyz.y) && isfinite(xyz.z);
         P.out_rgba[s.ordinal] = make_float4(xyz.x, xyz.y, xyz.z, valid ? alpha : -1.0f);
     } else {
         P.out_rgba[s.ordinal] = make_float4(s.res.x, s.res.y, s.res.z, alpha);
@@ -248,9 +278,7 @@ hipError_t launch_bounce(const RenderParams &p, hipStream_t s) {
     return hipGetLastError();
 }
 
-// ---------------------------------------------------------------------------------------------
-// ImageBlock::put as a gather: one wave per film pixel, lanes stride over the samples of the
-// (2R+1)^2 neighbouring pixels, fixed-order butterfly reduction -> bitwise reproducible film.
+// reconstruction filter (rfilter.h:62-65, gaussian.cpp:45-47, box.cpp:34-36)
 MTS_DEV float filter_eval(const FilterView &f, float x) {
     if (f.kind == 0) return fmaxf(0.0f, expf(f.alpha * (x * x)) - f.bias);
     return fabsf(x) <= f.radius ? 1.0f : 0.0f;
@@ -261,6 +289,112 @@ MTS_DEV float filter_weight(const FilterView &f, float x) {
     return f.table[idx];
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Reverse-mode derivative of the rendered image with respect to diffuse reflectances (constant colours and
+// bitmap texels), the role Enoki's autodiff plays for mitsuba.python.autodiff.render (autodiff.py:6-91,121-194).
+// One thread replays one camera sample with the same PCG32 stream as the primal pass, records its vertices,
+// and sweeps them backwards:   Y_k = Nc_k + X_{k+1},  dL/drho_k = delta * T'_k * Y_k,  X_k = E_k + invq_k rho_k Y_k,
+// where delta = dLoss/dRadiance of this sample = sum over its filter footprint of w * dLoss/dImage / (W + 1e-8)
+// (Image = values / (weight + 1e-8), autodiff.py:80-91); the sweep below also carries the derivative of the
+// Russian-roulette factor 1/q(T) (path.cpp:137-141), as Enoki's autodiff does.
+constexpr int kAdjointMaxDepth = 16;
+
+template <bool FLAT>
+__global__ __launch_bounds__(kBlock) void k_adjoint(const AdjointParams A) {
+    extern __shared__ float4 smem[];
+    const RenderParams &P = A.rp;
+    const LdsView lds = lds_stage<FLAT>(P.sv, smem);
+    __shared__ float s_grad[3 * 32];                       // per-workgroup sums for constant reflectances
+    for (uint32_t i = threadIdx.x; i < 3u * 32u; i += kBlock) s_grad[i] = 0.0f;
+    __syncthreads();
+    const FilterView &f = A.filter;
+    const uint32_t spp = (uint32_t) P.spp;
+    for (uint64_t k = (uint64_t) blockIdx.x * kBlock + threadIdx.x; k < A.n_samples; k += (uint64_t) gridDim.x * kBlock) {
+        PathState s; float2 pos;
+        generate_path(P, k, (uint32_t) (k / spp), (uint32_t) (k % spp), s, &pos);
+        // ---- delta: adjoint of ImageBlock::put (imageblock.cpp:117-169, block = the crop window, no border)
+        f3 delta = mk3(0.0f, 0.0f, 0.0f);
+        {
+            const float px = pos.x - ((float) P.crop_x + 0.5f), py = pos.y - ((float) P.crop_y + 0.5f);
+            if (f.radius > 1.0f) {
+                const int lox = max((int) ceilf(px - f.radius), 0), loy = max((int) ceilf(py - f.radius), 0);
+                const int hix = min((int) floorf(px + f.radius), P.crop_w - 1), hiy = min((int) floorf(py + f.radius), P.crop_h - 1);
+                const float bx = (float) (uint32_t) lox - px, by = (float) (uint32_t) loy - py;
+                for (int yr = 0; yr < f.taps && loy + yr <= hiy; ++yr) {
+                    const float wy = filter_weight(f, by + (float) yr);
+                    for (int xr = 0; xr < f.taps && lox + xr <= hix; ++xr) {
+                        const float w = wy * filter_weight(f, bx + (float) xr);
+                        const size_t pix = (size_t) (loy + yr) * P.crop_w + (size_t) (lox + xr);
+                        const float iw = w / (A.film[5 * pix + 4] + 1e-8f);
+                        delta.x += iw * A.dimage[3 * pix]; delta.y += iw * A.dimage[3 * pix + 1]; delta.z += iw * A.dimage[3 * pix + 2];
+                    }
+                }
+            } else {
+                const int lox = (int) ceilf(px - 0.5f), loy = (int) ceilf(py - 0.5f);
+                if (lox >= 0 && loy >= 0 && lox < P.crop_w && loy < P.crop_h) {
+                    const size_t pix = (size_t) loy * P.crop_w + (size_t) lox;
+                    const float iw = 1.0f / (A.film[5 * pix + 4] + 1e-8f);
+                    delta = mk3(iw * A.dimage[3 * pix], iw * A.dimage[3 * pix + 1], iw * A.dimage[3 * pix + 2]);
+                }
+            }
+        }
+        // ---- replay the path, remembering its vertices
+        VertexRec rec[kAdjointMaxDepth];
+        int n = 0;
+        Counters c = { 0u, 0u, 0u, 0u };
+        bool alive = true;
+        while (alive && n < kAdjointMaxDepth) { alive = bounce_step<FLAT, true>(P, lds, s, c, &rec[n]); ++n; }
+        // ---- backward sweep; a = dLoss/dT_v.  q = min(hmax(T) eta^2, .95) is differentiated like Enoki does (the
+        // gradient flows to the maximal channel when q is not clamped); the survival test is not differentiable.
+        f3 a = mk3(0.0f, 0.0f, 0.0f);
+        for (int v = n - 1; v >= 0; --v) {
+            const VertexRec &r = rec[v];
+            if (!r.has_bsdf) { a = mk3(delta.x * r.E.x, delta.y * r.E.y, delta.z * r.E.z); continue; }
+            const f3 Y = mk3(delta.x * r.Nc.x + a.x, delta.y * r.Nc.y + a.y, delta.z * r.Nc.z + a.z);
+            const f3 g = mk3(r.Tp.x * Y.x, r.Tp.y * Y.y, r.Tp.z * Y.z);
+            const f3 b = mk3(r.rho.x * Y.x, r.rho.y * Y.y, r.rho.z * Y.z);
+            if (r.texel != kNoPrim) {
+                const DevTexture t = P.sv.textures[P.sv.bsdfs[r.bsdf].texture];
+                if (A.grad_tex) {
+                    float *gt = A.grad_tex + t.grad_offset + 3u * (size_t) r.texel;
+                    const float w00 = (1.0f - r.w1.y) * (1.0f - r.w1.x), w10 = (1.0f - r.w1.y) * r.w1.x,
+                                w01 = r.w1.y * (1.0f - r.w1.x), w11 = r.w1.y * r.w1.x;
+                    const float gg[3] = { g.x, g.y, g.z };
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        atomicAdd(gt + ch, gg[ch] * w00); atomicAdd(gt + 3 + ch, gg[ch] * w10);
+                        atomicAdd(gt + 3 * t.w + ch, gg[ch] * w01); atomicAdd(gt + 3 * t.w + 3 + ch, gg[ch] * w11);
+                    }
+                }
+            } else if (A.grad_bsdf && r.bsdf >= 0 && r.bsdf < 32) {
+                atomicAdd(&s_grad[3 * r.bsdf], g.x); atomicAdd(&s_grad[3 * r.bsdf + 1], g.y); atomicAdd(&s_grad[3 * r.bsdf + 2], g.z);
+            }
+            a = mk3(delta.x * r.E.x + r.invq * b.x, delta.y * r.E.y + r.invq * b.y, delta.z * r.E.z + r.invq * b.z);
+            if (r.rr_channel >= 0) {
+                const float corr = (r.invq * r.invq) * (b.x * r.T.x + b.y * r.T.y + b.z * r.T.z);
+                if (r.rr_channel == 0) a.x -= corr; else if (r.rr_channel == 1) a.y -= corr; else a.z -= corr;
+            }
+        }
+    }
+    __syncthreads();
+    if (A.grad_bsdf)
+        for (uint32_t i = threadIdx.x; i < 3u * min(P.sv.n_bsdfs, 32u); i += kBlock)
+            if (s_grad[i] != 0.0f) atomicAdd(A.grad_bsdf + i, s_grad[i]);
+}
+
+hipError_t launch_adjoint(const AdjointParams &a, hipStream_t s) {
+    if (a.n_samples == 0) return hipSuccess;
+    uint64_t blocks = (a.n_samples + kBlock - 1) / kBlock;
+    if (blocks > 2048) blocks = 2048;
+    if (a.rp.sv.flat) hipLaunchKernelGGL(k_adjoint<true>, dim3((uint32_t) blocks), dim3(kBlock), bounce_lds_bytes(a.rp.sv), s, a);
+    else hipLaunchKernelGGL(k_adjoint<false>, dim3((uint32_t) blocks), dim3(kBlock), bounce_lds_bytes(a.rp.sv), s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// ImageBlock::put as a gather: one wave per film pixel, lanes stride over the samples of the
+// (2R+1)^2 neighbouring pixels, fixed-order butterfly reduction -> bitwise reproducible film.
 // weight of the sample at block-relative position `pos` for block pixel `t` along one axis
 // (imageblock.cpp:117-161); `size` = block extent incl. border
 MTS_DEV float axis_weight(const FilterView &f, float pos, int t, int size) {

@@ -334,19 +334,38 @@ class Scene:
             md[i].texcoords = uv.ctypes.data_as(L.f32p) if uv is not None else None
             md[i].bsdf, md[i].emitter = int(m["bsdf"]), int(m.get("emitter", -1))
         bd = (L.BsdfDesc * max(len(bsdfs), 1))()
+        tex = []                       # bitmap textures (src/textures/bitmap.cpp): reflectance = dict(type="bitmap", data=(H,W,3))
+        self._bsdf_texture = {}
         for i, b in enumerate(bsdfs):
             if b.get("type", "diffuse") != "diffuse":
                 raise RuntimeError("BSDF plugin '%s' is not supported by this backend (diffuse only)" % b.get("type"))
             bd[i].type = 0
-            bd[i].reflectance = (C.c_float * 3)(*[float(x) for x in b["reflectance"]])
-            bd[i].texture = -1
+            refl = b["reflectance"]
+            if isinstance(refl, dict):
+                if refl.get("type") != "bitmap":
+                    raise RuntimeError("Texture plugin '%s' is not supported by this backend (bitmap only)" % refl.get("type"))
+                data = _f32(refl["data"])
+                if data.ndim != 3 or data.shape[2] != 3:
+                    raise RuntimeError("bitmap texture: expected (H, W, 3) linear RGB data")
+                bd[i].reflectance = (C.c_float * 3)(0.5, 0.5, 0.5)
+                bd[i].texture = len(tex)
+                self._bsdf_texture[i] = len(tex)
+                tex.append(data)
+            else:
+                bd[i].reflectance = (C.c_float * 3)(*[float(x) for x in refl])
+                bd[i].texture = -1
+        td = (L.TextureDesc * max(len(tex), 1))()
+        for i, t in enumerate(tex):
+            td[i].width, td[i].height = t.shape[1], t.shape[0]
+            td[i].data = t.ctypes.data_as(L.f32p)
+        self._texture_shapes = [t.shape for t in tex]
         ed = (L.EmitterDesc * max(len(emitters), 1))()
         for i, e in enumerate(emitters):
             if e.get("type", "area") != "area":
                 raise RuntimeError("Emitter plugin '%s' is not supported by this backend (area only)" % e.get("type"))
             ed[i].type = 0
             ed[i].radiance = (C.c_float * 3)(*[float(x) for x in e["radiance"]])
-        sd = L.SceneDesc(md, len(meshes), bd, len(bsdfs), ed, len(emitters), None, 0)
+        sd = L.SceneDesc(md, len(meshes), bd, len(bsdfs), ed, len(emitters), td, len(tex))
         handle = C.c_void_p()
         L.check(lib.mtsamd_scene_create(C.byref(sd), self._device_index, C.byref(handle)))
         self._handle = handle
@@ -378,6 +397,26 @@ class Scene:
 
     def set_bsdf_reflectance(self, index, rgb):
         L.check(L.lib().mtsamd_scene_set_bsdf_reflectance(self._handle, int(index), (C.c_float * 3)(*[float(x) for x in rgb])))
+
+    def texture_index(self, bsdf):
+        """Index of the bitmap texture attached to BSDF `bsdf` (None if its reflectance is constant)."""
+        return self._bsdf_texture.get(int(bsdf))
+
+    def update_texture(self, texture, data):
+        """parameters_changed() for a BitmapTexture's `data` (bitmap.cpp:295-299); data: (H,W,3) tensor or array."""
+        shape = self._texture_shapes[int(texture)]
+        if isinstance(data, torch.Tensor):
+            t = data.detach().to(torch.device("cuda", self._device_index), torch.float32).contiguous()
+            if tuple(t.shape) != tuple(shape):
+                raise RuntimeError("texture data has shape %s, expected %s" % (tuple(t.shape), tuple(shape)))
+            L.check(L.lib().mtsamd_scene_update_texture(self._handle, int(texture), _ptr(t), _stream()))
+            torch.cuda.current_stream().synchronize()       # `t` may be a temporary
+        else:
+            a = _f32(data)
+            if tuple(a.shape) != tuple(shape):
+                raise RuntimeError("texture data has shape %s, expected %s" % (tuple(a.shape), tuple(shape)))
+            L.check(L.lib().mtsamd_scene_update_texture(self._handle, int(texture), a.ctypes.data_as(C.c_void_p), _stream()))
+            torch.cuda.current_stream().synchronize()
 
     def set_emitter_radiance(self, index, rgb):
         L.check(L.lib().mtsamd_scene_set_emitter_radiance(self._handle, int(index), (C.c_float * 3)(*[float(x) for x in rgb])))

@@ -50,8 +50,10 @@ def _box(quads, center):
     return pos, _orient(pos, faces, away_from=center)
 
 
-def cornell_box():
-    """36-triangle Cornell box.  Returns a scene dict; camera via :func:`cornell_box_sensor`."""
+def cornell_box(texture=None):
+    """36-triangle Cornell box.  Returns a scene dict; camera via :func:`cornell_box_sensor`.
+    texture: optional (H, W, 3) linear-RGB array used as the diffuse albedo of the back wall and the floor
+    (the five room quads then carry texcoords (0,0) (1,0) (1,1) (0,1)) -- the differentiable-rendering setup."""
     room_center = np.array([278.0, 274.4, 279.6])
     white, red, green = [0.725, 0.71, 0.68], [0.63, 0.065, 0.05], [0.14, 0.45, 0.091]
     meshes = []
@@ -67,9 +69,14 @@ def cornell_box():
         "right": ([[0, 0, 559.2], [0, 0, 0], [0, 548.8, 0], [0, 548.8, 559.2]], 2),
         "left": ([[552.8, 0, 0], [549.6, 0, 559.2], [556, 548.8, 559.2], [556, 548.8, 0]], 1),
     }
+    quad_uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], dtype=F32)
     for name, (q, bsdf) in walls.items():
         p, f = _quad(q)
+        if texture is not None and name in ("floor", "back"):
+            bsdf = 4
         add(p, _orient(p, f, towards=room_center), bsdf)
+        if texture is not None:
+            meshes[-1]["texcoords"] = quad_uv.copy()
     # area light, 0.5 below the ceiling (the cbox scene translates the luminaire by (0,-0.5,0))
     p, f = _quad([[343, 548.3, 227], [343, 548.3, 332], [213, 548.3, 332], [213, 548.3, 227]])
     add(p, _orient(p, f, towards=room_center), 3, emitter=0)
@@ -92,6 +99,8 @@ def cornell_box():
     p, f = _box(short, [185.5, 82.5, 169.0]); add(p, f, 0)
     p, f = _box(tall, [368.5, 165.0, 351.25]); add(p, f, 0)
     bsdfs = [dict(type="diffuse", reflectance=np.array(c, dtype=F32)) for c in (white, red, green, [0.78, 0.78, 0.78])]
+    if texture is not None:
+        bsdfs.append(dict(type="diffuse", reflectance=dict(type="bitmap", data=np.ascontiguousarray(texture, dtype=F32))))
     emitters = [dict(type="area", radiance=np.array([18.387, 13.9873, 6.75357], dtype=F32))]
     return dict(meshes=meshes, bsdfs=bsdfs, emitters=emitters)
 

@@ -22,6 +22,12 @@ int mo_scene_add_mesh(mo_scene *s, uint32_t n_verts, const float *positions,
                       const float *normals, const float *texcoords, uint32_t n_faces,
                       const uint32_t *faces, int bsdf_kind, const float *reflectance_rgb,
                       const float *emitter_rgb);
+/* Bitmap texture (src/textures/bitmap.cpp, linear RGB data, identity to_uv): returns its index.  A texture is
+ * attached to the reflectance of a shape's diffuse BSDF with mo_scene_set_texture (-1 detaches). */
+int mo_scene_add_texture(mo_scene *s, int width, int height, const float *rgb);
+int mo_scene_set_texture(mo_scene *s, uint32_t shape, int texture);
+int mo_scene_update_texture(mo_scene *s, uint32_t texture, const float *rgb);
+int mo_scene_set_reflectance(mo_scene *s, uint32_t shape, const float *rgb);
 /* Builds the oracle's own accelerator + emitter sampling tables. */
 int mo_scene_finalize(mo_scene *s);
 /* naive != 0: the render entry points answer every query by brute force. */
@@ -58,6 +64,7 @@ typedef struct {
     uint64_t base_seed;         /* sampler "seed" property */
     int32_t max_depth, rr_depth;
     int32_t filter_analytic;    /* 0: eval_discretized (scalar_rgb), 1: eval (gpu variants) */
+    int32_t film_rgb;           /* 0: film channels X,Y,Z,A,W; 1: R,G,B,A,W (autodiff.py:53-72) */
 } mo_render_desc;
 
 /* mode 0: scalar_rgb block mode (spiral blocks, Morton order, one PCG32 stream per block);
@@ -75,6 +82,12 @@ int mo_sample_radiance(const mo_scene *s, const mo_render_desc *d, uint64_t firs
  * [row0,row1) are traced; splats land in the full crop-sized film (for multi-GPU tests). */
 int mo_render_rows(const mo_scene *s, const mo_render_desc *d, int row0, int row1,
                    float *film_xyzaw);
+/* Reverse-mode derivative of Image = RGB / (W + 1e-8) (autodiff.py:80-91) w.r.t. diffuse reflectances, by path replay
+ * (restatement of what ek.backward() does through PathIntegrator::sample for these parameters; RR probabilities detached).
+ * dimage: crop_h*crop_w*3 = dLoss/dImage; film: the primal R,G,B,A,W film of the same desc (weights);
+ * grad_shape: n_shapes*3 (constant reflectance of each shape's BSDF), grad_tex: textures concatenated; both accumulated. */
+int mo_render_adjoint(const mo_scene *s, const mo_render_desc *d, const float *dimage, const float *film,
+                      float *grad_shape, float *grad_tex);
 /* HDRFilm::bitmap(): XYZAW -> RGBA float32 (hdrfilm.cpp:249-320, struct.cpp:1761-1811) */
 void mo_film_develop(const float *xyzaw, uint64_t n_pixels, float *rgba);
 

@@ -19,17 +19,19 @@ typedef struct { mo_v3 p, n, d; float dist, pdf; uint32_t emitter; } mo_dsample;
 typedef struct {
     uint32_t n_verts, n_faces;
     float *pos, *nrm, *uv; uint32_t *faces;
-    int bsdf_kind; float refl[3]; int emitter;
+    int bsdf_kind; float refl[3]; int emitter; int texture;
     uint32_t prim_offset;
     float *area_pmf, *area_cdf; float area_sum, area_norm; uint32_t valid_lo, valid_hi;
 } mo_mesh;
 
 typedef struct { uint32_t shape; float radiance[3]; } mo_emitter;
+typedef struct { int w, h; float *data; } mo_texture;
 typedef struct { double lo[3], hi[3]; uint32_t left, right, first, count; } mo_bvh_node;
 
 struct mo_scene {
     mo_mesh *meshes; uint32_t n_meshes;
     mo_emitter *emitters; uint32_t n_emitters;
+    mo_texture *textures; uint32_t n_textures;
     uint32_t n_prims; uint32_t *prim_shape, *prim_local;
     mo_bvh_node *bvh_nodes; uint32_t n_bvh_nodes; uint32_t *bvh_prims;
     double scene_extent; int force_naive;
@@ -47,5 +49,8 @@ uint32_t mo_distr_sample(const float *cdf, float sum, uint32_t lo, uint32_t hi, 
 uint32_t mo_distr_sample_reuse(const float *pmf, const float *cdf, float sum, float norm, uint32_t lo,
                                uint32_t hi, float value, float *reused);
 void mo_scene_set_naive(mo_scene *s, int naive);
+/* reflectance at a surface interaction: constant colour or BitmapTexture::interpolate (bitmap.cpp:250-293);
+ * footprint (may be NULL): texel index of v00 and the bilinear weights w1.x, w1.y */
+void mo_reflectance(const mo_scene *s, const mo_mesh *m, mo_v2 uv, float out[3], uint32_t *texel, float w1[2]);
 
 #endif

@@ -392,6 +392,8 @@ static void path_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, 
 
         /* --------------------- Emitter sampling --------------------- */
         const mo_mesh *mesh = &s->meshes[si.shape];
+        float refl[3];
+        mo_reflectance(s, mesh, si.uv, refl, NULL, NULL);
         {   /* diffuse has BSDFFlags::Smooth -> active_e = active */
             mo_v2 s2; s2.x = mo_pcg32_next_f32(rng); s2.y = mo_pcg32_next_f32(rng);
             mo_dsample ds; float emitter_val[3];
@@ -409,7 +411,7 @@ static void path_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, 
             if (active_e) {
                 mo_v3 wo = mo_to_local(&si.sh, ds.d);
                 float bsdf_val[3], bsdf_pdf;
-                mo_diffuse_eval_pdf(mesh->refl, si.wi, wo, bsdf_val, &bsdf_pdf);
+                mo_diffuse_eval_pdf(refl, si.wi, wo, bsdf_val, &bsdf_pdf);
                 float mis = mis_weight(ds.pdf, bsdf_pdf);
                 for (int k = 0; k < 3; ++k)
                     result[k] += ((mis * throughput[k]) * bsdf_val[k]) * emitter_val[k];
@@ -420,7 +422,7 @@ static void path_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, 
         float s1 = mo_pcg32_next_f32(rng); (void) s1;
         mo_v2 s2; s2.x = mo_pcg32_next_f32(rng); s2.y = mo_pcg32_next_f32(rng);
         mo_v3 bs_wo; float bs_pdf, bsdf_w[3];
-        mo_diffuse_sample(mesh->refl, si.wi, s2, &bs_wo, &bs_pdf, bsdf_w);
+        mo_diffuse_sample(refl, si.wi, s2, &bs_wo, &bs_pdf, bsdf_w);
         for (int k = 0; k < 3; ++k) throughput[k] = throughput[k] * bsdf_w[k];
         active = active && (throughput[0] != 0.0f || throughput[1] != 0.0f || throughput[2] != 0.0f);
         if (!active) break;
@@ -467,6 +469,7 @@ static void render_sample(const mo_scene *s, const mo_render_desc *d, const came
     path_sample(s, rng, &ray, d->max_depth, d->rr_depth, L, &valid, st);
     /* ray_weight == 1 in RGB mode (spectrum.h:304-309) */
     float xyz[3]; srgb_to_xyz(L, xyz);
+    if (d->film_rgb) { xyz[0] = L[0]; xyz[1] = L[1]; xyz[2] = L[2]; }     /* autodiff.py:53-57: linear RGB channels */
     aovs[0] = xyz[0]; aovs[1] = xyz[1]; aovs[2] = xyz[2]; aovs[3] = valid ? 1.0f : 0.0f; aovs[4] = 1.0f;
     pos_sample[0] = psx; pos_sample[1] = psy;
     if (rgb_out) { rgb_out[0] = L[0]; rgb_out[1] = L[1]; rgb_out[2] = L[2]; }
@@ -628,6 +631,175 @@ int mo_render(const mo_scene *s, const mo_render_desc *d, int mode, int n_thread
     omp_set_num_threads(prev);
 #endif
     return rc;
+}
+
+/* ================================================================== */
+/* adjoint of the path integrator w.r.t. diffuse reflectances */
+typedef struct {
+    float E[3], Nc[3], Tp[3], rho[3], invq;
+    float T[3]; int rr_channel;      /* throughput before Russian roulette; channel that sets q (-1: none / q clamped) */
+    uint32_t texel; float w1[2]; uint32_t shape; int has_bsdf;
+} vertex_rec;
+#define MO_ADJ_MAX_DEPTH 16
+
+/* PathIntegrator::sample (path.cpp:100-211) with per-vertex bookkeeping; returns the number of vertices */
+static int path_sample_rec(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, int max_depth, int rr_depth,
+                           vertex_rec *rec) {
+    mo_ray ray = *ray_in;
+    float eta = 1.0f, emission_weight = 1.0f;
+    float throughput[3] = { 1.0f, 1.0f, 1.0f };
+    ray_stats st = { 0, 0 };
+    mo_si si;
+    int si_valid = scene_intersect(s, &ray, &si, &st);
+    int emitter = si_valid ? s->meshes[si.shape].emitter : -1;
+    int active = 1, n = 0;
+    for (int depth = 1; n < MO_ADJ_MAX_DEPTH; ++depth) {
+        vertex_rec *r = &rec[n++];
+        memset(r, 0, sizeof(*r));
+        r->invq = 1.0f; r->texel = 0xffffffffu; r->rr_channel = -1;
+        if (emitter >= 0 && active && si.wi.z > 0.0f) {
+            const float *le = s->emitters[emitter].radiance;
+            for (int k = 0; k < 3; ++k) r->E[k] = emission_weight * le[k];
+        }
+        active = active && si_valid;
+        if (depth > rr_depth) {
+            float hm = fmaxf(fmaxf(throughput[0], throughput[1]), throughput[2]);
+            float q = fminf(hm * (eta * eta), 0.95f);
+            if (active) active = mo_pcg32_next_f32(rng) < q;
+            float rq = mo_rcp(q);
+            for (int k = 0; k < 3; ++k) r->T[k] = throughput[k];
+            if (hm * (eta * eta) < 0.95f) r->rr_channel = throughput[0] == hm ? 0 : (throughput[1] == hm ? 1 : 2);
+            for (int k = 0; k < 3; ++k) throughput[k] *= rq;
+            r->invq = rq;
+        }
+        if ((uint32_t) depth >= (uint32_t) max_depth || !active) break;
+        const mo_mesh *mesh = &s->meshes[si.shape];
+        float refl[3];
+        mo_reflectance(s, mesh, si.uv, refl, &r->texel, r->w1);
+        r->has_bsdf = 1; r->shape = si.shape;
+        for (int k = 0; k < 3; ++k) { r->Tp[k] = throughput[k]; r->rho[k] = refl[k]; }
+        {
+            mo_v2 s2; s2.x = mo_pcg32_next_f32(rng); s2.y = mo_pcg32_next_f32(rng);
+            mo_dsample ds; float emitter_val[3];
+            mo_sample_emitter_direction(s, si.p, s2, &ds, emitter_val);
+            if (ds.pdf != 0.0f && s->n_emitters > 0) {
+                mo_ray sr;
+                sr.o = si.p; sr.d = ds.d;
+                sr.mint = MO_RAY_EPSILON * (1.0f + mo_hmax_abs(si.p));
+                sr.maxt = ds.dist * (1.0f - MO_SHADOW_EPSILON);
+                if (mo_intersect(s, &sr, 1, 0, NULL)) emitter_val[0] = emitter_val[1] = emitter_val[2] = 0.0f;
+                mo_v3 wo = mo_to_local(&si.sh, ds.d);
+                if (si.wi.z > 0.0f && wo.z > 0.0f) {
+                    float bsdf_pdf = mo_square_to_cosine_hemisphere_pdf(wo);
+                    float k = mis_weight(ds.pdf, bsdf_pdf) * (MO_INV_PI * wo.z);
+                    for (int c = 0; c < 3; ++c) r->Nc[c] = k * emitter_val[c];
+                }
+            }
+        }
+        float s1 = mo_pcg32_next_f32(rng); (void) s1;
+        mo_v2 s2; s2.x = mo_pcg32_next_f32(rng); s2.y = mo_pcg32_next_f32(rng);
+        mo_v3 bs_wo; float bs_pdf, bsdf_w[3];
+        mo_diffuse_sample(refl, si.wi, s2, &bs_wo, &bs_pdf, bsdf_w);
+        for (int k = 0; k < 3; ++k) throughput[k] = throughput[k] * bsdf_w[k];
+        active = active && (throughput[0] != 0.0f || throughput[1] != 0.0f || throughput[2] != 0.0f);
+        if (!active) break;
+        ray.o = si.p; ray.d = mo_to_world(&si.sh, bs_wo);
+        ray.mint = (1.0f + mo_hmax_abs(si.p)) * MO_RAY_EPSILON;
+        ray.maxt = INFINITY;
+        mo_si si_bsdf;
+        int v2 = scene_intersect(s, &ray, &si_bsdf, &st);
+        emitter = v2 ? s->meshes[si_bsdf.shape].emitter : -1;
+        if (emitter >= 0) {
+            mo_v3 d = mo_sub(si_bsdf.p, si.p);
+            float dist = mo_norm(d);
+            d = mo_div_s(d, dist);
+            emission_weight = mis_weight(bs_pdf, mo_pdf_emitter_direction(s, (uint32_t) emitter, d, si_bsdf.sh.n, dist));
+        }
+        si = si_bsdf; si_valid = v2;
+    }
+    return n;
+}
+
+int mo_render_adjoint(const mo_scene *s, const mo_render_desc *d, const float *dimage, const float *film,
+                      float *grad_shape, float *grad_tex) {
+    if (desc_check(d) || d->max_depth < 0 || d->max_depth > MO_ADJ_MAX_DEPTH) return -1;
+    camera cam; camera_init(d, &cam);
+    rfilter f; rfilter_init(&f, d->rfilter, d->rfilter_param);
+    uint32_t taps = (uint32_t) ceilf((f.radius - 2.0f * MO_RAY_EPSILON) * 2.0f);
+    /* texture gradient offsets: concatenated in index order */
+    size_t *toff = (size_t *) calloc(s->n_textures + 1, sizeof(size_t));
+    for (uint32_t t = 0; t < s->n_textures; ++t) toff[t + 1] = toff[t] + 3 * (size_t) s->textures[t].w * s->textures[t].h;
+    uint64_t total = (uint64_t) d->crop_w * d->crop_h * (uint64_t) d->spp;
+    for (uint64_t i = 0; i < total; ++i) {
+        mo_pcg32 rng; seed_wavefront(&rng, i, d->base_seed);
+        uint64_t pixel = i / (uint64_t) d->spp;
+        float px0 = (float) (uint32_t) (pixel % (uint64_t) d->crop_w) + (float) d->crop_x, py0 = (float) (uint32_t) (pixel / (uint64_t) d->crop_w) + (float) d->crop_y;
+        float jx = mo_pcg32_next_f32(&rng), jy = mo_pcg32_next_f32(&rng);
+        float psx = px0 + jx, psy = py0 + jy;
+        (void) mo_pcg32_next_f32(&rng);
+        float ax = (psx - (float) d->crop_x) / (float) d->crop_w, ay = (psy - (float) d->crop_y) / (float) d->crop_h;
+        mo_ray ray; camera_sample_ray(&cam, ax, ay, &ray);
+        /* delta = dLoss/dRadiance of this sample */
+        float delta[3] = { 0, 0, 0 };
+        float px = psx - ((float) d->crop_x + 0.5f), py = psy - ((float) d->crop_y + 0.5f);
+        if (f.radius > 1.0f) {
+            int lox = (int) ceilf(px - f.radius), loy = (int) ceilf(py - f.radius);
+            int hix = (int) floorf(px + f.radius), hiy = (int) floorf(py + f.radius);
+            if (lox < 0) lox = 0;
+            if (loy < 0) loy = 0;
+            if (hix > d->crop_w - 1) hix = d->crop_w - 1;
+            if (hiy > d->crop_h - 1) hiy = d->crop_h - 1;
+            float bx = (float) (uint32_t) lox - px, by = (float) (uint32_t) loy - py;
+            for (uint32_t yr = 0; yr < taps && loy + (int) yr <= hiy; ++yr) {
+                float wy = d->filter_analytic ? rfilter_eval(&f, by + (float) yr) : rfilter_eval_discretized(&f, by + (float) yr);
+                for (uint32_t xr = 0; xr < taps && lox + (int) xr <= hix; ++xr) {
+                    float wx = d->filter_analytic ? rfilter_eval(&f, bx + (float) xr) : rfilter_eval_discretized(&f, bx + (float) xr);
+                    size_t pix = (size_t) (loy + (int) yr) * d->crop_w + (size_t) (lox + (int) xr);
+                    float iw = (wy * wx) / (film[5 * pix + 4] + 1e-8f);
+                    for (int c = 0; c < 3; ++c) delta[c] += iw * dimage[3 * pix + c];
+                }
+            }
+        } else {
+            int lox = (int) ceilf(px - 0.5f), loy = (int) ceilf(py - 0.5f);
+            if (lox >= 0 && loy >= 0 && lox < d->crop_w && loy < d->crop_h) {
+                size_t pix = (size_t) loy * d->crop_w + (size_t) lox;
+                float iw = 1.0f / (film[5 * pix + 4] + 1e-8f);
+                for (int c = 0; c < 3; ++c) delta[c] = iw * dimage[3 * pix + c];
+            }
+        }
+        vertex_rec rec[MO_ADJ_MAX_DEPTH];
+        int n = path_sample_rec(s, &rng, &ray, d->max_depth, d->rr_depth, rec);
+        /* backward sweep; a = dLoss/dT_v (throughput arriving at vertex v).  q = min(hmax(T) eta^2, .95) is
+         * differentiated like Enoki does (gradient flows to the maximal channel when q is not clamped); the
+         * survival test itself is not differentiable. */
+        float a[3] = { 0, 0, 0 };
+        for (int v = n - 1; v >= 0; --v) {
+            const vertex_rec *r = &rec[v];
+            if (!r->has_bsdf) { for (int c = 0; c < 3; ++c) a[c] = delta[c] * r->E[c]; continue; }
+            float Y[3], g[3], b[3];
+            for (int c = 0; c < 3; ++c) { Y[c] = delta[c] * r->Nc[c] + a[c]; g[c] = r->Tp[c] * Y[c]; b[c] = r->rho[c] * Y[c]; }
+            if (r->texel != 0xffffffffu) {
+                if (grad_tex) {
+                    int ti = s->meshes[r->shape].texture;
+                    const mo_texture *t = &s->textures[ti];
+                    float *gt = grad_tex + toff[ti] + 3 * (size_t) r->texel;
+                    float w00 = (1.0f - r->w1[1]) * (1.0f - r->w1[0]), w10 = (1.0f - r->w1[1]) * r->w1[0];
+                    float w01 = r->w1[1] * (1.0f - r->w1[0]), w11 = r->w1[1] * r->w1[0];
+                    for (int c = 0; c < 3; ++c) {
+                        gt[c] += g[c] * w00; gt[3 + c] += g[c] * w10;
+                        gt[3 * t->w + c] += g[c] * w01; gt[3 * t->w + 3 + c] += g[c] * w11;
+                    }
+                }
+            } else if (grad_shape) {
+                for (int c = 0; c < 3; ++c) grad_shape[3 * r->shape + c] += g[c];
+            }
+            for (int c = 0; c < 3; ++c) a[c] = delta[c] * r->E[c] + r->invq * b[c];
+            if (r->rr_channel >= 0)
+                a[r->rr_channel] -= (r->invq * r->invq) * (b[0] * r->T[0] + b[1] * r->T[1] + b[2] * r->T[2]);
+        }
+    }
+    free(toff);
+    return 0;
 }
 
 /* HDRFilm::bitmap: (X,Y,Z,A) * (1/W), RGB = M * XYZ (hdrfilm.cpp:278-299, struct.cpp:1761-1811) */

@@ -37,6 +37,8 @@ void mo_scene_free(mo_scene *s) {
         free(m->pos); free(m->nrm); free(m->uv); free(m->faces);
         free(m->area_pmf); free(m->area_cdf);
     }
+    for (uint32_t i = 0; i < s->n_textures; ++i) free(s->textures[i].data);
+    free(s->textures);
     free(s->meshes); free(s->emitters); free(s->prim_shape); free(s->prim_local);
     free(s->bvh_nodes); free(s->bvh_prims);
     free(s);
@@ -65,7 +67,7 @@ int mo_scene_add_mesh(mo_scene *s, uint32_t n_verts, const float *positions, con
     m->faces = (uint32_t *) dup_mem(faces, sizeof(uint32_t) * 3 * n_faces);
     m->bsdf_kind = bsdf_kind;
     for (int k = 0; k < 3; ++k) m->refl[k] = reflectance_rgb ? reflectance_rgb[k] : 0.5f;
-    m->emitter = -1;
+    m->emitter = -1; m->texture = -1;
     if (emitter_rgb) {
         s->emitters = (mo_emitter *) realloc(s->emitters, sizeof(mo_emitter) * (s->n_emitters + 1));
         mo_emitter *e = &s->emitters[s->n_emitters];
@@ -74,6 +76,55 @@ int mo_scene_add_mesh(mo_scene *s, uint32_t n_verts, const float *positions, con
         m->emitter = (int) s->n_emitters++;
     }
     return (int) s->n_meshes++;
+}
+
+int mo_scene_add_texture(mo_scene *s, int width, int height, const float *rgb) {
+    if (!s || width < 2 || height < 2 || !rgb) return -1;
+    s->textures = (mo_texture *) realloc(s->textures, sizeof(mo_texture) * (s->n_textures + 1));
+    mo_texture *t = &s->textures[s->n_textures];
+    t->w = width; t->h = height;
+    t->data = (float *) dup_mem(rgb, sizeof(float) * 3 * (size_t) width * height);
+    return (int) s->n_textures++;
+}
+int mo_scene_set_texture(mo_scene *s, uint32_t shape, int texture) {
+    if (!s || shape >= s->n_meshes || texture >= (int) s->n_textures) return -1;
+    s->meshes[shape].texture = texture;
+    return 0;
+}
+int mo_scene_update_texture(mo_scene *s, uint32_t texture, const float *rgb) {
+    if (!s || texture >= s->n_textures) return -1;
+    mo_texture *t = &s->textures[texture];
+    memcpy(t->data, rgb, sizeof(float) * 3 * (size_t) t->w * t->h);
+    return 0;
+}
+int mo_scene_set_reflectance(mo_scene *s, uint32_t shape, const float *rgb) {
+    if (!s || shape >= s->n_meshes) return -1;
+    for (int k = 0; k < 3; ++k) s->meshes[shape].refl[k] = rgb[k];
+    return 0;
+}
+
+/* BitmapTextureImpl::interpolate (bitmap.cpp:250-293), identity to_uv */
+void mo_reflectance(const mo_scene *s, const mo_mesh *m, mo_v2 uv, float out[3], uint32_t *texel, float w1o[2]) {
+    if (m->texture < 0) {
+        for (int k = 0; k < 3; ++k) out[k] = m->refl[k];
+        if (texel) *texel = 0xffffffffu;
+        return;
+    }
+    const mo_texture *t = &s->textures[m->texture];
+    float ux = uv.x - floorf(uv.x), uy = uv.y - floorf(uv.y);
+    ux *= (float) (uint32_t) (t->w - 1); uy *= (float) (uint32_t) (t->h - 1);
+    uint32_t px = (uint32_t) ux, py = (uint32_t) uy;
+    if (px > (uint32_t) (t->w - 2)) px = (uint32_t) (t->w - 2);
+    if (py > (uint32_t) (t->h - 2)) py = (uint32_t) (t->h - 2);
+    float w1x = ux - (float) px, w1y = uy - (float) py, w0x = 1.0f - w1x, w0y = 1.0f - w1y;
+    uint32_t index = px + py * (uint32_t) t->w, width = (uint32_t) t->w;
+    const float *v00 = t->data + 3 * (size_t) index, *v10 = v00 + 3, *v01 = t->data + 3 * (size_t) (index + width), *v11 = v01 + 3;
+    for (int k = 0; k < 3; ++k) {
+        float v0 = fmaf(w0x, v00[k], w1x * v10[k]), v1 = fmaf(w0x, v01[k], w1x * v11[k]);
+        out[k] = fmaf(w0y, v0, w1y * v1);
+    }
+    if (texel) *texel = index;
+    if (w1o) { w1o[0] = w1x; w1o[1] = w1y; }
 }
 
 static inline mo_v3 vtx(const mo_mesh *m, uint32_t i) {

@@ -18,7 +18,8 @@ class RenderDesc(C.Structure):
     _fields_ = [("to_world", C.c_float * 16), ("fov_x_deg", C.c_float), ("near_clip", C.c_float), ("far_clip", C.c_float),
                 ("film_w", C.c_int32), ("film_h", C.c_int32), ("crop_x", C.c_int32), ("crop_y", C.c_int32), ("crop_w", C.c_int32),
                 ("crop_h", C.c_int32), ("rfilter", C.c_int32), ("rfilter_param", C.c_float), ("spp", C.c_int32),
-                ("base_seed", C.c_uint64), ("max_depth", C.c_int32), ("rr_depth", C.c_int32), ("filter_analytic", C.c_int32)]
+                ("base_seed", C.c_uint64), ("max_depth", C.c_int32), ("rr_depth", C.c_int32), ("filter_analytic", C.c_int32),
+                ("film_rgb", C.c_int32)]
 
 
 _lib = None
@@ -38,6 +39,10 @@ def lib():
         L.mo_scene_free.argtypes = [C.c_void_p]
         L.mo_scene_add_mesh.argtypes = [C.c_void_p, C.c_uint32, f32p, f32p, f32p, C.c_uint32, u32p, C.c_int, f32p, f32p]
         L.mo_scene_finalize.argtypes = [C.c_void_p]
+        L.mo_scene_add_texture.argtypes = [C.c_void_p, C.c_int, C.c_int, f32p]
+        L.mo_scene_set_texture.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
+        L.mo_scene_update_texture.argtypes = [C.c_void_p, C.c_uint32, f32p]
+        L.mo_scene_set_reflectance.argtypes = [C.c_void_p, C.c_uint32, f32p]
         L.mo_scene_set_naive.argtypes = [C.c_void_p, C.c_int]
         L.mo_scene_prim_count.argtypes = [C.c_void_p]
         L.mo_scene_prim_count.restype = C.c_uint32
@@ -51,6 +56,7 @@ def lib():
         L.mo_sample_radiance.argtypes = [vp, C.POINTER(RenderDesc), C.c_uint64, C.c_uint64, vp, vp]
         L.mo_render_rows.argtypes = [vp, C.POINTER(RenderDesc), C.c_int, C.c_int, vp]
         L.mo_film_develop.argtypes = [vp, C.c_uint64, vp]
+        L.mo_render_adjoint.argtypes = [vp, C.POINTER(RenderDesc), vp, vp, vp, vp]
         L.mo_camera_rays.argtypes = [C.POINTER(RenderDesc), C.c_uint64] + [vp] * 6
         L.mo_imageblock_put.argtypes = [C.c_int] * 6 + [C.c_float, C.c_int, C.c_int, C.c_uint64, vp, vp, vp]
         L.mo_rfilter_table.argtypes = [C.c_int, C.c_float, vp, f32p, C.POINTER(C.c_int)]
@@ -89,17 +95,29 @@ class OracleScene:
     def __init__(self, scene_dict, naive=False):
         L = lib()
         self.h = C.c_void_p(L.mo_scene_new())
+        self.tex_of_bsdf = {}
+        for bi, b in enumerate(scene_dict["bsdfs"]):
+            if isinstance(b["reflectance"], dict):
+                data = _f(b["reflectance"]["data"])
+                self.tex_of_bsdf[bi] = L.mo_scene_add_texture(self.h, data.shape[1], data.shape[0], data.ctypes.data_as(f32p))
+                assert self.tex_of_bsdf[bi] >= 0
+        self.shapes_of_bsdf = {}
+        for si, m in enumerate(scene_dict["meshes"]):
+            self.shapes_of_bsdf.setdefault(m["bsdf"], []).append(si)
         for m in scene_dict["meshes"]:
             pos = _f(m["positions"]).reshape(-1, 3)
             faces = np.ascontiguousarray(m["faces"], dtype=np.uint32).reshape(-1, 3)
             nrm = _f(m["normals"]) if m.get("normals") is not None else None
             uv = _f(m["texcoords"]) if m.get("texcoords") is not None else None
-            refl = _f(scene_dict["bsdfs"][m["bsdf"]]["reflectance"])
+            rb = scene_dict["bsdfs"][m["bsdf"]]["reflectance"]
+            refl = _f([0.5, 0.5, 0.5]) if isinstance(rb, dict) else _f(rb)
             em = _f(scene_dict["emitters"][m["emitter"]]["radiance"]) if m.get("emitter", -1) >= 0 else None
             rc = L.mo_scene_add_mesh(self.h, pos.shape[0], pos.ctypes.data_as(f32p), nrm.ctypes.data_as(f32p) if nrm is not None else None,
                                      uv.ctypes.data_as(f32p) if uv is not None else None, faces.shape[0], faces.ctypes.data_as(u32p), 0,
                                      refl.ctypes.data_as(f32p), em.ctypes.data_as(f32p) if em is not None else None)
             assert rc >= 0, rc
+            if m["bsdf"] in self.tex_of_bsdf:
+                assert L.mo_scene_set_texture(self.h, rc, self.tex_of_bsdf[m["bsdf"]]) == 0
         assert L.mo_scene_finalize(self.h) == 0
         L.mo_scene_set_naive(self.h, 1 if naive else 0)
 
@@ -107,6 +125,15 @@ class OracleScene:
         if getattr(self, "h", None):
             lib().mo_scene_free(self.h)
             self.h = None
+
+    def update_texture(self, bsdf, data):
+        data = _f(data)
+        assert lib().mo_scene_update_texture(self.h, self.tex_of_bsdf[bsdf], data.ctypes.data_as(f32p)) == 0
+
+    def set_bsdf_reflectance(self, bsdf, rgb):
+        rgb = _f(rgb)
+        for si in self.shapes_of_bsdf.get(bsdf, []):
+            assert lib().mo_scene_set_reflectance(self.h, si, rgb.ctypes.data_as(f32p)) == 0
 
     def set_naive(self, naive):
         lib().mo_scene_set_naive(self.h, 1 if naive else 0)
@@ -149,6 +176,20 @@ class OracleScene:
         assert lib().mo_render_rows(self.h, C.byref(desc), row0, row1, _p(film)) == 0
         return film
 
+    def render_image(self, desc):
+        """mitsuba.python.autodiff._render_helper: RGB / (W + 1e-8), plus the film (desc.film_rgb must be 1)."""
+        assert desc.film_rgb == 1
+        film, _ = self.render(desc, mode=1)
+        return film[..., :3] / (film[..., 4:5] + np.float32(1e-8)), film
+
+    def render_adjoint(self, desc, dimage, film, n_shapes, tex_floats):
+        dimage = _f(dimage); film = _f(film)
+        gs = np.zeros((n_shapes, 3), np.float32); gt = np.zeros(max(tex_floats, 1), np.float32)
+        rc = lib().mo_render_adjoint(self.h, C.byref(desc), _p(dimage), _p(film), _p(gs), _p(gt))
+        if rc != 0:
+            raise RuntimeError("oracle adjoint failed (%d)" % rc)
+        return gs, gt[:tex_floats]
+
     def sample_radiance(self, desc, first, count):
         rgba = np.empty((count, 4), np.float32); pos = np.empty((count, 2), np.float32)
         assert lib().mo_sample_radiance(self.h, C.byref(desc), first, count, _p(rgba), _p(pos)) == 0
@@ -160,7 +201,7 @@ class OracleScene:
         return out
 
 
-def make_desc(params, analytic=False):
+def make_desc(params, analytic=False, film_rgb=False):
     """scenes.*_sensor() dict -> oracle RenderDesc (fov must already be the horizontal fov)."""
     d = RenderDesc()
     d.to_world = (C.c_float * 16)(*np.asarray(params["to_world"], dtype=np.float32).reshape(-1).tolist())
@@ -174,6 +215,7 @@ def make_desc(params, analytic=False):
     d.base_seed = params["seed"]
     d.max_depth, d.rr_depth = params["max_depth"], params["rr_depth"]
     d.filter_analytic = 1 if analytic else 0
+    d.film_rgb = 1 if film_rgb else 0
     return d
 
 

@@ -1,0 +1,67 @@
+"""The oracle's adjoint (reverse-mode derivative of Image = RGB / (W + 1e-8) w.r.t. diffuse reflectances) against
+central finite differences of the oracle's own forward render with identical sampler seeds.  The reference's
+gradients come from Enoki's autodiff, which is absent: no golden gradient exists in-tree ("parity unpinned"), so the
+derivative is pinned by the forward pass it differentiates."""
+import numpy as np
+import pytest
+
+from mitsuba2_amd import scenes
+
+
+def _setup(oracle, rfilter, max_depth, tex_res=(4, 5)):
+    rng = np.random.RandomState(1)
+    tex = (0.3 + 0.5 * rng.rand(tex_res[0], tex_res[1], 3)).astype(np.float32)
+    sd = scenes.cornell_box(texture=tex)
+    p = scenes.cornell_box_sensor(12, 10, 4, seed=5, max_depth=max_depth, rfilter=rfilter)
+    desc = oracle.make_desc(p, analytic=True, film_rgb=True)
+    return sd, tex, desc
+
+
+@pytest.mark.parametrize("rfilter,max_depth", [("box", 3), ("gaussian", 4), ("box", 8)])
+def test_oracle_adjoint_matches_finite_differences(oracle, rfilter, max_depth):
+    sd, tex, desc = _setup(oracle, rfilter, max_depth)
+    S = oracle.OracleScene(sd, naive=True)
+    image, film = S.render_image(desc)
+    rng = np.random.RandomState(2)
+    dimage = rng.randn(*image.shape).astype(np.float32)          # arbitrary cotangent: loss = <dimage, image>
+    n_shapes = len(sd["meshes"])
+    gs, gt = S.render_adjoint(desc, dimage, film, n_shapes, tex.size)
+    gt = gt.reshape(tex.shape)
+    loss = lambda img: float(np.sum(img.astype(np.float64) * dimage))
+
+    # (a) texels: central differences (the image is multilinear in the texels)
+    eps = 1e-2
+    checked = 0
+    for (ty, tx, c) in [(0, 0, 0), (1, 2, 1), (3, 4, 2), (2, 1, 0), (1, 3, 2)]:
+        tp, tm = tex.copy(), tex.copy()
+        tp[ty, tx, c] += eps; tm[ty, tx, c] -= eps
+        S.update_texture(4, tp); lp = loss(S.render_image(desc)[0])
+        S.update_texture(4, tm); lm = loss(S.render_image(desc)[0])
+        fd = (lp - lm) / (2 * eps)
+        assert abs(fd - gt[ty, tx, c]) <= 2e-3 * max(abs(fd), abs(gt).max()) + 1e-5, (ty, tx, c, fd, gt[ty, tx, c])
+        checked += abs(fd) > 1e-6
+    S.update_texture(4, tex)
+    assert checked >= 3
+
+    # (b) constant reflectance of the red wall (bsdf 1 -> the "left" quad) and of the white bsdf (ceiling, right-side boxes)
+    for bsdf, c in ((1, 0), (1, 2), (0, 1)):
+        base = np.array(sd["bsdfs"][bsdf]["reflectance"], np.float32)
+        shapes = [i for i, m in enumerate(sd["meshes"]) if m["bsdf"] == bsdf]
+        vp, vm = base.copy(), base.copy()
+        vp[c] += eps; vm[c] -= eps
+        S.set_bsdf_reflectance(bsdf, vp); lp = loss(S.render_image(desc)[0])
+        S.set_bsdf_reflectance(bsdf, vm); lm = loss(S.render_image(desc)[0])
+        S.set_bsdf_reflectance(bsdf, base)
+        fd = (lp - lm) / (2 * eps)
+        g = gs[shapes, c].sum()
+        # a BSDF shared by several vertices of one path makes the image polynomial, not linear: FD has O(eps^2) error
+        assert abs(fd - g) <= 5e-3 * max(abs(fd), 1e-3) + 1e-5, (bsdf, c, fd, g)
+
+
+def test_adjoint_argument_checks(oracle):
+    sd, tex, desc = _setup(oracle, "box", 3)
+    S = oracle.OracleScene(sd, naive=True)
+    image, film = S.render_image(desc)
+    desc.max_depth = -1
+    with pytest.raises(RuntimeError):
+        S.render_adjoint(desc, np.zeros_like(image), film, len(sd["meshes"]), tex.size)
