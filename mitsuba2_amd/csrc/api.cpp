@@ -378,11 +378,14 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     SceneView &v = s->view;
     v.nodes = s->d_nodes; v.tris = s->d_tris; v.root = s->bvh.root;
     v.n_nodes = s->bvh.n_nodes; v.n_slots = s->bvh.n_slots; v.n_prims = s->n_prims;
-    // LDS residency: the whole accelerator when it is small (Cornell-box class scenes), else the
-    // top of the tree (nodes are stored in BFS order).
+    // LDS residency: flat scenes keep everything in LDS (see flat_recs below).  For hierarchy scenes staging the
+    // top of the tree (nodes are stored in BFS order) was measured to LOSE: 384 staged nodes 2.5-3.2 Gray/s vs none
+    // 3.8-4.8 Gray/s on a 261 k-triangle mesh -- the 24 KB cost occupancy and the LDS/global select compiles to
+    // generic (flat) loads, while the top levels stay L1/L2-resident anyway.  Only the traversal stack lives in LDS.
     const size_t small_budget = 40 * 1024;
     if ((size_t) 64 * v.n_nodes + (size_t) 48 * v.n_slots <= small_budget) { v.lds_nodes = v.n_nodes; v.lds_slots = v.n_slots; }
-    else { v.lds_nodes = std::min<uint32_t>(v.n_nodes, 384); v.lds_slots = 0; }
+    else { v.lds_nodes = 0; v.lds_slots = 0; }
+    if (const char *e = getenv("MTSAMD_LDS_NODES")) { v.lds_nodes = std::min<uint32_t>(v.n_nodes, (uint32_t) atoi(e)); v.lds_slots = 0; }   // experiment switch
     v.stack_depth = std::max<uint32_t>(s->bvh.depth, 2);
     v.tri_pos = s->d_tri_pos; v.tri_nrm = any_nrm ? s->d_tri_nrm : nullptr; v.tri_uv = any_uv ? s->d_tri_uv : nullptr;
     v.prim_shape = s->d_prim_shape; v.shapes = s->d_shapes; v.bsdfs = s->d_bsdfs;
