@@ -82,6 +82,12 @@ typedef struct {
     const mtsamd_bsdf_desc *bsdfs;        uint32_t bsdf_count;
     const mtsamd_emitter_desc *emitters;  uint32_t emitter_count;
     const mtsamd_texture_desc *textures;  uint32_t texture_count;
+    /* variant: 0 = *_rgb, 1 = *_spectral (4 wavelength samples, mitsuba.conf.template:135-138).  In spectral mode
+     * RGB reflectances become SRGBReflectanceSpectrum and RGB radiances SRGBEmitterSpectrum (src/libcore/xml.cpp:1045-1146,
+     * src/spectra/srgb.cpp, srgb_d65.cpp) through the coefficient table at rgb2spec_path ("data/srgb.coeff" in the
+     * reference, src/librender/srgb.cpp:14-40; see mtsamd_rgb2spec_build). */
+    int32_t spectral;
+    const char *rgb2spec_path;
 } mtsamd_scene_desc;
 
 /* Scene::Scene + accel_init (src/librender/scene.cpp:22-98): uploads the geometry to
@@ -209,6 +215,13 @@ int mtsamd_render_adjoint(mtsamd_scene *scene, const mtsamd_render_desc *desc, c
 /* Size of a bitmap texture and its float offset inside the concatenated texture-gradient buffer. */
 int mtsamd_scene_texture_info(const mtsamd_scene *scene, uint32_t texture, int32_t *width, int32_t *height,
                               uint64_t *grad_offset);
+
+/* Generates the RGB -> spectrum coefficient table (the reference builds it at compile time with
+ * ext/rgb2spec/rgb2spec_opt.cpp <resolution = 64> srgb.coeff, ext/rgb2spec/CMakeLists.txt:49-54) and writes it to
+ * `path` in the same "SPEC" file format.  Host only; takes about a minute at resolution 64 on 8 threads. */
+int mtsamd_rgb2spec_build(const char *path, int32_t resolution, int32_t threads);
+/* srgb_model_fetch (src/librender/srgb.cpp:14-40): coefficients of the smooth spectrum for a linear sRGB colour. */
+int mtsamd_srgb_model_fetch(const char *path, const float *rgb3, float *coeff3);
 
 /* PerspectiveCamera::sample_ray (perspective.cpp:153-188) for n film-plane samples in [0,1)^2
  * (device SoA in, device SoA out). */

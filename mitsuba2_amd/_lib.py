@@ -37,7 +37,8 @@ class TextureDesc(C.Structure):
 class SceneDesc(C.Structure):
     _fields_ = [("meshes", C.POINTER(MeshDesc)), ("mesh_count", C.c_uint32), ("bsdfs", C.POINTER(BsdfDesc)),
                 ("bsdf_count", C.c_uint32), ("emitters", C.POINTER(EmitterDesc)), ("emitter_count", C.c_uint32),
-                ("textures", C.POINTER(TextureDesc)), ("texture_count", C.c_uint32)]
+                ("textures", C.POINTER(TextureDesc)), ("texture_count", C.c_uint32),
+                ("spectral", C.c_int32), ("rgb2spec_path", C.c_char_p)]
 
 
 class Rays(C.Structure):
@@ -72,6 +73,8 @@ SYMBOLS = {
     "mtsamd_ray_intersect_si": (C.c_int, [vp, C.c_uint64, C.POINTER(Rays), vp, vp, vp, vp, vp]),
     "mtsamd_render": (C.c_int, [vp, C.POINTER(RenderDesc), vp, u64p, vp]),
     "mtsamd_cancel": (C.c_int, [vp]),
+    "mtsamd_rgb2spec_build": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32]),
+    "mtsamd_srgb_model_fetch": (C.c_int, [C.c_char_p, f32p, f32p]),
     "mtsamd_render_adjoint": (C.c_int, [vp, C.POINTER(RenderDesc), vp, vp, vp, vp, vp]),
     "mtsamd_scene_texture_info": (C.c_int, [vp, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), u64p]),
     "mtsamd_sample_radiance": (C.c_int, [vp, C.POINTER(RenderDesc), C.c_uint64, C.c_uint64, vp, vp, vp]),

@@ -10,6 +10,8 @@
 #include "../../include/mtsamd.h"
 #include "bvh.h"
 #include "kernels.h"
+#include "spectral_upsampling.h"
+#include "cie_data.h"
 
 #include <algorithm>
 #include <atomic>
@@ -140,6 +142,7 @@ template <typename T> int upload(T **dst, const std::vector<T> &src) {
 struct Workspace {
     uint32_t n_waves = 0, seg_cap = 0;
     uint64_t pass_cap = 0;
+    bool spectral = false;
     PoolView pool[2] = {};
     uint32_t *count[2] = { nullptr, nullptr };
     uint64_t *cursor = nullptr, *cursor_end = nullptr, *wave_stats = nullptr;
@@ -155,6 +158,7 @@ struct Workspace {
         for (int k = 0; k < 2; ++k) {
             (void) hipFree(pool[k].ray_o); (void) hipFree(pool[k].ray_d); (void) hipFree(pool[k].thr); (void) hipFree(pool[k].res);
             (void) hipFree(pool[k].rng); (void) hipFree(pool[k].misc); (void) hipFree(count[k]);
+            (void) hipFree(pool[k].wav); (void) hipFree(pool[k].aux);
             pool[k] = PoolView{}; count[k] = nullptr;
         }
         (void) hipFree(cursor); (void) hipFree(cursor_end); (void) hipFree(wave_stats); (void) hipFree(cursor_pix); (void) hipFree(cursor_rem);
@@ -187,6 +191,7 @@ struct mtsamd_scene {
     std::vector<DevTexture> textures;       // device data pointers, owned
     DevTexture *d_textures = nullptr;
     SceneView view{};
+    bool spectral = false;
     Workspace ws;
     std::atomic<int> cancel{ 0 };
 };
@@ -309,12 +314,45 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         }
         off += m.face_count;
     }
+    // spectral variant: RGB -> spectrum coefficients on the host (srgb.cpp:31-41, srgb_d65.cpp:31-46)
+    Rgb2Spec model;
+    if (desc->spectral) {
+        if (desc->texture_count) { delete s; return fail(MTSAMD_ERR_UNSUPPORTED, "bitmap textures are not supported by the spectral variant"); }
+        if (!desc->rgb2spec_path || !rgb2spec_load(desc->rgb2spec_path, model)) {
+            delete s;
+            return fail(MTSAMD_ERR_INVALID, "Could not load sRGB-to-spectrum upsampling model ('%s'); build it with mtsamd_rgb2spec_build",
+                        desc->rgb2spec_path ? desc->rgb2spec_path : "(null)");
+        }
+        s->spectral = true;
+        for (uint32_t e = 0; e < desc->emitter_count; ++e) {
+            const float *c = desc->emitters[e].radiance;
+            float color[3] = { c[0], c[1], c[2] };
+            float scale = std::max(std::max(color[0], color[1]), color[2]) * 2.0f;
+            if (scale != 0.0f) { float r = 1.0f / scale; for (float &v : color) v *= r; }
+            float coeff[3];
+            srgb_model_fetch(model, color, coeff);
+            float d65_scale = 1.0f * scale;
+            d65_scale *= 1.0f / 10568.0f;                      // d65.cpp:44-50
+            DevEmitter &d = s->emitters[e];
+            d.c0 = coeff[0]; d.c1 = coeff[1]; d.c2 = coeff[2]; d.d65_scale = d65_scale;
+        }
+    }
     s->bsdfs.resize(desc->bsdf_count);
     for (uint32_t b = 0; b < desc->bsdf_count; ++b) {
         DevBsdf &d = s->bsdfs[b];
         std::memset(&d, 0, sizeof(d));
         d.r = desc->bsdfs[b].reflectance[0]; d.g = desc->bsdfs[b].reflectance[1]; d.b = desc->bsdfs[b].reflectance[2];
         d.type = desc->bsdfs[b].type; d.texture = desc->bsdfs[b].texture < 0 ? -1 : desc->bsdfs[b].texture;
+        if (desc->spectral) {
+            const float *c = desc->bsdfs[b].reflectance;
+            if (c[0] < 0 || c[1] < 0 || c[2] < 0 || c[0] > 1 || c[1] > 1 || c[2] > 1) {
+                delete s;
+                return fail(MTSAMD_ERR_INVALID, "Invalid RGB reflectance value [%g, %g, %g], must be in the range [0, 1]!", c[0], c[1], c[2]);
+            }
+            float coeff[3];
+            srgb_model_fetch(model, c, coeff);
+            d.c0 = coeff[0]; d.c1 = coeff[1]; d.c2 = coeff[2];
+        }
     }
 
     for (uint32_t t = 0; t < desc->texture_count; ++t) {
@@ -329,6 +367,12 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         }
         dt.data = ptr;
         s->textures.push_back(dt);
+    }
+
+    if (desc->spectral) {
+        float tx[95], ty[95], tz[95], td[95];
+        for (int i = 0; i < 95; ++i) { tx[i] = (float) kCie_x[i]; ty[i] = (float) kCie_y[i]; tz[i] = (float) kCie_z[i]; td[i] = (float) kCie_d65[i]; }
+        if (upload_spectral_tables(tx, ty, tz, td) != hipSuccess) { mtsamd_scene_destroy(s); return fail(MTSAMD_ERR_DEVICE, "spectral table upload failed"); }
     }
 
     // ---- accelerator -------------------------------------------------------------------------
@@ -503,7 +547,7 @@ static int check_desc(const mtsamd_render_desc *d) {
 
 static int ensure_workspace(mtsamd_scene *s, uint32_t n_waves, uint32_t seg_cap, uint64_t pass_cap) {
     Workspace &w = s->ws;
-    if (w.n_waves == n_waves && w.seg_cap == seg_cap && w.pass_cap >= pass_cap) return 0;
+    if (w.n_waves == n_waves && w.seg_cap == seg_cap && w.pass_cap >= pass_cap && w.spectral == s->spectral) return 0;
     w.release();
     size_t slots = (size_t) n_waves * seg_cap;
     for (int k = 0; k < 2; ++k) {
@@ -514,6 +558,10 @@ static int ensure_workspace(mtsamd_scene *s, uint32_t n_waves, uint32_t seg_cap,
         HIP_TRY(hipMalloc((void **) &w.pool[k].rng, slots * sizeof(uint4)));
         HIP_TRY(hipMalloc((void **) &w.pool[k].misc, slots * sizeof(uint2)));
         HIP_TRY(hipMalloc((void **) &w.count[k], n_waves * sizeof(uint32_t)));
+        if (s->spectral) {
+            HIP_TRY(hipMalloc((void **) &w.pool[k].wav, slots * sizeof(float4)));
+            HIP_TRY(hipMalloc((void **) &w.pool[k].aux, slots * sizeof(float2)));
+        }
     }
     HIP_TRY(hipMalloc((void **) &w.cursor, n_waves * sizeof(uint64_t)));
     HIP_TRY(hipMalloc((void **) &w.cursor_end, n_waves * sizeof(uint64_t)));
@@ -527,7 +575,7 @@ static int ensure_workspace(mtsamd_scene *s, uint32_t n_waves, uint32_t seg_cap,
     for (auto &e : w.ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : w.tev) HIP_TRY(hipEventCreate(&e));
     w.have_events = true;
-    w.n_waves = n_waves; w.seg_cap = seg_cap; w.pass_cap = pass_cap;
+    w.n_waves = n_waves; w.seg_cap = seg_cap; w.pass_cap = pass_cap; w.spectral = s->spectral;
     return 0;
 }
 
@@ -573,6 +621,7 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     p.n_waves = nw; p.seg_cap = w.seg_cap; p.target = j.target;
     p.spp = j.d->sample_count; p.crop_x = j.d->crop_x; p.crop_y = j.d->crop_y; p.crop_w = j.d->crop_width; p.crop_h = j.d->crop_height;
     p.max_depth = j.d->max_depth; p.rr_depth = j.d->rr_depth;
+    p.spectral = j.s->spectral ? 1 : 0;
 
     // the sample cursors cannot run dry before this many launches
     const uint64_t min_iters = (n + (uint64_t) nw * j.target - 1) / ((uint64_t) nw * j.target);
@@ -723,6 +772,7 @@ int mtsamd_render_adjoint(mtsamd_scene *s, const mtsamd_render_desc *d, const fl
     if (d->max_depth < 0 || d->max_depth > 16)
         return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass needs a finite max_depth <= 16 (got %d)", d->max_depth);
     if (d->part_count > 1 || d->row_begin != 0 || d->row_end > 0) return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass renders the whole crop window");
+    if (s->spectral) return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass is implemented for the RGB variant only");
     if (s->bsdfs.size() > 32 && grad_bsdf) return fail(MTSAMD_ERR_UNSUPPORTED, "at most 32 BSDFs with constant-reflectance gradients");
     HIP_TRY(hipSetDevice(s->device));
     AdjointParams a{};
@@ -746,6 +796,26 @@ int mtsamd_scene_texture_info(const mtsamd_scene *s, uint32_t texture, int32_t *
     if (width) *width = s->textures[texture].w;
     if (height) *height = s->textures[texture].h;
     if (grad_offset) *grad_offset = s->textures[texture].grad_offset;
+    return MTSAMD_OK;
+}
+
+int mtsamd_rgb2spec_build(const char *path, int32_t resolution, int32_t threads) {
+    if (!path || resolution < 2 || resolution > 256) return fail(MTSAMD_ERR_INVALID, "invalid rgb2spec arguments");
+    Rgb2Spec m;
+    rgb2spec_build((uint32_t) resolution, m, threads > 0 ? (unsigned) threads : 1u);
+    if (!rgb2spec_save(path, m)) return fail(MTSAMD_ERR_INVALID, "could not write '%s'", path);
+    return MTSAMD_OK;
+}
+
+int mtsamd_srgb_model_fetch(const char *path, const float *rgb, float *coeff) {
+    if (!path || !rgb || !coeff) return fail(MTSAMD_ERR_INVALID, "null argument");
+    static thread_local std::string cached_path;
+    static thread_local Rgb2Spec cached;
+    if (cached_path != path) {
+        if (!rgb2spec_load(path, cached)) { cached_path.clear(); return fail(MTSAMD_ERR_INVALID, "Could not load sRGB-to-spectrum upsampling model ('%s')", path); }
+        cached_path = path;
+    }
+    srgb_model_fetch(cached, rgb, coeff);
     return MTSAMD_OK;
 }
 

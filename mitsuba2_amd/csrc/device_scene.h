@@ -31,12 +31,13 @@ constexpr uint32_t kNoPrim = 0xffffffffu;
 
 struct DevShape { int32_t bsdf; int32_t emitter; uint32_t flags; uint32_t first_prim; };
 constexpr uint32_t kShapeHasNormals = 1u, kShapeHasUV = 2u;
-struct DevBsdf { float r, g, b; int32_t type; int32_t texture; int32_t pad0, pad1, pad2; };
+struct DevBsdf { float r, g, b; int32_t type; int32_t texture; float c0, c1, c2; };      // c*: srgb_model coefficients (spectral variant)
 struct DevTexture { const float *data; int32_t w, h; uint32_t grad_offset, pad; };   // grad_offset: float offset in the concatenated gradient buffer       // linear RGB bitmap (src/textures/bitmap.cpp), identity to_uv
 struct DevEmitter {
     float r, g, b; uint32_t shape;
     uint32_t first_prim, n_prims; float area_sum, area_norm;
     uint32_t valid_lo, valid_hi; uint32_t pad0, pad1;
+    float c0, c1, c2, d65_scale;       // spectral variant: SRGBEmitterSpectrum = D65 * d65_scale * srgb_model(c) (srgb_d65.cpp:27-63)
 };
 
 struct SceneView {
@@ -418,13 +419,14 @@ MTS_DEV void fill_si(const Geo<FLAT> &g, f3 ray_d, uint32_t prim, float b1, floa
 // ---------------------------------------------------------------------------
 struct DirectionSample { f3 p, n, d; float dist, pdf; uint32_t emitter; };
 
-// Scene::sample_emitter_direction without the visibility test; spec = radiance / pdf (masked).
+// Scene::sample_emitter_direction without the visibility test.  The emitted spectrum is returned in factored
+// form: spec = (radiance * r1) * r2 with r1 = 1/pdf (0 when the sample is masked) and r2 = emitter count.
 template <bool FLAT>
-MTS_DEV void sample_emitter_direction(const Geo<FLAT> &g, f3 ref_p, f2 sample, DirectionSample &ds, f3 &spec) {
+MTS_DEV void sample_emitter_direction(const Geo<FLAT> &g, f3 ref_p, f2 sample, DirectionSample &ds, float &r1, float &r2) {
     const SceneView &sv = g.sv;
     ds.pdf = 0.0f; ds.dist = 0.0f; ds.emitter = 0;
     ds.p = ds.n = ds.d = mk3(0, 0, 0);
-    spec = mk3(0, 0, 0);
+    r1 = 0.0f; r2 = 1.0f;
     if (sv.n_emitters == 0) return;
     uint32_t index = 0;
     float emitter_pdf = 1.0f;
@@ -476,15 +478,22 @@ MTS_DEV void sample_emitter_direction(const Geo<FLAT> &g, f3 ref_p, f2 sample, D
     ds.emitter = index;
     // AreaLight::sample_direction
     bool active = (dot(ds.d, ds.n) < 0.0f) && (ds.pdf != 0.0f);
-    if (active) {
-        float r = rcp(ds.pdf);
-        spec = mk3(e.r * r, e.g * r, e.b * r);
-    }
+    if (active) r1 = rcp(ds.pdf);
     if (sv.n_emitters > 1) {
         ds.pdf *= emitter_pdf;
-        float r = rcp(emitter_pdf);
-        spec = spec * r;
+        r2 = rcp(emitter_pdf);
     }
+}
+// RGB form: spec = radiance / pdf (masked)
+template <bool FLAT>
+MTS_DEV void sample_emitter_direction(const Geo<FLAT> &g, f3 ref_p, f2 sample, DirectionSample &ds, f3 &spec) {
+    float r1, r2;
+    sample_emitter_direction(g, ref_p, sample, ds, r1, r2);
+    spec = mk3(0, 0, 0);
+    if (g.sv.n_emitters == 0) return;
+    const DevEmitter e = g.emitter(ds.emitter);
+    spec = mk3(e.r * r1, e.g * r1, e.b * r1);
+    if (g.sv.n_emitters > 1) spec = spec * r2;
 }
 
 MTS_DEV float pdf_emitter_direction(uint32_t n_emitters, float area_norm, f3 d, f3 n, float dist) {

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "device_scene.h"
+#include "device_spectral.h"
 
 namespace mtsamd {
 
@@ -12,6 +13,9 @@ struct PoolView {
     float4 *ray_o, *ray_d, *thr, *res;
     uint4 *rng;
     uint2 *misc;
+    // spectral variant (112 B per path): thr / res hold 4 spectral samples, wav the wavelengths, aux = (bs_pdf, eta)
+    float4 *wav;
+    float2 *aux;
 };
 
 // Film rows owned by one render call.  count <= 1: the contiguous window [row0, row0 + local_rows);
@@ -58,6 +62,7 @@ struct RenderParams {
     uint32_t n_waves, seg_cap, target;
     int32_t spp, crop_x, crop_y, crop_w, crop_h;
     int32_t max_depth, rr_depth;
+    int32_t spectral;           // 0: RGB variant, 1: spectral variant (4 wavelengths per sample)
 };
 
 struct FilmParams {
@@ -90,6 +95,8 @@ struct RayStreams {
 size_t bounce_lds_bytes(const SceneView &sv);
 hipError_t launch_bounce(const RenderParams &p, hipStream_t s);
 hipError_t launch_adjoint(const AdjointParams &a, hipStream_t s);
+// CIE x, y, z and D65 tables (95 floats each) -> device; call once before the first spectral launch
+hipError_t upload_spectral_tables(const float *x, const float *y, const float *z, const float *d65);
 hipError_t launch_film_gather(const FilmParams &p, hipStream_t s);
 // tiled variant for the plane layout and filters with <= 4 taps (gaussian stddev 0.5, box)
 hipError_t launch_film_tiles(const FilmParams &p, hipStream_t s);

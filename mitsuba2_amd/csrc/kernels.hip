@@ -271,8 +271,243 @@ void k_bounce(const RenderParams P) {
 
 size_t bounce_lds_bytes(const SceneView &sv) { return lds_bytes(sv, kBlock); }
 
+
+// ---------------------------------------------------------------------------------------------
+// Spectral variant: the same path logic on 4 wavelengths per camera sample (scalar_spectral / gpu_spectral semantics).
+// Geometry, sampling decisions and the RNG consumption are wavelength independent; reflectances and emission are
+// smooth spectra evaluated per wavelength, and the result is converted to XYZ with the CIE 1931 observer.
+__device__ SpectralTables g_spectral;
+
+hipError_t upload_spectral_tables(const float *x, const float *y, const float *z, const float *d65) {
+    SpectralTables t;
+    for (int i = 0; i < 95; ++i) { t.x[i] = x[i]; t.y[i] = y[i]; t.z[i] = z[i]; t.d65[i] = d65[i]; }
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_spectral), &t, sizeof(t));
+}
+
+struct PathStateS {
+    f3 o, d; float mint, maxt;
+    Spec4 thr, res, wav; float bs_pdf, eta;
+    Pcg32 rng;
+    uint32_t ordinal, depth, flags;
+};
+
+MTS_DEV void load_state(const PoolView &p, size_t i, PathStateS &s) {
+    float4 a = p.ray_o[i], b = p.ray_d[i], c = p.thr[i], e = p.res[i], w = p.wav[i];
+    float2 x = p.aux[i]; uint4 r = p.rng[i]; uint2 m = p.misc[i];
+    s.o = mk3(a.x, a.y, a.z); s.mint = a.w;
+    s.d = mk3(b.x, b.y, b.z); s.maxt = b.w;
+    s.thr.v[0] = c.x; s.thr.v[1] = c.y; s.thr.v[2] = c.z; s.thr.v[3] = c.w;
+    s.res.v[0] = e.x; s.res.v[1] = e.y; s.res.v[2] = e.z; s.res.v[3] = e.w;
+    s.wav.v[0] = w.x; s.wav.v[1] = w.y; s.wav.v[2] = w.z; s.wav.v[3] = w.w;
+    s.bs_pdf = x.x; s.eta = x.y;
+    s.rng.state = (uint64_t) r.x | ((uint64_t) r.y << 32);
+    s.rng.inc = (uint64_t) r.z | ((uint64_t) r.w << 32);
+    s.ordinal = m.x; s.depth = m.y & 0xffffu; s.flags = m.y >> 16;
+}
+MTS_DEV void store_state(const PoolView &p, size_t i, const PathStateS &s) {
+    p.ray_o[i] = make_float4(s.o.x, s.o.y, s.o.z, s.mint);
+    p.ray_d[i] = make_float4(s.d.x, s.d.y, s.d.z, s.maxt);
+    p.thr[i] = make_float4(s.thr.v[0], s.thr.v[1], s.thr.v[2], s.thr.v[3]);
+    p.res[i] = make_float4(s.res.v[0], s.res.v[1], s.res.v[2], s.res.v[3]);
+    p.wav[i] = make_float4(s.wav.v[0], s.wav.v[1], s.wav.v[2], s.wav.v[3]);
+    p.aux[i] = make_float2(s.bs_pdf, s.eta);
+    p.rng[i] = make_uint4((uint32_t) s.rng.state, (uint32_t) (s.rng.state >> 32), (uint32_t) s.rng.inc,
+                          (uint32_t) (s.rng.inc >> 32));
+    p.misc[i] = make_uint2(s.ordinal, (s.depth & 0xffffu) | (s.flags << 16));
+}
+
+template <bool FLAT>
+MTS_DEV bool bounce_step_spectral(const RenderParams &P, const LdsView &lds, PathStateS &s, Counters &c) {
+    const SceneView &sv = P.sv;
+    const Geo<FLAT> geo{ sv, lds };
+    Hit hit;
+    ++c.closest; ++c.segments;
+    bool found = traverse<FLAT, false>(sv, lds, s.o, s.d, s.mint, s.maxt, hit, c.tri_tests);
+    if (s.depth == 1u) s.flags = found ? 1u : 0u;
+
+    SurfaceInteraction si;
+    if (found) {
+        fill_si(geo, s.d, hit.prim, hit.u, hit.v, si);
+        int32_t emitter = si.shape_rec.emitter;
+        if (emitter >= 0) {
+            const DevEmitter e = geo.emitter((uint32_t) emitter);
+            float ew = 1.0f;
+            if (s.depth > 1u) {
+                f3 dd = si.p - s.o;
+                float dist = sqrtf(sqnorm(dd));
+                dd = div_s(dd, dist);
+                ew = mis_weight(s.bs_pdf, pdf_emitter_direction(sv.n_emitters, e.area_norm, dd, si.sh.n, dist));
+            }
+            if (si.wi.z > 0.0f) {
+#pragma unroll
+                for (int k = 0; k < kWav; ++k) {       // SRGBEmitterSpectrum::eval = d65 * srgb_model_eval (srgb_d65.cpp:54-62)
+                    float le = table_eval(g_spectral.d65, e.d65_scale, s.wav.v[k]) * srgb_model_eval(e.c0, e.c1, e.c2, s.wav.v[k]);
+                    s.res.v[k] += (ew * s.thr.v[k]) * le;
+                }
+            }
+        }
+    }
+    bool active = found;
+
+    if ((int32_t) s.depth > P.rr_depth) {
+        float hm = fmaxf(fmaxf(s.thr.v[0], s.thr.v[1]), fmaxf(s.thr.v[2], s.thr.v[3]));
+        float q = fminf(hm * (s.eta * s.eta), 0.95f);
+        if (active) active = pcg_next_f32(s.rng) < q;
+        float rq = rcp(q);
+#pragma unroll
+        for (int k = 0; k < kWav; ++k) s.thr.v[k] *= rq;
+    }
+    if (s.depth >= (uint32_t) P.max_depth || !active) return false;
+
+    const DevBsdf bsdf = geo.bsdf((uint32_t) si.shape_rec.bsdf);
+    Spec4 refl;
+#pragma unroll
+    for (int k = 0; k < kWav; ++k) refl.v[k] = srgb_model_eval(bsdf.c0, bsdf.c1, bsdf.c2, s.wav.v[k]);   // srgb.cpp:45-52
+
+    {
+        f2 s2; s2.x = pcg_next_f32(s.rng); s2.y = pcg_next_f32(s.rng);
+        DirectionSample ds; float r1, r2;
+        sample_emitter_direction(geo, si.p, s2, ds, r1, r2);
+        if (ds.pdf != 0.0f) {
+            const DevEmitter e = geo.emitter(ds.emitter);
+            f3 wo = to_local(si.sh, ds.d);
+            bool front = si.wi.z > 0.0f && wo.z > 0.0f;
+            float bp = front ? kInvPi * wo.z : 0.0f;
+            float mis = mis_weight(ds.pdf, bp);
+            Spec4 contrib; bool nz = false;
+#pragma unroll
+            for (int k = 0; k < kWav; ++k) {
+                float le = table_eval(g_spectral.d65, e.d65_scale, s.wav.v[k]) * srgb_model_eval(e.c0, e.c1, e.c2, s.wav.v[k]);
+                float spec = le * r1;
+                if (sv.n_emitters > 1) spec *= r2;
+                float bv = front ? (refl.v[k] * kInvPi) * wo.z : 0.0f;
+                contrib.v[k] = ((mis * s.thr.v[k]) * bv) * spec;
+                nz = nz || contrib.v[k] != 0.0f;
+            }
+            if (nz) {
+                Hit sh;
+                ++c.any;
+                bool occluded = traverse<FLAT, true>(sv, lds, si.p, ds.d, kRayEpsilon * (1.0f + hmax_abs(si.p)),
+                                               ds.dist * (1.0f - kShadowEpsilon), sh, c.tri_tests);
+                if (!occluded) {
+#pragma unroll
+                    for (int k = 0; k < kWav; ++k) s.res.v[k] += contrib.v[k];
+                }
+            }
+        }
+    }
+
+    (void) pcg_next_f32(s.rng);
+    f2 s2; s2.x = pcg_next_f32(s.rng); s2.y = pcg_next_f32(s.rng);
+    f3 wo = mk3(0.0f, 0.0f, 0.0f); float pdf = 0.0f; bool ok = false;
+    if (si.wi.z > 0.0f) {
+        wo = square_to_cosine_hemisphere(s2);
+        pdf = kInvPi * wo.z;
+        ok = pdf > 0.0f;
+    }
+    bool nz = false;
+#pragma unroll
+    for (int k = 0; k < kWav; ++k) { s.thr.v[k] = s.thr.v[k] * (ok ? refl.v[k] : 0.0f); nz = nz || s.thr.v[k] != 0.0f; }
+    if (!nz) return false;
+    s.o = si.p;
+    s.d = to_world(si.sh, wo);
+    s.mint = (1.0f + hmax_abs(si.p)) * kRayEpsilon;
+    s.maxt = __builtin_inff();
+    s.bs_pdf = pdf;
+    s.depth += 1u;
+    return true;
+}
+
+MTS_DEV void generate_path_spectral(const RenderParams &P, uint64_t ordinal, uint32_t lp, uint32_t j, PathStateS &s) {
+    const uint32_t w = (uint32_t) P.crop_w;
+    const uint32_t lr = lp / w, px = lp - lr * w;
+    const uint32_t py = (uint32_t) row_to_global(P.rows, (int32_t) lr);
+    const uint64_t index = ((uint64_t) py * w + px) * (uint64_t) P.spp + j;
+    seed_sample(s.rng, index, P.base_seed);
+    float jx = pcg_next_f32(s.rng), jy = pcg_next_f32(s.rng);
+    float psx = ((float) px + (float) P.crop_x) + jx, psy = ((float) py + (float) P.crop_y) + jy;
+    Spec4 weight;
+    sample_wavelengths(pcg_next_f32(s.rng), s.wav, weight);    // integrator.cpp:237, perspective.cpp:196
+    float ax = (psx - (float) P.crop_x) / (float) P.crop_w, ay = (psy - (float) P.crop_y) / (float) P.crop_h;
+    camera_ray(P.cam, ax, ay, s.o, s.d, s.mint, s.maxt);
+#pragma unroll
+    for (int k = 0; k < kWav; ++k) { s.thr.v[k] = 1.0f; s.res.v[k] = 0.0f; }
+    s.bs_pdf = 0.0f; s.eta = 1.0f;
+    s.ordinal = P.plane_pixels ? j * P.plane_pixels + (lp - P.plane_pix0) : (uint32_t) (ordinal - P.first_ordinal);
+    s.depth = 1u; s.flags = 0u;
+    if (P.out_pos) P.out_pos[s.ordinal] = make_float2(psx, psy);
+}
+
+MTS_DEV void store_result_spectral(const RenderParams &P, const PathStateS &s) {
+    float alpha = (s.flags & 1u) ? 1.0f : 0.0f;
+    Spec4 v;
+#pragma unroll
+    for (int k = 0; k < kWav; ++k) v.v[k] = wavelength_weight(s.wav.v[k]) * s.res.v[k];    // ray_weight * L (integrator.cpp:250)
+    f3 xyz = spectrum_to_xyz(v, s.wav);                                                       // integrator.cpp:259-261
+    bool valid = (xyz.x >= -1e-5f) && (xyz.y >= -1e-5f) && (xyz.z >= -1e-5f) && isfinite(xyz.x) && isfinite(xyz.y) && isfinite(xyz.z);
+    P.out_rgba[s.ordinal] = make_float4(xyz.x, xyz.y, xyz.z, (valid || !P.store_xyz) ? alpha : -1.0f);
+}
+
+template <bool FLAT>
+__global__ __launch_bounds__(kBlock) void k_bounce_spectral(const RenderParams P) {
+    extern __shared__ float4 smem[];
+    const LdsView lds = lds_stage<FLAT>(P.sv, smem);
+    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    if (wave >= P.n_waves) return;
+    const uint32_t lane = lane_id();
+    const uint32_t n_in = __builtin_amdgcn_readfirstlane(P.count_in[wave]);
+    const size_t base = (size_t) wave * P.seg_cap;
+    uint32_t n_out = 0;
+    Counters c = { 0u, 0u, 0u, 0u };
+    for (uint32_t i0 = 0; i0 < n_in; i0 += 64u) {
+        PathStateS s;
+        bool alive = false;
+        if (i0 + lane < n_in) {
+            load_state(P.in, base + i0 + lane, s);
+            alive = bounce_step_spectral<FLAT>(P, lds, s, c);
+            if (!alive) store_result_spectral(P, s);
+        }
+        const uint64_t m = __ballot(alive);
+        if (alive) store_state(P.out, base + n_out + mask_rank(m), s);
+        n_out += (uint32_t) __popcll(m);
+    }
+    uint64_t cursor = P.cursor[wave];
+    const uint64_t end = P.cursor_end[wave];
+    uint32_t cpix = P.cursor_pix[wave], crem = P.cursor_rem[wave];
+    const uint32_t spp = (uint32_t) P.spp;
+    while (n_out < P.target && cursor < end) {
+        uint64_t left = end - cursor;
+        uint32_t n_new = min(64u, P.target - n_out);
+        if ((uint64_t) n_new > left) n_new = (uint32_t) left;
+        if (lane < n_new) {
+            PathStateS s;
+            uint32_t r = crem + lane, q = r / spp;
+            generate_path_spectral(P, cursor + lane, cpix + q, r - q * spp, s);
+            store_state(P.out, base + n_out + lane, s);
+        }
+        n_out += n_new; cursor += n_new;
+        uint32_t r = crem + n_new, q = r / spp;
+        cpix += q; crem = r - q * spp;
+    }
+    uint32_t tot[4] = { c.closest, c.any, c.segments, c.tri_tests };
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        for (int off = 32; off > 0; off >>= 1) tot[k] += __shfl_xor(tot[k], off);
+    if (lane == 0) {
+        P.count_out[wave] = n_out;
+        P.cursor[wave] = cursor; P.cursor_pix[wave] = cpix; P.cursor_rem[wave] = crem;
+        uint64_t *ws = P.wave_stats + 4u * (size_t) wave;
+        ws[0] += tot[0]; ws[1] += tot[1]; ws[2] += tot[2]; ws[3] += tot[3];
+    }
+}
+
 hipError_t launch_bounce(const RenderParams &p, hipStream_t s) {
     uint32_t blocks = (p.n_waves * 64u + kBlock - 1) / kBlock;
+    if (p.spectral) {
+        if (p.sv.flat) hipLaunchKernelGGL(k_bounce_spectral<true>, dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);
+        else hipLaunchKernelGGL(k_bounce_spectral<false>, dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);
+        return hipGetLastError();
+    }
     if (p.sv.flat) hipLaunchKernelGGL(k_bounce<true>, dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);
     else hipLaunchKernelGGL(k_bounce<false>, dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);
     return hipGetLastError();

@@ -307,12 +307,26 @@ class PerspectiveCamera:
         return Ray3f(o=out[0:3].t().contiguous(), d=out[3:6].t().contiguous(), mint=out[6].clone(), maxt=out[7].clone())
 
 
+def srgb_coeff_path(build=True):
+    """The RGB -> spectrum coefficient table ('data/srgb.coeff' of the reference, src/librender/srgb.cpp:24-27): generated
+    on first use with mtsamd_rgb2spec_build at the reference's resolution 64 (build artefact, not tracked)."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "srgb.coeff")
+    if not os.path.exists(path) and build:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        L.check(L.lib().mtsamd_rgb2spec_build(path.encode(), 64, min(os.cpu_count() or 1, 16)))
+    return path
+
+
 # --------------------------------------------------------------------------------------------
 class Scene:
     """src/librender/scene.cpp: shapes + BSDFs + emitters uploaded to one GPU, BVH built by the library."""
 
-    def __init__(self, scene_dict, device=0, sensor=None, integrator=None):
+    def __init__(self, scene_dict, device=0, sensor=None, integrator=None, variant="rgb"):
         lib = L.lib()
+        if variant not in ("rgb", "spectral"):
+            raise RuntimeError("unsupported variant '%s' (rgb or spectral)" % variant)
+        self._variant = variant
         if not torch.cuda.is_available():
             raise RuntimeError("mitsuba2_amd requires a HIP device (torch.cuda.is_available() is False)")
         self._device_index = int(device)
@@ -365,7 +379,10 @@ class Scene:
                 raise RuntimeError("Emitter plugin '%s' is not supported by this backend (area only)" % e.get("type"))
             ed[i].type = 0
             ed[i].radiance = (C.c_float * 3)(*[float(x) for x in e["radiance"]])
-        sd = L.SceneDesc(md, len(meshes), bd, len(bsdfs), ed, len(emitters), td, len(tex))
+        sd = L.SceneDesc(md, len(meshes), bd, len(bsdfs), ed, len(emitters), td, len(tex), 0, None)
+        if variant == "spectral":
+            sd.spectral = 1
+            sd.rgb2spec_path = srgb_coeff_path().encode()
         handle = C.c_void_p()
         L.check(lib.mtsamd_scene_create(C.byref(sd), self._device_index, C.byref(handle)))
         self._handle = handle

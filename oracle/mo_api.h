@@ -28,6 +28,13 @@ int mo_scene_add_texture(mo_scene *s, int width, int height, const float *rgb);
 int mo_scene_set_texture(mo_scene *s, uint32_t shape, int texture);
 int mo_scene_update_texture(mo_scene *s, uint32_t texture, const float *rgb);
 int mo_scene_set_reflectance(mo_scene *s, uint32_t shape, const float *rgb);
+/* Switches the scene to the spectral variant: every RGB reflectance / radiance is upsampled through the coefficient
+ * table at `coeff_path` ("data/srgb.coeff": srgb_model_fetch, src/librender/srgb.cpp:14-40; rgb2spec_fetch,
+ * ext/rgb2spec/rgb2spec.c:81-121).  Call after all meshes were added.  Returns 0 on success. */
+int mo_scene_set_spectral(mo_scene *s, const char *coeff_path);
+/* unit-level entry points of the spectral helpers */
+void mo_kat_srgb_model_fetch(const char *coeff_path, const float *rgb3, float *coeff3);
+void mo_kat_spectral(float sample, const float *coeff3, float d65_scale, float *out /* 4 wav, 4 weight, 4 refl, 4 d65, xyz(3) of refl */);
 /* Builds the oracle's own accelerator + emitter sampling tables. */
 int mo_scene_finalize(mo_scene *s);
 /* naive != 0: the render entry points answer every query by brute force. */

@@ -14,17 +14,18 @@ typedef struct {
 } mo_si;
 
 /* DirectionSample (include/mitsuba/render/records.h:121-174) */
-typedef struct { mo_v3 p, n, d; float dist, pdf; uint32_t emitter; } mo_dsample;
+typedef struct { mo_v3 p, n, d; float dist, pdf; uint32_t emitter; float pdf_single; } mo_dsample;   /* pdf_single: before the emitter-selection probability */
 
 typedef struct {
     uint32_t n_verts, n_faces;
     float *pos, *nrm, *uv; uint32_t *faces;
     int bsdf_kind; float refl[3]; int emitter; int texture;
+    float refl_coeff[3];            /* spectral variant: srgb_model coefficients of the reflectance */
     uint32_t prim_offset;
     float *area_pmf, *area_cdf; float area_sum, area_norm; uint32_t valid_lo, valid_hi;
 } mo_mesh;
 
-typedef struct { uint32_t shape; float radiance[3]; } mo_emitter;
+typedef struct { uint32_t shape; float radiance[3]; float coeff[3], d65_scale; } mo_emitter;
 typedef struct { int w, h; float *data; } mo_texture;
 typedef struct { double lo[3], hi[3]; uint32_t left, right, first, count; } mo_bvh_node;
 
@@ -35,6 +36,7 @@ struct mo_scene {
     uint32_t n_prims; uint32_t *prim_shape, *prim_local;
     mo_bvh_node *bvh_nodes; uint32_t n_bvh_nodes; uint32_t *bvh_prims;
     double scene_extent; int force_naive;
+    int spectral;                   /* 0: RGB variant, 1: spectral variant (4 wavelengths) */
 };
 
 int mo_intersect(const mo_scene *s, const mo_ray *ray, int shadow, int naive, mo_hit *hit);
@@ -53,4 +55,11 @@ void mo_scene_set_naive(mo_scene *s, int naive);
  * footprint (may be NULL): texel index of v00 and the bilinear weights w1.x, w1.y */
 void mo_reflectance(const mo_scene *s, const mo_mesh *m, mo_v2 uv, float out[3], uint32_t *texel, float w1[2]);
 
+
+/* spectral variant (mo_spectral.c) */
+#define MO_WAV 4
+void mo_sample_wavelengths(float sample, float wav[MO_WAV], float weight[MO_WAV]);
+float mo_srgb_model_eval(const float coeff[3], float lambda);
+float mo_d65_eval(float scale, float lambda);
+void mo_spectrum_to_xyz(const float value[MO_WAV], const float wav[MO_WAV], float xyz[3]);
 #endif

@@ -447,6 +447,93 @@ static void path_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, 
     }
 }
 
+/* PathIntegrator::sample for the spectral variant: identical control flow, 4 wavelength channels */
+static void path_sample_spectral(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, const float wav[MO_WAV],
+                                 int max_depth, int rr_depth, float result[MO_WAV], int *valid_ray, ray_stats *st) {
+    mo_ray ray = *ray_in;
+    float eta = 1.0f, emission_weight = 1.0f;
+    float throughput[MO_WAV];
+    for (int k = 0; k < MO_WAV; ++k) { throughput[k] = 1.0f; result[k] = 0.0f; }
+    mo_si si;
+    int si_valid = scene_intersect(s, &ray, &si, st);
+    *valid_ray = si_valid;
+    int emitter = si_valid ? s->meshes[si.shape].emitter : -1;
+    int active = 1;
+    for (int depth = 1;; ++depth) {
+        if (emitter >= 0 && active && si.wi.z > 0.0f) {
+            const mo_emitter *e = &s->emitters[emitter];
+            for (int k = 0; k < MO_WAV; ++k) {
+                float le = mo_d65_eval(e->d65_scale, wav[k]) * mo_srgb_model_eval(e->coeff, wav[k]);
+                result[k] += (emission_weight * throughput[k]) * le;
+            }
+        }
+        active = active && si_valid;
+        if (depth > rr_depth) {
+            float hm = fmaxf(fmaxf(throughput[0], throughput[1]), fmaxf(throughput[2], throughput[3]));
+            float q = fminf(hm * (eta * eta), 0.95f);
+            if (active) active = mo_pcg32_next_f32(rng) < q;
+            float rq = mo_rcp(q);
+            for (int k = 0; k < MO_WAV; ++k) throughput[k] *= rq;
+        }
+        if ((uint32_t) depth >= (uint32_t) max_depth || !active) break;
+        const mo_mesh *mesh = &s->meshes[si.shape];
+        float refl[MO_WAV];
+        for (int k = 0; k < MO_WAV; ++k) refl[k] = mo_srgb_model_eval(mesh->refl_coeff, wav[k]);
+        {
+            mo_v2 s2; s2.x = mo_pcg32_next_f32(rng); s2.y = mo_pcg32_next_f32(rng);
+            mo_dsample ds; float rgb_spec[3];
+            mo_sample_emitter_direction(s, si.p, s2, &ds, rgb_spec);
+            if (ds.pdf != 0.0f && s->n_emitters > 0) {
+                const mo_emitter *e = &s->emitters[ds.emitter];
+                /* AreaLight::sample_direction: spec = radiance / pdf, masked (area.cpp:110-116); Scene: * emitter count */
+                float r2 = s->n_emitters > 1 ? mo_rcp(1.0f / (float) s->n_emitters) : 1.0f;
+                float pdf_single = s->n_emitters > 1 ? ds.pdf_single : ds.pdf;
+                int act = mo_dot(ds.d, ds.n) < 0.0f && pdf_single != 0.0f;
+                float r1 = act ? mo_rcp(pdf_single) : 0.0f;
+                mo_ray sr;
+                sr.o = si.p; sr.d = ds.d;
+                sr.mint = MO_RAY_EPSILON * (1.0f + mo_hmax_abs(si.p));
+                sr.maxt = ds.dist * (1.0f - MO_SHADOW_EPSILON);
+                st->any++;
+                int occluded = mo_intersect(s, &sr, 1, 0, NULL);
+                mo_v3 wo = mo_to_local(&si.sh, ds.d);
+                int front = si.wi.z > 0.0f && wo.z > 0.0f;
+                float bsdf_pdf = front ? mo_square_to_cosine_hemisphere_pdf(wo) : 0.0f;
+                float mis = mis_weight(ds.pdf, bsdf_pdf);
+                for (int k = 0; k < MO_WAV; ++k) {
+                    float le = mo_d65_eval(e->d65_scale, wav[k]) * mo_srgb_model_eval(e->coeff, wav[k]);
+                    float spec = le * r1;
+                    if (s->n_emitters > 1) spec *= r2;
+                    if (occluded) spec = 0.0f;
+                    float bv = front ? (refl[k] * MO_INV_PI) * wo.z : 0.0f;
+                    result[k] += ((mis * throughput[k]) * bv) * spec;
+                }
+            }
+        }
+        float s1 = mo_pcg32_next_f32(rng); (void) s1;
+        mo_v2 s2; s2.x = mo_pcg32_next_f32(rng); s2.y = mo_pcg32_next_f32(rng);
+        mo_v3 bs_wo; float bs_pdf, dummy_w[3]; const float one[3] = { 1.0f, 1.0f, 1.0f };
+        int sampled = mo_diffuse_sample(one, si.wi, s2, &bs_wo, &bs_pdf, dummy_w) && bs_pdf > 0.0f;
+        int nz = 0;
+        for (int k = 0; k < MO_WAV; ++k) { throughput[k] = throughput[k] * (sampled ? refl[k] : 0.0f); nz = nz || throughput[k] != 0.0f; }
+        active = active && nz;
+        if (!active) break;
+        ray.o = si.p; ray.d = mo_to_world(&si.sh, bs_wo);
+        ray.mint = (1.0f + mo_hmax_abs(si.p)) * MO_RAY_EPSILON;
+        ray.maxt = INFINITY;
+        mo_si si_bsdf;
+        int v2 = scene_intersect(s, &ray, &si_bsdf, st);
+        emitter = v2 ? s->meshes[si_bsdf.shape].emitter : -1;
+        if (emitter >= 0) {
+            mo_v3 d = mo_sub(si_bsdf.p, si.p);
+            float dist = mo_norm(d);
+            d = mo_div_s(d, dist);
+            emission_weight = mis_weight(bs_pdf, mo_pdf_emitter_direction(s, (uint32_t) emitter, d, si_bsdf.sh.n, dist));
+        }
+        si = si_bsdf; si_valid = v2;
+    }
+}
+
 /* spectrum.h:220-227 (Matrix * Vector: column-wise fmadd) */
 static inline void srgb_to_xyz(const float rgb[3], float xyz[3]) {
     static const float M[3][3] = { { 0.412453f, 0.357580f, 0.180423f },
@@ -462,13 +549,24 @@ static void render_sample(const mo_scene *s, const mo_render_desc *d, const came
                           int *valid_out, ray_stats *st) {
     float jx = mo_pcg32_next_f32(rng), jy = mo_pcg32_next_f32(rng);
     float psx = pos_x + jx, psy = pos_y + jy;
-    float wavelength_sample = mo_pcg32_next_f32(rng); (void) wavelength_sample;
+    float wavelength_sample = mo_pcg32_next_f32(rng);
     float ax = (psx - (float) d->crop_x) / (float) d->crop_w, ay = (psy - (float) d->crop_y) / (float) d->crop_h;
     mo_ray ray; camera_sample_ray(cam, ax, ay, &ray);
-    float L[3]; int valid;
+    float L[3] = { 0, 0, 0 }; int valid;
+    float xyz[3];
+    if (s->spectral) {
+        /* sample_wavelength (perspective.cpp:196), ray_weight * L, spectrum_to_xyz (integrator.cpp:250-261) */
+        float wav[MO_WAV], weight[MO_WAV], Ls[MO_WAV];
+        mo_sample_wavelengths(wavelength_sample, wav, weight);
+        path_sample_spectral(s, rng, &ray, wav, d->max_depth, d->rr_depth, Ls, &valid, st);
+        for (int k = 0; k < MO_WAV; ++k) Ls[k] = weight[k] * Ls[k];
+        mo_spectrum_to_xyz(Ls, wav, xyz);
+        L[0] = xyz[0]; L[1] = xyz[1]; L[2] = xyz[2];       /* per-sample API: XYZ tristimulus in the spectral variant */
+    } else {
     path_sample(s, rng, &ray, d->max_depth, d->rr_depth, L, &valid, st);
     /* ray_weight == 1 in RGB mode (spectrum.h:304-309) */
-    float xyz[3]; srgb_to_xyz(L, xyz);
+    srgb_to_xyz(L, xyz);
+    }
     if (d->film_rgb) { xyz[0] = L[0]; xyz[1] = L[1]; xyz[2] = L[2]; }     /* autodiff.py:53-57: linear RGB channels */
     aovs[0] = xyz[0]; aovs[1] = xyz[1]; aovs[2] = xyz[2]; aovs[3] = valid ? 1.0f : 0.0f; aovs[4] = 1.0f;
     pos_sample[0] = psx; pos_sample[1] = psy;

@@ -468,6 +468,7 @@ void mo_sample_emitter_direction(const mo_scene *s, mo_v3 ref_p, mo_v2 sample, m
     float dp = fabsf(mo_dot(ds->d, ds->n));
     ds->pdf *= (dp != 0.0f) ? dist_squared / dp : 0.0f;
     ds->emitter = index;
+    ds->pdf_single = ds->pdf;
     int active = (mo_dot(ds->d, ds->n) < 0.0f) && (ds->pdf != 0.0f);
     if (active) {
         float r = mo_rcp(ds->pdf);

@@ -1,0 +1,151 @@
+/* ORACLE -- TEST INFRASTRUCTURE ONLY (see mo_math.h header for scope and pinning).
+ *
+ * Spectral variant, restated from:
+ *   sample_wavelength / sample_rgb_spectrum   include/mitsuba/core/spectrum.h:270-314
+ *   math::sample_shifted                      include/mitsuba/core/math.h:418-442
+ *   cie1931_xyz / spectrum_to_xyz             include/mitsuba/core/spectrum.h:127-217
+ *   srgb_model_eval                           include/mitsuba/render/srgb.h:8-24
+ *   srgb_model_fetch                          src/librender/srgb.cpp:14-40
+ *   rgb2spec_fetch                            ext/rgb2spec/rgb2spec.c:81-121
+ *   SRGBReflectanceSpectrum / SRGBEmitterSpectrum   src/spectra/srgb.cpp:27-52, src/spectra/srgb_d65.cpp:27-63
+ *   D65Spectrum / RegularSpectrum             src/spectra/d65.cpp:44-66, src/spectra/regular.cpp:68-75
+ *   ContinuousDistribution::eval_pdf          include/mitsuba/core/distr_1d.h:378-394
+ * The coefficient table is data (generated; "data/srgb.coeff" is a build artefact of the reference and absent from
+ * its tree); tests/ compare the generator against the reference's own tool compiled from ext/rgb2spec.
+ */
+#include "mo_internal.h"
+#include "mo_cie_data.h"
+#include <stdio.h>
+#include <stdlib.h>
+
+/* spectrum.h:287-291 + math.h:418-425 */
+void mo_sample_wavelengths(float sample, float wav[MO_WAV], float weight[MO_WAV]) {
+    for (int k = 0; k < MO_WAV; ++k) {
+        float v = sample + (float) k / (float) MO_WAV;
+        if (v > 1.0f) v -= 1.0f;
+        float l = 538.0f - atanhf(0.8569106254698279f - 1.8275019724092267f * v) * 138.88888888888889f;
+        float t = coshf(0.0072f * (l - 538.0f));
+        wav[k] = l; weight[k] = 253.82f * t * t;
+    }
+}
+
+/* srgb.h:8-24 */
+float mo_srgb_model_eval(const float c[3], float l) {
+    float v = fmaf(fmaf(c[0], l, c[1]), l, c[2]);
+    if (isinf(c[2])) return fmaf(copysignf(1.0f, c[2]), 0.5f, 0.5f);
+    return fmaxf(0.0f, fmaf(0.5f * v, 1.0f / sqrtf(fmaf(v, v, 1.0f)), 0.5f));
+}
+
+/* D65 table scaled by `scale` (d65.cpp:58-61) evaluated like RegularSpectrum (distr_1d.h:378-394) */
+float mo_d65_eval(float scale, float l) {
+    if (!(l >= 360.0f && l <= 830.0f)) return 0.0f;
+    float x = (l - 360.0f) * (float) (1.0 / (470.0 / 94.0));
+    uint32_t i = (uint32_t) x;
+    if (i > 93u) i = 93u;
+    float y0 = (float) mo_cie_d65[i] * scale, y1 = (float) mo_cie_d65[i + 1] * scale;
+    float w1 = x - (float) i, w0 = 1.0f - w1;
+    return fmaf(w0, y0, w1 * y1);
+}
+
+/* spectrum.h:145-217 */
+void mo_spectrum_to_xyz(const float value[MO_WAV], const float wav[MO_WAV], float xyz[3]) {
+    float X[MO_WAV], Y[MO_WAV], Z[MO_WAV];
+    for (int k = 0; k < MO_WAV; ++k) {
+        float l = wav[k];
+        float t = (l - 360.0f) * ((95 - 1) / (830.0f - 360.0f));
+        int active = l >= 360.0f && l <= 830.0f;
+        int i0 = (int) t;
+        if (i0 < 0) i0 = 0;
+        if (i0 > 93) i0 = 93;
+        float w1 = t - (float) i0, w0 = 1.0f - w1;
+        X[k] = active ? fmaf(w0, (float) mo_cie_x[i0], w1 * (float) mo_cie_x[i0 + 1]) : 0.0f;
+        Y[k] = active ? fmaf(w0, (float) mo_cie_y[i0], w1 * (float) mo_cie_y[i0 + 1]) : 0.0f;
+        Z[k] = active ? fmaf(w0, (float) mo_cie_z[i0], w1 * (float) mo_cie_z[i0 + 1]) : 0.0f;
+    }
+    xyz[0] = (((X[0] * value[0]) + (X[1] * value[1])) + ((X[2] * value[2]) + (X[3] * value[3]))) * 0.25f;
+    xyz[1] = (((Y[0] * value[0]) + (Y[1] * value[1])) + ((Y[2] * value[2]) + (Y[3] * value[3]))) * 0.25f;
+    xyz[2] = (((Z[0] * value[0]) + (Z[1] * value[1])) + ((Z[2] * value[2]) + (Z[3] * value[3]))) * 0.25f;
+}
+
+/* ---- coefficient table ("SPEC" file: u32 res, res floats scale, 3*res^3*3 floats) ---- */
+typedef struct { uint32_t res; float *scale, *data; } coeff_table;
+
+static int table_load(const char *path, coeff_table *t) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return -1;
+    char hdr[4];
+    if (fread(hdr, 4, 1, f) != 1 || memcmp(hdr, "SPEC", 4) != 0 || fread(&t->res, 4, 1, f) != 1) { fclose(f); return -1; }
+    size_t n = (size_t) 9 * t->res * t->res * t->res;
+    t->scale = (float *) malloc(sizeof(float) * t->res);
+    t->data = (float *) malloc(sizeof(float) * n);
+    int ok = fread(t->scale, sizeof(float) * t->res, 1, f) == 1 && fread(t->data, sizeof(float) * n, 1, f) == 1;
+    fclose(f);
+    return ok ? 0 : -1;
+}
+
+/* rgb2spec.c:81-121 + srgb.cpp:29-39 */
+static void model_fetch(const coeff_table *t, const float c[3], float out[3]) {
+    if (c[0] == 0.0f && c[1] == 0.0f && c[2] == 0.0f) { out[0] = out[1] = 0.0f; out[2] = -INFINITY; return; }
+    if (c[0] == 1.0f && c[1] == 1.0f && c[2] == 1.0f) { out[0] = out[1] = 0.0f; out[2] = INFINITY; return; }
+    int res = (int) t->res;
+    float rgb[3];
+    for (int j = 0; j < 3; ++j) rgb[j] = fmaxf(fminf(c[j], 1.0f), 0.0f);
+    int i = 0;
+    for (int j = 1; j < 3; ++j) if (rgb[j] >= rgb[i]) i = j;
+    float z = rgb[i], sc = (float) (res - 1) / z, x = rgb[(i + 1) % 3] * sc, y = rgb[(i + 2) % 3] * sc;
+    uint32_t xi = (uint32_t) x, yi = (uint32_t) y;
+    if (xi > (uint32_t) (res - 2)) xi = (uint32_t) (res - 2);
+    if (yi > (uint32_t) (res - 2)) yi = (uint32_t) (res - 2);
+    uint32_t zi = 0;                     /* last interval whose left end is <= z */
+    for (uint32_t k = 1; k + 1 < (uint32_t) res; ++k) if (t->scale[k] <= z) zi = k;
+    size_t off = ((((size_t) i * res + zi) * res + yi) * res + xi) * 3, dx = 3, dy = 3 * (size_t) res, dz = 3 * (size_t) res * res;
+    float x1 = x - (float) xi, x0 = 1.0f - x1, y1 = y - (float) yi, y0 = 1.0f - y1;
+    float z1 = (z - t->scale[zi]) / (t->scale[zi + 1] - t->scale[zi]), z0 = 1.0f - z1;
+    const float *d = t->data;
+    for (int j = 0; j < 3; ++j, ++off)
+        out[j] = ((d[off] * x0 + d[off + dx] * x1) * y0 + (d[off + dy] * x0 + d[off + dy + dx] * x1) * y1) * z0 +
+                 ((d[off + dz] * x0 + d[off + dz + dx] * x1) * y0 + (d[off + dz + dy] * x0 + d[off + dz + dy + dx] * x1) * y1) * z1;
+}
+
+int mo_scene_set_spectral(mo_scene *s, const char *coeff_path) {
+    coeff_table t = { 0, NULL, NULL };
+    if (!s || table_load(coeff_path, &t)) return -1;
+    for (uint32_t i = 0; i < s->n_meshes; ++i) {
+        mo_mesh *m = &s->meshes[i];
+        if (m->texture >= 0) { free(t.scale); free(t.data); return -2; }
+        for (int k = 0; k < 3; ++k) if (m->refl[k] < 0.0f || m->refl[k] > 1.0f) { free(t.scale); free(t.data); return -3; }   /* srgb.cpp:34-35 */
+        model_fetch(&t, m->refl, m->refl_coeff);
+    }
+    for (uint32_t e = 0; e < s->n_emitters; ++e) {
+        mo_emitter *em = &s->emitters[e];
+        float color[3] = { em->radiance[0], em->radiance[1], em->radiance[2] };
+        float scale = fmaxf(fmaxf(color[0], color[1]), color[2]) * 2.0f;            /* srgb_d65.cpp:36-40 */
+        if (scale != 0.0f) { float r = 1.0f / scale; for (int k = 0; k < 3; ++k) color[k] *= r; }
+        model_fetch(&t, color, em->coeff);
+        float m_scale = 1.0f * scale;
+        m_scale *= 1.0f / 10568.0f;                                                  /* d65.cpp:48-49 */
+        em->d65_scale = m_scale;
+    }
+    s->spectral = 1;
+    free(t.scale); free(t.data);
+    return 0;
+}
+
+void mo_kat_srgb_model_fetch(const char *coeff_path, const float *rgb3, float *coeff3) {
+    coeff_table t = { 0, NULL, NULL };
+    coeff3[0] = coeff3[1] = coeff3[2] = NAN;
+    if (table_load(coeff_path, &t)) return;
+    model_fetch(&t, rgb3, coeff3);
+    free(t.scale); free(t.data);
+}
+
+void mo_kat_spectral(float sample, const float *coeff3, float d65_scale, float *out) {
+    float wav[MO_WAV], weight[MO_WAV], refl[MO_WAV];
+    mo_sample_wavelengths(sample, wav, weight);
+    for (int k = 0; k < MO_WAV; ++k) {
+        out[k] = wav[k]; out[4 + k] = weight[k];
+        refl[k] = mo_srgb_model_eval(coeff3, wav[k]); out[8 + k] = refl[k];
+        out[12 + k] = mo_d65_eval(d65_scale, wav[k]);
+    }
+    mo_spectrum_to_xyz(refl, wav, out + 16);
+}

@@ -79,6 +79,9 @@ def lib():
         L.mo_kat_distr.argtypes = [C.c_uint32, vp, vp, C.c_uint32, vp, vp, vp]
         L.mo_kat_diffuse.argtypes = [vp] * 9
         L.mo_kat_sample_emitter.argtypes = [vp] * 4
+        L.mo_scene_set_spectral.argtypes = [vp, C.c_char_p]
+        L.mo_kat_srgb_model_fetch.argtypes = [C.c_char_p, vp, vp]
+        L.mo_kat_spectral.argtypes = [C.c_float, vp, C.c_float, vp]
         _lib = L
     return _lib
 
@@ -92,7 +95,7 @@ def _f(a):
 
 
 class OracleScene:
-    def __init__(self, scene_dict, naive=False):
+    def __init__(self, scene_dict, naive=False, spectral_path=None):
         L = lib()
         self.h = C.c_void_p(L.mo_scene_new())
         self.tex_of_bsdf = {}
@@ -120,6 +123,10 @@ class OracleScene:
                 assert L.mo_scene_set_texture(self.h, rc, self.tex_of_bsdf[m["bsdf"]]) == 0
         assert L.mo_scene_finalize(self.h) == 0
         L.mo_scene_set_naive(self.h, 1 if naive else 0)
+        if spectral_path is not None:
+            rc = L.mo_scene_set_spectral(self.h, spectral_path.encode())
+            if rc != 0:
+                raise RuntimeError("oracle: spectral setup failed (%d)" % rc)
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -250,3 +257,15 @@ def rfilter_table(rfilter, param):
     tbl = np.empty(32, np.float32); radius = C.c_float(); b = C.c_int()
     lib().mo_rfilter_table(rfilter, param, _p(tbl), C.byref(radius), C.byref(b))
     return tbl, radius.value, b.value
+
+
+def srgb_model_fetch(path, rgb):
+    out = np.empty(3, np.float32)
+    lib().mo_kat_srgb_model_fetch(path.encode(), _p(_f(rgb)), _p(out))
+    return out
+
+
+def spectral_kat(sample, coeff, d65_scale):
+    out = np.empty(19, np.float32)
+    lib().mo_kat_spectral(C.c_float(sample), _p(_f(coeff)), C.c_float(d65_scale), _p(out))
+    return dict(wav=out[0:4], weight=out[4:8], refl=out[8:12], d65=out[12:16], xyz=out[16:19])

@@ -1,0 +1,116 @@
+"""Spectral variant on the CPU: the RGB -> spectrum coefficient table against the
+reference's own tool (ext/rgb2spec/rgb2spec_opt.cpp compiled into oracle/_ref/, the one piece of the reference that
+builds from its own sources), the product's table lookup against the oracle's, and closed-form properties of the
+spectral helpers."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_TOOL = os.path.join(ROOT, "oracle", "_ref", "rgb2spec_opt")
+
+
+def _load(path):
+    b = open(path, "rb").read()
+    assert b[:4] == b"SPEC"
+    res = int(np.frombuffer(b[4:8], np.uint32)[0])
+    return res, np.frombuffer(b[8:8 + 4 * res], np.float32), np.frombuffer(b[8 + 4 * res:], np.float32).reshape(-1, 3)
+
+
+def _spectrum(coeff, lam):
+    c = coeff.astype(np.float64)
+    x = (c[..., 0:1] * lam + c[..., 1:2]) * lam + c[..., 2:3]
+    return 0.5 + 0.5 * x / np.sqrt(1 + x * x)
+
+
+def test_table_generator_matches_reference_tool(tmp_path):
+    from mitsuba2_amd import _lib as L
+    if not os.path.exists(REF_TOOL):
+        if not os.path.exists("/root/reference/ext/rgb2spec/rgb2spec_opt.cpp"):
+            pytest.skip("reference sources not present (GPU box): oracle/_ref cannot be rebuilt")
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "_ref/rgb2spec_opt"], stdout=subprocess.DEVNULL)
+    ours, ref = str(tmp_path / "ours.coeff"), str(tmp_path / "ref.coeff")
+    L.check(L.lib().mtsamd_rgb2spec_build(ours.encode(), 16, 4))
+    subprocess.check_call([REF_TOOL, "16", ref], stdout=subprocess.DEVNULL)
+    r0, s0, d0 = _load(ours)
+    r1, s1, d1 = _load(ref)
+    assert r0 == r1 == 16 and (s0 == s1).all() and d0.shape == d1.shape
+    assert (d0 == d1).mean() > 0.9                                   # same algorithm in double: mostly bit-identical
+    lam = np.linspace(360, 830, 48)
+    assert np.abs(_spectrum(d0, lam) - _spectrum(d1, lam)).max() < 2e-3   # ill-conditioned near-black cells differ most
+
+
+def test_fetch_product_vs_oracle(oracle):
+    from mitsuba2_amd import _lib as L, render
+    path = render.srgb_coeff_path()
+    res, scale, data = _load(path)
+    assert res == 64                                                 # ext/rgb2spec/CMakeLists.txt:49-54
+    rng = np.random.RandomState(0)
+    cols = np.concatenate([rng.rand(200, 3), [[0, 0, 0], [1, 1, 1], [1, 0, 0], [0.5, 0.5, 0.5], [0.63, 0.065, 0.05], [1e-4, 2e-4, 5e-5]]]).astype(np.float32)
+    for c in cols:
+        out = (C.c_float * 3)()
+        L.check(L.lib().mtsamd_srgb_model_fetch(path.encode(), (C.c_float * 3)(*c.tolist()), out))
+        ref = oracle.srgb_model_fetch(path, c)
+        assert np.array_equal(np.array(out, np.float32), ref, equal_nan=True), (c, list(out), ref)
+    # sentinels of srgb_model_fetch (srgb.cpp:29-32)
+    assert oracle.srgb_model_fetch(path, [0, 0, 0]).tolist() == [0, 0, -np.inf]
+    assert oracle.srgb_model_fetch(path, [1, 1, 1]).tolist() == [0, 0, np.inf]
+
+
+def test_upsampled_spectra_reproduce_their_colour(oracle):
+    # integrate S(lambda) * D65 * cmf -> XYZ -> sRGB and compare with the colour that was upsampled
+    from mitsuba2_amd import render
+    path = render.srgb_coeff_path()
+    # CIE data through the oracle header (data only)
+    txt = open(os.path.join(ROOT, "oracle", "mo_cie_data.h")).read()
+    import re
+    tab = {k: np.array([float(v) for v in re.findall(r"[-+]?\d*\.\d+", re.search(r"mo_cie_%s\[95\] = \{(.*?)\};" % k, txt, re.S).group(1))]) for k in ("x", "y", "z", "d65")}
+    lam5 = np.linspace(360, 830, 95)
+    lam = np.linspace(360, 830, 941)
+    cmf = np.stack([np.interp(lam, lam5, tab[k]) for k in "xyz"])
+    d65 = np.interp(lam, lam5, tab["d65"]) / 10566.864005283874576
+    M = np.array([[3.240479, -1.537150, -0.498535], [-0.969256, 1.875991, 0.041556], [0.055648, -0.204043, 1.057311]])
+    for rgb in ([0.725, 0.71, 0.68], [0.63, 0.065, 0.05], [0.14, 0.45, 0.091], [0.2, 0.2, 0.9], [0.05, 0.05, 0.05]):
+        c = oracle.srgb_model_fetch(path, rgb)
+        S = _spectrum(c[None, :], lam)[0]
+        xyz = np.trapezoid(cmf * d65 * S, lam, axis=1)
+        assert np.allclose(M @ xyz, rgb, atol=4e-3), (rgb, M @ xyz)
+
+
+def test_spectral_helpers(oracle):
+    # sample_wavelength: shifted samples, weight = 1 / pdf_rgb_spectrum (spectrum.h:287-303)
+    k = oracle.spectral_kat(0.3, [0.0, 0.0, np.inf], 1.0 / 10568.0)
+    assert (k["wav"] >= 360).all() and (k["wav"] <= 830).all()
+    pdf = 0.003939804229326285 / np.cosh(0.0072 * (k["wav"].astype(np.float64) - 538.0)) ** 2
+    assert np.allclose(k["weight"] * pdf, 1.0, atol=2e-5)
+    assert (k["refl"] == 1.0).all()                                    # +inf sentinel: white
+    assert (oracle.spectral_kat(0.3, [0.0, 0.0, -np.inf], 1.0)["refl"] == 0.0).all()
+    # the 4 samples are the shifted copies of one uniform variate (math.h:418-425)
+    u = (0.8569106254698279 - np.tanh((538.0 - k["wav"].astype(np.float64)) / 138.88888888888889)) / 1.8275019724092267
+    assert np.allclose(np.sort(np.mod(u - 0.3, 1.0)), [0, 0.25, 0.5, 0.75], atol=1e-4) or np.allclose(np.sort(np.mod(u - 0.3 + 1e-6, 1.0)), [0, 0.25, 0.5, 0.75], atol=1e-4)
+    # D65 is scaled to unit luminance: E[weight * d65 * ybar] ~ 1 (d65.cpp:44-50)
+    ys = [oracle.spectral_kat(float(u0), [0.0, 0.0, np.inf], 1.0 / 10568.0) for u0 in (np.arange(256) + 0.5) / 256]
+    # luminance of D65 under the sampling density: mean over samples of weight * d65 * ybar
+    txt = open(os.path.join(ROOT, "oracle", "mo_cie_data.h")).read()
+    import re
+    ybar = np.array([float(v) for v in re.findall(r"[-+]?\d*\.\d+", re.search(r"mo_cie_y\[95\] = \{(.*?)\};", txt, re.S).group(1))])
+    lam5 = np.linspace(360, 830, 95)
+    lum = np.mean([np.mean(kk["weight"] * kk["d65"] * np.interp(kk["wav"], lam5, ybar)) for kk in ys])
+    assert abs(lum - 1.0) < 0.01
+
+
+def test_spectral_oracle_render_is_close_to_rgb(oracle):
+    from mitsuba2_amd import scenes, render
+    sd = scenes.cornell_box()
+    p = scenes.cornell_box_sensor(32, 32, 32)
+    d = oracle.make_desc(p)
+    rgb_film, _ = oracle.OracleScene(sd).render(d, mode=1)
+    spec_film, _ = oracle.OracleScene(sd, spectral_path=render.srgb_coeff_path()).render(d, mode=1)
+    a, b = oracle.film_develop(rgb_film), oracle.film_develop(spec_film)
+    assert np.allclose(a[..., 3], b[..., 3], atol=1e-6)                # same geometry, same RNG consumption
+    # colours agree up to metamerism of multi-bounce transport + spectral sampling noise
+    assert abs(a[..., :3].mean() - b[..., :3].mean()) / a[..., :3].mean() < 0.1
+    assert np.all(np.abs(a[..., :3].mean(axis=(0, 1)) - b[..., :3].mean(axis=(0, 1))) / a[..., :3].mean(axis=(0, 1)) < 0.2)
