@@ -742,36 +742,64 @@ __global__ __launch_bounds__(kBlock) void k_film_tiles(const FilmParams F) {
     const float offx = (float) (F.crop_x - b) + 0.5f, offy = (float) (F.crop_y - b) + 0.5f;
     const uint32_t pix0 = F.plane_pix0, npix = F.plane_pixels;
     float acc[5] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+    // Every thread stages up to kStage records per chunk.  Their stream slots for sample plane s are slot0 + s * step;
+    // the loads of the NEXT chunk are issued before the gather of the current one so that their latency is hidden.
+    constexpr int kStage = 4;
+    int64_t slot0[kStage]; int64_t step[kStage]; int ent_c[kStage]; int tap_x0[kStage], tap_y0[kStage];
+#pragma unroll
+    for (int k = 0; k < kStage; ++k) {
+        const int e = (int) threadIdx.x + k * kBlock;
+        slot0[k] = -1; step[k] = 0; ent_c[k] = 0; tap_x0[k] = tap_y0[k] = 0;
+        if (e < kFilmChunk * NS) {
+            const int c = e / NS, sp = e - c * NS;
+            const int qx = tx0 - R + sp % SW, qy = ty0 - R + sp / SW;
+            ent_c[k] = c; tap_x0[k] = qx + b - R; tap_y0[k] = qy + b - R;
+            const int lr = (qx >= 0 && qx < F.crop_w && qy >= 0 && qy < F.crop_h) ? row_to_local(F.rows, qy) : -1;
+            if (lr >= 0) {
+                const uint32_t lp = (uint32_t) lr * (uint32_t) F.crop_w + (uint32_t) qx;
+                if (npix) {
+                    if (lp >= pix0 && lp - pix0 < npix) { slot0[k] = (int64_t) c * npix + (lp - pix0); step[k] = (int64_t) npix; }
+                } else {
+                    const uint64_t ord = (uint64_t) lp * (uint64_t) F.spp + (uint64_t) c;
+                    // passes hold whole film rows: a pixel is either completely inside the stream or not at all
+                    if (ord >= F.first_ordinal && ord - F.first_ordinal < F.n_samples) { slot0[k] = (int64_t) (ord - F.first_ordinal); step[k] = 1; }
+                }
+            }
+        }
+    }
+    float4 pv[kStage]; float2 pq[kStage];
+    auto prefetch = [&](int s0) {
+#pragma unroll
+        for (int k = 0; k < kStage; ++k) {
+            pv[k] = make_float4(0.0f, 0.0f, 0.0f, -1.0f); pq[k] = make_float2(0.0f, 0.0f);
+            if (slot0[k] >= 0 && s0 + ent_c[k] < F.spp) {
+                const size_t slot = (size_t) (slot0[k] + (int64_t) s0 * step[k]);
+                pv[k] = F.out_rgba[slot]; pq[k] = F.out_pos[slot];
+            }
+        }
+    };
+    prefetch(0);
     __syncthreads();
     for (int s0 = 0; s0 < F.spp; s0 += kFilmChunk) {
         // ---- stage: one record per (sample plane, source pixel): value + 2R+1 taps per axis
-        for (int e = (int) threadIdx.x; e < kFilmChunk * NS; e += kBlock) {
-            const int c = e / NS, sp = e - c * NS;
-            const int qx = tx0 - R + sp % SW, qy = ty0 - R + sp / SW;
+#pragma unroll
+        for (int k = 0; k < kStage; ++k) {
+            const int e = (int) threadIdx.x + k * kBlock;
+            if (e >= kFilmChunk * NS) continue;
             float4 val = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             float wxs[kFilmTaps], wys[kFilmTaps];
 #pragma unroll
-            for (int k = 0; k < kFilmTaps; ++k) wxs[k] = wys[k] = 0.0f;
-            const int lr = (qx >= 0 && qx < F.crop_w && qy >= 0 && qy < F.crop_h && s0 + c < F.spp) ? row_to_local(F.rows, qy) : -1;
-            if (lr >= 0) {
-                const uint32_t lp = (uint32_t) lr * (uint32_t) F.crop_w + (uint32_t) qx;
-                const uint64_t ord = (uint64_t) lp * (uint64_t) F.spp + (uint64_t) (s0 + c);
-                const bool have = npix ? (lp >= pix0 && lp - pix0 < npix) : (ord >= F.first_ordinal && ord - F.first_ordinal < F.n_samples);
-                if (have) {
-                    const size_t slot = npix ? (size_t) (s0 + c) * npix + (lp - pix0) : (size_t) (ord - F.first_ordinal);
-                    const float4 v = F.out_rgba[slot];          // (X, Y, Z, alpha), alpha < 0: invalid sample (dropped)
-                    if (v.w >= 0.0f) {
-                        const float2 pp = F.out_pos[slot];
-                        val = v;
-                        axis_taps(f, table, pp.x - offx, sx, qx + b - R, R, wxs);
-                        axis_taps(f, table, pp.y - offy, sy, qy + b - R, R, wys);
-                    }
-                }
+            for (int t = 0; t < kFilmTaps; ++t) wxs[t] = wys[t] = 0.0f;
+            if (pv[k].w >= 0.0f) {                          // (X, Y, Z, alpha); alpha < 0: invalid or absent sample
+                val = pv[k];
+                axis_taps(f, table, pq[k].x - offx, sx, tap_x0[k], R, wxs);
+                axis_taps(f, table, pq[k].y - offy, sy, tap_y0[k], R, wys);
             }
             V[e] = val;
 #pragma unroll
-            for (int k = 0; k < kFilmTaps; ++k) { WX[kFilmTaps * e + k] = wxs[k]; WY[kFilmTaps * e + k] = wys[k]; }
+            for (int t = 0; t < kFilmTaps; ++t) { WX[kFilmTaps * e + t] = wxs[t]; WY[kFilmTaps * e + t] = wys[t]; }
         }
+        if (s0 + kFilmChunk < F.spp) prefetch(s0 + kFilmChunk);
         __syncthreads();
         // ---- gather: film pixel (x, y) <- samples of the (2R+1)^2 neighbouring pixels, fixed order.  The source
         // pixel at offset (dx, dy) of the tile origin sees this film pixel as its tap (2R - dx, 2R - dy).
