@@ -177,18 +177,76 @@ class IndependentSampler:
 class HDRFilm:
     """src/films/hdrfilm.cpp + src/librender/film.cpp (defaults 768x576, gaussian filter)."""
 
-    def __init__(self, width=768, height=576, crop_offset=None, crop_size=None, rfilter=None):
+    def __init__(self, width=768, height=576, crop_offset=None, crop_size=None, rfilter=None, file_format="openexr",
+                 pixel_format="rgba", component_format="float16", high_quality_edges=False):
         self._size = (int(width), int(height))
         co = (0, 0) if crop_offset is None else (int(crop_offset[0]), int(crop_offset[1]))
         cs = self._size if crop_size is None else (int(crop_size[0]), int(crop_size[1]))
         self.set_crop_window(co, cs)
         self._filter = rfilter if rfilter is not None else GaussianFilter()
         self._storage = None
+        self._dest_file = None
+        self._hq_edges = bool(high_quality_edges)
+        # hdrfilm.cpp:42-123: parameter validation and the per-format overrides
+        ff, pf, cf = file_format.lower(), pixel_format.lower(), component_format.lower()
+        if ff in ("openexr", "exr"):
+            ff = "exr"
+        elif ff not in ("rgbe", "pfm"):
+            raise RuntimeError('The "file_format" parameter must either be equal to "openexr", "pfm", or "rgbe", found %s instead.' % ff)
+        if pf not in ("luminance", "luminance_alpha", "rgb", "rgba", "xyz", "xyza"):
+            raise RuntimeError('The "pixel_format" parameter must either be equal to "luminance", "luminance_alpha", "rgb", "rgba", '
+                               '"xyz", "xyza". Found %s.' % pf)
+        if cf not in ("float16", "float32", "uint32"):
+            raise RuntimeError('The "component_format" parameter must either be equal to "float16", "float32", or "uint32". Found %s instead.' % cf)
+        if ff == "rgbe":
+            pf, cf = "rgb", "float32"
+        elif ff == "pfm":
+            pf, cf = (pf if pf in ("rgb", "luminance") else "rgb"), "float32"
+        self._file_format, self._pixel_format, self._component_format = ff, pf, cf
 
     def size(self): return self._size
     def crop_size(self): return self._crop_size
     def crop_offset(self): return self._crop_offset
     def reconstruction_filter(self): return self._filter
+    def has_high_quality_edges(self): return self._hq_edges
+
+    def set_destination_file(self, filename):
+        """hdrfilm.cpp:205-209"""
+        self._dest_file = str(filename)
+
+    def develop(self):
+        """hdrfilm.cpp:322-342: convert the storage to pixel_format / component_format and write it to the destination
+        file (the extension is replaced by the file format's)."""
+        import os
+        from . import bitmap as B
+        if not self._dest_file:
+            raise RuntimeError("Destination file not specified, cannot develop.")
+        ext = {"exr": ".exr", "rgbe": ".rgbe", "pfm": ".pfm"}[self._file_format]
+        root, cur = os.path.splitext(self._dest_file)
+        filename = self._dest_file if cur.lower() == ext else root + ext
+        raw = self.bitmap(raw=True)
+        if raw.shape[2] != 5:
+            raise RuntimeError("HDRFilm::develop(): only the X, Y, Z, A, W storage layout can be written")
+        if self._pixel_format in ("rgb", "rgba"):
+            px = self.bitmap().cpu().numpy()
+            px = px if self._pixel_format == "rgba" else px[..., :3]
+            names = "RGBA"[:px.shape[2]]
+        else:                           # Bitmap::convert from XYZAW: divide by the weight, keep XYZ / take Y
+            r = raw.cpu().numpy()
+            w = r[..., 4:5]
+            inv = np.where(w != 0, 1.0 / np.where(w != 0, w, 1), 0).astype(np.float32)
+            xyz, a = r[..., :3] * inv, r[..., 3:4] * inv
+            px = {"xyz": xyz, "xyza": np.concatenate([xyz, a], 2), "luminance": xyz[..., 1:2],
+                  "luminance_alpha": np.concatenate([xyz[..., 1:2], a], 2)}[self._pixel_format]
+            names = {"xyz": "XYZ", "xyza": "XYZA", "luminance": "Y", "luminance_alpha": "YA"}[self._pixel_format]
+        if self._file_format == "pfm":
+            B.write_pfm(filename, px)
+        elif self._file_format == "rgbe":
+            B.write_rgbe(filename, px)
+        else:
+            dt = {"float16": np.float16, "float32": np.float32, "uint32": np.uint32}[self._component_format]
+            B.write_exr(filename, {n: np.ascontiguousarray(px[..., i]).astype(dt) for i, n in enumerate(names)})
+        return filename
 
     def set_crop_window(self, crop_offset, crop_size):
         """film.cpp:55-64"""

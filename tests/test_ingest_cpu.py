@@ -1,0 +1,285 @@
+"""Scene ingestion and image IO, CPU only: mesh loaders and normal generation against
+the reference's own fixtures and expected values (src/librender/tests/test_mesh.py:35-107, data/triangle*.ply copied
+to tests/golden/ as data), the XML subset's error behaviour (src/libcore/tests/test_xml.py) and file-format round trips.
+The EXR writer has no reference-produced file to compare with (the reference ships none): its byte layout is
+"parity unpinned" and covered by a write -> read round trip only."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from mitsuba2_amd import bitmap, loaders, scenes
+from mitsuba2_amd import xml as mxml
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+# ------------------------------------------------------------------------------------------------ meshes
+def test_ply_triangle():
+    """test_mesh.py:35-57 (test02_ply_triangle)"""
+    d = mxml.parse_string("""<scene version="2.0.0"><shape type="ply">
+            <string name="filename" value="triangle.ply"/>
+            <boolean name="face_normals" value="true"/>
+        </shape></scene>""", base_dir=GOLDEN)
+    m = d.scene_dict["meshes"][0]
+    assert m["normals"] is None
+    assert m["positions"].size == 9
+    assert np.allclose(m["positions"], [[0, 0, 0], [0, 0, 1], [0, 1, 0]])
+    assert m["faces"].tolist() == [[0, 1, 2]]
+
+
+def test_ply_computed_normals():
+    """test_mesh.py:60-77 (test03_ply_computed_normals)"""
+    m = loaders.load_ply(os.path.join(GOLDEN, "triangle.ply"))
+    assert m["normals"] is not None
+    assert np.allclose(m["normals"], [[-1, 0, 0]] * 3)
+
+
+def test_ply_binary_with_face_attributes():
+    """binary_little_endian file with normals and per-face float attributes (data/triangle_face_colors.ply)"""
+    m = loaders.load_ply(os.path.join(GOLDEN, "triangle_face_colors.ply"))
+    assert np.allclose(m["positions"], [[0, 0, 0], [0, 0, 1], [0, 1, 0]])
+    assert np.allclose(m["normals"], [[-1, 0, 0]] * 3)
+    assert m["faces"].tolist() == [[0, 1, 2]]
+
+
+def test_normal_weighting_scheme():
+    """test_mesh.py:80-107 (test04_normal_weighting_scheme)"""
+    a, b = 1.0, 0.5
+    vertices = np.array([0, 0, 0, -a, 1, 0, a, 1, 0, -b, 0, 1, b, 0, 1], dtype=np.float32).reshape(5, 3)
+    n0, n1 = np.array([0.0, 0.0, -1.0]), np.array([0.0, 1.0, 0.0])
+    n2 = n0 * (math.pi / 2.0) + n1 * math.acos(3.0 / 5.0)
+    n2 /= np.linalg.norm(n2)
+    expected = np.vstack([n2, n0, n0, n1, n1])
+    got = loaders.compute_vertex_normals(vertices, [[0, 1, 2], [0, 3, 4]])
+    assert np.allclose(got, expected, atol=5e-4)
+
+
+def test_normals_unreferenced_vertex_is_bogus():
+    """mesh.cpp:243-249: a vertex without a valid normal gets (1, 0, 0)"""
+    got = loaders.compute_vertex_normals([[0, 0, 0], [1, 0, 0], [0, 1, 0], [5, 5, 5]], [[0, 1, 2]])
+    assert np.allclose(got[3], [1, 0, 0]) and np.allclose(got[:3], [[0, 0, 1]] * 3)
+
+
+def _write_box_obj(path, with_normals, with_uv):
+    """the Cornell box's small box written the way the reference's cbox_smallbox.obj is: 24 vertices, 6 quads"""
+    cb = scenes.cornell_box()
+    m = cb["meshes"][7]
+    pos, faces = np.asarray(m["positions"]).reshape(-1, 3), np.asarray(m["faces"]).reshape(-1, 3)
+    with open(path, "w") as fh:
+        fh.write("# test\n")
+        for p in pos:
+            fh.write("v %g %g %g\n" % tuple(p))
+        if with_uv:
+            for k in range(len(pos)):
+                fh.write("vt %g %g\n" % (0.25 * (k % 4), 0.125 * (k // 4)))
+        if with_normals:
+            for f in faces:
+                n = np.cross(pos[f[1]] - pos[f[0]], pos[f[2]] - pos[f[0]])
+                fh.write("vn %g %g %g\n" % tuple(n / np.linalg.norm(n)))
+        for i, f in enumerate(faces):
+            def key(v):
+                return "%d%s%s" % (v + 1, ("/%d" % (v + 1)) if with_uv else ("/" if with_normals else ""), ("/%d" % (i + 1)) if with_normals else "")
+            fh.write("f %s %s %s\n" % tuple(key(v) for v in f))
+    return pos, faces
+
+
+@pytest.mark.parametrize("features", ["none", "normals", "uv", "normals_uv"])
+@pytest.mark.parametrize("face_normals", [True, False])
+def test_obj_features(tmp_path, features, face_normals):
+    """test_mesh.py:137-170 (test06_load_various_features): the loader honours vn / vt / face_normals combinations"""
+    path = str(tmp_path / "box.obj")
+    pos, faces = _write_box_obj(path, "normals" in features, "uv" in features)
+    m = loaders.load_obj(path, face_normals=face_normals)
+    assert m["faces"].shape == faces.shape
+    tri = m["positions"][m["faces"]]
+    assert np.allclose(tri, pos[faces])                              # same triangles, whatever the vertex split
+    assert (m["normals"] is None) == face_normals
+    assert (m["texcoords"] is not None) == ("uv" in features)
+    if not face_normals:
+        fn = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+        fn /= np.linalg.norm(fn, axis=1, keepdims=True)
+        if "normals" in features:                                     # per-face vn: every corner carries the face normal
+            assert np.allclose(m["normals"][m["faces"]], np.repeat(fn[:, None], 3, 1), atol=1e-5)
+        else:
+            assert np.allclose(np.linalg.norm(m["normals"], axis=1), 1, atol=1e-5)
+    if "uv" in features:                                              # flip_tex_coords default: v -> 1 - v (obj.cpp:188-195)
+        uv = m["texcoords"][m["faces"]]
+        assert np.allclose(uv[..., 0], 0.25 * (faces % 4)) and np.allclose(uv[..., 1], 1 - 0.125 * (faces // 4))
+
+
+def test_obj_quads_and_to_world(tmp_path):
+    """obj.cpp:255-264 fan triangulation; obj.cpp:176-178 to_world baked into positions"""
+    path = str(tmp_path / "quad.obj")
+    with open(path, "w") as fh:
+        fh.write("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv -0.5 0.5 0\nf 1 2 3 4 5\n")
+    m = loaders.load_obj(path, to_world=mxml.translate([1, 2, 3]) @ mxml.scale([2, 2, 2]))
+    assert m["faces"].tolist() == [[0, 1, 2], [0, 2, 3], [0, 3, 4]]
+    assert np.allclose(m["positions"][2], [3, 4, 3])
+    assert np.allclose(m["normals"], [[0, 0, 1]] * 5)
+    with open(path, "w") as fh:
+        fh.write("v 0 0 0\nv 1 0 0\nf 1 2 7\n")
+    with pytest.raises(RuntimeError, match="invalid vertex"):
+        loaders.load_obj(path)
+
+
+# ------------------------------------------------------------------------------------------------ XML
+def test_xml_invalid_roots():
+    """test_xml.py:7-27"""
+    with pytest.raises(Exception):
+        mxml.parse_string('<?xml version="1.0"?>')
+    with pytest.raises(Exception):
+        mxml.parse_string('<?xml version="1.0"?><invalid></invalid>')
+    with pytest.raises(Exception, match='root element "integer" must be an object'):
+        mxml.parse_string('<?xml version="1.0"?><integer name="a" value="10"></integer>')
+    assert mxml.parse_string('<?xml version="1.0"?>\n<scene version="2.0.0"></scene>').scene_dict["meshes"] == []
+
+
+@pytest.mark.parametrize("body,message", [
+    ('<shape type="ply" id="my_id"/><shape type="ply" id="my_id"/>', '"shape" has duplicate id "my_id"'),
+    ('<shape type="ply" id="_test"/>', 'invalid id "_test" in element "shape": leading underscores are reserved for internal identifiers.'),
+    ('<shape type="ply"><integer name="_test" value="1"/></shape>',
+     'invalid parameter name "_test" in element "integer": leading underscores are reserved for internal identifiers.'),
+    ('<shape type="ply"><integer name="value" value="1"><shape type="ply"/></integer></shape>', 'node "shape" cannot occur as child of a property'),
+    ('<shape type="ply"><integer name="value" value="1"><float name="value" value="1"/></integer></shape>',
+     'node "float" cannot occur as child of a property'),
+    ('<shape type="ply"><translate name="value" x="0" y="1" z="2"/></shape>', 'transform operations can only occur in a transform node'),
+    ('<shape type="ply"><transform name="toWorld"><integer name="value" value="10"/></transform></shape>',
+     'transform nodes can only contain transform operations'),
+    ('<ref id="unknown"/>', 'reference to unknown object "unknown"'),
+    ('<shape type="ply" param2="abc"></shape>', 'unexpected attribute "param2" in element "shape".'),
+    ('<integer name="a"/>', 'missing attribute "value" in element "integer".'),
+    ('<integer name="a" value="1"/><integer name="a" value="1"/>', 'Property "a" was specified multiple times'),
+    ('<shape type="ply"/>', 'Property "filename" has not been specified'),
+    ('<shape type="ply"><float name="filename" value="1.0"/></shape>', r'The property "filename" has the wrong type \(expected <string>\).'),
+    ('<integer name="n" value="a"/>', 'could not parse integer value "a".'),
+    ('<integer name="n" value="1.5"/>', 'could not parse integer value "1.5".'),
+    ('<float name="n" value="a"/>', 'could not parse floating point value "a".'),
+    ('<shape type="sphere"/>', 'Shape plugin "sphere" is not supported'),
+    ('<shape type="rectangle"><bsdf type="roughconductor"/></shape>', 'BSDF plugin "roughconductor" is not supported'),
+    ('<shape type="rectangle"><float name="bogus" value="1"/></shape>', 'unreferenced property "bogus"'),
+])
+def test_xml_errors(body, message):
+    """test_xml.py:40-215 (test05 .. test17): the same messages, minus the line/column prefix"""
+    with pytest.raises(Exception, match=message):
+        mxml.parse_string('<scene version="2.0.0">%s</scene>' % body)
+
+
+def test_xml_transform_order_and_lookat():
+    """xml.cpp:845-892: each operation is applied on the left of what came before it"""
+    d = mxml.parse_string("""<scene version="2.0.0"><shape type="rectangle"><transform name="to_world">
+        <scale value="2"/><rotate z="1" angle="90"/><translate x="1" y="2" z="3"/></transform></shape></scene>""")
+    p = d.scene_dict["meshes"][0]["positions"]
+    assert np.allclose(p[1], [1 + 2, 2 + 2, 3], atol=1e-5)          # (1,-1,0) -> scale (2,-2,0) -> rot z 90 (2,2,0) -> +t
+    m = mxml.look_at([0, 0, 5], [0, 0, 0], [0, 1, 0])
+    assert np.allclose(m[:3, 2], [0, 0, -1]) and np.allclose(m[:3, 3], [0, 0, 5]) and np.allclose(m[:3, 0], [-1, 0, 0])
+    with pytest.raises(Exception, match="invalid lookat transformation"):
+        mxml.parse_string('<scene version="2.0.0"><sensor type="perspective"><transform name="to_world">'
+                          '<lookat origin="0,0,0" target="0,1,0" up="0,1,0"/></transform></sensor></scene>')
+
+
+CBOX_XML = """<scene version="2.0.0">
+    <default name="spp" value="4"/>
+    <default name="res" value="32"/>
+    <integrator type="path"><integer name="max_depth" value="$depth"/></integrator>
+    <sensor type="perspective">
+        <string name="fov_axis" value="smaller"/>
+        <float name="near_clip" value="10"/> <float name="far_clip" value="2800"/>
+        <float name="fov" value="39.3077"/>
+        <transform name="to_world"><lookat origin="278, 273, -800" target="278, 273, -799" up="0, 1, 0"/></transform>
+        <sampler type="independent"><integer name="sample_count" value="$spp"/><integer name="seed" value="7"/></sampler>
+        <film type="hdrfilm"><integer name="width" value="$res"/><integer name="height" value="$res"/>
+            <rfilter type="gaussian"/></film>
+    </sensor>
+    <bsdf type="diffuse" id="white"><rgb name="reflectance" value="0.885809, 0.698859, 0.666422"/></bsdf>
+    <bsdf type="diffuse" id="light"><spectrum name="reflectance" value="0"/></bsdf>
+    <alias id="white" as="box"/>
+    <shape type="obj" id="floor"><string name="filename" value="floor.obj"/><ref id="box"/></shape>
+    <shape type="rectangle" id="lamp">
+        <transform name="to_world"><rotate x="1" angle="90"/><scale value="60"/><translate x="278" y="548" z="280"/></transform>
+        <ref id="light"/>
+        <emitter type="area"><rgb name="radiance" value="18.387, 13.9873, 6.75357"/></emitter>
+    </shape>
+</scene>"""
+
+
+def test_xml_scene_subset(tmp_path):
+    with open(str(tmp_path / "floor.obj"), "w") as fh:
+        fh.write("v 552.8 0 0\nv 0 0 0\nv 0 0 559.2\nv 549.6 0 559.2\nf 1 2 3 4\n")
+    with pytest.raises(Exception, match="undefined parameter"):
+        mxml.parse_string(CBOX_XML, base_dir=str(tmp_path))
+    d = mxml.parse_string(CBOX_XML, base_dir=str(tmp_path), depth=6, spp=16)
+    sd = d.scene_dict
+    assert d.integrator == dict(max_depth=6, rr_depth=5)
+    assert [b["id"] for b in sd["bsdfs"]] == ["white", "light"]
+    assert np.allclose(sd["bsdfs"][0]["reflectance"], [0.885809, 0.698859, 0.666422]) and sd["bsdfs"][1]["reflectance"] == [0.0] * 3
+    floor, lamp = sd["meshes"]
+    assert floor["bsdf"] == 0 and floor["emitter"] == -1 and floor["faces"].tolist() == [[0, 1, 2], [0, 2, 3]]
+    assert lamp["bsdf"] == 1 and lamp["emitter"] == 0 and np.allclose(sd["emitters"][0]["radiance"], [18.387, 13.9873, 6.75357])
+    assert np.allclose(lamp["positions"][:, 1], 548, atol=1e-3)                      # rotated into the xz plane, then lifted
+    n = np.cross(lamp["positions"][1] - lamp["positions"][0], lamp["positions"][2] - lamp["positions"][0])
+    assert n[1] < 0                                                                  # rotate x 90: +z -> -y (faces down)
+    s = d.sensors[0]
+    assert s["sampler"] == dict(sample_count=16, seed=7) and s["film"]["width"] == 32 and s["film"]["rfilter"] == ("gaussian", 0.5)
+    assert s["fov_axis"] == "smaller" and abs(s["fov"] - 39.3077) < 1e-6
+    assert np.allclose(s["to_world"][:3, 3], [278, 273, -800]) and np.allclose(s["to_world"][:3, 2], [0, 0, 1])
+
+
+def test_load_dict_subset():
+    """xml_v.cpp:100-260: nested dictionaries, rgb entries, references by key"""
+    d = mxml.parse_dict({
+        "type": "scene",
+        "red": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.8, 0.1, 0.1]}},
+        "wall": {"type": "rectangle", "to_world": mxml.translate([0, 0, -1]), "bsdf": {"type": "ref", "id": "red"}},
+        "lamp": {"type": "rectangle", "flip_normals": True, "emitter": {"type": "area", "radiance": {"type": "spectrum", "value": 3.0}}},
+        "integrator": {"type": "path", "max_depth": 3},
+    })
+    sd = d.scene_dict
+    assert len(sd["meshes"]) == 2 and sd["meshes"][0]["bsdf"] == 0 and np.allclose(sd["bsdfs"][0]["reflectance"], [0.8, 0.1, 0.1])
+    assert sd["meshes"][1]["emitter"] == 0 and sd["emitters"][0]["radiance"] == [3.0] * 3 and d.integrator["max_depth"] == 3
+    with pytest.raises(Exception, match='Referenced id "nope" not found'):
+        mxml.parse_dict({"type": "scene", "s": {"type": "rectangle", "b": {"type": "ref", "id": "nope"}}})
+    with pytest.raises(Exception, match="Missing key 'type'"):
+        mxml.parse_dict({"type": "scene", "s": {"to_world": 1}})
+
+
+# ------------------------------------------------------------------------------------------------ image files
+def test_image_roundtrips(tmp_path):
+    """test_hdrfilm.py:74-160 (test03_develop) checks write -> read for exr / rgbe / pfm with these tolerances"""
+    rng = np.random.default_rng(12345)
+    img = rng.uniform(size=(37, 41, 3)).astype(np.float32)
+    p = str(tmp_path / "a.pfm")
+    bitmap.write_pfm(p, img)
+    assert np.array_equal(bitmap.read_pfm(p), img)
+    p = str(tmp_path / "a.rgbe")
+    bitmap.write_rgbe(p, 1 + 0.1 * img)
+    assert np.allclose(bitmap.read_rgbe(p), 1 + 0.1 * img, atol=1e-2)
+    for comp in ("none", "zips", "zip"):
+        p = str(tmp_path / ("a_%s.exr" % comp))
+        ch = {"R": img[..., 0], "G": img[..., 1].astype(np.float16), "B": (img[..., 2] * 1000).astype(np.uint32)}
+        bitmap.write_exr(p, ch, compression=comp)
+        back, order = bitmap.read_exr(p)
+        assert order == ["B", "G", "R"]
+        for k in ch:
+            assert back[k].dtype == ch[k].dtype and np.array_equal(back[k], ch[k])
+    u8 = (img * 255).astype(np.uint8)
+    p = str(tmp_path / "a.png")
+    bitmap.write_png(p, u8)
+    assert np.array_equal(bitmap.read_png(p), u8)
+    tex = bitmap.read_rgb(p)
+    assert tex.shape == (37, 41, 3) and np.allclose(tex, bitmap.srgb_to_linear(u8 / np.float32(255)), atol=1e-6)
+
+
+def test_png_against_pillow(tmp_path):
+    """our PNG codec against an independent implementation (all five scanline filters appear in Pillow's output)"""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:64, 0:48]
+    img = np.stack([(xx * 5) % 256, (yy * 3 + xx) % 256, rng.integers(0, 255, (64, 48))], axis=2).astype(np.uint8)
+    p = str(tmp_path / "pil.png")
+    Image.fromarray(img).save(p, optimize=True)
+    assert np.array_equal(bitmap.read_png(p), img)
+    p2 = str(tmp_path / "ours.png")
+    bitmap.write_png(p2, img)
+    assert np.array_equal(np.asarray(Image.open(p2)), img)
