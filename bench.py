@@ -170,7 +170,7 @@ def main():
                        "partition": "interleaved 32-row film tiles + RCCL reduce" if n > 1 else "single GPU"},
             "mray_per_s": (tot_closest + tot_any) / dt / 1e6,
             "segments_per_sample": acc["segments"] / max(acc["samples"], 1),
-            "kernel_ms": {"k_bounce_per_step": acc["bounce_ns"] / args.steps * 1e-6, "k_film_gather_per_step": acc["film_ns"] / args.steps * 1e-6,
+            "kernel_ms": {"k_bounce_per_step": acc["bounce_ns"] / args.steps * 1e-6, "k_film_tiles_per_step": acc["film_ns"] / args.steps * 1e-6,
                           "k_bounce_launches_per_step": launches / args.steps, "k_bounce_avg_launch_us": bounce_s / launches * 1e6},
             "roofline": {"bound": "hbm", "kernel": "k_bounce", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
