@@ -175,7 +175,9 @@ typedef struct {
     int32_t part_index, part_count, part_tile_rows;
     /* scheduler knobs (0 = library default) */
     int32_t paths_per_wave;    /* in-flight path slots per scheduling wave */
-    int32_t pipeline;          /* 0 = fused bounce kernel (the only pipeline in this build) */
+    int32_t pipeline;          /* 0 = automatic: fused bounce kernel for LDS-resident scenes (<= 64 primitives), split
+                                  trace / shade / trace kernels for hierarchy scenes; 1 = force fused; 2 = force split.
+                                  All three produce identical samples. */
     int32_t film_rgb;          /* 0: film channels X,Y,Z,A,W (integrator.cpp:72-74, 254-268);
                                   1: R,G,B,A,W -- linear RGB as mitsuba.python.autodiff._render_helper accumulates (autodiff.py:53-72) */
 } mtsamd_render_desc;

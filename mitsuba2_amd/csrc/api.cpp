@@ -142,7 +142,7 @@ template <typename T> int upload(T **dst, const std::vector<T> &src) {
 struct Workspace {
     uint32_t n_waves = 0, seg_cap = 0;
     uint64_t pass_cap = 0;
-    bool spectral = false;
+    bool spectral = false, split = false;
     PoolView pool[2] = {};
     uint32_t *count[2] = { nullptr, nullptr };
     uint64_t *cursor = nullptr, *cursor_end = nullptr, *wave_stats = nullptr;
@@ -159,6 +159,7 @@ struct Workspace {
             (void) hipFree(pool[k].ray_o); (void) hipFree(pool[k].ray_d); (void) hipFree(pool[k].thr); (void) hipFree(pool[k].res);
             (void) hipFree(pool[k].rng); (void) hipFree(pool[k].misc); (void) hipFree(count[k]);
             (void) hipFree(pool[k].wav); (void) hipFree(pool[k].aux);
+            (void) hipFree(pool[k].hit); (void) hipFree(pool[k].sh_o); (void) hipFree(pool[k].sh_d); (void) hipFree(pool[k].nee);
             pool[k] = PoolView{}; count[k] = nullptr;
         }
         (void) hipFree(cursor); (void) hipFree(cursor_end); (void) hipFree(wave_stats); (void) hipFree(cursor_pix); (void) hipFree(cursor_rem);
@@ -426,10 +427,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     // top of the tree (nodes are stored in BFS order) was measured to LOSE: 384 staged nodes 2.5-3.2 Gray/s vs none
     // 3.8-4.8 Gray/s on a 261 k-triangle mesh -- the 24 KB cost occupancy and the LDS/global select compiles to
     // generic (flat) loads, while the top levels stay L1/L2-resident anyway.  Only the traversal stack lives in LDS.
-    const size_t small_budget = 40 * 1024;
-    if ((size_t) 64 * v.n_nodes + (size_t) 48 * v.n_slots <= small_budget) { v.lds_nodes = v.n_nodes; v.lds_slots = v.n_slots; }
-    else { v.lds_nodes = 0; v.lds_slots = 0; }
-    if (const char *e = getenv("MTSAMD_LDS_NODES")) { v.lds_nodes = std::min<uint32_t>(v.n_nodes, (uint32_t) atoi(e)); v.lds_slots = 0; }   // experiment switch
+    v.lds_nodes = 0; v.lds_slots = 0;      // nodes and triangle slots are always read through L1/L2
     v.stack_depth = std::max<uint32_t>(s->bvh.depth, 2);
     v.tri_pos = s->d_tri_pos; v.tri_nrm = any_nrm ? s->d_tri_nrm : nullptr; v.tri_uv = any_uv ? s->d_tri_uv : nullptr;
     v.prim_shape = s->d_prim_shape; v.shapes = s->d_shapes; v.bsdfs = s->d_bsdfs;
@@ -541,13 +539,13 @@ static int check_desc(const mtsamd_render_desc *d) {
         d->crop_x + d->crop_width > d->film_width || d->crop_y + d->crop_height > d->film_height)
         return fail(MTSAMD_ERR_INVALID, "Invalid crop window specification!");      // film.cpp:24-32
     if (d->sample_count <= 0) return fail(MTSAMD_ERR_INVALID, "sample_count must be positive");
-    if (d->pipeline != 0) return fail(MTSAMD_ERR_UNSUPPORTED, "pipeline %d is not available in this build", d->pipeline);
+    if (d->pipeline < 0 || d->pipeline > 2) return fail(MTSAMD_ERR_UNSUPPORTED, "pipeline %d is not available in this build", d->pipeline);
     return 0;
 }
 
-static int ensure_workspace(mtsamd_scene *s, uint32_t n_waves, uint32_t seg_cap, uint64_t pass_cap) {
+static int ensure_workspace(mtsamd_scene *s, uint32_t n_waves, uint32_t seg_cap, uint64_t pass_cap, bool split) {
     Workspace &w = s->ws;
-    if (w.n_waves == n_waves && w.seg_cap == seg_cap && w.pass_cap >= pass_cap && w.spectral == s->spectral) return 0;
+    if (w.n_waves == n_waves && w.seg_cap == seg_cap && w.pass_cap >= pass_cap && w.spectral == s->spectral && (w.split || !split)) return 0;
     w.release();
     size_t slots = (size_t) n_waves * seg_cap;
     for (int k = 0; k < 2; ++k) {
@@ -562,6 +560,12 @@ static int ensure_workspace(mtsamd_scene *s, uint32_t n_waves, uint32_t seg_cap,
             HIP_TRY(hipMalloc((void **) &w.pool[k].wav, slots * sizeof(float4)));
             HIP_TRY(hipMalloc((void **) &w.pool[k].aux, slots * sizeof(float2)));
         }
+        if (split) {
+            HIP_TRY(hipMalloc((void **) &w.pool[k].hit, slots * sizeof(float4)));
+            HIP_TRY(hipMalloc((void **) &w.pool[k].sh_o, slots * sizeof(float4)));
+            HIP_TRY(hipMalloc((void **) &w.pool[k].sh_d, slots * sizeof(float4)));
+            HIP_TRY(hipMalloc((void **) &w.pool[k].nee, slots * sizeof(float4)));
+        }
     }
     HIP_TRY(hipMalloc((void **) &w.cursor, n_waves * sizeof(uint64_t)));
     HIP_TRY(hipMalloc((void **) &w.cursor_end, n_waves * sizeof(uint64_t)));
@@ -575,7 +579,7 @@ static int ensure_workspace(mtsamd_scene *s, uint32_t n_waves, uint32_t seg_cap,
     for (auto &e : w.ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : w.tev) HIP_TRY(hipEventCreate(&e));
     w.have_events = true;
-    w.n_waves = n_waves; w.seg_cap = seg_cap; w.pass_cap = pass_cap; w.spectral = s->spectral;
+    w.n_waves = n_waves; w.seg_cap = seg_cap; w.pass_cap = pass_cap; w.spectral = s->spectral; w.split = split;
     return 0;
 }
 
@@ -589,6 +593,7 @@ struct Job {
     RowMap rows{};
     int store_xyz = 1;
     uint32_t plane_pix0 = 0, plane_pixels = 0;
+    bool split = false;
 };
 
 // Traces the local sample ordinals [first, first+n) of this render's rows to completion; results land in
@@ -622,6 +627,7 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     p.spp = j.d->sample_count; p.crop_x = j.d->crop_x; p.crop_y = j.d->crop_y; p.crop_w = j.d->crop_width; p.crop_h = j.d->crop_height;
     p.max_depth = j.d->max_depth; p.rr_depth = j.d->rr_depth;
     p.spectral = j.s->spectral ? 1 : 0;
+    p.split = j.split ? 1 : 0;
 
     // the sample cursors cannot run dry before this many launches
     const uint64_t min_iters = (n + (uint64_t) nw * j.target - 1) / ((uint64_t) nw * j.target);
@@ -672,7 +678,9 @@ int setup_job(Job &j, mtsamd_scene *s, const mtsamd_render_desc *d, hipStream_t 
     j.target = std::min<uint32_t>(std::max<uint32_t>(j.target, 64u), 4096u);
     j.n_waves = (uint32_t) s->cu_count * 16u;
     j.pass_cap = std::max<uint64_t>(std::min<uint64_t>(max_pass, 1ull << 26), 1);
-    if (int rc = ensure_workspace(s, j.n_waves, j.target, j.pass_cap)) return rc;
+    // pipeline 0: fused kernel for LDS-resident (flat) scenes, split kernels for hierarchy scenes; 1 / 2 force one of them
+    j.split = d->pipeline == 2 || (d->pipeline == 0 && !s->view.flat);
+    if (int rc = ensure_workspace(s, j.n_waves, j.target, j.pass_cap, j.split)) return rc;
     j.pass_cap = s->ws.pass_cap;
     HIP_TRY(hipMemsetAsync(s->ws.wave_stats, 0, 4 * (size_t) j.n_waves * sizeof(uint64_t), stream));
     s->cancel.store(0);

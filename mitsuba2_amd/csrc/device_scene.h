@@ -164,6 +164,8 @@ MTS_DEV float clamp_inv(float d) {
 // Among hits with exactly equal t the highest primitive index wins (what the brute-force loop of
 // ray_intersect_naive produces).  The slab test only culls; boxes are padded on the host so that it never
 // rejects a triangle the fp32 Moeller-Trumbore test would accept.
+constexpr uint32_t kNoNode = 0x7fffffffu;       // "nothing left": not a leaf, never a valid inner index
+
 template <bool ANY>
 MTS_DEV bool traverse_bvh(const SceneView &sv, const LdsView &lds, f3 o, f3 d, float mint, float maxt,
                           Hit &hit, uint32_t &tri_tests) {
@@ -176,16 +178,12 @@ MTS_DEV bool traverse_bvh(const SceneView &sv, const LdsView &lds, f3 o, f3 d, f
     uint32_t best_prim = kNoPrim;
     bool found = false;
 
-    while (true) {
-        if (!(cur & kLeafFlag)) {
-            float4 q0, q1, q2, q3;
-            if (cur < sv.lds_nodes) {
-                const float4 *p = lds.nodes + 4u * cur;
-                q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
-            } else {
-                const float4 *p = sv.nodes + 4u * cur;
-                q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
-            }
+    // "while-while" traversal: every lane descends until it holds a leaf (or nothing), then the wave tests leaves
+    // together -- the two phases are not interleaved lane by lane, which keeps more lanes busy in each of them.
+    while (cur != kNoNode) {
+        while ((int32_t) cur >= 0 && cur != kNoNode) {
+            const float4 *p = sv.nodes + 4u * cur;
+            const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
             float ax = (q0.x - o.x) * inv.x, bx = (q0.w - o.x) * inv.x;
             float ay = (q0.y - o.y) * inv.y, by = (q1.x - o.y) * inv.y;
             float az = (q0.z - o.z) * inv.z, bz = (q1.y - o.z) * inv.z;
@@ -196,43 +194,47 @@ MTS_DEV bool traverse_bvh(const SceneView &sv, const LdsView &lds, f3 o, f3 d, f
             az = (q2.x - o.z) * inv.z; bz = (q2.w - o.z) * inv.z;
             float nearR = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), mint));
             float farR = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best));
-            bool hl = nearL <= farL, hr = nearR <= farR;
-            uint32_t cl = __float_as_uint(q3.x), cr = __float_as_uint(q3.y);
+            const bool hl = nearL <= farL, hr = nearR <= farR;
+            const uint32_t cl = __float_as_uint(q3.x), cr = __float_as_uint(q3.y);
             if (hl && hr) {
-                bool lf = nearL <= nearR;
+                const bool lf = nearL <= nearR;
                 stack[sp * stride] = lf ? cr : cl;
                 ++sp;
                 cur = lf ? cl : cr;
-                continue;
-            } else if (hl) { cur = cl; continue; }
-            else if (hr) { cur = cr; continue; }
-        } else {
-            uint32_t start = cur & kLeafStartMask, count = (cur >> kLeafCountShift) & 0xfu;
+            } else if (hl) {
+                cur = cl;
+            } else if (hr) {
+                cur = cr;
+            } else if (sp) {
+                --sp;
+                cur = stack[sp * stride];
+            } else {
+                cur = kNoNode;
+            }
+        }
+        if (cur & kLeafFlag) {
+            const uint32_t start = cur & kLeafStartMask, count = (cur >> kLeafCountShift) & 0xfu;
             for (uint32_t i = 0; i < count; ++i) {
-                uint32_t s = start + i;
-                float4 t0, t1, t2;
-                if (s < sv.lds_slots) {
-                    const float4 *p = lds.tris + 3u * s;
-                    t0 = p[0]; t1 = p[1]; t2 = p[2];
-                } else {
-                    const float4 *p = sv.tris + 3u * s;
-                    t0 = p[0]; t1 = p[1]; t2 = p[2];
-                }
+                const float4 *p = sv.tris + 3u * (start + i);
+                const float4 t0 = p[0], t1 = p[1], t2 = p[2];
                 float u, v, t;
                 ++tri_tests;
                 if (tri_test(mk3(t0.x, t0.y, t0.z), mk3(t0.w, t1.x, t1.y), mk3(t1.z, t1.w, t2.x), o, d, mint, maxt, u, v, t)) {
                     if (ANY) return true;
-                    uint32_t prim = __float_as_uint(t2.y);
+                    const uint32_t prim = __float_as_uint(t2.y);
                     if (!found || t < best || (t == best && prim > best_prim)) {
                         found = true; best = t; best_prim = prim;
                         hit.t = t; hit.prim = prim; hit.u = u; hit.v = v;
                     }
                 }
             }
+            if (sp) {
+                --sp;
+                cur = stack[sp * stride];
+            } else {
+                cur = kNoNode;
+            }
         }
-        if (sp == 0) break;
-        --sp;
-        cur = stack[sp * stride];
     }
     return found;
 }

@@ -16,6 +16,9 @@ struct PoolView {
     // spectral variant (112 B per path): thr / res hold 4 spectral samples, wav the wavelengths, aux = (bs_pdf, eta)
     float4 *wav;
     float2 *aux;
+    // split pipeline (hierarchy scenes): hit = (t, prim bits, u, v) of the path's ray; pending shadow ray
+    // sh_o = (o, mint), sh_d = (d, maxt | -1: none) and the contribution `nee` it guards
+    float4 *hit, *sh_o, *sh_d, *nee;
 };
 
 // Film rows owned by one render call.  count <= 1: the contiguous window [row0, row0 + local_rows);
@@ -63,6 +66,7 @@ struct RenderParams {
     int32_t spp, crop_x, crop_y, crop_w, crop_h;
     int32_t max_depth, rr_depth;
     int32_t spectral;           // 0: RGB variant, 1: spectral variant (4 wavelengths per sample)
+    int32_t split;              // 0: fused k_bounce, 1: k_trace<closest> + k_shade + k_trace<any> per iteration
 };
 
 struct FilmParams {

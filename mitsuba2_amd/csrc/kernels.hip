@@ -61,10 +61,19 @@ struct VertexRec {
     uint32_t texel; f2 w1; int32_t bsdf; uint32_t has_bsdf;
 };
 
+// Split ("wavefront") pipeline: the two ray queries of a segment run in their own kernels.  `hit` / `found` carry the
+// closest hit computed by k_trace<false> into the shading step; the shadow ray and the contribution it guards are
+// handed back for k_trace<true>, which adds `nee` to the path's radiance if the ray is unoccluded.
+struct Deferred {
+    Hit hit; bool found;
+    bool pending; f3 so, sd; float smint, smaxt; float nee[4];
+};
+
 // One iteration of the path.cpp loop, rotated so that it starts with the intersection of the
 // ray spawned by the previous iteration (or by the sensor).  Returns true if the path survives.
-template <bool FLAT, bool REC = false>
-MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s, Counters &c, VertexRec *rec = nullptr) {
+template <bool FLAT, bool REC = false, bool DEFER = false>
+MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s, Counters &c, VertexRec *rec = nullptr,
+                         Deferred *df = nullptr) {
     const SceneView &sv = P.sv;
     if (REC) {
         rec->E = rec->Nc = rec->Tp = rec->rho = mk3(0.0f, 0.0f, 0.0f);
@@ -73,7 +82,9 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
     const Geo<FLAT> geo{ sv, lds };
     Hit hit;
     ++c.closest; ++c.segments;
-    bool found = traverse<FLAT, false>(sv, lds, s.o, s.d, s.mint, s.maxt, hit, c.tri_tests);
+    bool found;
+    if (DEFER) { hit = df->hit; found = df->found; df->pending = false; }
+    else found = traverse<FLAT, false>(sv, lds, s.o, s.d, s.mint, s.maxt, hit, c.tri_tests);
     if (s.depth == 1u) s.flags = found ? 1u : 0u;          // valid_ray (path.cpp:121)
 
     SurfaceInteraction si;
@@ -131,7 +142,14 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
                              ((mis * s.thr.z) * bv.z) * spec.z);
             // The visibility test only ever zeroes `spec` (scene.cpp:178-182): trace the shadow
             // ray only if an unoccluded sample would contribute.
-            if (contrib.x != 0.0f || contrib.y != 0.0f || contrib.z != 0.0f) {
+            if (DEFER) {
+                if (contrib.x != 0.0f || contrib.y != 0.0f || contrib.z != 0.0f) {
+                    ++c.any;
+                    df->pending = true; df->so = si.p; df->sd = ds.d;
+                    df->smint = kRayEpsilon * (1.0f + hmax_abs(si.p)); df->smaxt = ds.dist * (1.0f - kShadowEpsilon);
+                    df->nee[0] = contrib.x; df->nee[1] = contrib.y; df->nee[2] = contrib.z; df->nee[3] = 0.0f;
+                }
+            } else if (contrib.x != 0.0f || contrib.y != 0.0f || contrib.z != 0.0f) {
                 Hit sh;
                 ++c.any;
 #if defined(MTS_ABLATE_SHADOW)   // diagnostic build only: wrong image, used to price the any-hit loop in situ
@@ -316,13 +334,15 @@ MTS_DEV void store_state(const PoolView &p, size_t i, const PathStateS &s) {
     p.misc[i] = make_uint2(s.ordinal, (s.depth & 0xffffu) | (s.flags << 16));
 }
 
-template <bool FLAT>
-MTS_DEV bool bounce_step_spectral(const RenderParams &P, const LdsView &lds, PathStateS &s, Counters &c) {
+template <bool FLAT, bool DEFER = false>
+MTS_DEV bool bounce_step_spectral(const RenderParams &P, const LdsView &lds, PathStateS &s, Counters &c, Deferred *df = nullptr) {
     const SceneView &sv = P.sv;
     const Geo<FLAT> geo{ sv, lds };
     Hit hit;
     ++c.closest; ++c.segments;
-    bool found = traverse<FLAT, false>(sv, lds, s.o, s.d, s.mint, s.maxt, hit, c.tri_tests);
+    bool found;
+    if (DEFER) { hit = df->hit; found = df->found; df->pending = false; }
+    else found = traverse<FLAT, false>(sv, lds, s.o, s.d, s.mint, s.maxt, hit, c.tri_tests);
     if (s.depth == 1u) s.flags = found ? 1u : 0u;
 
     SurfaceInteraction si;
@@ -384,7 +404,15 @@ MTS_DEV bool bounce_step_spectral(const RenderParams &P, const LdsView &lds, Pat
                 contrib.v[k] = ((mis * s.thr.v[k]) * bv) * spec;
                 nz = nz || contrib.v[k] != 0.0f;
             }
-            if (nz) {
+            if (DEFER) {
+                if (nz) {
+                    ++c.any;
+                    df->pending = true; df->so = si.p; df->sd = ds.d;
+                    df->smint = kRayEpsilon * (1.0f + hmax_abs(si.p)); df->smaxt = ds.dist * (1.0f - kShadowEpsilon);
+#pragma unroll
+                    for (int k = 0; k < kWav; ++k) df->nee[k] = contrib.v[k];
+                }
+            } else if (nz) {
                 Hit sh;
                 ++c.any;
                 bool occluded = traverse<FLAT, true>(sv, lds, si.p, ds.d, kRayEpsilon * (1.0f + hmax_abs(si.p)),
@@ -501,7 +529,156 @@ __global__ __launch_bounds__(kBlock) void k_bounce_spectral(const RenderParams P
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split pipeline for hierarchy scenes.  In the fused kernel the BVH walks inherit the shading code's ~100 VGPRs
+// (4 waves / SIMD) and are latency-bound at that occupancy: 1.5 Gray/s on a 261 k-triangle mesh against ~5 Gray/s
+// for a kernel that only traverses.  So here every iteration runs k_trace<false> (closest hits of the in-flight
+// rays -> `hit`), k_shade (the path.cpp iteration on the precomputed hits; shadow rays are written next to the
+// state) and k_trace<true> (visibility; adds the guarded contribution to the path's radiance).  The order of the
+// floating-point additions into the radiance is the fused kernel's, so both pipelines produce identical samples.
+constexpr uint32_t kFlagZombie = 2u;      // path already terminated, kept one iteration for its pending shadow ray
+
+MTS_DEV bool step_deferred(const RenderParams &P, const LdsView &lds, PathState &s, Counters &c, Deferred &df) {
+    return bounce_step<false, false, true>(P, lds, s, c, nullptr, &df);
+}
+MTS_DEV bool step_deferred(const RenderParams &P, const LdsView &lds, PathStateS &s, Counters &c, Deferred &df) {
+    return bounce_step_spectral<false, true>(P, lds, s, c, &df);
+}
+MTS_DEV void finish_path(const RenderParams &P, const PathState &s) { store_result(P, s); }
+MTS_DEV void finish_path(const RenderParams &P, const PathStateS &s) { store_result_spectral(P, s); }
+MTS_DEV void start_path(const RenderParams &P, uint64_t ordinal, uint32_t lp, uint32_t j, PathState &s) { generate_path(P, ordinal, lp, j, s); }
+MTS_DEV void start_path(const RenderParams &P, uint64_t ordinal, uint32_t lp, uint32_t j, PathStateS &s) { generate_path_spectral(P, ordinal, lp, j, s); }
+
+template <typename State>
+__global__ __launch_bounds__(kBlock) void k_shade(const RenderParams P) {
+    LdsView lds = {};                      // Geo<false> reads the scene tables from global memory
+    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    if (wave >= P.n_waves) return;
+    const uint32_t lane = lane_id();
+    const uint32_t n_in = __builtin_amdgcn_readfirstlane(P.count_in[wave]);
+    const size_t base = (size_t) wave * P.seg_cap;
+    uint32_t n_out = 0;
+    Counters c = { 0u, 0u, 0u, 0u };
+    const float4 no_shadow = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+
+    for (uint32_t i0 = 0; i0 < n_in; i0 += 64u) {
+        State s;
+        Deferred df;
+        df.pending = false;
+        bool alive = false;
+        if (i0 + lane < n_in) {
+            const size_t i = base + i0 + lane;
+            load_state(P.in, i, s);
+            if (s.flags & kFlagZombie) {
+                finish_path(P, s);
+            } else {
+                const float4 h = P.in.hit[i];
+                df.hit.t = h.x; df.hit.prim = __float_as_uint(h.y); df.hit.u = h.z; df.hit.v = h.w;
+                df.found = df.hit.prim != kNoPrim;
+                alive = step_deferred(P, lds, s, c, df);
+                if (!alive) {
+                    if (df.pending) { s.flags |= kFlagZombie; alive = true; }
+                    else finish_path(P, s);
+                }
+            }
+        }
+        const uint64_t m = __ballot(alive);
+        if (alive) {
+            const size_t j = base + n_out + mask_rank(m);
+            store_state(P.out, j, s);
+            if (df.pending) {
+                P.out.sh_o[j] = make_float4(df.so.x, df.so.y, df.so.z, df.smint);
+                P.out.sh_d[j] = make_float4(df.sd.x, df.sd.y, df.sd.z, df.smaxt);
+                P.out.nee[j] = make_float4(df.nee[0], df.nee[1], df.nee[2], df.nee[3]);
+            } else {
+                P.out.sh_d[j] = no_shadow;
+            }
+        }
+        n_out += (uint32_t) __popcll(m);
+    }
+
+    uint64_t cursor = P.cursor[wave];
+    const uint64_t end = P.cursor_end[wave];
+    uint32_t cpix = P.cursor_pix[wave], crem = P.cursor_rem[wave];
+    const uint32_t spp = (uint32_t) P.spp;
+    while (n_out < P.target && cursor < end) {
+        uint64_t left = end - cursor;
+        uint32_t n_new = min(64u, P.target - n_out);
+        if ((uint64_t) n_new > left) n_new = (uint32_t) left;
+        if (lane < n_new) {
+            State s;
+            uint32_t r = crem + lane, q = r / spp;
+            start_path(P, cursor + lane, cpix + q, r - q * spp, s);
+            store_state(P.out, base + n_out + lane, s);
+            P.out.sh_d[base + n_out + lane] = no_shadow;
+        }
+        n_out += n_new; cursor += n_new;
+        uint32_t r = crem + n_new, q = r / spp;
+        cpix += q; crem = r - q * spp;
+    }
+
+    uint32_t tot[3] = { c.closest, c.any, c.segments };
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        for (int off = 32; off > 0; off >>= 1) tot[k] += __shfl_xor(tot[k], off);
+    if (lane == 0) {
+        P.count_out[wave] = n_out;
+        P.cursor[wave] = cursor; P.cursor_pix[wave] = cpix; P.cursor_rem[wave] = crem;
+        uint64_t *ws = P.wave_stats + 4u * (size_t) wave;
+        ws[0] += tot[0]; ws[1] += tot[1]; ws[2] += tot[2];
+    }
+}
+
+// One workgroup per scheduling wave, one thread per slot.  ANY = false: closest hit of the path's ray (input pool);
+// ANY = true: visibility of the pending shadow ray (output pool of k_shade), radiance += nee if unoccluded.
+template <bool ANY>
+__global__ __launch_bounds__(kBlock) void k_trace(const RenderParams P) {
+    extern __shared__ float4 smem[];
+    LdsView lds = {};
+    lds.stride = blockDim.x;
+    lds.stack = reinterpret_cast<uint32_t *>(smem);
+    const uint32_t wave = blockIdx.x;
+    const PoolView &pool = ANY ? P.out : P.in;
+    const uint32_t n = ANY ? P.count_out[wave] : P.count_in[wave];
+    const size_t base = (size_t) wave * P.seg_cap;
+    uint32_t tri_tests = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const size_t k = base + i;
+        Hit h;
+        if (ANY) {
+            const float4 d = pool.sh_d[k];
+            if (d.w < 0.0f) continue;
+            const float4 o = pool.sh_o[k];
+            if (!traverse_bvh<true>(P.sv, lds, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), o.w, d.w, h, tri_tests)) {
+                float4 r = pool.res[k];
+                const float4 e = pool.nee[k];
+                r.x += e.x; r.y += e.y; r.z += e.z; r.w += e.w;      // RGB: w = eta + 0
+                pool.res[k] = r;
+            }
+        } else {
+            if ((pool.misc[k].y >> 16) & kFlagZombie) continue;
+            const float4 o = pool.ray_o[k], d = pool.ray_d[k];
+            const bool found = traverse_bvh<false>(P.sv, lds, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), o.w, d.w, h, tri_tests);
+            pool.hit[k] = found ? make_float4(h.t, __uint_as_float(h.prim), h.u, h.v)
+                                : make_float4(__builtin_inff(), __uint_as_float(kNoPrim), 0.0f, 0.0f);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) tri_tests += __shfl_xor(tri_tests, off);
+    if (lane_id() == 0 && tri_tests)
+        atomicAdd(reinterpret_cast<unsigned long long *>(P.wave_stats + 4u * (size_t) wave + 3u), (unsigned long long) tri_tests);
+}
+
+size_t trace_lds_bytes(const SceneView &sv) { return (size_t) 4 * sv.stack_depth * kBlock; }
+
 hipError_t launch_bounce(const RenderParams &p, hipStream_t s) {
+    if (p.split) {
+        const uint32_t shade_blocks = (p.n_waves * 64u + kBlock - 1) / kBlock;
+        hipLaunchKernelGGL(k_trace<false>, dim3(p.n_waves), dim3(kBlock), trace_lds_bytes(p.sv), s, p);
+        if (p.spectral) hipLaunchKernelGGL(k_shade<PathStateS>, dim3(shade_blocks), dim3(kBlock), 0, s, p);
+        else hipLaunchKernelGGL(k_shade<PathState>, dim3(shade_blocks), dim3(kBlock), 0, s, p);
+        hipLaunchKernelGGL(k_trace<true>, dim3(p.n_waves), dim3(kBlock), trace_lds_bytes(p.sv), s, p);
+        return hipGetLastError();
+    }
     uint32_t blocks = (p.n_waves * 64u + kBlock - 1) / kBlock;
     if (p.spectral) {
         if (p.sv.flat) hipLaunchKernelGGL(k_bounce_spectral<true>, dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);

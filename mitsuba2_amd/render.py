@@ -549,13 +549,14 @@ class Scene:
 class PathIntegrator:
     """src/integrators/path.cpp + MonteCarloIntegrator (src/librender/integrator.cpp:283-296)."""
 
-    def __init__(self, max_depth=-1, rr_depth=5, paths_per_wave=0):
+    def __init__(self, max_depth=-1, rr_depth=5, paths_per_wave=0, pipeline=0):
         if max_depth < 0 and max_depth != -1:
             raise RuntimeError("\"max_depth\" must be set to -1 (infinite) or a value >= 0")
         if rr_depth <= 0:
             raise RuntimeError("\"rr_depth\" must be set to a value greater than zero!")
         self.max_depth, self.rr_depth = int(max_depth), int(rr_depth)
         self.paths_per_wave = int(paths_per_wave)
+        self.pipeline = int(pipeline)          # 0 automatic, 1 fused kernel, 2 split trace/shade kernels (same samples)
         self._scene = None
         self.stats = None
 
@@ -567,7 +568,7 @@ class PathIntegrator:
         if partition is not None:       # (index, count, tile_rows): interleaved row tiles of the film
             d.part_index, d.part_count, d.part_tile_rows = (int(x) for x in partition)
         d.paths_per_wave = self.paths_per_wave
-        d.pipeline = 0
+        d.pipeline = self.pipeline
         return d
 
     def render(self, scene, sensor=None, rows=None, partition=None):
