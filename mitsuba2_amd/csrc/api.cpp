@@ -146,7 +146,7 @@ struct Workspace {
     PoolView pool[2] = {};
     uint32_t *count[2] = { nullptr, nullptr };
     uint64_t *cursor = nullptr, *cursor_end = nullptr, *wave_stats = nullptr;
-    uint32_t *cursor_pix = nullptr, *cursor_rem = nullptr;
+    uint32_t *cursor_pix = nullptr, *cursor_rem = nullptr, *count_shadow = nullptr;
     float4 *out_rgba = nullptr; float2 *out_pos = nullptr;
     uint32_t *h_counts = nullptr;        // pinned, 4 * n_waves
     uint64_t *h_cursor = nullptr;        // pinned, 2 * n_waves
@@ -159,10 +159,11 @@ struct Workspace {
             (void) hipFree(pool[k].ray_o); (void) hipFree(pool[k].ray_d); (void) hipFree(pool[k].thr); (void) hipFree(pool[k].res);
             (void) hipFree(pool[k].rng); (void) hipFree(pool[k].misc); (void) hipFree(count[k]);
             (void) hipFree(pool[k].wav); (void) hipFree(pool[k].aux);
-            (void) hipFree(pool[k].hit); (void) hipFree(pool[k].sh_o); (void) hipFree(pool[k].sh_d); (void) hipFree(pool[k].nee);
+            (void) hipFree(pool[k].hit); (void) hipFree(pool[k].sh_o); (void) hipFree(pool[k].sh_d); (void) hipFree(pool[k].nee); (void) hipFree(pool[k].sh_slot);
             pool[k] = PoolView{}; count[k] = nullptr;
         }
         (void) hipFree(cursor); (void) hipFree(cursor_end); (void) hipFree(wave_stats); (void) hipFree(cursor_pix); (void) hipFree(cursor_rem);
+        (void) hipFree(count_shadow); count_shadow = nullptr;
         cursor_pix = cursor_rem = nullptr; (void) hipFree(out_rgba); (void) hipFree(out_pos);
         cursor = cursor_end = wave_stats = nullptr; out_rgba = nullptr; out_pos = nullptr;
         if (h_counts) (void) hipHostFree(h_counts);
@@ -565,6 +566,7 @@ static int ensure_workspace(mtsamd_scene *s, uint32_t n_waves, uint32_t seg_cap,
             HIP_TRY(hipMalloc((void **) &w.pool[k].sh_o, slots * sizeof(float4)));
             HIP_TRY(hipMalloc((void **) &w.pool[k].sh_d, slots * sizeof(float4)));
             HIP_TRY(hipMalloc((void **) &w.pool[k].nee, slots * sizeof(float4)));
+            HIP_TRY(hipMalloc((void **) &w.pool[k].sh_slot, slots * sizeof(uint32_t)));
         }
     }
     HIP_TRY(hipMalloc((void **) &w.cursor, n_waves * sizeof(uint64_t)));
@@ -572,6 +574,7 @@ static int ensure_workspace(mtsamd_scene *s, uint32_t n_waves, uint32_t seg_cap,
     HIP_TRY(hipMalloc((void **) &w.wave_stats, 4 * (size_t) n_waves * sizeof(uint64_t)));
     HIP_TRY(hipMalloc((void **) &w.cursor_pix, n_waves * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **) &w.cursor_rem, n_waves * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **) &w.count_shadow, n_waves * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **) &w.out_rgba, pass_cap * sizeof(float4)));
     HIP_TRY(hipMalloc((void **) &w.out_pos, pass_cap * sizeof(float2)));
     HIP_TRY(hipHostMalloc((void **) &w.h_counts, 4 * (size_t) n_waves * sizeof(uint32_t), hipHostMallocDefault));
@@ -619,7 +622,7 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     p.sv = j.s->view; p.cam = j.cam;
     p.cursor = w.cursor; p.cursor_end = w.cursor_end; p.wave_stats = w.wave_stats;
     p.out_rgba = w.out_rgba; p.out_pos = w.out_pos;
-    p.cursor_pix = w.cursor_pix; p.cursor_rem = w.cursor_rem;
+    p.cursor_pix = w.cursor_pix; p.cursor_rem = w.cursor_rem; p.count_shadow = w.count_shadow;
     p.first_ordinal = first; p.base_seed = j.d->seed;
     p.rows = j.rows; p.store_xyz = j.store_xyz;
     p.plane_pix0 = j.plane_pix0; p.plane_pixels = j.plane_pixels;
@@ -676,10 +679,19 @@ int setup_job(Job &j, mtsamd_scene *s, const mtsamd_render_desc *d, hipStream_t 
     if (int rc = make_filter(d->rfilter, d->rfilter_param, d->rfilter_analytic, j.filter)) return rc;
     j.target = d->paths_per_wave > 0 ? (uint32_t) d->paths_per_wave : 256u;
     j.target = std::min<uint32_t>(std::max<uint32_t>(j.target, 64u), 4096u);
-    j.n_waves = (uint32_t) s->cu_count * 16u;
-    j.pass_cap = std::max<uint64_t>(std::min<uint64_t>(max_pass, 1ull << 26), 1);
     // pipeline 0: fused kernel for LDS-resident (flat) scenes, split kernels for hierarchy scenes; 1 / 2 force one of them
     j.split = d->pipeline == 2 || (d->pipeline == 0 && !s->view.flat);
+    // Paths in flight.  Fused kernel: 16 scheduling waves per CU (one resident generation; the pool stays inside the
+    // Infinity Cache).  Split pipeline: its three launches per iteration are latency-bound walks whose tails and launch
+    // gaps only amortise over much larger launches -- measured on the 261 k-triangle mesh: 16 / 32 / 64 / 128 / 256 waves
+    // per CU -> 705 / 954 / 1162 / 1269 / 1309 Msample/s.
+    j.n_waves = (uint32_t) s->cu_count * 16u;
+    if (j.split) {      // no more scheduling waves than the pass can fill
+        const uint64_t want = (std::min<uint64_t>(max_pass, 1ull << 26) + j.target - 1) / j.target;
+        j.n_waves = (uint32_t) std::min<uint64_t>(std::max<uint64_t>(want, j.n_waves), (uint64_t) s->cu_count * 128u);
+    }
+    if (const char *e = getenv("MTSAMD_WAVES_PER_CU")) j.n_waves = (uint32_t) s->cu_count * (uint32_t) std::max(1, atoi(e));    // experiment switch
+    j.pass_cap = std::max<uint64_t>(std::min<uint64_t>(max_pass, 1ull << 26), 1);
     if (int rc = ensure_workspace(s, j.n_waves, j.target, j.pass_cap, j.split)) return rc;
     j.pass_cap = s->ws.pass_cap;
     HIP_TRY(hipMemsetAsync(s->ws.wave_stats, 0, 4 * (size_t) j.n_waves * sizeof(uint64_t), stream));

@@ -16,9 +16,10 @@ struct PoolView {
     // spectral variant (112 B per path): thr / res hold 4 spectral samples, wav the wavelengths, aux = (bs_pdf, eta)
     float4 *wav;
     float2 *aux;
-    // split pipeline (hierarchy scenes): hit = (t, prim bits, u, v) of the path's ray; pending shadow ray
-    // sh_o = (o, mint), sh_d = (d, maxt | -1: none) and the contribution `nee` it guards
+    // split pipeline (hierarchy scenes): hit = (t, prim bits, u, v) of the path's ray; per-wave dense queue of
+    // pending shadow rays sh_o = (o, mint), sh_d = (d, maxt), the contribution `nee` each guards and the slot it belongs to
     float4 *hit, *sh_o, *sh_d, *nee;
+    uint32_t *sh_slot;
 };
 
 // Film rows owned by one render call.  count <= 1: the contiguous window [row0, row0 + local_rows);
@@ -48,6 +49,7 @@ struct RenderParams {
     PoolView in, out;
     const uint32_t *count_in;   // per scheduling wave
     uint32_t *count_out;
+    uint32_t *count_shadow;     // split pipeline: queued shadow rays per scheduling wave (output pool)
     uint64_t *cursor;           // per wave: next sample ordinal to generate
     const uint64_t *cursor_end;
     uint64_t *wave_stats;       // per wave: closest, any, segments, tri tests

@@ -559,7 +559,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(const RenderParams P) {
     const size_t base = (size_t) wave * P.seg_cap;
     uint32_t n_out = 0;
     Counters c = { 0u, 0u, 0u, 0u };
-    const float4 no_shadow = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+    uint32_t n_sh = 0;
 
     for (uint32_t i0 = 0; i0 < n_in; i0 += 64u) {
         State s;
@@ -582,19 +582,21 @@ __global__ __launch_bounds__(kBlock) void k_shade(const RenderParams P) {
                 }
             }
         }
-        const uint64_t m = __ballot(alive);
+        // survivors are compacted to the front of the output segment, their shadow rays into a dense queue of their own
+        const uint64_t m = __ballot(alive), ms = __ballot(alive && df.pending);
         if (alive) {
-            const size_t j = base + n_out + mask_rank(m);
-            store_state(P.out, j, s);
+            const uint32_t slot = n_out + mask_rank(m);
+            store_state(P.out, base + slot, s);
             if (df.pending) {
-                P.out.sh_o[j] = make_float4(df.so.x, df.so.y, df.so.z, df.smint);
-                P.out.sh_d[j] = make_float4(df.sd.x, df.sd.y, df.sd.z, df.smaxt);
-                P.out.nee[j] = make_float4(df.nee[0], df.nee[1], df.nee[2], df.nee[3]);
-            } else {
-                P.out.sh_d[j] = no_shadow;
+                const size_t q = base + n_sh + mask_rank(ms);
+                P.out.sh_o[q] = make_float4(df.so.x, df.so.y, df.so.z, df.smint);
+                P.out.sh_d[q] = make_float4(df.sd.x, df.sd.y, df.sd.z, df.smaxt);
+                P.out.nee[q] = make_float4(df.nee[0], df.nee[1], df.nee[2], df.nee[3]);
+                P.out.sh_slot[q] = slot;
             }
         }
         n_out += (uint32_t) __popcll(m);
+        n_sh += (uint32_t) __popcll(ms);
     }
 
     uint64_t cursor = P.cursor[wave];
@@ -610,7 +612,6 @@ __global__ __launch_bounds__(kBlock) void k_shade(const RenderParams P) {
             uint32_t r = crem + lane, q = r / spp;
             start_path(P, cursor + lane, cpix + q, r - q * spp, s);
             store_state(P.out, base + n_out + lane, s);
-            P.out.sh_d[base + n_out + lane] = no_shadow;
         }
         n_out += n_new; cursor += n_new;
         uint32_t r = crem + n_new, q = r / spp;
@@ -623,39 +624,54 @@ __global__ __launch_bounds__(kBlock) void k_shade(const RenderParams P) {
         for (int off = 32; off > 0; off >>= 1) tot[k] += __shfl_xor(tot[k], off);
     if (lane == 0) {
         P.count_out[wave] = n_out;
+        P.count_shadow[wave] = n_sh;
         P.cursor[wave] = cursor; P.cursor_pix[wave] = cpix; P.cursor_rem[wave] = crem;
         uint64_t *ws = P.wave_stats + 4u * (size_t) wave;
         ws[0] += tot[0]; ws[1] += tot[1]; ws[2] += tot[2];
     }
 }
 
-// One workgroup per scheduling wave, one thread per slot.  ANY = false: closest hit of the path's ray (input pool);
-// ANY = true: visibility of the pending shadow ray (output pool of k_shade), radiance += nee if unoccluded.
+// k_trace<false>: closest hit of every path's ray (input pool), one workgroup per scheduling wave, one thread per slot.
+// k_trace<true>: visibility of the queued shadow rays (output pool of k_shade), radiance[slot] += nee if unoccluded.
+// Only about a third of the paths queue a shadow ray, so one workgroup drains the queues of kShadowGroup scheduling
+// waves back to back to keep its lanes filled.  (64-thread workgroups sized to the queues were measured slower.)
+constexpr uint32_t kShadowGroup = 8;
+
 template <bool ANY>
 __global__ __launch_bounds__(kBlock) void k_trace(const RenderParams P) {
     extern __shared__ float4 smem[];
     LdsView lds = {};
     lds.stride = blockDim.x;
     lds.stack = reinterpret_cast<uint32_t *>(smem);
-    const uint32_t wave = blockIdx.x;
-    const PoolView &pool = ANY ? P.out : P.in;
-    const uint32_t n = ANY ? P.count_out[wave] : P.count_in[wave];
-    const size_t base = (size_t) wave * P.seg_cap;
     uint32_t tri_tests = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const size_t k = base + i;
-        Hit h;
-        if (ANY) {
-            const float4 d = pool.sh_d[k];
-            if (d.w < 0.0f) continue;
-            const float4 o = pool.sh_o[k];
+    Hit h;
+    if (ANY) {
+        const PoolView &pool = P.out;
+        const uint32_t w0 = blockIdx.x * kShadowGroup;
+        uint32_t cnt[kShadowGroup], total = 0;
+#pragma unroll
+        for (uint32_t g = 0; g < kShadowGroup; ++g) { cnt[g] = (w0 + g < P.n_waves) ? P.count_shadow[w0 + g] : 0u; total += cnt[g]; }
+        for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
+            uint32_t wave = w0, i = idx;
+#pragma unroll
+            for (uint32_t g = 0; g + 1 < kShadowGroup; ++g)
+                if (wave == w0 + g && i >= cnt[g]) { i -= cnt[g]; ++wave; }
+            const size_t base = (size_t) wave * P.seg_cap, k = base + i;
+            const float4 o = pool.sh_o[k], d = pool.sh_d[k];
             if (!traverse_bvh<true>(P.sv, lds, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), o.w, d.w, h, tri_tests)) {
-                float4 r = pool.res[k];
+                const size_t slot = base + pool.sh_slot[k];
+                float4 r = pool.res[slot];
                 const float4 e = pool.nee[k];
                 r.x += e.x; r.y += e.y; r.z += e.z; r.w += e.w;      // RGB: w = eta + 0
-                pool.res[k] = r;
+                pool.res[slot] = r;
             }
-        } else {
+        }
+    } else {
+        const PoolView &pool = P.in;
+        const uint32_t wave = blockIdx.x, n = P.count_in[wave];
+        const size_t base = (size_t) wave * P.seg_cap;
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const size_t k = base + i;
             if ((pool.misc[k].y >> 16) & kFlagZombie) continue;
             const float4 o = pool.ray_o[k], d = pool.ray_d[k];
             const bool found = traverse_bvh<false>(P.sv, lds, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), o.w, d.w, h, tri_tests);
@@ -665,7 +681,8 @@ __global__ __launch_bounds__(kBlock) void k_trace(const RenderParams P) {
     }
     for (int off = 32; off > 0; off >>= 1) tri_tests += __shfl_xor(tri_tests, off);
     if (lane_id() == 0 && tri_tests)
-        atomicAdd(reinterpret_cast<unsigned long long *>(P.wave_stats + 4u * (size_t) wave + 3u), (unsigned long long) tri_tests);
+        atomicAdd(reinterpret_cast<unsigned long long *>(P.wave_stats + 4u * (size_t) (ANY ? blockIdx.x * kShadowGroup : blockIdx.x) + 3u),
+                  (unsigned long long) tri_tests);
 }
 
 size_t trace_lds_bytes(const SceneView &sv) { return (size_t) 4 * sv.stack_depth * kBlock; }
@@ -676,7 +693,7 @@ hipError_t launch_bounce(const RenderParams &p, hipStream_t s) {
         hipLaunchKernelGGL(k_trace<false>, dim3(p.n_waves), dim3(kBlock), trace_lds_bytes(p.sv), s, p);
         if (p.spectral) hipLaunchKernelGGL(k_shade<PathStateS>, dim3(shade_blocks), dim3(kBlock), 0, s, p);
         else hipLaunchKernelGGL(k_shade<PathState>, dim3(shade_blocks), dim3(kBlock), 0, s, p);
-        hipLaunchKernelGGL(k_trace<true>, dim3(p.n_waves), dim3(kBlock), trace_lds_bytes(p.sv), s, p);
+        hipLaunchKernelGGL(k_trace<true>, dim3((p.n_waves + kShadowGroup - 1) / kShadowGroup), dim3(kBlock), trace_lds_bytes(p.sv), s, p);
         return hipGetLastError();
     }
     uint32_t blocks = (p.n_waves * 64u + kBlock - 1) / kBlock;
