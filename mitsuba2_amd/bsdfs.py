@@ -1,0 +1,121 @@
+"""Host-side BSDF plugin parameters: turns the plugin dictionaries / XML properties of
+`diffuse`, `conductor`, `roughconductor`, `dielectric`, `plastic` and the `twosided` adapter into the flat record the C ABI
+takes (``mtsamd_bsdf_desc``), with the reference constructors' defaults and error behaviour:
+``src/bsdfs/diffuse.cpp:72-76``, ``conductor.cpp:185-200``, ``roughconductor.cpp:143-192``, ``dielectric.cpp:175-198``,
+``plastic.cpp:136-160``, ``twosided.cpp:63-92``, ``include/mitsuba/render/ior.h:20-101`` (named indices of refraction).
+"""
+import numpy as np
+
+DIFFUSE, CONDUCTOR, ROUGHCONDUCTOR, DIELECTRIC, PLASTIC = range(5)
+TYPE_IDS = {"diffuse": DIFFUSE, "conductor": CONDUCTOR, "roughconductor": ROUGHCONDUCTOR, "dielectric": DIELECTRIC, "plastic": PLASTIC}
+SMOOTH = {DIFFUSE: True, CONDUCTOR: False, ROUGHCONDUCTOR: True, DIELECTRIC: False, PLASTIC: True}      # BSDFFlags::Smooth
+TRANSMISSIVE = {DIELECTRIC}
+
+# ior.h:23-50
+IOR = {"vacuum": 1.0, "helium": 1.000036, "hydrogen": 1.000132, "air": 1.000277, "carbon dioxide": 1.00045, "water": 1.3330,
+       "acetone": 1.36, "ethanol": 1.361, "carbon tetrachloride": 1.461, "glycerol": 1.4729, "benzene": 1.501, "silicone oil": 1.52045,
+       "bromine": 1.661, "water ice": 1.31, "fused quartz": 1.458, "pyrex": 1.470, "acrylic glass": 1.49, "polypropylene": 1.49,
+       "bk7": 1.5046, "sodium chloride": 1.544, "amber": 1.55, "pet": 1.5750, "diamond": 2.419}
+
+
+def lookup_ior(value, default):
+    """lookup_ior (ior.h:52-101): a float, or the name of a material"""
+    if value is None:
+        value = default
+    if isinstance(value, (int, float)) and not isinstance(value, bool):
+        return float(value)
+    name = str(value).lower()
+    if name not in IOR:
+        raise RuntimeError('Unable to find an IOR value for "%s"! Valid choices are:%s' % (name, ", ".join(IOR)))
+    return IOR[name]
+
+
+def _rgb(v, default):
+    if v is None:
+        v = default
+    if isinstance(v, (int, float)):
+        v = [float(v)] * 3
+    a = np.asarray(v, dtype=np.float32).reshape(-1)
+    if a.size == 1:
+        a = np.repeat(a, 3)
+    if a.size != 3:
+        raise RuntimeError("expected a colour (3 values) or a constant")
+    return [float(x) for x in a]
+
+
+def normalize(b):
+    """Plugin dictionary -> flat record: dict(type, twosided, reflectance (rgb list or bitmap dict), specular_reflectance,
+    specular_transmittance, eta, k, int_ior, ext_ior, alpha_u, alpha_v, distribution, sample_visible, nonlinear)."""
+    t = b.get("type", "diffuse")
+    twosided = False
+    if t == "twosided":                                      # twosided.cpp:63-92
+        nested = [v for k, v in b.items() if k not in ("type", "id") and isinstance(v, dict)]
+        if len(nested) == 0:
+            raise RuntimeError("A nested one-sided material is required!")
+        if len(nested) > 2:
+            raise RuntimeError("At most two nested BSDFs can be specified!")
+        if len(nested) == 2 and nested[0] != nested[1]:
+            raise RuntimeError("twosided: two different nested BSDFs are not supported by this backend")
+        out = normalize(nested[0])
+        if out["type"] in TRANSMISSIVE:
+            raise RuntimeError("Only materials without a transmission component can be nested!")
+        out["twosided"] = True
+        if "id" in b:
+            out["id"] = b["id"]
+        return out
+    if t not in TYPE_IDS:
+        raise RuntimeError("BSDF plugin '%s' is not supported by this backend (diffuse, conductor, roughconductor, dielectric, plastic, twosided)" % t)
+    tid = TYPE_IDS[t]
+    out = dict(type=tid, twosided=twosided, reflectance=[0.5, 0.5, 0.5], specular_reflectance=[1.0] * 3, specular_transmittance=[1.0] * 3,
+               eta=[0.0] * 3, k=[1.0] * 3, int_ior=1.0, ext_ior=1.0, alpha_u=0.1, alpha_v=0.1, distribution=0, sample_visible=True,
+               nonlinear=False)
+    if "id" in b:
+        out["id"] = b["id"]
+    known = {"type", "id"}
+    if tid == DIFFUSE:
+        refl = b.get("reflectance", [0.5, 0.5, 0.5])
+        out["reflectance"] = refl if isinstance(refl, dict) else _rgb(refl, None)
+        known |= {"reflectance"}
+    if tid in (CONDUCTOR, ROUGHCONDUCTOR):
+        material = b.get("material", "none" if tid == CONDUCTOR else ("none" if "eta" in b else "Cu"))
+        if "eta" in b or material == "none":
+            if "material" in b and b["material"] != "none" and "eta" in b:
+                raise RuntimeError("Should specify either (eta, k) or material, not both.")
+            out["eta"], out["k"] = _rgb(b.get("eta"), 0.0), _rgb(b.get("k"), 1.0)
+        else:
+            raise RuntimeError('conductor material "%s": the measured IOR tables (data/ior/*.spd) are not shipped; specify eta and k' % material)
+        out["specular_reflectance"] = _rgb(b.get("specular_reflectance"), 1.0)
+        known |= {"material", "eta", "k", "specular_reflectance"}
+    if tid == ROUGHCONDUCTOR:
+        distr = str(b.get("distribution", "beckmann")).lower()
+        if distr not in ("beckmann", "ggx"):
+            raise RuntimeError('Specified an invalid distribution "%s", must be "beckmann" or "ggx"!' % distr)
+        out["distribution"] = 1 if distr == "ggx" else 0
+        out["sample_visible"] = bool(b.get("sample_visible", True))
+        if "alpha_u" in b or "alpha_v" in b:
+            if "alpha_u" not in b or "alpha_v" not in b:
+                raise RuntimeError("Microfacet model: both 'alpha_u' and 'alpha_v' must be specified.")
+            if "alpha" in b:
+                raise RuntimeError("Microfacet model: please specify either 'alpha' or 'alpha_u'/'alpha_v'.")
+            out["alpha_u"], out["alpha_v"] = float(b["alpha_u"]), float(b["alpha_v"])
+        else:
+            out["alpha_u"] = out["alpha_v"] = float(b.get("alpha", 0.1))
+        known |= {"distribution", "sample_visible", "alpha", "alpha_u", "alpha_v"}
+    if tid in (DIELECTRIC, PLASTIC):
+        out["int_ior"] = lookup_ior(b.get("int_ior"), "bk7" if tid == DIELECTRIC else "polypropylene")
+        out["ext_ior"] = lookup_ior(b.get("ext_ior"), "air")
+        if out["int_ior"] < 0 or out["ext_ior"] < 0:
+            raise RuntimeError("The interior and exterior indices of refraction must be positive!")
+        out["specular_reflectance"] = _rgb(b.get("specular_reflectance"), 1.0)
+        known |= {"int_ior", "ext_ior", "specular_reflectance"}
+    if tid == DIELECTRIC:
+        out["specular_transmittance"] = _rgb(b.get("specular_transmittance"), 1.0)
+        known |= {"specular_transmittance"}
+    if tid == PLASTIC:
+        out["reflectance"] = _rgb(b.get("diffuse_reflectance"), 0.5)
+        out["nonlinear"] = bool(b.get("nonlinear", False))
+        known |= {"diffuse_reflectance", "nonlinear"}
+    extra = [k for k in b if k not in known]
+    if extra:
+        raise RuntimeError('Error while loading: unreferenced property "%s" in bsdf plugin of type "%s"' % (extra[0], t))
+    return out

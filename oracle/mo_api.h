@@ -28,6 +28,29 @@ int mo_scene_add_texture(mo_scene *s, int width, int height, const float *rgb);
 int mo_scene_set_texture(mo_scene *s, uint32_t shape, int texture);
 int mo_scene_update_texture(mo_scene *s, uint32_t texture, const float *rgb);
 int mo_scene_set_reflectance(mo_scene *s, uint32_t shape, const float *rgb);
+/* BSDF models beyond `diffuse` (oracle/mo_bsdf.c).  `twosided` wraps the model in the TwoSidedBRDF adapter. */
+enum { MO_BSDF_DIFFUSE = 0, MO_BSDF_CONDUCTOR = 1, MO_BSDF_ROUGHCONDUCTOR = 2, MO_BSDF_DIELECTRIC = 3, MO_BSDF_PLASTIC = 4 };
+typedef struct {
+    int32_t type, twosided;
+    float reflectance[3];              /* diffuse.reflectance / plastic.diffuse_reflectance (constant part) */
+    float specular_reflectance[3];     /* default 1 */
+    float specular_transmittance[3];   /* dielectric, default 1 */
+    float eta[3], k[3];                /* conductors: complex index of refraction per colour channel */
+    float int_ior, ext_ior;            /* dielectric / plastic */
+    float alpha_u, alpha_v;            /* roughconductor */
+    int32_t distribution;              /* 0 beckmann, 1 ggx */
+    int32_t sample_visible;
+    int32_t nonlinear;                 /* plastic */
+} mo_bsdf_desc;
+/* Replaces the BSDF of a shape (keeps an attached reflectance texture). */
+int mo_scene_set_bsdf(mo_scene *s, uint32_t shape, const mo_bsdf_desc *desc);
+void mo_kat_fresnel(float cos_theta_i, float eta, float *out4);
+float mo_kat_fresnel_conductor(float cos_theta_i, float eta_r, float eta_i);
+float mo_kat_fresnel_diffuse(float eta);
+void mo_kat_microfacet(int ggx, float alpha_u, float alpha_v, int visible, int which, uint64_t n, const float *v3, const float *wi3, float *out);
+void mo_kat_microfacet_sample(int ggx, float alpha_u, float alpha_v, int visible, uint64_t n, const float *wi3, const float *sample2, float *m3, float *pdf);
+void mo_kat_bsdf(const mo_bsdf_desc *desc, uint64_t n, const float *wi3, const float *wo3, const float *sample3, float *out14);
+
 /* Switches the scene to the spectral variant: every RGB reflectance / radiance is upsampled through the coefficient
  * table at `coeff_path` ("data/srgb.coeff": srgb_model_fetch, src/librender/srgb.cpp:14-40; rgb2spec_fetch,
  * ext/rgb2spec/rgb2spec.c:81-121).  Call after all meshes were added.  Returns 0 on success. */

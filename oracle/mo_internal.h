@@ -16,10 +16,16 @@ typedef struct {
 /* DirectionSample (include/mitsuba/render/records.h:121-174) */
 typedef struct { mo_v3 p, n, d; float dist, pdf; uint32_t emitter; float pdf_single; } mo_dsample;   /* pdf_single: before the emitter-selection probability */
 
+/* a BSDF instance: the descriptor plus the constants its constructor derives (plastic.cpp:162-176) */
+typedef struct { mo_bsdf_desc d; float eta_rel, inv_eta_2, fdr_int, fdr_ext, spec_weight; } mo_bsdf;
+/* BSDFSample3 (bsdf.h:193-252): delta = has_flag(sampled_type, BSDFFlags::Delta) */
+typedef struct { mo_v3 wo; float pdf, eta; int delta; } mo_bsample;
+
 typedef struct {
     uint32_t n_verts, n_faces;
     float *pos, *nrm, *uv; uint32_t *faces;
     int bsdf_kind; float refl[3]; int emitter; int texture;
+    mo_bsdf bsdf;                   /* bsdf.d.type == bsdf_kind; bsdf.d.reflectance mirrors refl */
     float refl_coeff[3];            /* spectral variant: srgb_model coefficients of the reflectance */
     uint32_t prim_offset;
     float *area_pmf, *area_cdf; float area_sum, area_norm; uint32_t valid_lo, valid_hi;
@@ -55,6 +61,15 @@ void mo_scene_set_naive(mo_scene *s, int naive);
  * footprint (may be NULL): texel index of v00 and the bilinear weights w1.x, w1.y */
 void mo_reflectance(const mo_scene *s, const mo_mesh *m, mo_v2 uv, float out[3], uint32_t *texel, float w1[2]);
 
+
+/* BSDF models (mo_bsdf.c) */
+void mo_fresnel(float cos_theta_i, float eta, float out[4]);
+float mo_fresnel_conductor(float cos_theta_i, float eta_r, float eta_i);
+float mo_fresnel_diffuse_reflectance(float eta);
+void mo_bsdf_prepare(mo_bsdf *b);
+int mo_bsdf_is_smooth(const mo_bsdf *b);
+int mo_bsdf_sample(const mo_bsdf *b, const float refl[3], mo_v3 wi, float sample1, mo_v2 sample2, mo_bsample *bs, float weight[3]);
+void mo_bsdf_eval_pdf(const mo_bsdf *b, const float refl[3], mo_v3 wi, mo_v3 wo, float value[3], float *pdf);
 
 /* spectral variant (mo_spectral.c) */
 #define MO_WAV 4

@@ -392,9 +392,10 @@ static void path_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, 
 
         /* --------------------- Emitter sampling --------------------- */
         const mo_mesh *mesh = &s->meshes[si.shape];
+        const mo_bsdf *bsdf = &mesh->bsdf;
         float refl[3];
         mo_reflectance(s, mesh, si.uv, refl, NULL, NULL);
-        {   /* diffuse has BSDFFlags::Smooth -> active_e = active */
+        if (mo_bsdf_is_smooth(bsdf)) {   /* active_e = active && has_flag(bsdf->flags(), BSDFFlags::Smooth) (path.cpp:154) */
             mo_v2 s2; s2.x = mo_pcg32_next_f32(rng); s2.y = mo_pcg32_next_f32(rng);
             mo_dsample ds; float emitter_val[3];
             mo_sample_emitter_direction(s, si.p, s2, &ds, emitter_val);
@@ -411,25 +412,25 @@ static void path_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, 
             if (active_e) {
                 mo_v3 wo = mo_to_local(&si.sh, ds.d);
                 float bsdf_val[3], bsdf_pdf;
-                mo_diffuse_eval_pdf(refl, si.wi, wo, bsdf_val, &bsdf_pdf);
-                float mis = mis_weight(ds.pdf, bsdf_pdf);
+                mo_bsdf_eval_pdf(bsdf, refl, si.wi, wo, bsdf_val, &bsdf_pdf);
+                float mis = mis_weight(ds.pdf, bsdf_pdf);      /* area lights are never delta (path.cpp:170) */
                 for (int k = 0; k < 3; ++k)
                     result[k] += ((mis * throughput[k]) * bsdf_val[k]) * emitter_val[k];
             }
         }
 
         /* ----------------------- BSDF sampling ---------------------- */
-        float s1 = mo_pcg32_next_f32(rng); (void) s1;
+        float s1 = mo_pcg32_next_f32(rng);
         mo_v2 s2; s2.x = mo_pcg32_next_f32(rng); s2.y = mo_pcg32_next_f32(rng);
-        mo_v3 bs_wo; float bs_pdf, bsdf_w[3];
-        mo_diffuse_sample(refl, si.wi, s2, &bs_wo, &bs_pdf, bsdf_w);
+        mo_bsample bs; float bsdf_w[3];
+        mo_bsdf_sample(bsdf, refl, si.wi, s1, s2, &bs, bsdf_w);
         for (int k = 0; k < 3; ++k) throughput[k] = throughput[k] * bsdf_w[k];
         active = active && (throughput[0] != 0.0f || throughput[1] != 0.0f || throughput[2] != 0.0f);
         if (!active) break;
-        eta *= 1.0f; /* bs.eta == 1 for diffuse */
+        eta *= bs.eta;
 
         /* spawn_ray (interaction.h:58-61) */
-        ray.o = si.p; ray.d = mo_to_world(&si.sh, bs_wo);
+        ray.o = si.p; ray.d = mo_to_world(&si.sh, bs.wo);
         ray.mint = (1.0f + mo_hmax_abs(si.p)) * MO_RAY_EPSILON;
         ray.maxt = INFINITY;
         mo_si si_bsdf;
@@ -440,8 +441,9 @@ static void path_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, 
             mo_v3 d = mo_sub(si_bsdf.p, si.p);
             float dist = mo_norm(d);
             d = mo_div_s(d, dist);
-            float emitter_pdf = mo_pdf_emitter_direction(s, (uint32_t) emitter, d, si_bsdf.sh.n, dist);
-            emission_weight = mis_weight(bs_pdf, emitter_pdf);
+            /* delta lobes cannot be hit by emitter sampling (path.cpp:198-203) */
+            float emitter_pdf = bs.delta ? 0.0f : mo_pdf_emitter_direction(s, (uint32_t) emitter, d, si_bsdf.sh.n, dist);
+            emission_weight = mis_weight(bs.pdf, emitter_pdf);
         }
         si = si_bsdf; si_valid = v2;
     }

@@ -67,6 +67,12 @@ int mo_scene_add_mesh(mo_scene *s, uint32_t n_verts, const float *positions, con
     m->faces = (uint32_t *) dup_mem(faces, sizeof(uint32_t) * 3 * n_faces);
     m->bsdf_kind = bsdf_kind;
     for (int k = 0; k < 3; ++k) m->refl[k] = reflectance_rgb ? reflectance_rgb[k] : 0.5f;
+    m->bsdf.d.type = MO_BSDF_DIFFUSE;
+    for (int k = 0; k < 3; ++k) {
+        m->bsdf.d.reflectance[k] = m->refl[k];
+        m->bsdf.d.specular_reflectance[k] = m->bsdf.d.specular_transmittance[k] = 1.0f;
+    }
+    mo_bsdf_prepare(&m->bsdf);
     m->emitter = -1; m->texture = -1;
     if (emitter_rgb) {
         s->emitters = (mo_emitter *) realloc(s->emitters, sizeof(mo_emitter) * (s->n_emitters + 1));
@@ -99,7 +105,18 @@ int mo_scene_update_texture(mo_scene *s, uint32_t texture, const float *rgb) {
 }
 int mo_scene_set_reflectance(mo_scene *s, uint32_t shape, const float *rgb) {
     if (!s || shape >= s->n_meshes) return -1;
-    for (int k = 0; k < 3; ++k) s->meshes[shape].refl[k] = rgb[k];
+    for (int k = 0; k < 3; ++k) s->meshes[shape].refl[k] = s->meshes[shape].bsdf.d.reflectance[k] = rgb[k];
+    mo_bsdf_prepare(&s->meshes[shape].bsdf);
+    return 0;
+}
+int mo_scene_set_bsdf(mo_scene *s, uint32_t shape, const mo_bsdf_desc *desc) {
+    if (!s || shape >= s->n_meshes || !desc || desc->type < MO_BSDF_DIFFUSE || desc->type > MO_BSDF_PLASTIC) return -1;
+    if (s->spectral && desc->type != MO_BSDF_DIFFUSE) return -2;      /* spectral variant: diffuse only */
+    mo_mesh *m = &s->meshes[shape];
+    m->bsdf.d = *desc;
+    m->bsdf_kind = desc->type;
+    for (int k = 0; k < 3; ++k) m->refl[k] = desc->reflectance[k];
+    mo_bsdf_prepare(&m->bsdf);
     return 0;
 }
 

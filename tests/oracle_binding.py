@@ -22,6 +22,28 @@ class RenderDesc(C.Structure):
                 ("film_rgb", C.c_int32)]
 
 
+class BsdfDesc(C.Structure):
+    _fields_ = [("type", C.c_int32), ("twosided", C.c_int32), ("reflectance", C.c_float * 3), ("specular_reflectance", C.c_float * 3),
+                ("specular_transmittance", C.c_float * 3), ("eta", C.c_float * 3), ("k", C.c_float * 3), ("int_ior", C.c_float),
+                ("ext_ior", C.c_float), ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("distribution", C.c_int32),
+                ("sample_visible", C.c_int32), ("nonlinear", C.c_int32)]
+
+
+def bsdf_desc(plugin_dict):
+    """plugin dictionary -> mo_bsdf_desc (parameter defaults via the host module mitsuba2_amd.bsdfs, shared with the product)"""
+    from mitsuba2_amd import bsdfs
+    n = bsdfs.normalize(plugin_dict)
+    d = BsdfDesc()
+    d.type, d.twosided = n["type"], int(n["twosided"])
+    refl = [0.5, 0.5, 0.5] if isinstance(n["reflectance"], dict) else n["reflectance"]
+    for name, v in (("reflectance", refl), ("specular_reflectance", n["specular_reflectance"]),
+                    ("specular_transmittance", n["specular_transmittance"]), ("eta", n["eta"]), ("k", n["k"])):
+        setattr(d, name, (C.c_float * 3)(*v))
+    d.int_ior, d.ext_ior, d.alpha_u, d.alpha_v = n["int_ior"], n["ext_ior"], n["alpha_u"], n["alpha_v"]
+    d.distribution, d.sample_visible, d.nonlinear = n["distribution"], int(n["sample_visible"]), int(n["nonlinear"])
+    return d, n
+
+
 _lib = None
 
 
@@ -80,6 +102,15 @@ def lib():
         L.mo_kat_diffuse.argtypes = [vp] * 9
         L.mo_kat_sample_emitter.argtypes = [vp] * 4
         L.mo_scene_set_spectral.argtypes = [vp, C.c_char_p]
+        L.mo_scene_set_bsdf.argtypes = [vp, C.c_uint32, C.POINTER(BsdfDesc)]
+        L.mo_kat_fresnel.argtypes = [C.c_float, C.c_float, vp]
+        L.mo_kat_fresnel_conductor.argtypes = [C.c_float] * 3
+        L.mo_kat_fresnel_conductor.restype = C.c_float
+        L.mo_kat_fresnel_diffuse.argtypes = [C.c_float]
+        L.mo_kat_fresnel_diffuse.restype = C.c_float
+        L.mo_kat_microfacet.argtypes = [C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_uint64, vp, vp, vp]
+        L.mo_kat_microfacet_sample.argtypes = [C.c_int, C.c_float, C.c_float, C.c_int, C.c_uint64, vp, vp, vp, vp]
+        L.mo_kat_bsdf.argtypes = [C.POINTER(BsdfDesc), C.c_uint64, vp, vp, vp, vp]
         L.mo_kat_srgb_model_fetch.argtypes = [C.c_char_p, vp, vp]
         L.mo_kat_spectral.argtypes = [C.c_float, vp, C.c_float, vp]
         _lib = L
@@ -100,7 +131,8 @@ class OracleScene:
         self.h = C.c_void_p(L.mo_scene_new())
         self.tex_of_bsdf = {}
         for bi, b in enumerate(scene_dict["bsdfs"]):
-            if isinstance(b["reflectance"], dict):
+            b = b.get("bsdf", b) if b.get("type") == "twosided" else b
+            if isinstance(b.get("reflectance"), dict):
                 data = _f(b["reflectance"]["data"])
                 self.tex_of_bsdf[bi] = L.mo_scene_add_texture(self.h, data.shape[1], data.shape[0], data.ctypes.data_as(f32p))
                 assert self.tex_of_bsdf[bi] >= 0
@@ -112,13 +144,16 @@ class OracleScene:
             faces = np.ascontiguousarray(m["faces"], dtype=np.uint32).reshape(-1, 3)
             nrm = _f(m["normals"]) if m.get("normals") is not None else None
             uv = _f(m["texcoords"]) if m.get("texcoords") is not None else None
-            rb = scene_dict["bsdfs"][m["bsdf"]]["reflectance"]
+            bd, bn = bsdf_desc(scene_dict["bsdfs"][m["bsdf"]])
+            rb = bn["reflectance"]
             refl = _f([0.5, 0.5, 0.5]) if isinstance(rb, dict) else _f(rb)
             em = _f(scene_dict["emitters"][m["emitter"]]["radiance"]) if m.get("emitter", -1) >= 0 else None
             rc = L.mo_scene_add_mesh(self.h, pos.shape[0], pos.ctypes.data_as(f32p), nrm.ctypes.data_as(f32p) if nrm is not None else None,
                                      uv.ctypes.data_as(f32p) if uv is not None else None, faces.shape[0], faces.ctypes.data_as(u32p), 0,
                                      refl.ctypes.data_as(f32p), em.ctypes.data_as(f32p) if em is not None else None)
             assert rc >= 0, rc
+            if bn["type"] != 0 or bn["twosided"]:
+                assert L.mo_scene_set_bsdf(self.h, rc, C.byref(bd)) == 0
             if m["bsdf"] in self.tex_of_bsdf:
                 assert L.mo_scene_set_texture(self.h, rc, self.tex_of_bsdf[m["bsdf"]]) == 0
         assert L.mo_scene_finalize(self.h) == 0
@@ -269,3 +304,38 @@ def spectral_kat(sample, coeff, d65_scale):
     out = np.empty(19, np.float32)
     lib().mo_kat_spectral(C.c_float(sample), _p(_f(coeff)), C.c_float(d65_scale), _p(out))
     return dict(wav=out[0:4], weight=out[4:8], refl=out[8:12], d65=out[12:16], xyz=out[16:19])
+
+
+def fresnel(cos_theta_i, eta):
+    out = np.zeros(4, np.float32)
+    lib().mo_kat_fresnel(float(cos_theta_i), float(eta), _p(out))
+    return out
+
+
+def fresnel_conductor(cos_theta_i, eta_r, eta_i):
+    return lib().mo_kat_fresnel_conductor(float(cos_theta_i), float(eta_r), float(eta_i))
+
+
+def microfacet(ggx, alpha_u, alpha_v, visible, which, v, wi):
+    """which: 'eval' (m = v), 'pdf' (wi, m = v), 'smith_g1' (v, m = wi)"""
+    v, wi = _f(v).reshape(-1, 3), _f(wi).reshape(-1, 3)
+    out = np.zeros(v.shape[0], np.float32)
+    lib().mo_kat_microfacet(int(ggx), alpha_u, alpha_v, int(visible), {"eval": 0, "pdf": 1, "smith_g1": 2}[which], v.shape[0], _p(v), _p(wi), _p(out))
+    return out
+
+
+def microfacet_sample(ggx, alpha_u, alpha_v, visible, wi, sample2):
+    wi, s = _f(wi).reshape(-1, 3), _f(sample2).reshape(-1, 2)
+    m, pdf = np.zeros((wi.shape[0], 3), np.float32), np.zeros(wi.shape[0], np.float32)
+    lib().mo_kat_microfacet_sample(int(ggx), alpha_u, alpha_v, int(visible), wi.shape[0], _p(wi), _p(s), _p(m), _p(pdf))
+    return m, pdf
+
+
+def bsdf_kat(plugin_dict, wi, wo, sample3):
+    """-> dict(eval (N,3), pdf, s_wo (N,3), s_pdf, s_eta, s_delta, s_weight (N,3), s_valid) for the oracle's BSDF models"""
+    d, _ = bsdf_desc(plugin_dict)
+    wi, wo, s = _f(wi).reshape(-1, 3), _f(wo).reshape(-1, 3), _f(sample3).reshape(-1, 3)
+    out = np.zeros((wi.shape[0], 14), np.float32)
+    lib().mo_kat_bsdf(C.byref(d), wi.shape[0], _p(wi), _p(wo), _p(s), _p(out))
+    return dict(eval=out[:, 0:3], pdf=out[:, 3], s_wo=out[:, 4:7], s_pdf=out[:, 7], s_eta=out[:, 8], s_delta=out[:, 9] > 0.5,
+                s_weight=out[:, 10:13], s_valid=out[:, 13] > 0.5)

@@ -1,0 +1,272 @@
+"""Oracle BSDF models (oracle/mo_bsdf.c) pinned by the reference's own vectors: Fresnel spot values
+(src/librender/tests/test_fresnel.py:7-80), the Mitsuba 0.6 microfacet tables (test_microfacet.py:18-300), dielectric
+sampling (src/bsdfs/tests/test_dielectric.py:36-98), twosided consistency (test_twosided.py:45-101), plus the generic
+sample / eval / pdf consistency the reference checks with chi^2 tests (a Monte Carlo normalisation test stands in for
+mitsuba.python.chi2, which needs the compiled reference)."""
+import math
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+
+
+# ------------------------------------------------------------------------------------------------ Fresnel
+def test_fresnel_spot_values():
+    """test_fresnel.py:7-40"""
+    ct_crit = -math.sqrt(1 - 1 / 1.5 ** 2)
+    assert np.allclose(ob.fresnel(1, 1.5), (0.04, -1, 1.5, 1 / 1.5))
+    assert np.allclose(ob.fresnel(-1, 1.5), (0.04, 1, 1 / 1.5, 1.5))
+    assert np.allclose(ob.fresnel(1, 1 / 1.5), (0.04, -1, 1 / 1.5, 1.5))
+    assert np.allclose(ob.fresnel(-1, 1 / 1.5), (0.04, 1, 1.5, 1 / 1.5))
+    assert np.allclose(ob.fresnel(0, 1.5), (1, ct_crit, 1.5, 1 / 1.5))
+    assert np.allclose(ob.fresnel(0, 1 / 1.5), (1, 0, 1 / 1.5, 1.5))
+    c45 = math.cos(math.radians(45))
+    F, cos_theta_t, _, scale = ob.fresnel(c45, 1.5)
+    assert np.isclose((scale * math.sqrt(1 - c45 ** 2)) ** 2 + cos_theta_t ** 2, 1)
+    assert np.isclose(cos_theta_t, -math.cos(math.radians(28.1255057020557)))
+    assert np.isclose(F, 0.5 * (0.09201336304552442 ** 2 + 0.3033370452904235 ** 2))
+    F, cos_theta_t, _, _ = ob.fresnel(c45, 1 / 1.5)
+    assert np.isclose(F, 1) and np.isclose(cos_theta_t, 0)
+    c10 = math.cos(math.radians(10))
+    F, cos_theta_t, _, scale = ob.fresnel(c10, 1 / 1.5)
+    assert np.isclose(cos_theta_t, -math.cos(math.radians(15.098086605159006)))
+    assert np.isclose(F, 0.5 * (0.19046797197779405 ** 2 + 0.20949431963852014 ** 2))
+
+
+def test_fresnel_index_matched_conductor_and_snell():
+    """test_fresnel.py:53-91"""
+    for c in np.linspace(-1, 1, 20):
+        F, ct, _, _ = ob.fresnel(c, 1)
+        assert F == 0 and abs(ct + c) < 5e-7
+    for theta in np.linspace(0, math.pi / 2, 20):
+        c = math.cos(theta)
+        for eta in (1.5, 1 / 1.5):
+            assert np.isclose(ob.fresnel(c, eta)[0], ob.fresnel_conductor(c, eta, 0.0), atol=1e-6)
+        ct = ob.fresnel(c, 1.5)[1]
+        assert abs(math.sin(theta) - 1.5 * math.sin(math.acos(ct))) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ microfacet
+def _dirs(theta, phi):
+    theta, phi = np.broadcast_arrays(np.asarray(theta, np.float32), np.asarray(phi, np.float32))
+    return np.stack([np.cos(phi) * np.sin(theta), np.sin(phi) * np.sin(theta), np.cos(theta)], 1).astype(np.float32)
+
+
+Z = lambda n: np.tile(np.array([0, 0, 1], np.float32), (n, 1))
+
+
+def test_microfacet_eval_pdf_beckmann():
+    """test_microfacet.py:18-97 (test02_eval_pdf_beckmann)"""
+    steps = 20
+    v = _dirs(np.linspace(0, np.pi, steps), np.full(steps, np.pi / 2))
+    aniso, iso = (0, 0.1, 0.3, 0), (0, 0.1, 0.1, 0)
+    assert np.allclose(ob.microfacet(*aniso, "eval", v, Z(steps)),
+                       [1.06103287e+01, 8.22650051e+00, 3.57923722e+00, 6.84863329e-01, 3.26460004e-02, 1.01964230e-04, 5.87322635e-10] + [0] * 13, rtol=1e-4, atol=1e-12)
+    assert np.allclose(ob.microfacet(*aniso, "pdf", v, Z(steps)),
+                       [1.06103287e+01, 8.11430168e+00, 3.38530421e+00, 6.02319300e-01, 2.57622823e-02, 6.90584930e-05, 3.21235011e-10] + [0] * 13, rtol=1e-4, atol=1e-12)
+    assert np.allclose(ob.microfacet(*iso, "eval", v, Z(steps)), [3.18309879e+01, 2.07673073e+00, 3.02855828e-04, 1.01591990e-11] + [0] * 16, rtol=1e-4, atol=1e-13)
+    assert np.allclose(ob.microfacet(*iso, "pdf", v, Z(steps)), [3.18309879e+01, 2.04840684e+00, 2.86446273e-04, 8.93474877e-12] + [0] * 16, rtol=1e-4, atol=1e-13)
+    v = _dirs(np.full(steps, 0.1), np.linspace(0, 2 * np.pi, steps))
+    ref = np.array([3.95569706, 4.34706259, 5.54415846, 7.4061389, 9.17129803, 9.62056446, 8.37803268, 6.42071199, 4.84459257, 4.05276537,
+                    4.05276537, 4.84459257, 6.42071199, 8.37803268, 9.62056446, 9.17129803, 7.4061389, 5.54415846, 4.34706259, 3.95569706])
+    assert np.allclose(ob.microfacet(*aniso, "eval", v, Z(steps)), ref, rtol=1e-4)
+    assert np.allclose(ob.microfacet(*aniso, "pdf", v, Z(steps)), ref * math.cos(0.1), rtol=1e-4)
+    assert np.allclose(ob.microfacet(*iso, "eval", v, Z(steps)), 11.86709118, rtol=1e-4)
+    assert np.allclose(ob.microfacet(*iso, "pdf", v, Z(steps)), 11.86709118 * math.cos(0.1), rtol=1e-4)
+
+
+def test_microfacet_smith_g1():
+    """test_microfacet.py:100-141 (beckmann) and :205-245 (ggx)"""
+    steps = 20
+    v = _dirs(np.linspace(np.pi / 3, np.pi / 2, steps), np.full(steps, np.pi / 2))
+    tol = dict(rtol=2e-4, atol=1e-5)     # last entry: theta = fl(pi/2), v.z = -4e-8 depends on the cosine's last bit
+    assert np.allclose(ob.microfacet(0, 0.1, 0.3, 0, "smith_g1", v, Z(steps)),
+                       [1.0, 1.0, 1.0, 1.0000523, 9.9941480e-01, 9.9757767e-01, 9.9420297e-01, 9.8884594e-01, 9.8091525e-01, 9.6961778e-01,
+                        9.5387781e-01, 9.3222123e-01, 9.0260512e-01, 8.6216795e-01, 8.0686140e-01, 7.3091686e-01, 6.2609726e-01, 4.8074335e-01,
+                        2.7883825e-01, 1.9197471e-06], **tol)
+    assert np.allclose(ob.microfacet(0, 0.1, 0.1, 0, "smith_g1", v, Z(steps)),
+                       [1.0] * 14 + [9.9828446e-01, 9.8627287e-01, 9.5088160e-01, 8.5989666e-01, 6.2535185e-01, 5.7592310e-06], **tol)
+    assert np.allclose(ob.microfacet(1, 0.1, 0.3, 0, "smith_g1", v, Z(steps)),
+                       [9.4031686e-01, 9.3310797e-01, 9.2485082e-01, 9.1534841e-01, 9.0435863e-01, 8.9158219e-01, 8.7664890e-01, 8.5909742e-01,
+                        8.3835226e-01, 8.1369340e-01, 7.8421932e-01, 7.4880326e-01, 7.0604056e-01, 6.5419233e-01, 5.9112519e-01, 5.1425743e-01,
+                        4.2051861e-01, 3.0633566e-01, 1.6765384e-01, 1.0861372e-06], **tol)
+    assert np.allclose(ob.microfacet(1, 0.1, 0.1, 0, "smith_g1", v, Z(steps)),
+                       [9.9261039e-01, 9.9160647e-01, 9.9042398e-01, 9.8901933e-01, 9.8733366e-01, 9.8528832e-01, 9.8277503e-01, 9.7964239e-01,
+                        9.7567332e-01, 9.7054905e-01, 9.6378750e-01, 9.5463598e-01, 9.4187391e-01, 9.2344058e-01, 8.9569420e-01, 8.5189372e-01,
+                        7.7902949e-01, 6.5144652e-01, 4.1989169e-01, 3.2584082e-06], **tol)
+    v = _dirs(np.full(steps, np.pi / 2 * 0.98), np.linspace(0, 2 * np.pi, steps))
+    assert np.allclose(ob.microfacet(0, 0.1, 0.3, 0, "smith_g1", v, Z(steps)),
+                       [0.67333597, 0.56164336, 0.42798978, 0.35298213, 0.31838724, 0.31201753, 0.33166203, 0.38421196, 0.48717275, 0.63746351,
+                        0.63746351, 0.48717275, 0.38421196, 0.33166203, 0.31201753, 0.31838724, 0.35298213, 0.42798978, 0.56164336, 0.67333597], rtol=2e-4)
+    assert np.allclose(ob.microfacet(0, 0.1, 0.1, 0, "smith_g1", v, Z(steps)), 0.67333597, rtol=2e-4)
+    assert np.allclose(ob.microfacet(1, 0.1, 0.3, 0, "smith_g1", v, Z(steps)),
+                       [0.46130955, 0.36801264, 0.26822716, 0.21645154, 0.19341162, 0.18922243, 0.20219423, 0.23769052, 0.31108665, 0.43013984,
+                        0.43013984, 0.31108665, 0.23769052, 0.20219423, 0.18922243, 0.19341162, 0.21645154, 0.26822716, 0.36801264, 0.46130955], rtol=2e-4)
+    assert np.allclose(ob.microfacet(1, 0.1, 0.1, 0, "smith_g1", v, Z(steps)), 0.46130955, rtol=2e-4)
+
+
+SAMPLE_REF = {
+    0: (np.array([[0, 0, 1], [4.71862517e-02, 0, 9.98886108e-01], [7.12896436e-02, 0, 9.97455657e-01], [9.52876359e-02, 0, 9.95449781e-01],
+                  [1.25854731e-01, 0, 9.92048681e-01], [1, 0, 0], [0, 0, 1], [1.44650340e-02, 1.33556545e-01, 9.90935624e-01],
+                  [2.16356069e-02, 1.99762881e-01, 9.79605377e-01], [2.85233315e-02, 2.63357669e-01, 9.64276493e-01],
+                  [3.68374363e-02, 3.40122312e-01, 9.39659417e-01], [1.07676744e-01, 9.94185984e-01, 0], [0, 0, 1],
+                  [-3.80569659e-02, 8.29499215e-02, 9.95826781e-01], [-5.72742373e-02, 1.24836378e-01, 9.90522861e-01],
+                  [-7.61397704e-02, 1.65956154e-01, 9.83189344e-01], [-9.96606201e-02, 2.17222810e-01, 9.71021116e-01],
+                  [-4.17001039e-01, 9.08905983e-01, 0]]),
+        np.array([10.61032867, 8.51669121, 6.41503906, 4.302598, 2.17350101, 0, 10.61032867, 8.72333431, 6.77215099, 4.7335186, 2.55768704, 0,
+                  10.61032867, 8.59542656, 6.55068302, 4.46557426, 2.31778312, 0])),
+    1: (np.array([[0, 0, 1], [4.99384739e-02, 0, 9.98752296e-01], [8.13788623e-02, 0, 9.96683240e-01], [1.21566132e-01, 0, 9.92583334e-01],
+                  [1.96116075e-01, 0, 9.80580688e-01], [1, 0, 0], [0, 0, 1], [1.52942007e-02, 1.41212299e-01, 9.89861190e-01],
+                  [2.45656986e-02, 2.26816610e-01, 9.73627627e-01], [3.57053429e-02, 3.29669625e-01, 9.43420947e-01],
+                  [5.36015145e-02, 4.94906068e-01, 8.67291689e-01], [1.07676744e-01, 9.94185984e-01, 0], [0, 0, 1],
+                  [-4.02617380e-02, 8.77555013e-02, 9.95328069e-01], [-6.52425364e-02, 1.42204270e-01, 9.87684846e-01],
+                  [-9.64000970e-02, 2.10116088e-01, 9.72912252e-01], [-1.50845990e-01, 3.28787714e-01, 9.32278991e-01],
+                  [-4.17001039e-01, 9.08905983e-01, 0]]),
+        np.array([10.61032867, 6.81609201, 3.85797882, 1.73599267, 0.45013079, 0, 10.61032867, 7.00141668, 4.13859272, 2.02177191, 0.65056872, 0,
+                  10.61032867, 6.88668203, 3.96438813, 1.84343493, 0.52378261, 0])),
+}
+
+
+@pytest.mark.parametrize("ggx", [0, 1])
+def test_microfacet_sample_tables(ggx):
+    """test_microfacet.py:144-202 (test04_sample_beckmann) and :248-306 (test05_sample_ggx): first three rows of the
+    6 x 6 (u1, u2) grid, anisotropic alpha = (0.1, 0.3), sampling of all normals"""
+    u = np.linspace(0, 1, 6)
+    u1, u2 = np.meshgrid(u, u)
+    s = np.stack([u1.reshape(-1), u2.reshape(-1)], 1)[:18]
+    m, pdf = ob.microfacet_sample(ggx, 0.1, 0.3, 0, Z(18), s)
+    ref_m, ref_pdf = SAMPLE_REF[ggx]
+    assert np.allclose(m, ref_m, atol=5e-4)
+    assert np.allclose(pdf, ref_pdf, atol=1e-4 * 10.7)
+
+
+@pytest.mark.parametrize("ggx", [0, 1])
+@pytest.mark.parametrize("visible", [0, 1])
+@pytest.mark.parametrize("alpha", [(0.1, 0.1), (0.5, 0.5), (0.2, 0.05)])
+def test_microfacet_sampling_matches_pdf(ggx, visible, alpha):
+    """what test_microfacet.py:309-335 (test06_chi2) establishes: sample() is distributed according to pdf().  Here: the
+    density returned with each sample equals pdf() at that normal, and the sampled density integrates test functions
+    to the values obtained by quadrature of pdf()."""
+    rng = np.random.default_rng(7)
+    n = 200000
+    wi = np.tile(np.array([math.sin(math.radians(30)), 0, math.cos(math.radians(30))], np.float32), (n, 1))
+    s = rng.uniform(size=(n, 2)).astype(np.float32)
+    m, pdf = ob.microfacet_sample(ggx, alpha[0], alpha[1], visible, wi, s)
+    again = ob.microfacet(ggx, alpha[0], alpha[1], visible, "pdf", m, wi)
+    ok = pdf > 1e-6
+    assert np.allclose(pdf[ok], again[ok], rtol=2e-3, atol=1e-5)
+    # E[f(m)] under the sampler vs quadrature of f * pdf over the hemisphere, f = m.z^2 and f = m.x
+    th, ph = np.meshgrid((np.arange(1024) + 0.5) / 1024 * (math.pi / 2), (np.arange(512) + 0.5) / 512 * (2 * math.pi), indexing="ij")
+    q = _dirs(th.reshape(-1), ph.reshape(-1))
+    dens = ob.microfacet(ggx, alpha[0], alpha[1], visible, "pdf", q, np.tile(wi[:1], (q.shape[0], 1))).astype(np.float64)
+    w = np.sin(th.reshape(-1)) * (math.pi / 2 / 1024) * (2 * math.pi / 512)
+    total = np.sum(dens * w)
+    assert abs(total - 1) < 2e-2
+    for f_s, f_q in ((m[:, 2] ** 2, q[:, 2] ** 2), (m[:, 0], q[:, 0])):
+        assert abs(np.mean(f_s) - np.sum(f_q * dens * w) / total) < 6e-3
+
+
+# ------------------------------------------------------------------------------------------------ BSDF plugins
+def test_dielectric_sample():
+    """test_dielectric.py:36-98 (test02_sample, test03_sample_reverse), radiance transport"""
+    b = {"type": "dielectric", "specular_reflectance": 0.3, "specular_transmittance": 0.6, "int_ior": 1.5, "ext_ior": 1}
+    for wz, eta, scale in ((1.0, 1.5, 1 / 1.5 ** 2), (-1.0, 1 / 1.5, 1.5 ** 2)):
+        r = ob.bsdf_kat(b, [[0, 0, wz]] * 2, [[0, 0, 1]] * 2, [[0, 0, 0], [0.05, 0, 0]])
+        assert np.allclose(r["s_weight"][0], 0.3) and np.isclose(r["s_pdf"][0], 0.04) and r["s_eta"][0] == 1 and np.allclose(r["s_wo"][0], [0, 0, wz])
+        assert np.allclose(r["s_weight"][1], 0.6 * scale) and np.isclose(r["s_pdf"][1], 0.96) and np.isclose(r["s_eta"][1], eta)
+        assert np.allclose(r["s_wo"][1], [0, 0, -wz]) and r["s_delta"].all()
+        assert (r["eval"] == 0).all() and (r["pdf"] == 0).all()
+    with pytest.raises(RuntimeError):
+        ob.bsdf_desc({"type": "dielectric", "int_ior": -0.5})
+
+
+def test_conductor_mirror():
+    """conductor.cpp:185-252: a delta reflection weighted by the conductor Fresnel term (test_conductor.py:47-50 checks the
+    same identity through the Mueller matrix)"""
+    eta, k = 0.136125, 4.010625
+    wi = np.array([-math.sin(math.pi / 4), 0, math.cos(math.pi / 4)], np.float32)
+    r = ob.bsdf_kat({"type": "conductor", "eta": eta, "k": k}, [wi, -wi], [[0, 0, 1]] * 2, [[0, 0, 0]] * 2)
+    F = ob.fresnel_conductor(wi[2], eta, k)
+    assert np.allclose(r["s_weight"][0], F, atol=1e-6) and 0.9 < F < 1 and np.allclose(r["s_wo"][0], [-wi[0], 0, wi[2]])
+    assert r["s_delta"][0] and r["s_pdf"][0] == 1 and not r["s_valid"][1] and (r["s_weight"][1] == 0).all()
+    r = ob.bsdf_kat({"type": "conductor"}, [wi], [[0, 0, 1]], [[0, 0, 0]])       # material "none": 100 % mirror
+    assert np.allclose(r["s_weight"][0], 1.0, atol=1e-6)
+
+
+def _sphere(n):
+    """square_to_uniform_sphere on the (n x n) grid of test_twosided.py:62-77"""
+    g = np.arange(n) / float(n - 1)
+    u, v = np.meshgrid(g, g, indexing="ij")
+    z = 1 - 2 * v.reshape(-1)
+    r = np.sqrt(np.maximum(0, 1 - z * z))
+    ph = 2 * math.pi * u.reshape(-1)
+    return np.stack([r * np.cos(ph), r * np.sin(ph), z], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("nested", [{"type": "diffuse", "reflectance": [0.1, 0.5, 0.9]},
+                                    {"type": "roughconductor", "alpha": 0.3, "distribution": "ggx", "eta": [0.2, 0.9, 1.1], "k": [3.9, 2.4, 2.2]},
+                                    {"type": "plastic", "diffuse_reflectance": [0.1, 0.27, 0.36]}])
+def test_twosided(nested):
+    """test_twosided.py:28-101: pdf on both sides, sample / eval / pdf agreement for wi over the whole sphere"""
+    b = {"type": "twosided", "bsdf": nested}
+    if nested["type"] == "diffuse":
+        r = ob.bsdf_kat(b, [[0, 0, 1]] * 2, [[0, 0, 1], [0, 0, -1]], [[0, 0, 0]] * 2)
+        assert np.isclose(r["pdf"][0], 1 / math.pi) and r["pdf"][1] == 0
+    wis = _sphere(5)
+    g = np.arange(5) / 4.0
+    sx, sy = np.meshgrid(g, g, indexing="ij")
+    for wi in wis:
+        s3 = np.stack([np.full(25, 0.5), sx.reshape(-1), sy.reshape(-1)], 1)
+        r = ob.bsdf_kat(b, np.tile(wi, (25, 1)), np.tile([0, 0, 1], (25, 1)), s3)
+        ok = r["s_valid"] & (r["s_weight"] > 0).any(1) & ~r["s_delta"]
+        if not ok.any():
+            continue
+        e = ob.bsdf_kat(b, np.tile(wi, (int(ok.sum()), 1)), r["s_wo"][ok], s3[ok])
+        assert np.allclose(r["s_weight"][ok] * r["s_pdf"][ok][:, None], e["eval"], rtol=2e-3, atol=1e-5)
+        assert np.allclose(r["s_pdf"][ok], e["pdf"], rtol=2e-3, atol=1e-6)
+        assert np.all(np.sign(r["s_wo"][ok][:, 2]) == np.sign(wi[2]))          # reflection stays on wi's side
+        assert not np.isnan(e["eval"]).any()
+    one = ob.bsdf_kat(nested, [[0.3, 0.2, -0.9]], [[0, 0, -1]], [[0.5, 0.5, 0.5]])
+    assert not one["s_valid"][0] and (one["eval"] == 0).all()                   # the bare BSDF is one-sided
+    with pytest.raises(RuntimeError, match="without a transmission component"):
+        ob.bsdf_desc({"type": "twosided", "bsdf": {"type": "dielectric"}})
+
+
+@pytest.mark.parametrize("b", [{"type": "roughconductor", "alpha": 0.05, "eta": 0.0, "k": 1.0},
+                               {"type": "roughconductor", "alpha_u": 0.2, "alpha_v": 0.05, "distribution": "beckmann", "sample_visible": False, "eta": 0.0, "k": 1.0},
+                               {"type": "roughconductor", "alpha_u": 0.2, "alpha_v": 0.05, "distribution": "beckmann", "sample_visible": True, "eta": 0.0, "k": 1.0},
+                               {"type": "roughconductor", "alpha_u": 0.2, "alpha_v": 0.05, "distribution": "ggx", "sample_visible": False, "eta": 0.0, "k": 1.0},
+                               {"type": "roughconductor", "alpha_u": 0.2, "alpha_v": 0.05, "distribution": "ggx", "sample_visible": True, "eta": 0.0, "k": 1.0},
+                               {"type": "plastic", "diffuse_reflectance": [0.5, 0.2, 0.1], "nonlinear": True},
+                               {"type": "diffuse", "reflectance": [0.5, 0.2, 0.1]}])
+def test_bsdf_sample_eval_pdf_consistency(b):
+    """the configurations of test_rough_conductor.py:6-97 (chi^2 tests of sample vs pdf for wi = normalize(1,1,1)):
+    weight * pdf == eval and the sampled pdf == pdf() at the sampled direction; white-furnace bound on the mean weight"""
+    rng = np.random.default_rng(5)
+    n = 50000
+    wi = np.tile(np.array([1, 1, 1], np.float32) / np.float32(math.sqrt(3)), (n, 1))
+    s3 = rng.uniform(size=(n, 3)).astype(np.float32)
+    r = ob.bsdf_kat(b, wi, wi, s3)
+    ok = r["s_valid"] & ~r["s_delta"] & (r["s_pdf"] > 1e-4)
+    assert ok.mean() > 0.5
+    e = ob.bsdf_kat(b, wi[ok], r["s_wo"][ok], s3[ok])
+    assert np.allclose(r["s_pdf"][ok], e["pdf"], rtol=5e-3, atol=1e-5)
+    assert np.allclose(r["s_weight"][ok] * r["s_pdf"][ok][:, None], e["eval"], rtol=5e-3, atol=1e-4)
+    mean_w = np.where(r["s_valid"][:, None], r["s_weight"], 0).mean(0)
+    assert (mean_w <= 1.0 + 1e-3).all() and (mean_w > 0.05).all()
+
+
+def test_bsdf_parameter_errors():
+    """roughconductor.cpp:160-185, conductor.cpp:196, ior.h:52-73"""
+    from mitsuba2_amd import bsdfs
+    with pytest.raises(RuntimeError, match='invalid distribution "phong"'):
+        bsdfs.normalize({"type": "roughconductor", "eta": 0, "k": 1, "distribution": "phong"})
+    with pytest.raises(RuntimeError, match="both 'alpha_u' and 'alpha_v' must be specified"):
+        bsdfs.normalize({"type": "roughconductor", "eta": 0, "k": 1, "alpha_u": 0.1})
+    with pytest.raises(RuntimeError, match="either \\(eta, k\\) or material"):
+        bsdfs.normalize({"type": "conductor", "eta": 0.2, "k": 3, "material": "Au"})
+    with pytest.raises(RuntimeError, match="Unable to find an IOR value"):
+        bsdfs.normalize({"type": "dielectric", "int_ior": "unobtainium"})
+    assert bsdfs.normalize({"type": "dielectric"})["int_ior"] == pytest.approx(1.5046) and bsdfs.normalize({"type": "plastic"})["int_ior"] == pytest.approx(1.49)
+    assert bsdfs.normalize({"type": "dielectric", "int_ior": "water"})["ext_ior"] == pytest.approx(1.000277)
