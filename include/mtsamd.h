@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MTSAMD_ABI_VERSION 1
+#define MTSAMD_ABI_VERSION 2
 
 typedef enum {
     MTSAMD_OK = 0,
@@ -59,11 +59,24 @@ typedef struct {
     int32_t emitter;           /* index into the emitter table, or -1 */
 } mtsamd_mesh_desc;
 
-typedef enum { MTSAMD_BSDF_DIFFUSE = 0 } mtsamd_bsdf_type;
+/* BSDF plugins (constructor parameters after the host resolved defaults and named IORs):
+ *   diffuse src/bsdfs/diffuse.cpp, conductor conductor.cpp, roughconductor roughconductor.cpp + microfacet.h,
+ *   dielectric dielectric.cpp, plastic plastic.cpp; `twosided` = wrapped in the TwoSidedBRDF adapter (twosided.cpp). */
+typedef enum { MTSAMD_BSDF_DIFFUSE = 0, MTSAMD_BSDF_CONDUCTOR = 1, MTSAMD_BSDF_ROUGHCONDUCTOR = 2, MTSAMD_BSDF_DIELECTRIC = 3,
+               MTSAMD_BSDF_PLASTIC = 4 } mtsamd_bsdf_type;
 typedef struct {
-    int32_t type;              /* mtsamd_bsdf_type; SmoothDiffuse = src/bsdfs/diffuse.cpp */
-    float reflectance[3];      /* constant `srgb` texture value in RGB mode (src/spectra/srgb.cpp:27-52) */
-    int32_t texture;           /* index into the bitmap-texture table or -1 (src/textures/bitmap.cpp) */
+    int32_t type;              /* mtsamd_bsdf_type */
+    float reflectance[3];      /* diffuse.reflectance / plastic.diffuse_reflectance: constant `srgb` value (src/spectra/srgb.cpp:27-52) */
+    int32_t texture;           /* diffuse.reflectance as a bitmap: index into the texture table or -1 (src/textures/bitmap.cpp) */
+    int32_t twosided;          /* != 0: both sides scatter like the front side (twosided.cpp:94-175) */
+    float specular_reflectance[3];     /* default 1 */
+    float specular_transmittance[3];   /* dielectric, default 1 */
+    float eta[3], k[3];        /* conductors: complex index of refraction per colour channel (material "none": 0, 1) */
+    float int_ior, ext_ior;    /* dielectric / plastic (ior.h) */
+    float alpha_u, alpha_v;    /* roughconductor roughness */
+    int32_t distribution;      /* 0 = beckmann, 1 = ggx */
+    int32_t sample_visible;    /* visible-normal sampling (default true) */
+    int32_t nonlinear;         /* plastic.nonlinear */
 } mtsamd_bsdf_desc;
 
 typedef enum { MTSAMD_EMITTER_AREA = 0 } mtsamd_emitter_type;

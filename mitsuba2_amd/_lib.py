@@ -23,7 +23,10 @@ class MeshDesc(C.Structure):
 
 
 class BsdfDesc(C.Structure):
-    _fields_ = [("type", C.c_int32), ("reflectance", C.c_float * 3), ("texture", C.c_int32)]
+    _fields_ = [("type", C.c_int32), ("reflectance", C.c_float * 3), ("texture", C.c_int32), ("twosided", C.c_int32),
+                ("specular_reflectance", C.c_float * 3), ("specular_transmittance", C.c_float * 3), ("eta", C.c_float * 3),
+                ("k", C.c_float * 3), ("int_ior", C.c_float), ("ext_ior", C.c_float), ("alpha_u", C.c_float), ("alpha_v", C.c_float),
+                ("distribution", C.c_int32), ("sample_visible", C.c_int32), ("nonlinear", C.c_int32)]
 
 
 class EmitterDesc(C.Structure):
@@ -101,7 +104,7 @@ def lib():
             fn = getattr(handle, name)      # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if handle.mtsamd_abi_version() != 1:
+        if handle.mtsamd_abi_version() != 2:
             raise RuntimeError("libmtsamd.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -30,7 +30,9 @@ class ParameterMap:
         self.properties = {}
         self._kind = {}
         dev = torch.device("cuda", scene._device_index)
-        for i, b in enumerate(scene._dict["bsdfs"]):
+        for i, b in enumerate(scene._bsdf_records):
+            if b["type"] != 0:            # only diffuse reflectances are exposed (the adjoint pass covers those)
+                continue
             name = b.get("id", "bsdf_%d" % i)
             refl = b["reflectance"]
             if isinstance(refl, dict):

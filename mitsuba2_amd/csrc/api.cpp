@@ -177,7 +177,36 @@ struct Workspace {
 
 } // namespace
 
+// Model parameters of a BSDF -> device record (see DevBsdf in device_bsdf.h), with the constants the reference's
+// constructors derive (plastic.cpp:162-176; fresnel_diffuse_reflectance: fresnel.h:331-358).
+static float fresnel_diffuse_reflectance(float eta) {
+    if (eta < 1.0f) return -1.4399f * (eta * eta) + 0.7099f * eta + 0.6681f + 0.0636f / eta;
+    const float i1 = 1.0f / eta, i2 = i1 * i1, i3 = i2 * i1, i4 = i3 * i1, i5 = i4 * i1;
+    return 0.919317f - 3.4793f * i1 + 6.75335f * i2 - 7.80989f * i3 + 4.98554f * i4 - 1.36881f * i5;
+}
+static void fill_bsdf_model(const mtsamd_bsdf_desc &bd, DevBsdf &d) {
+    d.flags = (bd.twosided ? kBsdfTwoSided : 0u) | (bd.distribution == 1 ? kBsdfGGX : 0u) | (bd.sample_visible ? kBsdfSampleVisible : 0u) |
+              (bd.nonlinear ? kBsdfNonlinear : 0u);
+    if (bd.type == MTSAMD_BSDF_DIFFUSE) d.flags &= kBsdfTwoSided;
+    d.sr = bd.specular_reflectance[0]; d.sg = bd.specular_reflectance[1]; d.sb = bd.specular_reflectance[2];
+    d.alpha_u = bd.alpha_u; d.alpha_v = bd.alpha_v;
+    if (bd.type == MTSAMD_BSDF_CONDUCTOR || bd.type == MTSAMD_BSDF_ROUGHCONDUCTOR) {
+        d.er = bd.eta[0]; d.eg = bd.eta[1]; d.eb = bd.eta[2];
+        d.kr = bd.k[0]; d.kg = bd.k[1]; d.kb = bd.k[2];
+    } else if (bd.type == MTSAMD_BSDF_DIELECTRIC) {
+        d.er = bd.int_ior / bd.ext_ior;
+        d.kr = bd.specular_transmittance[0]; d.kg = bd.specular_transmittance[1]; d.kb = bd.specular_transmittance[2];
+    } else if (bd.type == MTSAMD_BSDF_PLASTIC) {
+        const float eta = bd.int_ior / bd.ext_ior;
+        d.er = eta; d.eg = 1.0f / (eta * eta); d.eb = fresnel_diffuse_reflectance(1.0f / eta);
+        const float d_mean = (bd.reflectance[0] + bd.reflectance[1] + bd.reflectance[2]) * (1.0f / 3.0f);
+        const float s_mean = (bd.specular_reflectance[0] + bd.specular_reflectance[1] + bd.specular_reflectance[2]) * (1.0f / 3.0f);
+        d.kr = s_mean / (d_mean + s_mean);
+    }
+}
+
 struct mtsamd_scene {
+    bool general_bsdfs = false;      // any BSDF other than one-sided `diffuse`: the kernels with the BSDF switch are used
     int device = 0;
     int cu_count = 256;
     BvhOutput bvh;
@@ -257,7 +286,15 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         if (desc->emitters[e].type != MTSAMD_EMITTER_AREA) return fail(MTSAMD_ERR_UNSUPPORTED, "emitter %u: only 'area' emitters are implemented", e);
     }
     for (uint32_t b = 0; b < desc->bsdf_count; ++b) {
-        if (desc->bsdfs[b].type != MTSAMD_BSDF_DIFFUSE) return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u: only 'diffuse' is implemented", b);
+        const mtsamd_bsdf_desc &bd = desc->bsdfs[b];
+        if (bd.type < MTSAMD_BSDF_DIFFUSE || bd.type > MTSAMD_BSDF_PLASTIC) return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u: unknown BSDF type %d", b, bd.type);
+        if (desc->spectral && (bd.type != MTSAMD_BSDF_DIFFUSE || bd.twosided))
+            return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u: the spectral variant implements 'diffuse' only", b);
+        if (bd.texture >= 0 && bd.type != MTSAMD_BSDF_DIFFUSE) return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u: bitmap textures are implemented for diffuse.reflectance only", b);
+        if ((bd.type == MTSAMD_BSDF_DIELECTRIC || bd.type == MTSAMD_BSDF_PLASTIC) && (bd.int_ior < 0.0f || bd.ext_ior < 0.0f || bd.ext_ior == 0.0f))
+            return fail(MTSAMD_ERR_INVALID, "The interior and exterior indices of refraction must be positive!");      // dielectric.cpp:183-185
+        if (bd.type == MTSAMD_BSDF_DIELECTRIC && bd.twosided)
+            return fail(MTSAMD_ERR_INVALID, "Only materials without a transmission component can be nested!");          // twosided.cpp:90-91
         if (desc->bsdfs[b].texture >= (int32_t) desc->texture_count) return fail(MTSAMD_ERR_INVALID, "bsdf %u: invalid texture index %d", b, desc->bsdfs[b].texture);
     }
     for (uint32_t t = 0; t < desc->texture_count; ++t)
@@ -345,6 +382,8 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         std::memset(&d, 0, sizeof(d));
         d.r = desc->bsdfs[b].reflectance[0]; d.g = desc->bsdfs[b].reflectance[1]; d.b = desc->bsdfs[b].reflectance[2];
         d.type = desc->bsdfs[b].type; d.texture = desc->bsdfs[b].texture < 0 ? -1 : desc->bsdfs[b].texture;
+        fill_bsdf_model(desc->bsdfs[b], d);
+        if (d.type != kBsdfDiffuse || d.flags) s->general_bsdfs = true;
         if (desc->spectral) {
             const float *c = desc->bsdfs[b].reflectance;
             if (c[0] < 0 || c[1] < 0 || c[2] < 0 || c[0] > 1 || c[1] > 1 || c[2] > 1) {
@@ -437,6 +476,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     v.n_shapes = desc->mesh_count; v.n_bsdfs = desc->bsdf_count;
     v.textures = s->d_textures; v.n_textures = desc->texture_count;
     v.flat_recs = s->d_flat; v.flat = flat ? 1u : 0u;
+    v.general = s->general_bsdfs ? 1u : 0u;
     v.flat_pairs = s->d_pairs; v.n_pairs = n_pairs;
     if (bounce_lds_bytes(v) > 150 * 1024) {
         mtsamd_scene_destroy(s);
@@ -463,6 +503,11 @@ int mtsamd_scene_set_bsdf_reflectance(mtsamd_scene *s, uint32_t bsdf, const floa
     if (!s || !rgb || bsdf >= s->bsdfs.size()) return fail(MTSAMD_ERR_INVALID, "invalid bsdf index");
     HIP_TRY(hipSetDevice(s->device));
     s->bsdfs[bsdf].r = rgb[0]; s->bsdfs[bsdf].g = rgb[1]; s->bsdfs[bsdf].b = rgb[2];
+    if (s->bsdfs[bsdf].type == kBsdfPlastic) {       // parameters_changed(): specular sampling weight (plastic.cpp:170-175)
+        DevBsdf &d = s->bsdfs[bsdf];
+        const float d_mean = (d.r + d.g + d.b) * (1.0f / 3.0f), s_mean = (d.sr + d.sg + d.sb) * (1.0f / 3.0f);
+        d.kr = s_mean / (d_mean + s_mean);
+    }
     HIP_TRY(hipMemcpy(s->d_bsdfs + bsdf, &s->bsdfs[bsdf], sizeof(DevBsdf), hipMemcpyHostToDevice));
     return MTSAMD_OK;
 }
@@ -793,6 +838,7 @@ int mtsamd_render_adjoint(mtsamd_scene *s, const mtsamd_render_desc *d, const fl
         return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass needs a finite max_depth <= 16 (got %d)", d->max_depth);
     if (d->part_count > 1 || d->row_begin != 0 || d->row_end > 0) return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass renders the whole crop window");
     if (s->spectral) return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass is implemented for the RGB variant only");
+    if (s->general_bsdfs) return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass is implemented for one-sided diffuse BSDFs only");
     if (s->bsdfs.size() > 32 && grad_bsdf) return fail(MTSAMD_ERR_UNSUPPORTED, "at most 32 BSDFs with constant-reflectance gradients");
     HIP_TRY(hipSetDevice(s->device));
     AdjointParams a{};

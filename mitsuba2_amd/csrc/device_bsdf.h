@@ -1,0 +1,326 @@
+// device_bsdf.h -- BSDF models beyond `diffuse` for the path kernels.
+//
+//   fresnel / fresnel_conductor                      include/mitsuba/render/fresnel.h:34-122
+//   MicrofacetDistribution (Beckmann, GGX, visible normals)   include/mitsuba/render/microfacet.h:187-440
+//   SmoothConductor   src/bsdfs/conductor.cpp:203-262        RoughConductor  src/bsdfs/roughconductor.cpp:196-391
+//   SmoothDielectric  src/bsdfs/dielectric.cpp:201-318       SmoothPlastic   src/bsdfs/plastic.cpp:178-297
+//   TwoSidedBRDF      src/bsdfs/twosided.cpp:94-175 (one nested BSDF for both sides)
+//
+// Arithmetic is written out operation by operation (explicit fmaf where the reference fuses) so that the results agree
+// with the test oracle's to the last bit wherever no transcendental function is involved.
+#pragma once
+#include "device_math.h"
+
+namespace mtsamd {
+
+constexpr int kBsdfDiffuse = 0, kBsdfConductor = 1, kBsdfRoughConductor = 2, kBsdfDielectric = 3, kBsdfPlastic = 4;
+constexpr uint32_t kBsdfTwoSided = 1u, kBsdfGGX = 2u, kBsdfSampleVisible = 4u, kBsdfNonlinear = 8u;
+constexpr float kInvSqrtPi = 0.56418958354775628695f, kEps = kEpsilon;
+
+MTS_DEV float sqr(float x) { return x * x; }
+
+struct Fresnel { float r, cos_theta_t, eta_it, eta_ti; };
+MTS_DEV Fresnel fresnel(float cos_theta_i, float eta) {
+    const bool outside = cos_theta_i >= 0.0f;
+    const float rcp_eta = rcp(eta), eta_it = outside ? eta : rcp_eta, eta_ti = outside ? rcp_eta : eta;
+    const float cos_theta_t_sqr = fmaf(-fmaf(-cos_theta_i, cos_theta_i, 1.0f), eta_ti * eta_ti, 1.0f);
+    const float ci = fabsf(cos_theta_i), ct = safe_sqrt(cos_theta_t_sqr);
+    const bool index_matched = eta == 1.0f, special = index_matched || ci == 0.0f;
+    const float a_s = fmaf(-eta_it, ct, ci) / fmaf(eta_it, ct, ci);
+    const float a_p = fmaf(-eta_it, ci, ct) / fmaf(eta_it, ci, ct);
+    float r = 0.5f * (sqr(a_s) + sqr(a_p));
+    if (special) r = index_matched ? 0.0f : 1.0f;
+    Fresnel f = { r, mulsign_neg(ct, cos_theta_i), eta_it, eta_ti };
+    return f;
+}
+
+MTS_DEV float fresnel_conductor(float cos_theta_i, float eta_r, float eta_i) {
+    const float c2 = cos_theta_i * cos_theta_i, s2 = 1.0f - c2, s4 = s2 * s2;
+    const float temp_1 = eta_r * eta_r - eta_i * eta_i - s2;
+    const float a_2_pb_2 = safe_sqrt(temp_1 * temp_1 + 4.0f * eta_i * eta_i * eta_r * eta_r);
+    const float a = safe_sqrt(0.5f * (a_2_pb_2 + temp_1));
+    const float term_1 = a_2_pb_2 + c2, term_2 = 2.0f * cos_theta_i * a;
+    const float r_s = (term_1 - term_2) / (term_1 + term_2);
+    const float term_3 = a_2_pb_2 * c2 + s4, term_4 = term_2 * s2;
+    const float r_p = r_s * (term_3 - term_4) / (term_3 + term_4);
+    return 0.5f * (r_s + r_p);
+}
+
+MTS_DEV f3 reflect_z(f3 wi) { return mk3(-wi.x, -wi.y, wi.z); }
+MTS_DEV f3 reflect_m(f3 wi, f3 m) {
+    const float k = 2.0f * dot(wi, m);
+    return mk3(fmaf(m.x, k, -wi.x), fmaf(m.y, k, -wi.y), fmaf(m.z, k, -wi.z));
+}
+
+// ---------------------------------------------------------------------------------------------
+struct Mdf { bool ggx; float au, av; bool visible; };
+MTS_DEV Mdf mdf_make(bool ggx, float au, float av, bool visible) {
+    Mdf d = { ggx, fmaxf(au, 1e-4f), fmaxf(av, 1e-4f), visible };
+    return d;
+}
+MTS_DEV float mdf_eval(const Mdf &d, f3 m) {
+    const float alpha_uv = d.au * d.av, cos_theta = m.z, cos_theta_2 = sqr(cos_theta);
+    float result;
+    if (!d.ggx) result = expf(-(sqr(m.x / d.au) + sqr(m.y / d.av)) / cos_theta_2) / (kPi * alpha_uv * sqr(cos_theta_2));
+    else result = rcp(kPi * alpha_uv * sqr(sqr(m.x / d.au) + sqr(m.y / d.av) + sqr(m.z)));
+    return result * cos_theta > 1e-20f ? result : 0.0f;
+}
+MTS_DEV float mdf_smith_g1(const Mdf &d, f3 v, f3 m) {
+    const float xy_alpha_2 = sqr(d.au * v.x) + sqr(d.av * v.y), tan_theta_alpha_2 = xy_alpha_2 / sqr(v.z);
+    float result;
+    if (!d.ggx) {
+        const float a = 1.0f / sqrtf(tan_theta_alpha_2), a_sqr = sqr(a);
+        result = a >= 1.6f ? 1.0f : (3.535f * a + 2.181f * a_sqr) / (1.0f + 2.276f * a + 2.577f * a_sqr);
+    } else {
+        result = 2.0f / (1.0f + sqrtf(1.0f + tan_theta_alpha_2));
+    }
+    if (xy_alpha_2 == 0.0f) result = 1.0f;
+    if (dot(v, m) * v.z <= 0.0f) result = 0.0f;
+    return result;
+}
+MTS_DEV float mdf_G(const Mdf &d, f3 wi, f3 wo, f3 m) { return mdf_smith_g1(d, wi, m) * mdf_smith_g1(d, wo, m); }
+MTS_DEV float mdf_pdf(const Mdf &d, f3 wi, f3 m) {
+    float result = mdf_eval(d, m);
+    if (d.visible) result *= mdf_smith_g1(d, wi, m) * fabsf(dot(wi, m)) / wi.z;
+    else result *= m.z;
+    return result;
+}
+
+// Giles, "Approximating the erfinv function" (single precision)
+MTS_DEV float erfinv_f(float x) {
+    float w = -logf((1.0f - x) * (1.0f + x)), p;
+    if (w < 5.0f) {
+        w = w - 2.5f;
+        p = 2.81022636e-08f; p = fmaf(p, w, 3.43273939e-07f); p = fmaf(p, w, -3.5233877e-06f);
+        p = fmaf(p, w, -4.39150654e-06f); p = fmaf(p, w, 0.00021858087f); p = fmaf(p, w, -0.00125372503f);
+        p = fmaf(p, w, -0.00417768164f); p = fmaf(p, w, 0.246640727f); p = fmaf(p, w, 1.50140941f);
+    } else {
+        w = sqrtf(w) - 3.0f;
+        p = -0.000200214257f; p = fmaf(p, w, 0.000100950558f); p = fmaf(p, w, 0.00134934322f);
+        p = fmaf(p, w, -0.00367342844f); p = fmaf(p, w, 0.00573950773f); p = fmaf(p, w, -0.0076224613f);
+        p = fmaf(p, w, 0.00943887047f); p = fmaf(p, w, 1.00167406f); p = fmaf(p, w, 2.83297682f);
+    }
+    return p * x;
+}
+
+MTS_DEV f2 mdf_sample_visible_11(const Mdf &d, float cos_theta_i, f2 sample) {
+    f2 r;
+    if (!d.ggx) {
+        const float tan_theta_i = safe_sqrt(fmaf(-cos_theta_i, cos_theta_i, 1.0f)) / cos_theta_i;
+        const float cot_theta_i = rcp(tan_theta_i);
+        const float maxval = erff(cot_theta_i);
+        sample.x = fmaxf(fminf(sample.x, 1.0f - 1e-6f), 1e-6f);
+        sample.y = fmaxf(fminf(sample.y, 1.0f - 1e-6f), 1e-6f);
+        float x = maxval - (maxval + 1.0f) * erff(sqrtf(-logf(sample.x)));
+        sample.x *= 1.0f + maxval + kInvSqrtPi * tan_theta_i * expf(-sqr(cot_theta_i));
+        for (int i = 0; i < 3; ++i) {
+            const float slope = erfinv_f(x);
+            const float value = 1.0f + x + kInvSqrtPi * tan_theta_i * expf(-sqr(slope)) - sample.x;
+            const float derivative = 1.0f - slope * tan_theta_i;
+            x -= value / derivative;
+        }
+        r.x = erfinv_f(x); r.y = erfinv_f(fmaf(2.0f, sample.y, -1.0f));
+        return r;
+    }
+    f2 p = square_to_uniform_disk_concentric(sample);
+    const float s = 0.5f * (1.0f + cos_theta_i);
+    const float a = safe_sqrt(1.0f - sqr(p.x));
+    p.y = fmaf(p.y - a, s, a);
+    const float x = p.x, y = p.y, z = safe_sqrt(1.0f - (sqr(p.x) + sqr(p.y)));
+    const float sin_theta_i = safe_sqrt(1.0f - sqr(cos_theta_i));
+    const float norm = rcp(fmaf(sin_theta_i, y, cos_theta_i * z));
+    r.x = fmaf(cos_theta_i, y, -(sin_theta_i * z)) * norm; r.y = x * norm;
+    return r;
+}
+
+MTS_DEV f3 mdf_sample(const Mdf &d, f3 wi, f2 sample, float &pdf) {
+    if (!d.visible) {
+        float sin_phi, cos_phi, cos_theta, cos_theta_2, alpha_2;
+        if (d.au == d.av) {
+            const float ang = (2.0f * kPi) * sample.y;
+            sin_phi = sinf(ang); cos_phi = cosf(ang);
+            alpha_2 = d.au * d.au;
+        } else {
+            const float ratio = d.av / d.au, tmp = ratio * tanf((2.0f * kPi) * sample.y);
+            cos_phi = 1.0f / sqrtf(fmaf(tmp, tmp, 1.0f));
+            cos_phi = mulsign(cos_phi, fabsf(sample.y - 0.5f) - 0.25f);
+            sin_phi = cos_phi * tmp;
+            alpha_2 = rcp(sqr(cos_phi / d.au) + sqr(sin_phi / d.av));
+        }
+        if (!d.ggx) {
+            cos_theta = 1.0f / sqrtf(fmaf(-alpha_2, logf(1.0f - sample.x), 1.0f));
+            cos_theta_2 = sqr(cos_theta);
+            const float cos_theta_3 = fmaxf(cos_theta_2 * cos_theta, 1e-20f);
+            pdf = (1.0f - sample.x) / (kPi * d.au * d.av * cos_theta_3);
+        } else {
+            const float tan_theta_m_2 = alpha_2 * sample.x / (1.0f - sample.x);
+            cos_theta = 1.0f / sqrtf(1.0f + tan_theta_m_2);
+            cos_theta_2 = sqr(cos_theta);
+            const float temp = 1.0f + tan_theta_m_2 / alpha_2, cos_theta_3 = fmaxf(cos_theta_2 * cos_theta, 1e-20f);
+            pdf = rcp(kPi * d.au * d.av * cos_theta_3 * sqr(temp));
+        }
+        const float sin_theta = sqrtf(1.0f - cos_theta_2);
+        return mk3(cos_phi * sin_theta, sin_phi * sin_theta, cos_theta);
+    }
+    const f3 wi_p = normalize(mk3(d.au * wi.x, d.av * wi.y, wi.z));
+    const float st2 = fmaf(wi_p.x, wi_p.x, sqr(wi_p.y)), inv = 1.0f / sqrtf(st2);
+    float cos_phi = 1.0f, sin_phi = 0.0f;
+    if (!(fabsf(st2) <= 4.0f * kEps)) {
+        cos_phi = fminf(fmaxf(wi_p.x * inv, -1.0f), 1.0f);
+        sin_phi = fminf(fmaxf(wi_p.y * inv, -1.0f), 1.0f);
+    }
+    const f2 slope = mdf_sample_visible_11(d, wi_p.z, sample);
+    const float sx = fmaf(cos_phi, slope.x, -(sin_phi * slope.y)) * d.au;
+    const float sy = fmaf(sin_phi, slope.x, cos_phi * slope.y) * d.av;
+    const f3 m = normalize(mk3(-sx, -sy, 1.0f));
+    pdf = mdf_eval(d, m) * mdf_smith_g1(d, wi, m) * fabsf(dot(wi, m)) / wi.z;
+    return m;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device-side BSDF record (80 B).  Roles of the generic fields per model:
+//   conductor / roughconductor   e = eta (rgb), k = extinction (rgb), s = specular_reflectance
+//   dielectric                   e.x = eta = int_ior / ext_ior, k = specular_transmittance, s = specular_reflectance
+//   plastic                      e.x = eta, e.y = 1 / eta^2, e.z = fdr_int, k.x = specular sampling weight,
+//                                (r, g, b) = diffuse_reflectance, s = specular_reflectance
+struct DevBsdf {
+    float r, g, b; int32_t type;
+    int32_t texture; float c0, c1, c2;       // c*: srgb_model coefficients of (r, g, b) (spectral variant)
+    float sr, sg, sb; uint32_t flags;
+    float er, eg, eb, alpha_u;
+    float kr, kg, kb, alpha_v;
+};
+
+struct BsdfSample { f3 wo; float pdf, eta; bool delta; };
+
+MTS_DEV bool bsdf_is_smooth(const DevBsdf &b) {          // BSDFFlags::Smooth: any diffuse / glossy component
+    return b.type == kBsdfDiffuse || b.type == kBsdfRoughConductor || b.type == kBsdfPlastic;
+}
+
+MTS_DEV f3 plastic_diffuse(const DevBsdf &b, f3 refl) {
+    const bool nl = (b.flags & kBsdfNonlinear) != 0u;
+    return mk3(refl.x / (1.0f - (nl ? (refl.x * b.eb) : b.eb)), refl.y / (1.0f - (nl ? (refl.y * b.eb) : b.eb)),
+               refl.z / (1.0f - (nl ? (refl.z * b.eb) : b.eb)));
+}
+
+// BSDF::sample; `refl` = diffuse reflectance at the hit point.  Returns false (weight 0) for an invalid sample.
+MTS_DEV bool bsdf_sample(const DevBsdf &b, f3 refl, f3 wi, float sample1, f2 sample2, BsdfSample &bs, f3 &weight) {
+    bs.wo = mk3(0.0f, 0.0f, 0.0f); bs.pdf = 0.0f; bs.eta = 0.0f; bs.delta = false;
+    weight = mk3(0.0f, 0.0f, 0.0f);
+    const bool two = (b.flags & kBsdfTwoSided) != 0u;
+    if (two && wi.z == 0.0f) return false;
+    const bool flip = two && wi.z < 0.0f;
+    if (flip) wi.z = -wi.z;
+    bool ok = false;
+    if (b.type == kBsdfDiffuse) {
+        bs.eta = 1.0f;
+        if (wi.z > 0.0f) {
+            bs.wo = square_to_cosine_hemisphere(sample2);
+            bs.pdf = kInvPi * bs.wo.z;
+            if (bs.pdf > 0.0f) { weight = refl; ok = true; }
+        }
+    } else if (b.type == kBsdfConductor) {
+        if (wi.z > 0.0f) {
+            bs.wo = reflect_z(wi); bs.eta = 1.0f; bs.pdf = 1.0f; bs.delta = true;
+            weight = mk3(b.sr * fresnel_conductor(wi.z, b.er, b.kr), b.sg * fresnel_conductor(wi.z, b.eg, b.kg),
+                         b.sb * fresnel_conductor(wi.z, b.eb, b.kb));
+            ok = true;
+        }
+    } else if (b.type == kBsdfRoughConductor) {
+        const float cos_theta_i = wi.z;
+        if (cos_theta_i > 0.0f) {
+            const bool vis = (b.flags & kBsdfSampleVisible) != 0u;
+            const Mdf d = mdf_make((b.flags & kBsdfGGX) != 0u, b.alpha_u, b.alpha_v, vis);
+            const f3 m = mdf_sample(d, wi, sample2, bs.pdf);
+            bs.wo = reflect_m(wi, m); bs.eta = 1.0f;
+            const bool active = bs.pdf != 0.0f && bs.wo.z > 0.0f;
+            float w;
+            if (vis) w = mdf_smith_g1(d, bs.wo, m);
+            else w = mdf_G(d, wi, bs.wo, m) * dot(wi, m) / (cos_theta_i * m.z);
+            bs.pdf /= 4.0f * dot(bs.wo, m);
+            const float dwm = dot(wi, m);
+            if (active)
+                weight = mk3(fresnel_conductor(dwm, b.er, b.kr) * (w * b.sr), fresnel_conductor(dwm, b.eg, b.kg) * (w * b.sg),
+                             fresnel_conductor(dwm, b.eb, b.kb) * (w * b.sb));
+            ok = active;
+        }
+    } else if (b.type == kBsdfDielectric) {
+        const Fresnel f = fresnel(wi.z, b.er);
+        const float r_i = f.r, t_i = 1.0f - r_i;
+        const bool selected_r = sample1 <= r_i;
+        bs.pdf = selected_r ? r_i : t_i;
+        bs.wo = selected_r ? reflect_z(wi) : mk3(-f.eta_ti * wi.x, -f.eta_ti * wi.y, f.cos_theta_t);
+        bs.eta = selected_r ? 1.0f : f.eta_it;
+        bs.delta = true;
+        if (selected_r) weight = mk3(1.0f * b.sr, 1.0f * b.sg, 1.0f * b.sb);
+        else { const float q = sqr(f.eta_ti); weight = mk3((1.0f * b.kr) * q, (1.0f * b.kg) * q, (1.0f * b.kb) * q); }
+        ok = true;
+    } else if (b.type == kBsdfPlastic) {
+        const float cos_theta_i = wi.z;
+        if (cos_theta_i > 0.0f) {
+            const float f_i = fresnel(cos_theta_i, b.er).r;
+            float prob_specular = f_i * b.kr, prob_diffuse = (1.0f - f_i) * (1.0f - b.kr);
+            prob_specular = prob_specular / (prob_specular + prob_diffuse);
+            prob_diffuse = 1.0f - prob_specular;
+            bs.eta = 1.0f;
+            if (sample1 < prob_specular) {
+                bs.wo = reflect_z(wi); bs.pdf = prob_specular; bs.delta = true;
+                const float v = f_i / bs.pdf;
+                weight = mk3(v * b.sr, v * b.sg, v * b.sb);
+            } else {
+                bs.wo = square_to_cosine_hemisphere(sample2);
+                bs.pdf = prob_diffuse * (kInvPi * bs.wo.z);
+                const float f_o = fresnel(bs.wo.z, b.er).r;
+                const f3 value = plastic_diffuse(b, refl);
+                const float k = b.eg * (1.0f - f_i) * (1.0f - f_o) / prob_diffuse;
+                weight = mk3(value.x * k, value.y * k, value.z * k);
+            }
+            ok = true;
+        }
+    }
+    if (!ok) weight = mk3(0.0f, 0.0f, 0.0f);
+    if (flip) bs.wo.z = -bs.wo.z;
+    return ok;
+}
+
+// BSDF::eval and BSDF::pdf
+MTS_DEV void bsdf_eval_pdf(const DevBsdf &b, f3 refl, f3 wi, f3 wo, f3 &value, float &pdf) {
+    value = mk3(0.0f, 0.0f, 0.0f); pdf = 0.0f;
+    if (b.flags & kBsdfTwoSided) {
+        if (wi.z == 0.0f) return;
+        if (wi.z < 0.0f) { wi.z = -wi.z; wo.z = -wo.z; }
+    }
+    const float cos_theta_i = wi.z, cos_theta_o = wo.z;
+    if (!(cos_theta_i > 0.0f && cos_theta_o > 0.0f)) return;      // every reflective model here is one-sided
+    if (b.type == kBsdfDiffuse) {
+        value = mk3((refl.x * kInvPi) * wo.z, (refl.y * kInvPi) * wo.z, (refl.z * kInvPi) * wo.z);
+        pdf = kInvPi * wo.z;
+    } else if (b.type == kBsdfRoughConductor) {
+        const f3 H = normalize(wo + wi);
+        const bool vis = (b.flags & kBsdfSampleVisible) != 0u;
+        const Mdf d = mdf_make((b.flags & kBsdfGGX) != 0u, b.alpha_u, b.alpha_v, vis);
+        const float D = mdf_eval(d, H);
+        if (D != 0.0f) {
+            const float G = mdf_G(d, wi, wo, H);
+            const float result = D * G / (4.0f * cos_theta_i);
+            const float dwh = dot(wi, H);
+            value = mk3(fresnel_conductor(dwh, b.er, b.kr) * (result * b.sr), fresnel_conductor(dwh, b.eg, b.kg) * (result * b.sg),
+                        fresnel_conductor(dwh, b.eb, b.kb) * (result * b.sb));
+        }
+        if (dot(wi, H) > 0.0f && dot(wo, H) > 0.0f) {
+            if (vis) pdf = mdf_eval(d, H) * mdf_smith_g1(d, wi, H) / (4.0f * cos_theta_i);
+            else pdf = mdf_pdf(d, wi, H) / (4.0f * dot(wo, H));
+        }
+    } else if (b.type == kBsdfPlastic) {
+        const float f_i = fresnel(cos_theta_i, b.er).r, f_o = fresnel(cos_theta_o, b.er).r;
+        const f3 diff = plastic_diffuse(b, refl);
+        const float k2 = (kInvPi * wo.z) * b.eg * (1.0f - f_i) * (1.0f - f_o);
+        value = mk3(diff.x * k2, diff.y * k2, diff.z * k2);
+        const float prob_specular = f_i * b.kr;
+        float prob_diffuse = (1.0f - f_i) * (1.0f - b.kr);
+        prob_diffuse = prob_diffuse / (prob_specular + prob_diffuse);
+        pdf = (kInvPi * wo.z) * prob_diffuse;
+    }
+}
+
+} // namespace mtsamd

@@ -15,6 +15,7 @@
 //   SmoothDiffuse                          src/bsdfs/diffuse.cpp:78-135
 #pragma once
 #include "device_math.h"
+#include "device_bsdf.h"
 
 namespace mtsamd {
 
@@ -31,7 +32,6 @@ constexpr uint32_t kNoPrim = 0xffffffffu;
 
 struct DevShape { int32_t bsdf; int32_t emitter; uint32_t flags; uint32_t first_prim; };
 constexpr uint32_t kShapeHasNormals = 1u, kShapeHasUV = 2u;
-struct DevBsdf { float r, g, b; int32_t type; int32_t texture; float c0, c1, c2; };      // c*: srgb_model coefficients (spectral variant)
 struct DevTexture { const float *data; int32_t w, h; uint32_t grad_offset, pad; };   // grad_offset: float offset in the concatenated gradient buffer       // linear RGB bitmap (src/textures/bitmap.cpp), identity to_uv
 struct DevEmitter {
     float r, g, b; uint32_t shape;
@@ -66,6 +66,7 @@ struct SceneView {
     const float4 *flat_recs;
     const float4 *flat_pairs;
     uint32_t flat, n_pairs;
+    uint32_t general;          // some BSDF is not a one-sided `diffuse`: kernels instantiated with the BSDF switch are used
 };
 constexpr uint32_t kFlatMaxPrims = 64;
 

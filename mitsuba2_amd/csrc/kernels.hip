@@ -71,9 +71,14 @@ struct Deferred {
 
 // One iteration of the path.cpp loop, rotated so that it starts with the intersection of the
 // ray spawned by the previous iteration (or by the sensor).  Returns true if the path survives.
-template <bool FLAT, bool REC = false, bool DEFER = false>
+// GENERAL = false: every BSDF is a one-sided `diffuse` (the code path of the Cornell-box benchmark, unchanged);
+// GENERAL = true: switch over the BSDF models of device_bsdf.h (delta lobes, eta, twosided).
+constexpr uint32_t kFlagDelta = 4u;       // the ray was spawned by a delta lobe: no emitter-sampling counterpart (path.cpp:198-203)
+
+template <bool FLAT, bool REC = false, bool DEFER = false, bool GENERAL = false>
 MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s, Counters &c, VertexRec *rec = nullptr,
                          Deferred *df = nullptr) {
+    static_assert(!(REC && GENERAL), "the adjoint replay handles diffuse BSDFs only");
     const SceneView &sv = P.sv;
     if (REC) {
         rec->E = rec->Nc = rec->Tp = rec->rho = mk3(0.0f, 0.0f, 0.0f);
@@ -99,7 +104,8 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
                 f3 dd = si.p - s.o;                         // DirectionSample(si_bsdf, si), records.h:168-174
                 float dist = sqrtf(sqnorm(dd));
                 dd = div_s(dd, dist);
-                ew = mis_weight(s.bs_pdf, pdf_emitter_direction(sv.n_emitters, e.area_norm, dd, si.sh.n, dist));
+                const float pe = pdf_emitter_direction(sv.n_emitters, e.area_norm, dd, si.sh.n, dist);
+                ew = mis_weight(s.bs_pdf, (GENERAL && (s.flags & kFlagDelta)) ? 0.0f : pe);
             }
             if (si.wi.z > 0.0f) {                           // AreaLight::eval (area.cpp:71-79)
                 s.res.x += (ew * s.thr.x) * e.r; s.res.y += (ew * s.thr.y) * e.g; s.res.z += (ew * s.thr.z) * e.b;
@@ -129,14 +135,15 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
     if (REC) { rec->Tp = s.thr; rec->rho = refl; rec->texel = texel; rec->w1 = tw1; rec->bsdf = si.shape_rec.bsdf; rec->has_bsdf = 1u; }
 
     // --------------------- Emitter sampling (path.cpp:153-172) ---------------------
-    {
+    if (!GENERAL || bsdf_is_smooth(bsdf)) {                  // active_e: only BSDFs with a smooth component (path.cpp:154)
         f2 s2; s2.x = pcg_next_f32(s.rng); s2.y = pcg_next_f32(s.rng);
         DirectionSample ds; f3 spec;
         sample_emitter_direction(geo, si.p, s2, ds, spec);
         if (ds.pdf != 0.0f) {
             f3 wo = to_local(si.sh, ds.d);
             f3 bv; float bp;
-            diffuse_eval_pdf(refl, si.wi, wo, bv, bp);
+            if (GENERAL) bsdf_eval_pdf(bsdf, refl, si.wi, wo, bv, bp);
+            else diffuse_eval_pdf(refl, si.wi, wo, bv, bp);
             float mis = mis_weight(ds.pdf, bp);
             f3 contrib = mk3(((mis * s.thr.x) * bv.x) * spec.x, ((mis * s.thr.y) * bv.y) * spec.y,
                              ((mis * s.thr.z) * bv.z) * spec.z);
@@ -170,13 +177,20 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
     }
 
     // ----------------------- BSDF sampling (path.cpp:177-190) ----------------------
-    (void) pcg_next_f32(s.rng);                              // sample1, unused by SmoothDiffuse
+    const float s1 = pcg_next_f32(s.rng);                    // sample1 (lobe selection; unused by SmoothDiffuse)
     f2 s2; s2.x = pcg_next_f32(s.rng); s2.y = pcg_next_f32(s.rng);
     f3 wo, weight; float pdf;
-    diffuse_sample(refl, si.wi, s2, wo, pdf, weight);
+    if (GENERAL) {
+        BsdfSample bs;
+        bsdf_sample(bsdf, refl, si.wi, s1, s2, bs, weight);
+        wo = bs.wo; pdf = bs.pdf;
+        s.eta *= bs.eta;                                     // harmless for a failed sample: the path ends below
+        s.flags = bs.delta ? (s.flags | kFlagDelta) : (s.flags & ~kFlagDelta);
+    } else {
+        diffuse_sample(refl, si.wi, s2, wo, pdf, weight);    // eta *= bs.eta (== 1)
+    }
     s.thr = mk3(s.thr.x * weight.x, s.thr.y * weight.y, s.thr.z * weight.z);
     if (!(s.thr.x != 0.0f || s.thr.y != 0.0f || s.thr.z != 0.0f)) return false;
-    // eta *= bs.eta (== 1)
     s.o = si.p;                                              // spawn_ray (interaction.h:58-61)
     s.d = to_world(si.sh, wo);
     s.mint = (1.0f + hmax_abs(si.p)) * kRayEpsilon;
@@ -226,7 +240,7 @@ MTS_DEV void store_result(const RenderParams &P, const PathState &s) {
 #ifndef MTS_BOUNCE_WAVES
 #define MTS_BOUNCE_WAVES 4
 #endif
-template <bool FLAT>
+template <bool FLAT, bool GENERAL>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MTS_BOUNCE_WAVES, MTS_BOUNCE_WAVES)))
 void k_bounce(const RenderParams P) {
     extern __shared__ float4 smem[];
@@ -244,7 +258,7 @@ void k_bounce(const RenderParams P) {
         bool alive = false;
         if (i0 + lane < n_in) {
             load_state(P.in, base + i0 + lane, s);
-            alive = bounce_step<FLAT>(P, lds, s, c);
+            alive = bounce_step<FLAT, false, false, GENERAL>(P, lds, s, c);
             if (!alive) store_result(P, s);
         }
         // wavefront ballot + prefix rank: compact the survivors to the front of the output segment
@@ -538,9 +552,11 @@ __global__ __launch_bounds__(kBlock) void k_bounce_spectral(const RenderParams P
 // floating-point additions into the radiance is the fused kernel's, so both pipelines produce identical samples.
 constexpr uint32_t kFlagZombie = 2u;      // path already terminated, kept one iteration for its pending shadow ray
 
+template <bool GENERAL>
 MTS_DEV bool step_deferred(const RenderParams &P, const LdsView &lds, PathState &s, Counters &c, Deferred &df) {
-    return bounce_step<false, false, true>(P, lds, s, c, nullptr, &df);
+    return bounce_step<false, false, true, GENERAL>(P, lds, s, c, nullptr, &df);
 }
+template <bool GENERAL>
 MTS_DEV bool step_deferred(const RenderParams &P, const LdsView &lds, PathStateS &s, Counters &c, Deferred &df) {
     return bounce_step_spectral<false, true>(P, lds, s, c, &df);
 }
@@ -549,7 +565,7 @@ MTS_DEV void finish_path(const RenderParams &P, const PathStateS &s) { store_res
 MTS_DEV void start_path(const RenderParams &P, uint64_t ordinal, uint32_t lp, uint32_t j, PathState &s) { generate_path(P, ordinal, lp, j, s); }
 MTS_DEV void start_path(const RenderParams &P, uint64_t ordinal, uint32_t lp, uint32_t j, PathStateS &s) { generate_path_spectral(P, ordinal, lp, j, s); }
 
-template <typename State>
+template <typename State, bool GENERAL>
 __global__ __launch_bounds__(kBlock) void k_shade(const RenderParams P) {
     LdsView lds = {};                      // Geo<false> reads the scene tables from global memory
     const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
@@ -575,7 +591,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(const RenderParams P) {
                 const float4 h = P.in.hit[i];
                 df.hit.t = h.x; df.hit.prim = __float_as_uint(h.y); df.hit.u = h.z; df.hit.v = h.w;
                 df.found = df.hit.prim != kNoPrim;
-                alive = step_deferred(P, lds, s, c, df);
+                alive = step_deferred<GENERAL>(P, lds, s, c, df);
                 if (!alive) {
                     if (df.pending) { s.flags |= kFlagZombie; alive = true; }
                     else finish_path(P, s);
@@ -691,8 +707,9 @@ hipError_t launch_bounce(const RenderParams &p, hipStream_t s) {
     if (p.split) {
         const uint32_t shade_blocks = (p.n_waves * 64u + kBlock - 1) / kBlock;
         hipLaunchKernelGGL(k_trace<false>, dim3(p.n_waves), dim3(kBlock), trace_lds_bytes(p.sv), s, p);
-        if (p.spectral) hipLaunchKernelGGL(k_shade<PathStateS>, dim3(shade_blocks), dim3(kBlock), 0, s, p);
-        else hipLaunchKernelGGL(k_shade<PathState>, dim3(shade_blocks), dim3(kBlock), 0, s, p);
+        if (p.spectral) hipLaunchKernelGGL((k_shade<PathStateS, false>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
+        else if (p.sv.general) hipLaunchKernelGGL((k_shade<PathState, true>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
+        else hipLaunchKernelGGL((k_shade<PathState, false>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
         hipLaunchKernelGGL(k_trace<true>, dim3((p.n_waves + kShadowGroup - 1) / kShadowGroup), dim3(kBlock), trace_lds_bytes(p.sv), s, p);
         return hipGetLastError();
     }
@@ -702,8 +719,13 @@ hipError_t launch_bounce(const RenderParams &p, hipStream_t s) {
         else hipLaunchKernelGGL(k_bounce_spectral<false>, dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);
         return hipGetLastError();
     }
-    if (p.sv.flat) hipLaunchKernelGGL(k_bounce<true>, dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);
-    else hipLaunchKernelGGL(k_bounce<false>, dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);
+    if (p.sv.general) {
+        if (p.sv.flat) hipLaunchKernelGGL((k_bounce<true, true>), dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);
+        else hipLaunchKernelGGL((k_bounce<false, true>), dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);
+    } else {
+        if (p.sv.flat) hipLaunchKernelGGL((k_bounce<true, false>), dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);
+        else hipLaunchKernelGGL((k_bounce<false, false>), dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);
+    }
     return hipGetLastError();
 }
 

@@ -408,11 +408,15 @@ class Scene:
         bd = (L.BsdfDesc * max(len(bsdfs), 1))()
         tex = []                       # bitmap textures (src/textures/bitmap.cpp): reflectance = dict(type="bitmap", data=(H,W,3))
         self._bsdf_texture = {}
+        from . import bsdfs as B
+        self._bsdf_records = []
         for i, b in enumerate(bsdfs):
-            if b.get("type", "diffuse") != "diffuse":
-                raise RuntimeError("BSDF plugin '%s' is not supported by this backend (diffuse only)" % b.get("type"))
-            bd[i].type = 0
-            refl = b["reflectance"]
+            n = B.normalize(b)             # plugin defaults / validation (src/bsdfs/*.cpp constructors)
+            self._bsdf_records.append(n)
+            if variant == "spectral" and (n["type"] != B.DIFFUSE or n["twosided"]):
+                raise RuntimeError("BSDF plugin '%s' is not supported by the spectral variant of this backend (diffuse only)" % b.get("type"))
+            bd[i].type, bd[i].twosided = n["type"], int(n["twosided"])
+            refl = n["reflectance"]
             if isinstance(refl, dict):
                 if refl.get("type") != "bitmap":
                     raise RuntimeError("Texture plugin '%s' is not supported by this backend (bitmap only)" % refl.get("type"))
@@ -426,6 +430,10 @@ class Scene:
             else:
                 bd[i].reflectance = (C.c_float * 3)(*[float(x) for x in refl])
                 bd[i].texture = -1
+            for name in ("specular_reflectance", "specular_transmittance", "eta", "k"):
+                setattr(bd[i], name, (C.c_float * 3)(*n[name]))
+            bd[i].int_ior, bd[i].ext_ior, bd[i].alpha_u, bd[i].alpha_v = n["int_ior"], n["ext_ior"], n["alpha_u"], n["alpha_v"]
+            bd[i].distribution, bd[i].sample_visible, bd[i].nonlinear = n["distribution"], int(n["sample_visible"]), int(n["nonlinear"])
         td = (L.TextureDesc * max(len(tex), 1))()
         for i, t in enumerate(tex):
             td[i].width, td[i].height = t.shape[1], t.shape[0]

@@ -26,7 +26,7 @@ def test_header_symbols_are_exported():
     handle = C.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(handle, name), "libmtsamd.so does not export %s" % name
-    assert _lib.lib().mtsamd_abi_version() == 1
+    assert _lib.lib().mtsamd_abi_version() == 2
 
 
 def test_every_entry_point_cites_the_reference():

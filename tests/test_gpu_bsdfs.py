@@ -1,0 +1,79 @@
+"""BSDF models on the GPU against the oracle: per-sample radiance of the path integrator with
+conductor / roughconductor / dielectric / plastic / twosided materials in the Cornell box (same PCG32 stream per sample on
+both sides; the only unshared arithmetic is libm vs OCML exp / log / erf / sincos), through the fused and the split
+pipeline, plus the film-level relMSE bar of north_star (< 1e-3)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+MATERIALS = {
+    "conductor": {"type": "conductor", "eta": [0.2, 0.92, 1.1], "k": [3.9, 2.45, 2.14]},
+    "mirror": {"type": "conductor"},
+    "rough_ggx": {"type": "roughconductor", "alpha": 0.2, "distribution": "ggx", "eta": [0.2, 0.92, 1.1], "k": [3.9, 2.45, 2.14]},
+    "rough_beckmann_aniso": {"type": "roughconductor", "alpha_u": 0.3, "alpha_v": 0.1, "distribution": "beckmann", "eta": 0.0, "k": 1.0,
+                             "specular_reflectance": [0.9, 0.8, 0.7]},
+    "rough_ggx_all": {"type": "roughconductor", "alpha": 0.25, "distribution": "ggx", "sample_visible": False, "eta": 0.0, "k": 1.0},
+    "rough_beckmann_all": {"type": "roughconductor", "alpha": 0.25, "distribution": "beckmann", "sample_visible": False, "eta": 0.0, "k": 1.0},
+    "glass": {"type": "dielectric", "int_ior": "bk7", "ext_ior": "air", "specular_transmittance": [0.9, 0.95, 1.0]},
+    "plastic": {"type": "plastic", "diffuse_reflectance": [0.1, 0.27, 0.36], "int_ior": 1.9},
+    "plastic_nl": {"type": "plastic", "diffuse_reflectance": [0.5, 0.2, 0.1], "nonlinear": True, "specular_reflectance": 0.8},
+    "twosided_diffuse": {"type": "twosided", "bsdf": {"type": "diffuse", "reflectance": [0.6, 0.3, 0.2]}},
+    "twosided_rough": {"type": "twosided", "bsdf": {"type": "roughconductor", "alpha": 0.15, "distribution": "ggx", "eta": 0.0, "k": 1.0}},
+}
+
+
+def _scene(material):
+    from mitsuba2_amd import scenes
+    cb = scenes.cornell_box()
+    cb["bsdfs"] = list(cb["bsdfs"]) + [MATERIALS[material], {"type": "twosided", "bsdf": {"type": "diffuse", "reflectance": [0.7, 0.7, 0.7]}}]
+    cb["meshes"][6] = dict(cb["meshes"][6], bsdf=len(cb["bsdfs"]) - 2)       # tall box: the material under test
+    cb["meshes"][0] = dict(cb["meshes"][0], bsdf=len(cb["bsdfs"]) - 1)       # floor: twosided diffuse
+    return cb
+
+
+@pytest.mark.parametrize("material", sorted(MATERIALS))
+@pytest.mark.parametrize("pipeline", [1, 2])
+def test_sample_radiance_matches_oracle(material, pipeline):
+    from mitsuba2_amd import render as R, scenes
+    cb, sp = _scene(material), scenes.cornell_box_sensor(64, 64, spp=8, seed=21)
+    sp["max_depth"] = 6
+    scene, sensor = R.Scene(cb), R.make_sensor(sp)
+    integ = R.PathIntegrator(max_depth=6, pipeline=pipeline)
+    n = 64 * 64 * 8
+    rgb, mask, pos = integ.sample(scene, sensor, 0, n)
+    rgb, mask, pos = rgb.cpu().numpy(), mask.cpu().numpy(), pos.cpu().numpy()
+    oracle = ob.OracleScene(cb)
+    want, wpos = oracle.sample_radiance(ob.make_desc(sp), 0, n)
+    assert np.array_equal(pos, wpos) and np.array_equal(mask, want[:, 3] > 0.5)
+    close = np.isclose(rgb, want[:, :3], rtol=5e-3, atol=1e-4).all(1)
+    # transcendental functions differ in the last bits between libm and OCML; a sample whose path takes another branch
+    # because of that (lobe choice, Russian roulette, shadow test) may differ: they are rare and unbiased
+    assert close.mean() > 0.995, (material, close.mean())
+    assert abs(rgb.mean() - want[:, :3].mean()) < 2e-2 * max(want[:, :3].mean(), 1e-3)
+
+
+@pytest.mark.parametrize("material", ["rough_ggx", "glass", "plastic"])
+def test_film_relmse(material):
+    from mitsuba2_amd import render as R, scenes
+    cb, sp = _scene(material), scenes.cornell_box_sensor(48, 48, spp=32, seed=4)
+    scene, sensor = R.Scene(cb), R.make_sensor(sp)
+    assert R.PathIntegrator(max_depth=8).render(scene, sensor)
+    got = sensor.film().bitmap().cpu().numpy()[..., :3]
+    sp["max_depth"] = 8
+    film, _ = ob.OracleScene(cb).render(ob.make_desc(sp), mode=1)
+    want = ob.film_develop(film)[..., :3]
+    relmse = np.mean((got - want) ** 2 / (want ** 2 + 1e-2))
+    assert relmse < 1e-3, relmse
+
+
+def test_unsupported_combinations():
+    from mitsuba2_amd import render as R, scenes
+    cb = _scene("glass")
+    with pytest.raises(RuntimeError, match="spectral variant"):
+        R.Scene(cb, variant="spectral")
+    with pytest.raises(RuntimeError, match="not supported by this backend"):
+        R.Scene(dict(cb, bsdfs=[{"type": "roughdielectric"}] * len(cb["bsdfs"])))
