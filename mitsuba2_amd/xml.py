@@ -384,22 +384,47 @@ def _texture(ctx, node, base_dir):
     return dict(type="bitmap", data=bitmap.read_rgb(path, linearize=not raw))
 
 
+def _bsdf_plugin_dict(ctx, node, base_dir):
+    """property tree of a <bsdf> -> plugin dictionary understood by mitsuba2_amd.bsdfs.normalize"""
+    if node.tag != "bsdf":
+        raise XMLError('expected a bsdf, got "%s"' % node.tag)
+    d = {"type": node.type}
+    if node.id is not None:
+        d["id"] = node.id
+    nested = 0
+    for k, v in list(node.props.items()):
+        v = _resolve(ctx, v)
+        node.queried.add(k)
+        if isinstance(v, Node):
+            if v.tag == "texture":
+                d[k] = _texture(ctx, v, base_dir)
+            elif v.tag == "bsdf":
+                d["bsdf_%d" % nested] = _bsdf_plugin_dict(ctx, v, base_dir)
+                nested += 1
+            else:
+                raise XMLError('bsdf: unexpected nested object "%s"' % v.tag)
+        elif isinstance(v, tuple) and v and v[0] in ("rgb", "spectrum"):
+            d[k] = _colour(v, k)
+        else:
+            d[k] = v
+    for c in node.children:
+        c = _resolve(ctx, c)
+        if c.tag != "bsdf":
+            raise XMLError('bsdf: unexpected nested object "%s"' % c.tag)
+        d["bsdf_%d" % nested] = _bsdf_plugin_dict(ctx, c, base_dir)
+        nested += 1
+    return d
+
+
 def _bsdf(ctx, node, desc, cache, base_dir):
     if id(node) in cache:
         return cache[id(node)]
-    if node.tag != "bsdf":
-        raise XMLError('expected a bsdf, got "%s"' % node.tag)
-    if node.type != "diffuse":
-        raise XMLError('BSDF plugin "%s" is not supported by this backend (diffuse only)' % node.type)
-    refl = _resolve(ctx, node.get("reflectance", ("rgb", (0.5, 0.5, 0.5))))
-    if isinstance(refl, Node):
-        value = _texture(ctx, refl, base_dir)
-    else:
-        value = _colour(refl, "diffuse.reflectance")
-    node.check_unqueried()
-    entry = dict(type="diffuse", reflectance=value)
-    if node.id is not None:
-        entry["id"] = node.id
+    from . import bsdfs
+    entry = _bsdf_plugin_dict(ctx, node, base_dir)
+    try:
+        bsdfs.normalize(entry)                       # constructor-time validation (unknown plugin, bad parameters)
+    except RuntimeError as e:
+        raise XMLError(str(e))
     desc.scene_dict["bsdfs"].append(entry)
     cache[id(node)] = len(desc.scene_dict["bsdfs"]) - 1
     return cache[id(node)]
@@ -580,7 +605,7 @@ def load_file(path, device=0, variant="rgb", **params):
 
 
 # -------------------------------------------------------------------------------------------- load_dict
-_PLUGIN_CLASS = {"path": "integrator", "perspective": "sensor", "hdrfilm": "film", "independent": "sampler", "gaussian": "rfilter", "box": "rfilter",
+_PLUGIN_CLASS = {"twosided": "bsdf", "conductor": "bsdf", "roughconductor": "bsdf", "dielectric": "bsdf", "plastic": "bsdf", "path": "integrator", "perspective": "sensor", "hdrfilm": "film", "independent": "sampler", "gaussian": "rfilter", "box": "rfilter",
                  "obj": "shape", "ply": "shape", "rectangle": "shape", "diffuse": "bsdf", "area": "emitter", "bitmap": "texture", "scene": "scene"}
 
 
