@@ -193,6 +193,10 @@ typedef struct {
                                   All three produce identical samples. */
     int32_t film_rgb;          /* 0: film channels X,Y,Z,A,W (integrator.cpp:72-74, 254-268);
                                   1: R,G,B,A,W -- linear RGB as mitsuba.python.autodiff._render_helper accumulates (autodiff.py:53-72) */
+    int32_t integrator;        /* 0 = path (src/integrators/path.cpp), 1 = direct (direct.cpp), 2 = depth (depth.cpp) */
+    int32_t emitter_samples;   /* direct: samples per technique; 0 and 0 = the shading_samples default (1, 1) (direct.cpp:80-103) */
+    int32_t bsdf_samples;
+    int32_t hide_emitters;     /* direct: do not add directly visible emitters (integrator.cpp:39, direct.cpp:117-121) */
 } mtsamd_render_desc;
 
 /* SamplingIntegrator::render for the `path` integrator (src/librender/integrator.cpp:52-176,

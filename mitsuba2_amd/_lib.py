@@ -55,7 +55,8 @@ class RenderDesc(C.Structure):
                 ("rfilter_analytic", C.c_int32), ("sample_count", C.c_int32), ("seed", C.c_uint64), ("max_depth", C.c_int32),
                 ("rr_depth", C.c_int32), ("row_begin", C.c_int32), ("row_end", C.c_int32), ("part_index", C.c_int32),
                 ("part_count", C.c_int32), ("part_tile_rows", C.c_int32), ("paths_per_wave", C.c_int32),
-                ("pipeline", C.c_int32), ("film_rgb", C.c_int32)]
+                ("pipeline", C.c_int32), ("film_rgb", C.c_int32), ("integrator", C.c_int32), ("emitter_samples", C.c_int32),
+                ("bsdf_samples", C.c_int32), ("hide_emitters", C.c_int32)]
 
 
 # every symbol include/mtsamd.h declares: name -> (restype, argtypes)

@@ -585,6 +585,8 @@ static int check_desc(const mtsamd_render_desc *d) {
         d->crop_x + d->crop_width > d->film_width || d->crop_y + d->crop_height > d->film_height)
         return fail(MTSAMD_ERR_INVALID, "Invalid crop window specification!");      // film.cpp:24-32
     if (d->sample_count <= 0) return fail(MTSAMD_ERR_INVALID, "sample_count must be positive");
+    if (d->integrator < 0 || d->integrator > 2) return fail(MTSAMD_ERR_UNSUPPORTED, "integrator %d is not implemented (0 path, 1 direct, 2 depth)", d->integrator);
+    if (d->emitter_samples < 0 || d->bsdf_samples < 0) return fail(MTSAMD_ERR_INVALID, "Must have at least 1 BSDF or emitter sample!");
     if (d->pipeline < 0 || d->pipeline > 2) return fail(MTSAMD_ERR_UNSUPPORTED, "pipeline %d is not available in this build", d->pipeline);
     return 0;
 }
@@ -676,6 +678,18 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     p.max_depth = j.d->max_depth; p.rr_depth = j.d->rr_depth;
     p.spectral = j.s->spectral ? 1 : 0;
     p.split = j.split ? 1 : 0;
+    p.integrator = j.d->integrator; p.emitter_samples = j.d->emitter_samples; p.bsdf_samples = j.d->bsdf_samples;
+    p.hide_emitters = j.d->hide_emitters;
+    if (j.d->integrator != 0) {          // direct / depth: one launch finishes the whole pass
+        HIP_TRY(hipEventRecord(w.tev[0], j.stream));
+        HIP_TRY(launch_direct(p, n, j.stream));
+        HIP_TRY(hipEventRecord(w.tev[1], j.stream));
+        HIP_TRY(hipEventSynchronize(w.tev[1]));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, w.tev[0], w.tev[1]));
+        j.bounce_ms += ms; j.iterations += 1;
+        return 0;
+    }
 
     // the sample cursors cannot run dry before this many launches
     const uint64_t min_iters = (n + (uint64_t) nw * j.target - 1) / ((uint64_t) nw * j.target);
@@ -725,7 +739,8 @@ int setup_job(Job &j, mtsamd_scene *s, const mtsamd_render_desc *d, hipStream_t 
     j.target = d->paths_per_wave > 0 ? (uint32_t) d->paths_per_wave : 256u;
     j.target = std::min<uint32_t>(std::max<uint32_t>(j.target, 64u), 4096u);
     // pipeline 0: fused kernel for LDS-resident (flat) scenes, split kernels for hierarchy scenes; 1 / 2 force one of them
-    j.split = d->pipeline == 2 || (d->pipeline == 0 && !s->view.flat);
+    if (s->spectral && d->integrator != 0) return fail(MTSAMD_ERR_UNSUPPORTED, "the direct and depth integrators are implemented for the RGB variant only");
+    j.split = d->integrator == 0 && (d->pipeline == 2 || (d->pipeline == 0 && !s->view.flat));
     // Paths in flight.  Fused kernel: 16 scheduling waves per CU (one resident generation; the pool stays inside the
     // Infinity Cache).  Split pipeline: its three launches per iteration are latency-bound walks whose tails and launch
     // gaps only amortise over much larger launches -- measured on the 261 k-triangle mesh: 16 / 32 / 64 / 128 / 256 waves

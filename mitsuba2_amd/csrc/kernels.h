@@ -68,6 +68,7 @@ struct RenderParams {
     int32_t spp, crop_x, crop_y, crop_w, crop_h;
     int32_t max_depth, rr_depth;
     int32_t spectral;           // 0: RGB variant, 1: spectral variant (4 wavelengths per sample)
+    int32_t integrator, emitter_samples, bsdf_samples, hide_emitters;   // 0 path; 1 direct (direct.cpp); 2 depth (depth.cpp)
     int32_t split;              // 0: fused k_bounce, 1: k_trace<closest> + k_shade + k_trace<any> per iteration
 };
 
@@ -100,6 +101,8 @@ struct RayStreams {
 
 size_t bounce_lds_bytes(const SceneView &sv);
 hipError_t launch_bounce(const RenderParams &p, hipStream_t s);
+// `direct` / `depth` integrators: every sample of [first_ordinal, first_ordinal + n) is finished by one thread
+hipError_t launch_direct(const RenderParams &p, uint64_t n, hipStream_t s);
 hipError_t launch_adjoint(const AdjointParams &a, hipStream_t s);
 // CIE x, y, z and D65 tables (95 floats each) -> device; call once before the first spectral launch
 hipError_t upload_spectral_tables(const float *x, const float *y, const float *z, const float *d65);

@@ -544,6 +544,119 @@ __global__ __launch_bounds__(kBlock) void k_bounce_spectral(const RenderParams P
 }
 
 // ---------------------------------------------------------------------------------------------
+// `direct` (src/integrators/direct.cpp:105-196) and `depth` (depth.cpp:19-33): no path state survives a sample, so one
+// thread carries a camera sample from the sensor to its result.
+template <bool FLAT, bool GENERAL>
+__global__ __launch_bounds__(kBlock) void k_direct(const RenderParams P, uint64_t n) {
+    extern __shared__ float4 smem[];
+    const LdsView lds = lds_stage<FLAT>(P.sv, smem);
+    const uint64_t gid = (uint64_t) blockIdx.x * kBlock + threadIdx.x;
+    Counters c = { 0u, 0u, 0u, 0u };
+    if (gid < n) {
+        const SceneView &sv = P.sv;
+        const Geo<FLAT> geo{ sv, lds };
+        const uint64_t ordinal = P.first_ordinal + gid;
+        const uint32_t lp = (uint32_t) (ordinal / (uint64_t) P.spp), j = (uint32_t) (ordinal - (uint64_t) lp * (uint64_t) P.spp);
+        PathState s;
+        generate_path(P, ordinal, lp, j, s);
+        Hit hit;
+        ++c.closest; ++c.segments;
+        const bool found = traverse<FLAT, false>(sv, lds, s.o, s.d, s.mint, s.maxt, hit, c.tri_tests);
+        s.flags = found ? 1u : 0u;
+        if (P.integrator == 2) {
+            const float t = found ? hit.t : 0.0f;
+            s.res = mk3(t, t, t);
+        } else if (found) {
+            int32_t ne = P.emitter_samples, nb = P.bsdf_samples;
+            if (ne == 0 && nb == 0) ne = nb = 1;
+            const float sum = (float) (ne + nb);
+            const float weight_bsdf = 1.0f / (float) nb, weight_lum = 1.0f / (float) ne;
+            const float frac_bsdf = (float) nb / sum, frac_lum = (float) ne / sum;
+            SurfaceInteraction si;
+            fill_si(geo, s.d, hit.prim, hit.u, hit.v, si);
+            if (!P.hide_emitters && si.shape_rec.emitter >= 0 && si.wi.z > 0.0f) {
+                const DevEmitter e = geo.emitter((uint32_t) si.shape_rec.emitter);
+                s.res = mk3(s.res.x + e.r, s.res.y + e.g, s.res.z + e.b);
+            }
+            const DevBsdf bsdf = geo.bsdf((uint32_t) si.shape_rec.bsdf);
+            uint32_t texel; f2 tw1;
+            const f3 refl = eval_reflectance(sv, bsdf, si.uv, texel, tw1);
+            if (!GENERAL || bsdf_is_smooth(bsdf)) {
+                for (int32_t i = 0; i < ne; ++i) {
+                    f2 s2; s2.x = pcg_next_f32(s.rng); s2.y = pcg_next_f32(s.rng);
+                    DirectionSample ds; f3 spec;
+                    sample_emitter_direction(geo, si.p, s2, ds, spec);
+                    if (ds.pdf == 0.0f) continue;
+                    const f3 wo = to_local(si.sh, ds.d);
+                    f3 bv; float bp;
+                    if (GENERAL) bsdf_eval_pdf(bsdf, refl, si.wi, wo, bv, bp);
+                    else diffuse_eval_pdf(refl, si.wi, wo, bv, bp);
+                    const float mis = mis_weight(ds.pdf * frac_lum, bp * frac_bsdf) * weight_lum;
+                    const f3 contrib = mk3((mis * bv.x) * spec.x, (mis * bv.y) * spec.y, (mis * bv.z) * spec.z);
+                    if (contrib.x != 0.0f || contrib.y != 0.0f || contrib.z != 0.0f) {
+                        Hit sh;
+                        ++c.any;
+                        if (!traverse<FLAT, true>(sv, lds, si.p, ds.d, kRayEpsilon * (1.0f + hmax_abs(si.p)),
+                                                  ds.dist * (1.0f - kShadowEpsilon), sh, c.tri_tests))
+                            s.res = s.res + contrib;
+                    }
+                }
+            }
+            for (int32_t i = 0; i < nb; ++i) {
+                const float s1 = pcg_next_f32(s.rng);
+                f2 s2; s2.x = pcg_next_f32(s.rng); s2.y = pcg_next_f32(s.rng);
+                f3 wo, weight; float pdf; bool delta = false;
+                if (GENERAL) {
+                    BsdfSample bs;
+                    bsdf_sample(bsdf, refl, si.wi, s1, s2, bs, weight);
+                    wo = bs.wo; pdf = bs.pdf; delta = bs.delta;
+                } else {
+                    diffuse_sample(refl, si.wi, s2, wo, pdf, weight);
+                }
+                if (!(weight.x != 0.0f || weight.y != 0.0f || weight.z != 0.0f)) continue;
+                Hit h2;
+                ++c.closest; ++c.segments;
+                const f3 d2 = to_world(si.sh, wo);
+                if (!traverse<FLAT, false>(sv, lds, si.p, d2, (1.0f + hmax_abs(si.p)) * kRayEpsilon, __builtin_inff(), h2, c.tri_tests)) continue;
+                SurfaceInteraction si2;
+                fill_si(geo, d2, h2.prim, h2.u, h2.v, si2);
+                if (si2.shape_rec.emitter < 0) continue;
+                const DevEmitter e = geo.emitter((uint32_t) si2.shape_rec.emitter);
+                const f3 le = si2.wi.z > 0.0f ? mk3(e.r, e.g, e.b) : mk3(0.0f, 0.0f, 0.0f);
+                f3 dd = si2.p - si.p;
+                const float dist = sqrtf(sqnorm(dd));
+                dd = div_s(dd, dist);
+                const float pe = delta ? 0.0f : pdf_emitter_direction(sv.n_emitters, e.area_norm, dd, si2.sh.n, dist);
+                const float w = mis_weight(pdf * frac_bsdf, pe * frac_lum) * weight_bsdf;
+                s.res = mk3(s.res.x + (weight.x * le.x) * w, s.res.y + (weight.y * le.y) * w, s.res.z + (weight.z * le.z) * w);
+            }
+        }
+        store_result(P, s);
+    }
+    uint32_t tot[4] = { c.closest, c.any, c.segments, c.tri_tests };
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        for (int off = 32; off > 0; off >>= 1) tot[k] += __shfl_xor(tot[k], off);
+    if (lane_id() == 0) {
+        unsigned long long *ws = reinterpret_cast<unsigned long long *>(P.wave_stats + 4u * (size_t) ((gid >> 6) % P.n_waves));
+        for (int k = 0; k < 4; ++k) if (tot[k]) atomicAdd(ws + k, (unsigned long long) tot[k]);
+    }
+}
+
+hipError_t launch_direct(const RenderParams &p, uint64_t n, hipStream_t s) {
+    const uint32_t blocks = (uint32_t) ((n + kBlock - 1) / kBlock);
+    const size_t lds = bounce_lds_bytes(p.sv);
+    if (p.sv.general) {
+        if (p.sv.flat) hipLaunchKernelGGL((k_direct<true, true>), dim3(blocks), dim3(kBlock), lds, s, p, n);
+        else hipLaunchKernelGGL((k_direct<false, true>), dim3(blocks), dim3(kBlock), lds, s, p, n);
+    } else {
+        if (p.sv.flat) hipLaunchKernelGGL((k_direct<true, false>), dim3(blocks), dim3(kBlock), lds, s, p, n);
+        else hipLaunchKernelGGL((k_direct<false, false>), dim3(blocks), dim3(kBlock), lds, s, p, n);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Split pipeline for hierarchy scenes.  In the fused kernel the BVH walks inherit the shading code's ~100 VGPRs
 // (4 waves / SIMD) and are latency-bound at that occupancy: 1.5 Gray/s on a 261 k-triangle mesh against ~5 Gray/s
 // for a kernel that only traverses.  So here every iteration runs k_trace<false> (closest hits of the in-flight

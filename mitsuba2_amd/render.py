@@ -577,7 +577,11 @@ class PathIntegrator:
             d.part_index, d.part_count, d.part_tile_rows = (int(x) for x in partition)
         d.paths_per_wave = self.paths_per_wave
         d.pipeline = self.pipeline
+        self._fill_integrator(d)
         return d
+
+    def _fill_integrator(self, d):
+        d.integrator = 0
 
     def render(self, scene, sensor=None, rows=None, partition=None):
         """Integrator::render (integrator.h:42): renders into sensor.film(); returns False if cancelled.
@@ -610,6 +614,32 @@ class PathIntegrator:
         pos = torch.empty((count, 2), dtype=torch.float32, device=dev)
         L.check(L.lib().mtsamd_sample_radiance(scene._handle, C.byref(d), int(first), int(count), _ptr(rgba), _ptr(pos), _stream()))
         return rgba[:, :3], rgba[:, 3] > 0.5, pos
+
+
+class DirectIntegrator(PathIntegrator):
+    """src/integrators/direct.cpp: direct illumination with multiple importance sampling of emitter and BSDF samples."""
+
+    def __init__(self, shading_samples=None, emitter_samples=None, bsdf_samples=None, hide_emitters=False, paths_per_wave=0):
+        super().__init__(paths_per_wave=paths_per_wave)
+        if shading_samples is not None and (emitter_samples is not None or bsdf_samples is not None):      # direct.cpp:80-86
+            raise RuntimeError("Cannot specify both 'shading_samples' and ('emitter_samples' and/or 'bsdf_samples').")
+        base = 1 if shading_samples is None else int(shading_samples)
+        self.emitter_samples = base if emitter_samples is None else int(emitter_samples)
+        self.bsdf_samples = base if bsdf_samples is None else int(bsdf_samples)
+        if self.emitter_samples < 0 or self.bsdf_samples < 0 or self.emitter_samples + self.bsdf_samples == 0:
+            raise RuntimeError("Must have at least 1 BSDF or emitter sample!")
+        self.hide_emitters = bool(hide_emitters)
+
+    def _fill_integrator(self, d):
+        d.integrator = 1
+        d.emitter_samples, d.bsdf_samples, d.hide_emitters = self.emitter_samples, self.bsdf_samples, int(self.hide_emitters)
+
+
+class DepthIntegrator(PathIntegrator):
+    """src/integrators/depth.cpp: distance to the first intersection"""
+
+    def _fill_integrator(self, d):
+        d.integrator = 2
 
 
 def make_sensor(params):

@@ -539,9 +539,17 @@ def _instantiate(ctx, root, base_dir):
         elif it.tag == "sensor":
             desc.sensors.append(_sensor(ctx, it))
         elif it.tag == "integrator":
-            if it.type != "path":
-                raise XMLError('Integrator plugin "%s" is not supported by this backend (path only)' % it.type)
-            desc.integrator = dict(max_depth=it.get("max_depth", -1, "int"), rr_depth=it.get("rr_depth", 5, "int"))
+            if it.type == "path":
+                desc.integrator = dict(type="path", max_depth=it.get("max_depth", -1, "int"), rr_depth=it.get("rr_depth", 5, "int"))
+            elif it.type == "direct":
+                desc.integrator = dict(type="direct", hide_emitters=it.get("hide_emitters", False, "bool"))
+                for k in ("shading_samples", "emitter_samples", "bsdf_samples"):
+                    if k in it.props:
+                        desc.integrator[k] = it.get(k, kind="int")
+            elif it.type == "depth":
+                desc.integrator = dict(type="depth")
+            else:
+                raise XMLError('Integrator plugin "%s" is not supported by this backend (path, direct, depth)' % it.type)
             it.check_unqueried()
         elif it.tag == "texture":
             continue                                 # instantiated where referenced
@@ -588,7 +596,10 @@ def instantiate(desc, device=0, variant="rgb"):
         sampler = R.IndependentSampler(s["sampler"]["sample_count"], s["sampler"]["seed"])
         sensors.append(R.PerspectiveCamera(to_world=s["to_world"], fov=s["fov"], focal_length=s["focal_length"], fov_axis=s["fov_axis"],
                                            near_clip=s["near_clip"], far_clip=s["far_clip"], film=film, sampler=sampler))
-    integ = R.PathIntegrator(**desc.integrator) if desc.integrator is not None else None
+    integ = None
+    if desc.integrator is not None:
+        args = {k: v for k, v in desc.integrator.items() if k != "type"}
+        integ = {"path": R.PathIntegrator, "direct": R.DirectIntegrator, "depth": R.DepthIntegrator}[desc.integrator.get("type", "path")](**args)
     scene = R.Scene(desc.scene_dict, device=device, integrator=integ, variant=variant)
     scene._sensors = sensors
     return scene
@@ -606,7 +617,7 @@ def load_file(path, device=0, variant="rgb", **params):
 
 # -------------------------------------------------------------------------------------------- load_dict
 _PLUGIN_CLASS = {"twosided": "bsdf", "conductor": "bsdf", "roughconductor": "bsdf", "dielectric": "bsdf", "plastic": "bsdf", "path": "integrator", "perspective": "sensor", "hdrfilm": "film", "independent": "sampler", "gaussian": "rfilter", "box": "rfilter",
-                 "obj": "shape", "ply": "shape", "rectangle": "shape", "diffuse": "bsdf", "area": "emitter", "bitmap": "texture", "scene": "scene"}
+                 "direct": "integrator", "depth": "integrator", "obj": "shape", "ply": "shape", "rectangle": "shape", "diffuse": "bsdf", "area": "emitter", "bitmap": "texture", "scene": "scene"}
 
 
 def _node_from_dict(d, ctx):

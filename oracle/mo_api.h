@@ -95,6 +95,9 @@ typedef struct {
     int32_t max_depth, rr_depth;
     int32_t filter_analytic;    /* 0: eval_discretized (scalar_rgb), 1: eval (gpu variants) */
     int32_t film_rgb;           /* 0: film channels X,Y,Z,A,W; 1: R,G,B,A,W (autodiff.py:53-72) */
+    int32_t integrator;         /* 0: path (src/integrators/path.cpp), 1: direct (direct.cpp), 2: depth (depth.cpp) */
+    int32_t emitter_samples, bsdf_samples;   /* direct: samples per technique (0, 0 = shading_samples default 1, 1) */
+    int32_t hide_emitters;      /* direct (integrator.cpp:39, direct.cpp:117-121) */
 } mo_render_desc;
 
 /* mode 0: scalar_rgb block mode (spiral blocks, Morton order, one PCG32 stream per block);

@@ -449,6 +449,78 @@ static void path_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, 
     }
 }
 
+/* DirectIntegrator::sample (direct.cpp:105-196) */
+static void direct_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray, int emitter_samples, int bsdf_samples,
+                          int hide_emitters, float result[3], int *valid_ray, ray_stats *st) {
+    if (emitter_samples == 0 && bsdf_samples == 0) emitter_samples = bsdf_samples = 1;      /* shading_samples = 1 (direct.cpp:88-95) */
+    const float sum = (float) (emitter_samples + bsdf_samples);
+    const float weight_bsdf = 1.0f / (float) bsdf_samples, weight_lum = 1.0f / (float) emitter_samples;
+    const float frac_bsdf = (float) bsdf_samples / sum, frac_lum = (float) emitter_samples / sum;
+    result[0] = result[1] = result[2] = 0.0f;
+    mo_si si;
+    int valid = scene_intersect(s, ray, &si, st);
+    *valid_ray = valid;
+    if (!valid) return;
+    const mo_mesh *mesh = &s->meshes[si.shape];
+    if (!hide_emitters && mesh->emitter >= 0 && si.wi.z > 0.0f)                                /* visible emitters (direct.cpp:117-121) */
+        for (int k = 0; k < 3; ++k) result[k] += s->emitters[mesh->emitter].radiance[k];
+    const mo_bsdf *bsdf = &mesh->bsdf;
+    float refl[3];
+    mo_reflectance(s, mesh, si.uv, refl, NULL, NULL);
+    if (mo_bsdf_is_smooth(bsdf)) {
+        for (int i = 0; i < emitter_samples; ++i) {
+            mo_v2 s2; s2.x = mo_pcg32_next_f32(rng); s2.y = mo_pcg32_next_f32(rng);
+            mo_dsample ds; float emitter_val[3];
+            mo_sample_emitter_direction(s, si.p, s2, &ds, emitter_val);
+            int active_e = ds.pdf != 0.0f;
+            if (active_e && s->n_emitters > 0) {
+                mo_ray sr;
+                sr.o = si.p; sr.d = ds.d;
+                sr.mint = MO_RAY_EPSILON * (1.0f + mo_hmax_abs(si.p));
+                sr.maxt = ds.dist * (1.0f - MO_SHADOW_EPSILON);
+                st->any++;
+                if (mo_intersect(s, &sr, 1, 0, NULL)) emitter_val[0] = emitter_val[1] = emitter_val[2] = 0.0f;
+            }
+            if (!active_e) continue;
+            mo_v3 wo = mo_to_local(&si.sh, ds.d);
+            float bsdf_val[3], bsdf_pdf;
+            mo_bsdf_eval_pdf(bsdf, refl, si.wi, wo, bsdf_val, &bsdf_pdf);
+            float mis = mis_weight(ds.pdf * frac_lum, bsdf_pdf * frac_bsdf) * weight_lum;
+            for (int k = 0; k < 3; ++k) result[k] += (mis * bsdf_val[k]) * emitter_val[k];
+        }
+    }
+    for (int i = 0; i < bsdf_samples; ++i) {
+        float s1 = mo_pcg32_next_f32(rng);
+        mo_v2 s2; s2.x = mo_pcg32_next_f32(rng); s2.y = mo_pcg32_next_f32(rng);
+        mo_bsample bs; float bsdf_val[3];
+        mo_bsdf_sample(bsdf, refl, si.wi, s1, s2, &bs, bsdf_val);
+        if (!(bsdf_val[0] != 0.0f || bsdf_val[1] != 0.0f || bsdf_val[2] != 0.0f)) continue;
+        mo_ray r2;
+        r2.o = si.p; r2.d = mo_to_world(&si.sh, bs.wo);
+        r2.mint = (1.0f + mo_hmax_abs(si.p)) * MO_RAY_EPSILON; r2.maxt = INFINITY;
+        mo_si si_bsdf;
+        if (!scene_intersect(s, &r2, &si_bsdf, st)) continue;
+        int emitter = s->meshes[si_bsdf.shape].emitter;
+        if (emitter < 0) continue;
+        float emitter_val[3] = { 0.0f, 0.0f, 0.0f };
+        if (si_bsdf.wi.z > 0.0f) for (int k = 0; k < 3; ++k) emitter_val[k] = s->emitters[emitter].radiance[k];
+        mo_v3 d = mo_sub(si_bsdf.p, si.p);
+        float dist = mo_norm(d);
+        d = mo_div_s(d, dist);
+        float emitter_pdf = bs.delta ? 0.0f : mo_pdf_emitter_direction(s, (uint32_t) emitter, d, si_bsdf.sh.n, dist);
+        float w = mis_weight(bs.pdf * frac_bsdf, emitter_pdf * frac_lum) * weight_bsdf;
+        for (int k = 0; k < 3; ++k) result[k] += (bsdf_val[k] * emitter_val[k]) * w;
+    }
+}
+
+/* DepthIntegrator::sample (depth.cpp:19-33) */
+static void depth_sample(const mo_scene *s, const mo_ray *ray, float result[3], int *valid_ray, ray_stats *st) {
+    mo_si si;
+    int valid = scene_intersect(s, ray, &si, st);
+    *valid_ray = valid;
+    result[0] = result[1] = result[2] = valid ? si.t : 0.0f;
+}
+
 /* PathIntegrator::sample for the spectral variant: identical control flow, 4 wavelength channels */
 static void path_sample_spectral(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, const float wav[MO_WAV],
                                  int max_depth, int rr_depth, float result[MO_WAV], int *valid_ray, ray_stats *st) {
@@ -565,7 +637,9 @@ static void render_sample(const mo_scene *s, const mo_render_desc *d, const came
         mo_spectrum_to_xyz(Ls, wav, xyz);
         L[0] = xyz[0]; L[1] = xyz[1]; L[2] = xyz[2];       /* per-sample API: XYZ tristimulus in the spectral variant */
     } else {
-    path_sample(s, rng, &ray, d->max_depth, d->rr_depth, L, &valid, st);
+    if (d->integrator == 1) direct_sample(s, rng, &ray, d->emitter_samples, d->bsdf_samples, d->hide_emitters, L, &valid, st);
+    else if (d->integrator == 2) depth_sample(s, &ray, L, &valid, st);
+    else path_sample(s, rng, &ray, d->max_depth, d->rr_depth, L, &valid, st);
     /* ray_weight == 1 in RGB mode (spectrum.h:304-309) */
     srgb_to_xyz(L, xyz);
     }
@@ -586,6 +660,7 @@ static int desc_check(const mo_render_desc *d) {
     if (d->max_depth < 0 && d->max_depth != -1) return -1;   /* integrator.cpp:290-292 */
     if (d->rr_depth <= 0) return -1;
     if (d->crop_w <= 0 || d->crop_h <= 0 || d->spp <= 0) return -1;
+    if (d->integrator < 0 || d->integrator > 2 || d->emitter_samples < 0 || d->bsdf_samples < 0) return -1;
     return 0;
 }
 

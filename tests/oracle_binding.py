@@ -19,7 +19,8 @@ class RenderDesc(C.Structure):
                 ("film_w", C.c_int32), ("film_h", C.c_int32), ("crop_x", C.c_int32), ("crop_y", C.c_int32), ("crop_w", C.c_int32),
                 ("crop_h", C.c_int32), ("rfilter", C.c_int32), ("rfilter_param", C.c_float), ("spp", C.c_int32),
                 ("base_seed", C.c_uint64), ("max_depth", C.c_int32), ("rr_depth", C.c_int32), ("filter_analytic", C.c_int32),
-                ("film_rgb", C.c_int32)]
+                ("film_rgb", C.c_int32), ("integrator", C.c_int32), ("emitter_samples", C.c_int32), ("bsdf_samples", C.c_int32),
+                ("hide_emitters", C.c_int32)]
 
 
 class BsdfDesc(C.Structure):
@@ -258,6 +259,9 @@ def make_desc(params, analytic=False, film_rgb=False):
     d.max_depth, d.rr_depth = params["max_depth"], params["rr_depth"]
     d.filter_analytic = 1 if analytic else 0
     d.film_rgb = 1 if film_rgb else 0
+    d.integrator = {"path": 0, "direct": 1, "depth": 2}[params.get("integrator", "path")]
+    d.emitter_samples, d.bsdf_samples = params.get("emitter_samples", 0), params.get("bsdf_samples", 0)
+    d.hide_emitters = 1 if params.get("hide_emitters", False) else 0
     return d
 
 

@@ -214,7 +214,7 @@ def test_xml_scene_subset(tmp_path):
         mxml.parse_string(CBOX_XML, base_dir=str(tmp_path))
     d = mxml.parse_string(CBOX_XML, base_dir=str(tmp_path), depth=6, spp=16)
     sd = d.scene_dict
-    assert d.integrator == dict(max_depth=6, rr_depth=5)
+    assert d.integrator == dict(type="path", max_depth=6, rr_depth=5)
     assert [b["id"] for b in sd["bsdfs"]] == ["white", "light"]
     assert np.allclose(sd["bsdfs"][0]["reflectance"], [0.885809, 0.698859, 0.666422]) and sd["bsdfs"][1]["reflectance"] == [0.0] * 3
     floor, lamp = sd["meshes"]
