@@ -197,6 +197,8 @@ typedef struct {
     int32_t emitter_samples;   /* direct: samples per technique; 0 and 0 = the shading_samples default (1, 1) (direct.cpp:80-103) */
     int32_t bsdf_samples;
     int32_t hide_emitters;     /* direct: do not add directly visible emitters (integrator.cpp:39, direct.cpp:117-121) */
+    int32_t moment;            /* != 0: `moment` integrator around the selected one (src/integrators/moment.cpp:56-99): the film
+                                  has 11 channels X,Y,Z,A,W, nested.X,nested.Y,nested.Z, m2_nested.X,m2_nested.Y,m2_nested.Z */
 } mtsamd_render_desc;
 
 /* SamplingIntegrator::render for the `path` integrator (src/librender/integrator.cpp:52-176,

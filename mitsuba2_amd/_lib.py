@@ -56,7 +56,7 @@ class RenderDesc(C.Structure):
                 ("rr_depth", C.c_int32), ("row_begin", C.c_int32), ("row_end", C.c_int32), ("part_index", C.c_int32),
                 ("part_count", C.c_int32), ("part_tile_rows", C.c_int32), ("paths_per_wave", C.c_int32),
                 ("pipeline", C.c_int32), ("film_rgb", C.c_int32), ("integrator", C.c_int32), ("emitter_samples", C.c_int32),
-                ("bsdf_samples", C.c_int32), ("hide_emitters", C.c_int32)]
+                ("bsdf_samples", C.c_int32), ("hide_emitters", C.c_int32), ("moment", C.c_int32)]
 
 
 # every symbol include/mtsamd.h declares: name -> (restype, argtypes)

@@ -148,6 +148,7 @@ struct Workspace {
     uint64_t *cursor = nullptr, *cursor_end = nullptr, *wave_stats = nullptr;
     uint32_t *cursor_pix = nullptr, *cursor_rem = nullptr, *count_shadow = nullptr;
     float4 *out_rgba = nullptr; float2 *out_pos = nullptr;
+    float *moment_film = nullptr; uint64_t moment_pixels = 0;     // moment integrator: two scratch 5-channel films
     uint32_t *h_counts = nullptr;        // pinned, 4 * n_waves
     uint64_t *h_cursor = nullptr;        // pinned, 2 * n_waves
     hipEvent_t ev[4] = {};
@@ -164,6 +165,7 @@ struct Workspace {
         }
         (void) hipFree(cursor); (void) hipFree(cursor_end); (void) hipFree(wave_stats); (void) hipFree(cursor_pix); (void) hipFree(cursor_rem);
         (void) hipFree(count_shadow); count_shadow = nullptr;
+        (void) hipFree(moment_film); moment_film = nullptr; moment_pixels = 0;
         cursor_pix = cursor_rem = nullptr; (void) hipFree(out_rgba); (void) hipFree(out_pos);
         cursor = cursor_end = wave_stats = nullptr; out_rgba = nullptr; out_pos = nullptr;
         if (h_counts) (void) hipHostFree(h_counts);
@@ -808,6 +810,20 @@ int mtsamd_render(mtsamd_scene *s, const mtsamd_render_desc *d, float *film, uin
     if (per_row > j.pass_cap) return fail(MTSAMD_ERR_UNSUPPORTED, "one film row (%llu samples) exceeds the pass capacity", (unsigned long long) per_row);
     const uint64_t rows_per_pass = std::max<uint64_t>(1, j.pass_cap / per_row);
     const bool tiled = film_tiles_supported(j.filter);
+    // moment integrator: the sample stream is splatted twice (values, then squared values) into two scratch films
+    float *film_target = film, *film_sq = nullptr;
+    const uint64_t n_pixels = (uint64_t) d->crop_width * (uint64_t) d->crop_height;
+    if (d->moment) {
+        if (d->film_rgb) return fail(MTSAMD_ERR_UNSUPPORTED, "the moment integrator writes XYZ channels (film_rgb must be 0)");
+        Workspace &w = s->ws;
+        if (w.moment_pixels < n_pixels) {
+            (void) hipFree(w.moment_film); w.moment_film = nullptr; w.moment_pixels = 0;
+            HIP_TRY(hipMalloc((void **) &w.moment_film, 2 * 5 * n_pixels * sizeof(float)));
+            w.moment_pixels = n_pixels;
+        }
+        HIP_TRY(hipMemsetAsync(w.moment_film, 0, 2 * 5 * n_pixels * sizeof(float), stream));
+        film_target = w.moment_film; film_sq = w.moment_film + 5 * n_pixels;
+    }
     for (uint64_t lr0 = 0; lr0 < (uint64_t) rows.local_rows; lr0 += rows_per_pass) {
         const uint64_t nrows = std::min<uint64_t>(rows_per_pass, (uint64_t) rows.local_rows - lr0);
         const uint64_t a = lr0 * per_row, n = nrows * per_row;
@@ -819,7 +835,7 @@ int mtsamd_render(mtsamd_scene *s, const mtsamd_render_desc *d, float *film, uin
         if (int rc = trace_pass(j, a, n)) return rc;
         // Film::put: splat this pass into the film rows its samples can reach
         FilmParams f{};
-        f.out_rgba = s->ws.out_rgba; f.out_pos = s->ws.out_pos; f.film = film; f.filter = j.filter;
+        f.out_rgba = s->ws.out_rgba; f.out_pos = s->ws.out_pos; f.film = film_target; f.filter = j.filter;
         f.first_ordinal = a; f.n_samples = n; f.spp = d->sample_count; f.rows = rows;
         f.plane_pix0 = j.plane_pix0; f.plane_pixels = j.plane_pixels;
         f.crop_x = d->crop_x; f.crop_y = d->crop_y; f.crop_w = d->crop_width; f.crop_h = d->crop_height;
@@ -834,12 +850,19 @@ int mtsamd_render(mtsamd_scene *s, const mtsamd_render_desc *d, float *film, uin
         f.row0 = std::max<int32_t>(0, g0 - R); f.row1 = std::min<int32_t>(d->crop_height, g1 + R + 1);
         if (tiled) HIP_TRY(launch_film_tiles(f, stream));
         else HIP_TRY(launch_film_gather(f, stream));
+        if (film_sq) {
+            HIP_TRY(launch_square_stream(s->ws.out_rgba, n, stream));
+            f.film = film_sq;
+            if (tiled) HIP_TRY(launch_film_tiles(f, stream));
+            else HIP_TRY(launch_film_gather(f, stream));
+        }
         HIP_TRY(hipEventRecord(s->ws.tev[2], stream));
         HIP_TRY(hipEventSynchronize(s->ws.tev[2]));
         float fms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&fms, s->ws.tev[1], s->ws.tev[2]));
         j.film_ms += fms;
     }
+    if (film_sq) HIP_TRY(launch_moment_pack(film_target, film_sq, film, n_pixels, stream));
     if (int rc = collect_stats(j, total, stats_host)) return rc;
     HIP_TRY(hipStreamSynchronize(stream));
     return MTSAMD_OK;

@@ -124,6 +124,10 @@ hipError_t launch_imageblock_put(const FilterView &f, int32_t w, int32_t h, int3
 hipError_t launch_put_block(const float *src, int32_t sw, int32_t sh, int32_t sox, int32_t soy, int32_t sb,
                             float *dst, int32_t dw, int32_t dh, int32_t dox, int32_t doy, int32_t db, int32_t ch,
                             hipStream_t s);
+// moment integrator: squares the (X,Y,Z) of every valid sample of the stream in place; packs the two 5-channel films
+// (values, squared values) into the 11-channel film of moment.cpp (accumulating)
+hipError_t launch_square_stream(float4 *rgba, uint64_t n, hipStream_t s);
+hipError_t launch_moment_pack(const float *values5, const float *squares5, float *film11, uint64_t n_pixels, hipStream_t s);
 hipError_t launch_film_develop(const float *xyzaw, uint64_t n, float *rgba, hipStream_t s);
 
 } // namespace mtsamd

@@ -1346,6 +1346,31 @@ hipError_t launch_put_block(const float *src, int32_t sw, int32_t sh, int32_t so
 }
 
 // HDRFilm::bitmap: (X,Y,Z,A) / W, RGB = M * XYZ (hdrfilm.cpp:278-299, struct.cpp:1761-1811)
+__global__ __launch_bounds__(kBlock) void k_square_stream(float4 *rgba, uint64_t n) {
+    const uint64_t i = (uint64_t) blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float4 v = rgba[i];
+    v.x *= v.x; v.y *= v.y; v.z *= v.z;            // m2 AOVs: sqr of the nested integrator's XYZ (moment.cpp:91-93)
+    rgba[i] = v;
+}
+__global__ __launch_bounds__(kBlock) void k_moment_pack(const float *a, const float *b, float *out, uint64_t n) {
+    const uint64_t i = (uint64_t) blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float *pa = a + 5u * i, *pb = b + 5u * i;
+    float *o = out + 11u * i;
+    o[0] += pa[0]; o[1] += pa[1]; o[2] += pa[2]; o[3] += pa[3]; o[4] += pa[4];
+    o[5] += pa[0]; o[6] += pa[1]; o[7] += pa[2];
+    o[8] += pb[0]; o[9] += pb[1]; o[10] += pb[2];
+}
+hipError_t launch_square_stream(float4 *rgba, uint64_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_square_stream, dim3((uint32_t) ((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, rgba, n);
+    return hipGetLastError();
+}
+hipError_t launch_moment_pack(const float *values5, const float *squares5, float *film11, uint64_t n_pixels, hipStream_t s) {
+    if (n_pixels) hipLaunchKernelGGL(k_moment_pack, dim3((uint32_t) ((n_pixels + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, values5, squares5, film11, n_pixels);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(kBlock) void k_film_develop(const float *xyzaw, uint64_t n, float *rgba) {
     for (uint64_t i = (uint64_t) blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t) gridDim.x * kBlock) {
         const float *p = xyzaw + 5 * i;

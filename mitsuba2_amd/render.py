@@ -583,13 +583,21 @@ class PathIntegrator:
     def _fill_integrator(self, d):
         d.integrator = 0
 
+    def aov_names(self):
+        """SamplingIntegrator::aov_names (integrator.h:128-133)"""
+        return []
+
+    def aov_channels(self):
+        """film channels of a render: X, Y, Z, A, W followed by the AOVs (integrator.cpp:72-77)"""
+        return ["X", "Y", "Z", "A", "W"] + self.aov_names()
+
     def render(self, scene, sensor=None, rows=None, partition=None):
         """Integrator::render (integrator.h:42): renders into sensor.film(); returns False if cancelled.
         rows=(begin, end) / partition=(index, count, tile_rows) restrict the call to a part of the film
         (multi-GPU film partition); the film then holds that part's contribution only."""
         sensor = sensor if sensor is not None else scene.sensors()[0]
         film = sensor.film()
-        film.prepare(("X", "Y", "Z", "A", "W"), device="cuda:%d" % scene._device_index)
+        film.prepare(self.aov_channels(), device="cuda:%d" % scene._device_index)
         d = self._desc(sensor, rows, partition)
         stats = (C.c_uint64 * 8)()
         self._scene = scene
@@ -640,6 +648,36 @@ class DepthIntegrator(PathIntegrator):
 
     def _fill_integrator(self, d):
         d.integrator = 2
+
+
+class MomentIntegrator(PathIntegrator):
+    """src/integrators/moment.cpp: wraps a sampling integrator and adds its XYZ result and the second moments of it as AOVs
+    (``<name>.X/Y/Z`` and ``m2_<name>.X/Y/Z``), from which a per-pixel variance estimate follows."""
+
+    def __init__(self, nested, name="nested"):
+        if not isinstance(nested, PathIntegrator) or isinstance(nested, MomentIntegrator):
+            raise RuntimeError("Child objects must be of type 'SamplingIntegrator'!")
+        super().__init__(paths_per_wave=nested.paths_per_wave, pipeline=nested.pipeline)
+        self.nested, self.name = nested, name
+
+    def aov_names(self):
+        base = ["%s.%s" % (self.name, c) for c in "XYZ"]
+        return base + ["m2_" + n for n in base]
+
+    def _desc(self, sensor, rows=None, partition=None):
+        d = self.nested._desc(sensor, rows, partition)
+        d.moment = 1
+        return d
+
+    @staticmethod
+    def mean_and_variance(film):
+        """what test_renders.py:55-60 (bitmap_extract) takes from the developed film: the nested integrator's XYZ image and
+        m2 - mean^2, both normalised by the accumulated filter weight"""
+        raw = film.bitmap(raw=True)
+        w = raw[..., 4:5]
+        inv = torch.where(w != 0, 1.0 / torch.where(w != 0, w, torch.ones_like(w)), torch.zeros_like(w))
+        mean, m2 = raw[..., 5:8] * inv, raw[..., 8:11] * inv
+        return mean, m2 - mean * mean
 
 
 def make_sensor(params):

@@ -61,3 +61,35 @@ def test_depth_matches_ray_intersect():
     want, wpos = ob.OracleScene(sd).sample_radiance(ob.make_desc(dict(sp, integrator="depth")), 0, n)
     assert np.array_equal(pos.cpu().numpy(), wpos)
     assert np.array_equal(rgb.cpu().numpy(), want[:, :3]) and np.array_equal(mask.cpu().numpy(), want[:, 3] > 0.5)
+
+
+def test_moment_integrator_and_z_test():
+    """src/integrators/moment.cpp:56-99 + the protocol of test_renders.py:60-134: the GPU render (wavefront seeding) must
+    be statistically indistinguishable from the oracle's scalar_rgb block-mode samples, pixel by pixel."""
+    from mitsuba2_amd import render as R, scenes, testing
+    cb = scenes.cornell_box()
+    sp = dict(scenes.cornell_box_sensor(32, 32, spp=256, seed=3), rfilter="box", rfilter_param=0.5)
+    scene, sensor = R.Scene(cb), R.make_sensor(sp)
+    integ = R.MomentIntegrator(R.PathIntegrator(max_depth=6))
+    assert integ.aov_channels() == ["X", "Y", "Z", "A", "W", "nested.X", "nested.Y", "nested.Z", "m2_nested.X", "m2_nested.Y", "m2_nested.Z"]
+    assert integ.render(scene, sensor)
+    raw = sensor.film().bitmap(raw=True).cpu().numpy()
+    assert raw.shape == (32, 32, 11) and np.array_equal(raw[..., 5:8], raw[..., 0:3]) and (raw[..., 4] == 256).all()
+    mean, var = (x.cpu().numpy() for x in integ.mean_and_variance(sensor.film()))
+    # second moments against the per-sample API (box filter: every sample lands in its own pixel with weight 1)
+    rgb, _, _ = R.PathIntegrator(max_depth=6).sample(scene, sensor, 0, 32 * 32 * 256)
+    m = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]], np.float32)
+    xyz = (rgb.cpu().numpy() @ m.T).reshape(32, 32, 256, 3)
+    assert np.allclose(mean, xyz.mean(2), rtol=1e-4, atol=1e-5)
+    assert np.allclose(raw[..., 8:11] / 256, (xyz.astype(np.float64) ** 2).mean(2), rtol=1e-4, atol=1e-6)
+    assert np.allclose(var, xyz.astype(np.float64).var(2), rtol=2e-2, atol=1e-3)      # m2 - mean^2 cancels in fp32
+    # reference mean / variance: a different set of random numbers (the oracle's block seeding, another seed), 1024 spp
+    ref_sp = dict(sp, sample_count=1024, seed=77, max_depth=6)
+    film, _ = ob.OracleScene(cb).render(ob.make_desc(ref_sp), mode=0)
+    ref_mean = film[..., :3] / film[..., 4:5]
+    vals, _ = ob.OracleScene(cb).sample_radiance(ob.make_desc(ref_sp), 0, 32 * 32 * 1024)
+    ref_var = (vals[:, :3] @ m.T).reshape(32, 32, 1024, 3).var(2)
+    ok, p_min, alpha = testing.accept(mean, 256, ref_mean, ref_var)
+    assert ok, (p_min, alpha)
+    bad, _, _ = testing.accept(mean * 1.05, 256, ref_mean, ref_var)      # a 5 % bias is detected
+    assert not bad
