@@ -79,7 +79,8 @@ typedef struct {
     int32_t nonlinear;         /* plastic.nonlinear */
 } mtsamd_bsdf_desc;
 
-typedef enum { MTSAMD_EMITTER_AREA = 0 } mtsamd_emitter_type;
+/* area: src/emitters/area.cpp (attached to a mesh); constant: src/emitters/constant.cpp (environment, RGB variant) */
+typedef enum { MTSAMD_EMITTER_AREA = 0, MTSAMD_EMITTER_CONSTANT = 1 } mtsamd_emitter_type;
 typedef struct {
     int32_t type;              /* mtsamd_emitter_type; AreaLight = src/emitters/area.cpp */
     float radiance[3];

@@ -208,6 +208,7 @@ static void fill_bsdf_model(const mtsamd_bsdf_desc &bd, DevBsdf &d) {
 }
 
 struct mtsamd_scene {
+    int32_t environment = -1;        // index of the `constant` emitter
     bool general_bsdfs = false;      // any BSDF other than one-sided `diffuse`: the kernels with the BSDF switch are used
     int device = 0;
     int cu_count = 256;
@@ -283,9 +284,18 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         total += m.face_count;
         any_nrm |= m.normals != nullptr; any_uv |= m.texcoords != nullptr;
     }
+    int32_t environment = -1;
     for (uint32_t e = 0; e < desc->emitter_count; ++e) {
+        const int32_t et = desc->emitters[e].type;
+        if (et == MTSAMD_EMITTER_CONSTANT) {
+            if (emitter_shape[e] >= 0) return fail(MTSAMD_ERR_INVALID, "emitter %u: an environment emitter cannot be attached to a shape", e);
+            if (environment >= 0) return fail(MTSAMD_ERR_INVALID, "Only one environment emitter can be specified per scene.");      // scene.cpp:45-46
+            if (desc->spectral) return fail(MTSAMD_ERR_UNSUPPORTED, "emitter %u: the constant emitter is implemented for the RGB variant only", e);
+            environment = (int32_t) e;
+            continue;
+        }
+        if (et != MTSAMD_EMITTER_AREA) return fail(MTSAMD_ERR_UNSUPPORTED, "emitter %u: only 'area' and 'constant' emitters are implemented", e);
         if (emitter_shape[e] < 0) return fail(MTSAMD_ERR_INVALID, "emitter %u is not attached to a shape", e);
-        if (desc->emitters[e].type != MTSAMD_EMITTER_AREA) return fail(MTSAMD_ERR_UNSUPPORTED, "emitter %u: only 'area' emitters are implemented", e);
     }
     for (uint32_t b = 0; b < desc->bsdf_count; ++b) {
         const mtsamd_bsdf_desc &bd = desc->bsdfs[b];
@@ -315,6 +325,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     std::vector<DevShape> shapes(desc->mesh_count);
     std::vector<float> area_pmf(total, 0.0f), area_cdf(total, 0.0f);
     s->emitters.resize(desc->emitter_count);
+    s->environment = environment;
     uint32_t off = 0;
     for (uint32_t i = 0; i < desc->mesh_count; ++i) {
         const mtsamd_mesh_desc &m = desc->meshes[i];
@@ -420,6 +431,18 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
 
     // ---- accelerator -------------------------------------------------------------------------
     build_bvh(tri_pos.data(), s->n_prims, 4, s->bvh);
+    if (s->environment >= 0) {       // ConstantBackgroundEmitter::set_scene (constant.cpp:47-51): bounding sphere of Scene::bbox()
+        DevEmitter &e = s->emitters[s->environment];
+        std::memset(&e, 0, sizeof(e));
+        const mtsamd_emitter_desc &ed = desc->emitters[s->environment];
+        e.r = ed.radiance[0]; e.g = ed.radiance[1]; e.b = ed.radiance[2];
+        e.shape = 0xffffffffu; e.pad0 = kEmitterConstant;
+        const float *bb = s->bvh.bbox;
+        e.cx = (bb[3] + bb[0]) * 0.5f; e.cy = (bb[4] + bb[1]) * 0.5f; e.cz = (bb[5] + bb[2]) * 0.5f;
+        const float dx = e.cx - bb[3], dy = e.cy - bb[4], dz = e.cz - bb[5];
+        const float r = std::sqrt(std::fma(dz, dz, std::fma(dy, dy, dx * dx)));
+        e.radius = std::max(kRayEpsilon, r * (1.0f + kRayEpsilon));
+    }
 
     std::vector<float4> nodes(4 * (size_t) s->bvh.n_nodes), tris(3 * (size_t) s->bvh.n_slots);
     std::memcpy(nodes.data(), s->bvh.nodes.data(), s->bvh.nodes.size() * sizeof(float));
@@ -474,6 +497,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     v.tri_pos = s->d_tri_pos; v.tri_nrm = any_nrm ? s->d_tri_nrm : nullptr; v.tri_uv = any_uv ? s->d_tri_uv : nullptr;
     v.prim_shape = s->d_prim_shape; v.shapes = s->d_shapes; v.bsdfs = s->d_bsdfs;
     v.emitters = s->d_emitters; v.n_emitters = desc->emitter_count;
+    v.env_emitter = s->environment;
     v.area_pmf = s->d_area_pmf; v.area_cdf = s->d_area_cdf;
     v.n_shapes = desc->mesh_count; v.n_bsdfs = desc->bsdf_count;
     v.textures = s->d_textures; v.n_textures = desc->texture_count;
@@ -877,6 +901,7 @@ int mtsamd_render_adjoint(mtsamd_scene *s, const mtsamd_render_desc *d, const fl
     if (d->part_count > 1 || d->row_begin != 0 || d->row_end > 0) return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass renders the whole crop window");
     if (s->spectral) return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass is implemented for the RGB variant only");
     if (s->general_bsdfs) return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass is implemented for one-sided diffuse BSDFs only");
+    if (s->environment >= 0) return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass does not handle environment emitters");
     if (s->bsdfs.size() > 32 && grad_bsdf) return fail(MTSAMD_ERR_UNSUPPORTED, "at most 32 BSDFs with constant-reflectance gradients");
     HIP_TRY(hipSetDevice(s->device));
     AdjointParams a{};

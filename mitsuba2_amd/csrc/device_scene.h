@@ -38,7 +38,10 @@ struct DevEmitter {
     uint32_t first_prim, n_prims; float area_sum, area_norm;
     uint32_t valid_lo, valid_hi; uint32_t pad0, pad1;
     float c0, c1, c2, d65_scale;       // spectral variant: SRGBEmitterSpectrum = D65 * d65_scale * srgb_model(c) (srgb_d65.cpp:27-63)
+    float cx, cy, cz, radius;          // constant emitter (pad0 == 1): the scene's bounding sphere (constant.cpp:47-51)
 };
+constexpr uint32_t kEmitterConstant = 1u;     // DevEmitter::pad0
+constexpr float kInvFourPi = 0.07957747154594766788f;
 
 struct SceneView {
     const float4 *nodes;       // 4 per node
@@ -66,6 +69,7 @@ struct SceneView {
     const float4 *flat_recs;
     const float4 *flat_pairs;
     uint32_t flat, n_pairs;
+    int32_t env_emitter;       // index of the environment emitter or -1 (scene.cpp:44-48)
     uint32_t general;          // some BSDF is not a one-sided `diffuse`: kernels instantiated with the BSDF switch are used
 };
 constexpr uint32_t kFlatMaxPrims = 64;
@@ -441,6 +445,20 @@ MTS_DEV void sample_emitter_direction(const Geo<FLAT> &g, f3 ref_p, f2 sample, D
         sample.x = (sample.x - (float) index * emitter_pdf) * nf;
     }
     const DevEmitter e = g.emitter(index);
+    if (e.pad0 == kEmitterConstant) {
+        // ConstantBackgroundEmitter::sample_direction (constant.cpp:82-107), square_to_uniform_sphere (warp.h:262-267)
+        const float z = fmaf(-2.0f, sample.y, 1.0f), r = safe_sqrt(fmaf(-z, z, 1.0f));
+        const float ang = 2.0f * kPi * sample.x;
+        const f3 d = mk3(r * cosf(ang), r * sinf(ang), z);
+        ds.dist = 2.0f * e.radius;
+        ds.p = ref_p + d * ds.dist;
+        ds.n = -d; ds.d = d;
+        ds.pdf = kInvFourPi;
+        ds.emitter = index;
+        r1 = rcp(ds.pdf);
+        if (sv.n_emitters > 1) { ds.pdf *= emitter_pdf; r2 = rcp(emitter_pdf); }
+        return;
+    }
     // Mesh::sample_position: DiscreteDistribution::sample_reuse (distr_1d.h:144-203)
     uint32_t f;
     {
@@ -499,6 +517,11 @@ MTS_DEV void sample_emitter_direction(const Geo<FLAT> &g, f3 ref_p, f2 sample, D
     if (g.sv.n_emitters > 1) spec = spec * r2;
 }
 
+MTS_DEV float pdf_environment(uint32_t n_emitters) {        // ConstantBackgroundEmitter::pdf_direction + Scene (scene.cpp:191-206)
+    float pdf = kInvFourPi;
+    if (n_emitters > 1) pdf *= 1.0f / (float) n_emitters;
+    return pdf;
+}
 MTS_DEV float pdf_emitter_direction(uint32_t n_emitters, float area_norm, f3 d, f3 n, float dist) {
     float pdf = 0.0f;
     if (dot(d, n) < 0.0f) {

@@ -113,6 +113,12 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
             }
         }
     }
+    if (!REC && !found && sv.env_emitter >= 0) {             // si.emitter(scene) of an escaped ray: the environment
+        const DevEmitter e = geo.emitter((uint32_t) sv.env_emitter);
+        float ew = 1.0f;
+        if (s.depth > 1u) ew = mis_weight(s.bs_pdf, (GENERAL && (s.flags & kFlagDelta)) ? 0.0f : pdf_environment(sv.n_emitters));
+        s.res.x += (ew * s.thr.x) * e.r; s.res.y += (ew * s.thr.y) * e.g; s.res.z += (ew * s.thr.z) * e.b;
+    }
     bool active = found;
 
     // Russian roulette (path.cpp:137-141)
@@ -566,7 +572,12 @@ __global__ __launch_bounds__(kBlock) void k_direct(const RenderParams P, uint64_
         if (P.integrator == 2) {
             const float t = found ? hit.t : 0.0f;
             s.res = mk3(t, t, t);
-        } else if (found) {
+        } else if (!found) {
+            if (!P.hide_emitters && sv.env_emitter >= 0) {
+                const DevEmitter e = geo.emitter((uint32_t) sv.env_emitter);
+                s.res = mk3(s.res.x + e.r, s.res.y + e.g, s.res.z + e.b);
+            }
+        } else {
             int32_t ne = P.emitter_samples, nb = P.bsdf_samples;
             if (ne == 0 && nb == 0) ne = nb = 1;
             const float sum = (float) (ne + nb);
@@ -617,16 +628,23 @@ __global__ __launch_bounds__(kBlock) void k_direct(const RenderParams P, uint64_
                 Hit h2;
                 ++c.closest; ++c.segments;
                 const f3 d2 = to_world(si.sh, wo);
-                if (!traverse<FLAT, false>(sv, lds, si.p, d2, (1.0f + hmax_abs(si.p)) * kRayEpsilon, __builtin_inff(), h2, c.tri_tests)) continue;
-                SurfaceInteraction si2;
-                fill_si(geo, d2, h2.prim, h2.u, h2.v, si2);
-                if (si2.shape_rec.emitter < 0) continue;
-                const DevEmitter e = geo.emitter((uint32_t) si2.shape_rec.emitter);
-                const f3 le = si2.wi.z > 0.0f ? mk3(e.r, e.g, e.b) : mk3(0.0f, 0.0f, 0.0f);
-                f3 dd = si2.p - si.p;
-                const float dist = sqrtf(sqnorm(dd));
-                dd = div_s(dd, dist);
-                const float pe = delta ? 0.0f : pdf_emitter_direction(sv.n_emitters, e.area_norm, dd, si2.sh.n, dist);
+                f3 le; float pe;
+                if (!traverse<FLAT, false>(sv, lds, si.p, d2, (1.0f + hmax_abs(si.p)) * kRayEpsilon, __builtin_inff(), h2, c.tri_tests)) {
+                    if (sv.env_emitter < 0) continue;
+                    const DevEmitter e = geo.emitter((uint32_t) sv.env_emitter);
+                    le = mk3(e.r, e.g, e.b);
+                    pe = delta ? 0.0f : pdf_environment(sv.n_emitters);
+                } else {
+                    SurfaceInteraction si2;
+                    fill_si(geo, d2, h2.prim, h2.u, h2.v, si2);
+                    if (si2.shape_rec.emitter < 0) continue;
+                    const DevEmitter e = geo.emitter((uint32_t) si2.shape_rec.emitter);
+                    le = si2.wi.z > 0.0f ? mk3(e.r, e.g, e.b) : mk3(0.0f, 0.0f, 0.0f);
+                    f3 dd = si2.p - si.p;
+                    const float dist = sqrtf(sqnorm(dd));
+                    dd = div_s(dd, dist);
+                    pe = delta ? 0.0f : pdf_emitter_direction(sv.n_emitters, e.area_norm, dd, si2.sh.n, dist);
+                }
                 const float w = mis_weight(pdf * frac_bsdf, pe * frac_lum) * weight_bsdf;
                 s.res = mk3(s.res.x + (weight.x * le.x) * w, s.res.y + (weight.y * le.y) * w, s.res.z + (weight.z * le.z) * w);
             }

@@ -441,9 +441,10 @@ class Scene:
         self._texture_shapes = [t.shape for t in tex]
         ed = (L.EmitterDesc * max(len(emitters), 1))()
         for i, e in enumerate(emitters):
-            if e.get("type", "area") != "area":
-                raise RuntimeError("Emitter plugin '%s' is not supported by this backend (area only)" % e.get("type"))
-            ed[i].type = 0
+            et = e.get("type", "area")
+            if et not in ("area", "constant"):
+                raise RuntimeError("Emitter plugin '%s' is not supported by this backend (area, constant)" % et)
+            ed[i].type = 0 if et == "area" else 1
             ed[i].radiance = (C.c_float * 3)(*[float(x) for x in e["radiance"]])
         sd = L.SceneDesc(md, len(meshes), bd, len(bsdfs), ed, len(emitters), td, len(tex), 0, None)
         if variant == "spectral":

@@ -522,6 +522,37 @@ def _sensor(ctx, node):
     return out
 
 
+def _integrator(ctx, it):
+    if it.type == "path":
+        out = dict(type="path", max_depth=it.get("max_depth", -1, "int"), rr_depth=it.get("rr_depth", 5, "int"))
+    elif it.type == "direct":
+        out = dict(type="direct", hide_emitters=it.get("hide_emitters", False, "bool"))
+        for k in ("shading_samples", "emitter_samples", "bsdf_samples"):
+            if k in it.props:
+                out[k] = it.get(k, kind="int")
+    elif it.type == "depth":
+        out = dict(type="depth")
+    elif it.type == "moment":                            # moment.cpp:36-55: nested sampling integrators, named by their property name
+        nested = [(k, _resolve(ctx, v)) for k, v in it.props.items()] + [("integrator_%d" % i, _resolve(ctx, c)) for i, c in enumerate(it.children)]
+        for k, _ in nested:
+            it.queried.add(k)
+        nested = [(k, v) for k, v in nested if isinstance(v, Node)]
+        if len(nested) != 1 or nested[0][1].tag != "integrator":
+            raise XMLError("moment: exactly one nested integrator is supported by this backend")
+        out = dict(type="moment", name=nested[0][0], nested=_integrator(ctx, nested[0][1]))
+    else:
+        raise XMLError('Integrator plugin "%s" is not supported by this backend (path, direct, depth, moment)' % it.type)
+    return out
+
+
+def _make_integrator(spec):
+    from . import render as R
+    args = {k: v for k, v in spec.items() if k not in ("type", "nested", "name")}
+    if spec.get("type") == "moment":
+        return R.MomentIntegrator(_make_integrator(spec["nested"]), spec.get("name", "nested"))
+    return {"path": R.PathIntegrator, "direct": R.DirectIntegrator, "depth": R.DepthIntegrator}[spec.get("type", "path")](**args)
+
+
 def _instantiate(ctx, root, base_dir):
     if root.tag != "scene":
         raise XMLError('root element "%s" must be a scene in this backend' % root.tag)
@@ -539,22 +570,16 @@ def _instantiate(ctx, root, base_dir):
         elif it.tag == "sensor":
             desc.sensors.append(_sensor(ctx, it))
         elif it.tag == "integrator":
-            if it.type == "path":
-                desc.integrator = dict(type="path", max_depth=it.get("max_depth", -1, "int"), rr_depth=it.get("rr_depth", 5, "int"))
-            elif it.type == "direct":
-                desc.integrator = dict(type="direct", hide_emitters=it.get("hide_emitters", False, "bool"))
-                for k in ("shading_samples", "emitter_samples", "bsdf_samples"):
-                    if k in it.props:
-                        desc.integrator[k] = it.get(k, kind="int")
-            elif it.type == "depth":
-                desc.integrator = dict(type="depth")
-            else:
-                raise XMLError('Integrator plugin "%s" is not supported by this backend (path, direct, depth)' % it.type)
+            desc.integrator = _integrator(ctx, it)
             it.check_unqueried()
         elif it.tag == "texture":
             continue                                 # instantiated where referenced
         elif it.tag == "emitter":
-            raise XMLError('Emitter plugin "%s" is not supported by this backend (area emitters attached to shapes only)' % it.type)
+            if it.type != "constant":
+                raise XMLError('Emitter plugin "%s" is not supported by this backend (area emitters attached to shapes, constant)' % it.type)
+            rad = _colour(_resolve(ctx, it.get("radiance", ("spectrum", 1.0))), "constant.radiance", True)
+            it.check_unqueried()
+            desc.scene_dict["emitters"].append(dict(type="constant", radiance=rad))
         else:
             raise XMLError('scene: unsupported child "%s"' % it.tag)
     return desc
@@ -596,10 +621,7 @@ def instantiate(desc, device=0, variant="rgb"):
         sampler = R.IndependentSampler(s["sampler"]["sample_count"], s["sampler"]["seed"])
         sensors.append(R.PerspectiveCamera(to_world=s["to_world"], fov=s["fov"], focal_length=s["focal_length"], fov_axis=s["fov_axis"],
                                            near_clip=s["near_clip"], far_clip=s["far_clip"], film=film, sampler=sampler))
-    integ = None
-    if desc.integrator is not None:
-        args = {k: v for k, v in desc.integrator.items() if k != "type"}
-        integ = {"path": R.PathIntegrator, "direct": R.DirectIntegrator, "depth": R.DepthIntegrator}[desc.integrator.get("type", "path")](**args)
+    integ = _make_integrator(desc.integrator) if desc.integrator is not None else None
     scene = R.Scene(desc.scene_dict, device=device, integrator=integ, variant=variant)
     scene._sensors = sensors
     return scene
@@ -617,7 +639,7 @@ def load_file(path, device=0, variant="rgb", **params):
 
 # -------------------------------------------------------------------------------------------- load_dict
 _PLUGIN_CLASS = {"twosided": "bsdf", "conductor": "bsdf", "roughconductor": "bsdf", "dielectric": "bsdf", "plastic": "bsdf", "path": "integrator", "perspective": "sensor", "hdrfilm": "film", "independent": "sampler", "gaussian": "rfilter", "box": "rfilter",
-                 "direct": "integrator", "depth": "integrator", "obj": "shape", "ply": "shape", "rectangle": "shape", "diffuse": "bsdf", "area": "emitter", "bitmap": "texture", "scene": "scene"}
+                 "direct": "integrator", "depth": "integrator", "moment": "integrator", "obj": "shape", "ply": "shape", "rectangle": "shape", "diffuse": "bsdf", "area": "emitter", "constant": "emitter", "bitmap": "texture", "scene": "scene"}
 
 
 def _node_from_dict(d, ctx):

@@ -22,6 +22,11 @@ int mo_scene_add_mesh(mo_scene *s, uint32_t n_verts, const float *positions,
                       const float *normals, const float *texcoords, uint32_t n_faces,
                       const uint32_t *faces, int bsdf_kind, const float *reflectance_rgb,
                       const float *emitter_rgb);
+/* `constant` environment emitter (src/emitters/constant.cpp); RGB variant only.  Returns the emitter index. */
+int mo_scene_add_constant_emitter(mo_scene *s, const float *radiance_rgb);
+/* Re-orders the emitter list: new emitter i = old emitter order[i] (Scene::m_emitters follows the order of the scene's
+ * children, scene.cpp:31-56). */
+int mo_scene_set_emitter_order(mo_scene *s, uint32_t n, const uint32_t *order);
 /* Bitmap texture (src/textures/bitmap.cpp, linear RGB data, identity to_uv): returns its index.  A texture is
  * attached to the reflectance of a shape's diffuse BSDF with mo_scene_set_texture (-1 detaches). */
 int mo_scene_add_texture(mo_scene *s, int width, int height, const float *rgb);

@@ -31,7 +31,9 @@ typedef struct {
     float *area_pmf, *area_cdf; float area_sum, area_norm; uint32_t valid_lo, valid_hi;
 } mo_mesh;
 
-typedef struct { uint32_t shape; float radiance[3]; float coeff[3], d65_scale; } mo_emitter;
+/* type 0: `area` (src/emitters/area.cpp) attached to `shape`; type 1: `constant` environment (src/emitters/constant.cpp)
+ * with the scene's bounding sphere (set_scene, constant.cpp:47-51) */
+typedef struct { uint32_t shape; float radiance[3]; float coeff[3], d65_scale; int type; mo_v3 center; float radius; } mo_emitter;
 typedef struct { int w, h; float *data; } mo_texture;
 typedef struct { double lo[3], hi[3]; uint32_t left, right, first, count; } mo_bvh_node;
 
@@ -42,6 +44,7 @@ struct mo_scene {
     uint32_t n_prims; uint32_t *prim_shape, *prim_local;
     mo_bvh_node *bvh_nodes; uint32_t n_bvh_nodes; uint32_t *bvh_prims;
     double scene_extent; int force_naive;
+    int environment;                /* index of the environment emitter or -1 (scene.cpp:44-48) */
     int spectral;                   /* 0: RGB variant, 1: spectral variant (4 wavelengths) */
 };
 

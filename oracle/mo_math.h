@@ -40,6 +40,8 @@ typedef struct { float x, y; } mo_v2;
 
 /* include/mitsuba/core/math.h:17-38 */
 #define MO_PI          3.14159265358979323846f
+#define MO_INV_FOUR_PI 0.07957747154594766788f
+#define MO_PI_F 3.14159265358979323846f
 #define MO_INV_PI      0.31830988618379067154f
 #define MO_EPSILON     (1.1920928955078125e-07f / 2.0f)
 #define MO_RAY_EPSILON (MO_EPSILON * 1500.0f)

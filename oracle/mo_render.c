@@ -351,6 +351,7 @@ static int scene_intersect(const mo_scene *s, const mo_ray *ray, mo_si *si, ray_
     mo_hit h;
     st->closest++;
     if (mo_intersect(s, ray, 0, 0, &h)) { mo_make_si(s, ray, &h, si); return 1; }
+    memset(si, 0, sizeof(*si));
     si->t = INFINITY;
     si->wi = mo_neg(ray->d);
     return 0;
@@ -366,14 +367,14 @@ static void path_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, 
     mo_si si;
     int si_valid = scene_intersect(s, &ray, &si, st);
     *valid_ray = si_valid;
-    int emitter = si_valid ? s->meshes[si.shape].emitter : -1;
+    int emitter = si_valid ? s->meshes[si.shape].emitter : s->environment;     /* si.emitter(scene): interaction.h:236-243 */
     int active = 1;
 
     for (int depth = 1;; ++depth) {
         /* ---------------- Intersection with emitters ---------------- */
         if (emitter >= 0 && active) {
-            /* AreaLight::eval (area.cpp:71-79) */
-            if (si.wi.z > 0.0f) {
+            /* AreaLight::eval (area.cpp:71-79); ConstantBackgroundEmitter::eval (constant.cpp:53-57) */
+            if (s->emitters[emitter].type == 1 || si.wi.z > 0.0f) {
                 const float *le = s->emitters[emitter].radiance;
                 for (int k = 0; k < 3; ++k) result[k] += (emission_weight * throughput[k]) * le[k];
             }
@@ -435,12 +436,13 @@ static void path_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, 
         ray.maxt = INFINITY;
         mo_si si_bsdf;
         int v2 = scene_intersect(s, &ray, &si_bsdf, st);
-        emitter = v2 ? s->meshes[si_bsdf.shape].emitter : -1;
+        emitter = v2 ? s->meshes[si_bsdf.shape].emitter : s->environment;
         if (emitter >= 0) {
-            /* DirectionSample(si_bsdf, si) (records.h:168-174) */
+            /* DirectionSample(si_bsdf, si) (records.h:168-174); d = -wi for environment emitters */
             mo_v3 d = mo_sub(si_bsdf.p, si.p);
             float dist = mo_norm(d);
             d = mo_div_s(d, dist);
+            if (!v2) { d = mo_neg(si_bsdf.wi); dist = 0.0f; si_bsdf.sh.n = d; }
             /* delta lobes cannot be hit by emitter sampling (path.cpp:198-203) */
             float emitter_pdf = bs.delta ? 0.0f : mo_pdf_emitter_direction(s, (uint32_t) emitter, d, si_bsdf.sh.n, dist);
             emission_weight = mis_weight(bs.pdf, emitter_pdf);
@@ -460,7 +462,10 @@ static void direct_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray, i
     mo_si si;
     int valid = scene_intersect(s, ray, &si, st);
     *valid_ray = valid;
-    if (!valid) return;
+    if (!valid) {                                                                              /* environment seen directly */
+        if (!hide_emitters && s->environment >= 0) for (int k = 0; k < 3; ++k) result[k] += s->emitters[s->environment].radiance[k];
+        return;
+    }
     const mo_mesh *mesh = &s->meshes[si.shape];
     if (!hide_emitters && mesh->emitter >= 0 && si.wi.z > 0.0f)                                /* visible emitters (direct.cpp:117-121) */
         for (int k = 0; k < 3; ++k) result[k] += s->emitters[mesh->emitter].radiance[k];
@@ -499,14 +504,15 @@ static void direct_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray, i
         r2.o = si.p; r2.d = mo_to_world(&si.sh, bs.wo);
         r2.mint = (1.0f + mo_hmax_abs(si.p)) * MO_RAY_EPSILON; r2.maxt = INFINITY;
         mo_si si_bsdf;
-        if (!scene_intersect(s, &r2, &si_bsdf, st)) continue;
-        int emitter = s->meshes[si_bsdf.shape].emitter;
+        int v2 = scene_intersect(s, &r2, &si_bsdf, st);
+        int emitter = v2 ? s->meshes[si_bsdf.shape].emitter : s->environment;
         if (emitter < 0) continue;
         float emitter_val[3] = { 0.0f, 0.0f, 0.0f };
-        if (si_bsdf.wi.z > 0.0f) for (int k = 0; k < 3; ++k) emitter_val[k] = s->emitters[emitter].radiance[k];
+        if (!v2 || si_bsdf.wi.z > 0.0f) for (int k = 0; k < 3; ++k) emitter_val[k] = s->emitters[emitter].radiance[k];
         mo_v3 d = mo_sub(si_bsdf.p, si.p);
         float dist = mo_norm(d);
         d = mo_div_s(d, dist);
+        if (!v2) { d = mo_neg(si_bsdf.wi); dist = 0.0f; si_bsdf.sh.n = d; }
         float emitter_pdf = bs.delta ? 0.0f : mo_pdf_emitter_direction(s, (uint32_t) emitter, d, si_bsdf.sh.n, dist);
         float w = mis_weight(bs.pdf * frac_bsdf, emitter_pdf * frac_lum) * weight_bsdf;
         for (int k = 0; k < 3; ++k) result[k] += (bsdf_val[k] * emitter_val[k]) * w;

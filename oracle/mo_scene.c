@@ -27,6 +27,7 @@
 /* ------------------------------------------------------------------ */
 mo_scene *mo_scene_new(void) {
     mo_scene *s = (mo_scene *) calloc(1, sizeof(mo_scene));
+    if (s) s->environment = -1;
     return s;
 }
 
@@ -77,11 +78,36 @@ int mo_scene_add_mesh(mo_scene *s, uint32_t n_verts, const float *positions, con
     if (emitter_rgb) {
         s->emitters = (mo_emitter *) realloc(s->emitters, sizeof(mo_emitter) * (s->n_emitters + 1));
         mo_emitter *e = &s->emitters[s->n_emitters];
+        memset(e, 0, sizeof(*e));
         e->shape = s->n_meshes;
         for (int k = 0; k < 3; ++k) e->radiance[k] = emitter_rgb[k];
         m->emitter = (int) s->n_emitters++;
     }
     return (int) s->n_meshes++;
+}
+
+int mo_scene_add_constant_emitter(mo_scene *s, const float *rgb) {
+    if (!s || !rgb || s->environment >= 0) return -1;        /* "Only one environment emitter can be specified per scene." */
+    s->emitters = (mo_emitter *) realloc(s->emitters, sizeof(mo_emitter) * (s->n_emitters + 1));
+    mo_emitter *e = &s->emitters[s->n_emitters];
+    memset(e, 0, sizeof(*e));
+    e->type = 1; e->shape = 0xffffffffu;
+    for (int k = 0; k < 3; ++k) e->radiance[k] = rgb[k];
+    e->radius = 1.0f;                                        /* unit sphere until set_scene (constant.cpp:40-42) */
+    s->environment = (int) s->n_emitters;
+    return (int) s->n_emitters++;
+}
+int mo_scene_set_emitter_order(mo_scene *s, uint32_t n, const uint32_t *order) {
+    if (!s || n != s->n_emitters) return -1;
+    mo_emitter *ne = (mo_emitter *) malloc(sizeof(mo_emitter) * (n ? n : 1));
+    for (uint32_t i = 0; i < n; ++i) { if (order[i] >= n) { free(ne); return -1; } ne[i] = s->emitters[order[i]]; }
+    free(s->emitters); s->emitters = ne;
+    s->environment = -1;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (ne[i].type == 1) s->environment = (int) i;
+        else s->meshes[ne[i].shape].emitter = (int) i;
+    }
+    return 0;
 }
 
 int mo_scene_add_texture(mo_scene *s, int width, int height, const float *rgb) {
@@ -299,6 +325,16 @@ int mo_scene_finalize(mo_scene *s) {
     for (uint32_t i = 0; i < total; ++i) s->bvh_prims[i] = i;
     s->n_bvh_nodes = 0;
     bvh_build(s, 0, total);
+    /* ConstantBackgroundEmitter::set_scene (constant.cpp:47-51): bounding sphere of the scene's bounding box
+     * (bbox.h:329-332), radius * (1 + RayEpsilon) */
+    for (uint32_t i = 0; i < s->n_emitters; ++i) {
+        mo_emitter *e = &s->emitters[i];
+        if (e->type != 1) continue;
+        mo_v3 mn = mo_v3_make((float) lo[0], (float) lo[1], (float) lo[2]), mx = mo_v3_make((float) hi[0], (float) hi[1], (float) hi[2]);
+        e->center = mo_scale(mo_add(mx, mn), 0.5f);
+        float r = mo_norm(mo_sub(e->center, mx));
+        e->radius = fmaxf(MO_RAY_EPSILON, r * (1.0f + MO_RAY_EPSILON));
+    }
     return 0;
 }
 
@@ -476,6 +512,21 @@ void mo_sample_emitter_direction(const mo_scene *s, mo_v3 ref_p, mo_v2 sample, m
         sample.x = (sample.x - (float) index * emitter_pdf) * nf;
     }
     const mo_emitter *e = &s->emitters[index];
+    int active;
+    if (e->type == 1) {
+        /* ConstantBackgroundEmitter::sample_direction (constant.cpp:82-107); square_to_uniform_sphere (warp.h:262-267) */
+        float z = fmaf(-2.0f, sample.y, 1.0f), r = mo_safe_sqrt(fmaf(-z, z, 1.0f));
+        float ang = 2.0f * MO_PI_F * sample.x;
+        mo_v3 d = mo_v3_make(r * cosf(ang), r * sinf(ang), z);
+        ds->dist = 2.0f * e->radius;
+        ds->p = mo_add(ref_p, mo_scale(d, ds->dist));
+        ds->n = mo_neg(d);
+        ds->pdf = MO_INV_FOUR_PI;
+        ds->d = d;
+        ds->emitter = index;
+        ds->pdf_single = ds->pdf;
+        active = 1;
+    } else {
     const mo_mesh *m = &s->meshes[e->shape];
     mesh_sample_position(m, sample, &ds->p, &ds->n, &ds->pdf);
     ds->d = mo_sub(ds->p, ref_p);
@@ -486,7 +537,8 @@ void mo_sample_emitter_direction(const mo_scene *s, mo_v3 ref_p, mo_v2 sample, m
     ds->pdf *= (dp != 0.0f) ? dist_squared / dp : 0.0f;
     ds->emitter = index;
     ds->pdf_single = ds->pdf;
-    int active = (mo_dot(ds->d, ds->n) < 0.0f) && (ds->pdf != 0.0f);
+    active = (mo_dot(ds->d, ds->n) < 0.0f) && (ds->pdf != 0.0f);
+    }
     if (active) {
         float r = mo_rcp(ds->pdf);
         for (int k = 0; k < 3; ++k) spec[k] = e->radiance[k] * r;
@@ -500,6 +552,11 @@ void mo_sample_emitter_direction(const mo_scene *s, mo_v3 ref_p, mo_v2 sample, m
 
 /* scene.cpp:191-206; area.cpp:119-125; shape.cpp:272-283 */
 float mo_pdf_emitter_direction(const mo_scene *s, uint32_t emitter, mo_v3 d, mo_v3 n, float dist) {
+    if (s->emitters[emitter].type == 1) {                    /* constant.cpp:109-114 */
+        float pdf = MO_INV_FOUR_PI;
+        if (s->n_emitters > 1) pdf *= 1.0f / (float) s->n_emitters;
+        return pdf;
+    }
     const mo_mesh *m = &s->meshes[s->emitters[emitter].shape];
     float pdf = 0.0f;
     if (mo_dot(d, n) < 0.0f) {

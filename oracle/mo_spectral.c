@@ -108,6 +108,7 @@ static void model_fetch(const coeff_table *t, const float c[3], float out[3]) {
 }
 
 int mo_scene_set_spectral(mo_scene *s, const char *coeff_path) {
+    if (s && s->environment >= 0) return -5;      /* the constant emitter is restated for the RGB variant only */
     coeff_table t = { 0, NULL, NULL };
     if (!s || table_load(coeff_path, &t)) return -1;
     for (uint32_t i = 0; i < s->n_meshes; ++i) {

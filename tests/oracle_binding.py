@@ -104,6 +104,8 @@ def lib():
         L.mo_kat_sample_emitter.argtypes = [vp] * 4
         L.mo_scene_set_spectral.argtypes = [vp, C.c_char_p]
         L.mo_scene_set_bsdf.argtypes = [vp, C.c_uint32, C.POINTER(BsdfDesc)]
+        L.mo_scene_add_constant_emitter.argtypes = [vp, f32p]
+        L.mo_scene_set_emitter_order.argtypes = [vp, C.c_uint32, vp]
         L.mo_kat_fresnel.argtypes = [C.c_float, C.c_float, vp]
         L.mo_kat_fresnel_conductor.argtypes = [C.c_float] * 3
         L.mo_kat_fresnel_conductor.restype = C.c_float
@@ -157,6 +159,17 @@ class OracleScene:
                 assert L.mo_scene_set_bsdf(self.h, rc, C.byref(bd)) == 0
             if m["bsdf"] in self.tex_of_bsdf:
                 assert L.mo_scene_set_texture(self.h, rc, self.tex_of_bsdf[m["bsdf"]]) == 0
+        # emitter order = the scene dictionary's (Scene::m_emitters follows the scene description, scene.cpp:31-56)
+        emitters = scene_dict.get("emitters", [])
+        created = [m["emitter"] for m in scene_dict["meshes"] if m.get("emitter", -1) >= 0]      # dict index of oracle emitter k
+        for ei, e in enumerate(emitters):
+            if e.get("type", "area") == "constant":
+                rad = _f(e["radiance"])
+                assert L.mo_scene_add_constant_emitter(self.h, rad.ctypes.data_as(f32p)) == len(created)
+                created.append(ei)
+        if created != list(range(len(created))):
+            order = np.array([created.index(i) for i in range(len(created))], dtype=np.uint32)
+            assert L.mo_scene_set_emitter_order(self.h, len(created), _p(order)) == 0
         assert L.mo_scene_finalize(self.h) == 0
         L.mo_scene_set_naive(self.h, 1 if naive else 0)
         if spectral_path is not None:

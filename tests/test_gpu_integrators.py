@@ -1,6 +1,7 @@
 """`direct` and `depth` integrators on the GPU against the oracle, sample by sample (same PCG32 streams)."""
 import numpy as np
 import pytest
+import torch
 
 import oracle_binding as ob
 
@@ -93,3 +94,53 @@ def test_moment_integrator_and_z_test():
     assert ok, (p_min, alpha)
     bad, _, _ = testing.accept(mean * 1.05, 256, ref_mean, ref_var)      # a 5 % bias is detected
     assert not bad
+
+
+def _open_scene(with_area):
+    """the Cornell box without ceiling and back wall under a `constant` environment (optionally keeping the area light)"""
+    from mitsuba2_amd import scenes
+    cb = scenes.cornell_box()
+    keep = [i for i, m in enumerate(cb["meshes"]) if i not in (1, 2) and (with_area or m.get("emitter", -1) < 0)]
+    cb["meshes"] = [dict(cb["meshes"][i]) for i in keep]
+    cb["bsdfs"] = list(cb["bsdfs"]) + [{"type": "roughconductor", "alpha": 0.2, "distribution": "ggx", "eta": 0.0, "k": 1.0}, {"type": "dielectric"}]
+    cb["meshes"][-1]["bsdf"] = len(cb["bsdfs"]) - 2
+    cb["meshes"][-2]["bsdf"] = len(cb["bsdfs"]) - 1
+    if with_area:
+        cb["emitters"] = [{"type": "constant", "radiance": [0.4, 0.6, 1.0]}] + list(cb["emitters"])     # environment first: index 0
+        for m in cb["meshes"]:
+            if m.get("emitter", -1) >= 0:
+                m["emitter"] = 1
+    else:
+        cb["emitters"] = [{"type": "constant", "radiance": [0.4, 0.6, 1.0]}]
+    return cb
+
+
+@pytest.mark.parametrize("with_area", [False, True])
+@pytest.mark.parametrize("integrator", ["path", "direct"])
+def test_constant_emitter_matches_oracle(with_area, integrator):
+    """src/emitters/constant.cpp through path and direct: escaped rays see the environment, emitter sampling picks it with
+    probability 1 / #emitters, MIS against BSDF sampling"""
+    from mitsuba2_amd import render as R, scenes
+    cb = _open_scene(with_area)
+    sp = dict(scenes.cornell_box_sensor(64, 64, spp=4, seed=8), max_depth=5)
+    scene, sensor = R.Scene(cb), R.make_sensor(sp)
+    integ = R.PathIntegrator(max_depth=5) if integrator == "path" else R.DirectIntegrator(shading_samples=2)
+    n = 64 * 64 * 4
+    rgb, mask, pos = integ.sample(scene, sensor, 0, n)
+    op = dict(sp, integrator=integrator, emitter_samples=2 if integrator == "direct" else 0, bsdf_samples=2 if integrator == "direct" else 0)
+    want, wpos = ob.OracleScene(cb).sample_radiance(ob.make_desc(op), 0, n)
+    assert np.array_equal(pos.cpu().numpy(), wpos) and np.array_equal(mask.cpu().numpy(), want[:, 3] > 0.5)
+    assert (~mask.cpu().numpy()).any() and (rgb.cpu().numpy()[~mask.cpu().numpy()] == np.float32([0.4, 0.6, 1.0])).all()
+    close = np.isclose(rgb.cpu().numpy(), want[:, :3], rtol=5e-3, atol=1e-4).all(1)
+    assert close.mean() > 0.995, close.mean()
+    if integrator == "path":
+        a, _, _ = R.PathIntegrator(max_depth=5, pipeline=2).sample(scene, sensor, 0, n)
+        assert torch.equal(a, rgb)
+
+
+def test_constant_emitter_restrictions():
+    from mitsuba2_amd import render as R
+    cb = _open_scene(False)
+    cb["emitters"] = cb["emitters"] * 2
+    with pytest.raises(RuntimeError, match="Only one environment emitter"):
+        R.Scene(cb)
