@@ -257,8 +257,9 @@ void mtsamd_scene_destroy(mtsamd_scene *s) {
 int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene **out) {
     if (!desc || !out) return fail(MTSAMD_ERR_INVALID, "mtsamd_scene_create: null argument");
     *out = nullptr;
-    if (desc->mesh_count == 0 || !desc->meshes) return fail(MTSAMD_ERR_INVALID, "scene has no shapes");
-    if (desc->bsdf_count == 0 || !desc->bsdfs) return fail(MTSAMD_ERR_INVALID, "scene has no BSDFs");
+    // an empty scene is valid (it renders to zeros: scenes.py:262-267 of the reference's integrator tests)
+    if (desc->mesh_count > 0 && !desc->meshes) return fail(MTSAMD_ERR_INVALID, "scene has no shapes");
+    if (desc->mesh_count > 0 && (desc->bsdf_count == 0 || !desc->bsdfs)) return fail(MTSAMD_ERR_INVALID, "scene has no BSDFs");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(MTSAMD_ERR_INVALID, "invalid device index %d (have %d)", device, ndev);
@@ -430,7 +431,8 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     }
 
     // ---- accelerator -------------------------------------------------------------------------
-    build_bvh(tri_pos.data(), s->n_prims, 4, s->bvh);
+    if (s->n_prims > 0) build_bvh(tri_pos.data(), s->n_prims, 4, s->bvh);
+    else { s->bvh = BvhOutput{}; s->bvh.root = 0x80000000u; }       // a leaf with no triangles
     if (s->environment >= 0) {       // ConstantBackgroundEmitter::set_scene (constant.cpp:47-51): bounding sphere of Scene::bbox()
         DevEmitter &e = s->emitters[s->environment];
         std::memset(&e, 0, sizeof(e));
@@ -555,8 +557,9 @@ int mtsamd_scene_set_emitter_radiance(mtsamd_scene *s, uint32_t emitter, const f
 }
 
 // ---- scene queries -------------------------------------------------------------------------
-static int check_rays(const mtsamd_scene *s, const mtsamd_rays *r) {
+static int check_rays(const mtsamd_scene *s, const mtsamd_rays *r, uint64_t n) {
     if (!s || !r) return fail(MTSAMD_ERR_INVALID, "null argument");
+    if (n == 0) return 1;               // empty ray stream: nothing to do (pointers may be null)
     if (!r->ox || !r->oy || !r->oz || !r->dx || !r->dy || !r->dz || !r->mint || !r->maxt)
         return fail(MTSAMD_ERR_INVALID, "ray stream has a null component");
     return 0;
@@ -567,7 +570,7 @@ static RayStreams to_streams(const mtsamd_rays *r) {
 
 int mtsamd_ray_intersect(const mtsamd_scene *s, uint64_t n, const mtsamd_rays *rays, float *t, uint32_t *prim,
                          uint32_t *shape, float *u, float *v, void *stream) {
-    if (int rc = check_rays(s, rays)) return rc;
+    if (int rc = check_rays(s, rays, n)) return rc > 0 ? MTSAMD_OK : rc;
     if (!t || !prim) return fail(MTSAMD_ERR_INVALID, "t and prim outputs are required");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(launch_ray_intersect(s->view, n, to_streams(rays), 0, t, prim, shape, u, v, nullptr, (hipStream_t) stream));
@@ -576,7 +579,7 @@ int mtsamd_ray_intersect(const mtsamd_scene *s, uint64_t n, const mtsamd_rays *r
 
 int mtsamd_ray_intersect_naive(const mtsamd_scene *s, uint64_t n, const mtsamd_rays *rays, float *t, uint32_t *prim,
                                uint32_t *shape, float *u, float *v, void *stream) {
-    if (int rc = check_rays(s, rays)) return rc;
+    if (int rc = check_rays(s, rays, n)) return rc > 0 ? MTSAMD_OK : rc;
     if (!t || !prim) return fail(MTSAMD_ERR_INVALID, "t and prim outputs are required");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(launch_ray_intersect(s->view, n, to_streams(rays), 1, t, prim, shape, u, v, nullptr, (hipStream_t) stream));
@@ -585,7 +588,7 @@ int mtsamd_ray_intersect_naive(const mtsamd_scene *s, uint64_t n, const mtsamd_r
 
 int mtsamd_ray_intersect_si(const mtsamd_scene *s, uint64_t n, const mtsamd_rays *rays, float *t, uint32_t *prim,
                             uint32_t *shape, float *si26, void *stream) {
-    if (int rc = check_rays(s, rays)) return rc;
+    if (int rc = check_rays(s, rays, n)) return rc > 0 ? MTSAMD_OK : rc;
     if (!t || !prim || !si26) return fail(MTSAMD_ERR_INVALID, "t, prim and si26 outputs are required");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(launch_ray_intersect(s->view, n, to_streams(rays), 0, t, prim, shape, nullptr, nullptr, si26, (hipStream_t) stream));
@@ -593,7 +596,7 @@ int mtsamd_ray_intersect_si(const mtsamd_scene *s, uint64_t n, const mtsamd_rays
 }
 
 int mtsamd_ray_test(const mtsamd_scene *s, uint64_t n, const mtsamd_rays *rays, uint8_t *hit, void *stream) {
-    if (int rc = check_rays(s, rays)) return rc;
+    if (int rc = check_rays(s, rays, n)) return rc > 0 ? MTSAMD_OK : rc;
     if (!hit) return fail(MTSAMD_ERR_INVALID, "hit output is required");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(launch_ray_test(s->view, n, to_streams(rays), hit, (hipStream_t) stream));

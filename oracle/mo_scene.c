@@ -284,7 +284,8 @@ static uint32_t bvh_build(mo_scene *s, uint32_t first, uint32_t count) {
 }
 
 int mo_scene_finalize(mo_scene *s) {
-    if (!s || s->n_meshes == 0) return -1;
+    if (!s) return -1;
+    if (s->n_meshes == 0) { s->n_prims = 0; return 0; }      /* empty scene: every ray escapes */
     uint32_t total = 0;
     for (uint32_t i = 0; i < s->n_meshes; ++i) { s->meshes[i].prim_offset = total; total += s->meshes[i].n_faces; }
     s->n_prims = total;
@@ -421,6 +422,7 @@ static int intersect_bvh(const mo_scene *s, const mo_ray *ray, int shadow, mo_hi
 int mo_intersect(const mo_scene *s, const mo_ray *ray, int shadow, int naive, mo_hit *hit) {
     mo_hit tmp;
     if (!hit) hit = &tmp;
+    if (s->n_prims == 0) return 0;
     if (naive || s->force_naive) return intersect_naive(s, ray, shadow, hit);
     return intersect_bvh(s, ray, shadow, hit);
 }

@@ -1,0 +1,72 @@
+"""Edge cases of the hot path: empty scene (the reference's integrator smoke test renders it to zeros, scenes.py:262-267),
+empty ray streams, scenes without emitters, degenerate triangles, 1 x 1 and odd-sized films, crop windows."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+def test_empty_scene_renders_zero():
+    from mitsuba2_amd import render as R, scenes
+    sd = dict(meshes=[], bsdfs=[], emitters=[])
+    scene = R.Scene(sd)
+    sensor = R.make_sensor(scenes.cornell_box_sensor(24, 17, spp=3, seed=1))
+    for integ in (R.PathIntegrator(), R.DirectIntegrator(), R.DepthIntegrator(), R.PathIntegrator(pipeline=2)):
+        assert integ.render(scene, sensor)
+        raw = sensor.film().bitmap(raw=True).cpu().numpy()
+        assert (raw[..., :4] == 0).all() and (raw[..., 4] > 0).all()
+        assert (sensor.film().bitmap().cpu().numpy() == 0).all()
+    o = torch.zeros((5, 3), device="cuda"); d = torch.tensor([[0.0, 0, 1]] * 5, device="cuda")
+    si = scene.ray_intersect(R.Ray3f(o=o, d=d))
+    assert not si.is_valid().any() and torch.isinf(si.t).all() and not scene.ray_test(R.Ray3f(o=o, d=d)).any()
+    film, _ = ob.OracleScene(sd).render(ob.make_desc(scenes.cornell_box_sensor(24, 17, spp=3, seed=1)), mode=1)
+    assert np.allclose(film, raw, rtol=1e-6, atol=0)        # weights: same taps, different summation order
+
+
+def test_empty_ray_stream():
+    from mitsuba2_amd import render as R, scenes
+    scene = R.Scene(scenes.cornell_box())
+    ray = R.Ray3f(o=torch.zeros((0, 3), device="cuda"), d=torch.zeros((0, 3), device="cuda"))
+    assert scene.ray_intersect(ray).t.shape == (0,) and scene.ray_test(ray).shape == (0,) and scene.ray_intersect_naive(ray).t.shape == (0,)
+
+
+@pytest.mark.parametrize("size,crop,spp", [((1, 1), None, 1), ((1, 1), None, 7), ((3, 5), None, 2), ((37, 23), (5, 3, 19, 11), 3)])
+def test_small_and_cropped_films_match_oracle(size, crop, spp):
+    from mitsuba2_amd import render as R, scenes
+    cb = scenes.cornell_box()
+    sp = scenes.cornell_box_sensor(size[0], size[1], spp=spp, seed=6)
+    if crop is not None:
+        sp["crop"] = crop
+    scene, sensor = R.Scene(cb), R.make_sensor(sp)
+    assert R.PathIntegrator(max_depth=4).render(scene, sensor)
+    got = sensor.film().bitmap(raw=True).cpu().numpy()
+    want, _ = ob.OracleScene(cb).render(ob.make_desc(dict(sp, max_depth=4)), mode=1)
+    assert got.shape == want.shape
+    assert np.allclose(got, want, rtol=2e-3, atol=2e-4)
+    assert np.allclose(got[..., 4], want[..., 4], rtol=1e-6, atol=0)
+
+
+def test_no_emitters_and_degenerate_triangles():
+    from mitsuba2_amd import render as R, scenes
+    cb = scenes.cornell_box()
+    m = dict(cb["meshes"][0])
+    p = np.array(m["positions"], np.float32).reshape(-1, 3).copy()
+    p[1] = p[0]                                             # zero-area triangle: det = 0 -> never hit (mesh.h:195-221)
+    cb["meshes"][0] = dict(m, positions=p)
+    sp = scenes.cornell_box_sensor(32, 32, spp=4, seed=2)
+    scene, sensor = R.Scene(cb), R.make_sensor(sp)
+    assert R.PathIntegrator(max_depth=5).render(scene, sensor)
+    got = sensor.film().bitmap(raw=True).cpu().numpy()
+    want, _ = ob.OracleScene(cb).render(ob.make_desc(dict(sp, max_depth=5)), mode=1)
+    assert np.isfinite(got).all() and np.allclose(got, want, rtol=2e-3, atol=2e-4)
+    dark = scenes.cornell_box()
+    for mm in dark["meshes"]:
+        mm["emitter"] = -1
+    dark["emitters"] = []
+    scene = R.Scene(dark)
+    assert R.PathIntegrator().render(scene, sensor)
+    raw = sensor.film().bitmap(raw=True).cpu().numpy()
+    assert (raw[..., :3] == 0).all() and raw[..., 3].max() > 0

@@ -290,8 +290,8 @@ def test_empty_scene_and_parameter_errors(gpu):
         bad.render(scene, sensor)
     with pytest.raises(RuntimeError):
         gpu.HDRFilm(32, 32, (16, 16), (32, 32))                           # film.cpp:24-32
-    with pytest.raises(RuntimeError):
-        gpu.Scene(dict(meshes=[], bsdfs=[dict(type="diffuse", reflectance=[0.5] * 3)], emitters=[]))
+    empty = gpu.Scene(dict(meshes=[], bsdfs=[dict(type="diffuse", reflectance=[0.5] * 3)], emitters=[]))     # valid: renders to zeros
+    assert gpu.PathIntegrator().render(empty, sensor) and (sensor.film().bitmap().cpu().numpy() == 0).all()
 
 
 def test_parameter_update(gpu, oracle):
