@@ -77,6 +77,9 @@ typedef struct {
     int32_t distribution;      /* 0 = beckmann, 1 = ggx */
     int32_t sample_visible;    /* visible-normal sampling (default true) */
     int32_t nonlinear;         /* plastic.nonlinear */
+    int32_t uniform_mask;      /* spectral variant: bit 0 / 1 / 2 = reflectance / specular_reflectance / specular_transmittance is a
+                                  constant (`uniform` spectrum, xml.cpp:1069-1083) rather than an RGB colour (`srgb`, upsampled);
+                                  conductors need the same eta and k in all three channels (uniform) */
 } mtsamd_bsdf_desc;
 
 /* area: src/emitters/area.cpp (attached to a mesh); constant: src/emitters/constant.cpp (environment, RGB variant) */

@@ -26,7 +26,7 @@ class BsdfDesc(C.Structure):
     _fields_ = [("type", C.c_int32), ("reflectance", C.c_float * 3), ("texture", C.c_int32), ("twosided", C.c_int32),
                 ("specular_reflectance", C.c_float * 3), ("specular_transmittance", C.c_float * 3), ("eta", C.c_float * 3),
                 ("k", C.c_float * 3), ("int_ior", C.c_float), ("ext_ior", C.c_float), ("alpha_u", C.c_float), ("alpha_v", C.c_float),
-                ("distribution", C.c_int32), ("sample_visible", C.c_int32), ("nonlinear", C.c_int32)]
+                ("distribution", C.c_int32), ("sample_visible", C.c_int32), ("nonlinear", C.c_int32), ("uniform_mask", C.c_int32)]
 
 
 class EmitterDesc(C.Structure):

@@ -30,6 +30,14 @@ def lookup_ior(value, default):
     return IOR[name]
 
 
+def _is_uniform(v, default):
+    """True if the parameter is a constant (`<spectrum value="c"/>` / a float: a `uniform` texture in the spectral variant,
+    xml.cpp:1069-1083); False for an RGB colour (`srgb` texture, upsampled)"""
+    if v is None:
+        v = default
+    return isinstance(v, (int, float)) and not isinstance(v, bool)
+
+
 def _rgb(v, default):
     if v is None:
         v = default
@@ -68,13 +76,14 @@ def normalize(b):
     tid = TYPE_IDS[t]
     out = dict(type=tid, twosided=twosided, reflectance=[0.5, 0.5, 0.5], specular_reflectance=[1.0] * 3, specular_transmittance=[1.0] * 3,
                eta=[0.0] * 3, k=[1.0] * 3, int_ior=1.0, ext_ior=1.0, alpha_u=0.1, alpha_v=0.1, distribution=0, sample_visible=True,
-               nonlinear=False)
+               nonlinear=False, uniform_mask=0)
     if "id" in b:
         out["id"] = b["id"]
     known = {"type", "id"}
     if tid == DIFFUSE:
-        refl = b.get("reflectance", [0.5, 0.5, 0.5])
+        refl = b.get("reflectance", 0.5)                  # props.texture("reflectance", .5f): a uniform spectrum (diffuse.cpp:74)
         out["reflectance"] = refl if isinstance(refl, dict) else _rgb(refl, None)
+        out["uniform_mask"] |= 1 if _is_uniform(refl, None) else 0
         known |= {"reflectance"}
     if tid in (CONDUCTOR, ROUGHCONDUCTOR):
         material = b.get("material", "none" if tid == CONDUCTOR else ("none" if "eta" in b else "Cu"))
@@ -85,6 +94,7 @@ def normalize(b):
         else:
             raise RuntimeError('conductor material "%s": the measured IOR tables (data/ior/*.spd) are not shipped; specify eta and k' % material)
         out["specular_reflectance"] = _rgb(b.get("specular_reflectance"), 1.0)
+        out["uniform_mask"] |= 2 if _is_uniform(b.get("specular_reflectance"), 1.0) else 0
         known |= {"material", "eta", "k", "specular_reflectance"}
     if tid == ROUGHCONDUCTOR:
         distr = str(b.get("distribution", "beckmann")).lower()
@@ -107,12 +117,15 @@ def normalize(b):
         if out["int_ior"] < 0 or out["ext_ior"] < 0:
             raise RuntimeError("The interior and exterior indices of refraction must be positive!")
         out["specular_reflectance"] = _rgb(b.get("specular_reflectance"), 1.0)
+        out["uniform_mask"] |= 2 if _is_uniform(b.get("specular_reflectance"), 1.0) else 0
         known |= {"int_ior", "ext_ior", "specular_reflectance"}
     if tid == DIELECTRIC:
         out["specular_transmittance"] = _rgb(b.get("specular_transmittance"), 1.0)
+        out["uniform_mask"] |= 4 if _is_uniform(b.get("specular_transmittance"), 1.0) else 0
         known |= {"specular_transmittance"}
     if tid == PLASTIC:
         out["reflectance"] = _rgb(b.get("diffuse_reflectance"), 0.5)
+        out["uniform_mask"] |= 1 if _is_uniform(b.get("diffuse_reflectance"), 0.5) else 0
         out["nonlinear"] = bool(b.get("nonlinear", False))
         known |= {"diffuse_reflectance", "nonlinear"}
     extra = [k for k in b if k not in known]

@@ -190,6 +190,8 @@ static void fill_bsdf_model(const mtsamd_bsdf_desc &bd, DevBsdf &d) {
     d.flags = (bd.twosided ? kBsdfTwoSided : 0u) | (bd.distribution == 1 ? kBsdfGGX : 0u) | (bd.sample_visible ? kBsdfSampleVisible : 0u) |
               (bd.nonlinear ? kBsdfNonlinear : 0u);
     if (bd.type == MTSAMD_BSDF_DIFFUSE) d.flags &= kBsdfTwoSided;
+    d.flags |= ((bd.uniform_mask & 1) ? kBsdfUniformRefl : 0u) | ((bd.uniform_mask & 2) ? kBsdfUniformSpec : 0u) |
+               ((bd.uniform_mask & 4) ? kBsdfUniformTrans : 0u);
     d.sr = bd.specular_reflectance[0]; d.sg = bd.specular_reflectance[1]; d.sb = bd.specular_reflectance[2];
     d.alpha_u = bd.alpha_u; d.alpha_v = bd.alpha_v;
     if (bd.type == MTSAMD_BSDF_CONDUCTOR || bd.type == MTSAMD_BSDF_ROUGHCONDUCTOR) {
@@ -301,8 +303,9 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     for (uint32_t b = 0; b < desc->bsdf_count; ++b) {
         const mtsamd_bsdf_desc &bd = desc->bsdfs[b];
         if (bd.type < MTSAMD_BSDF_DIFFUSE || bd.type > MTSAMD_BSDF_PLASTIC) return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u: unknown BSDF type %d", b, bd.type);
-        if (desc->spectral && (bd.type != MTSAMD_BSDF_DIFFUSE || bd.twosided))
-            return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u: the spectral variant implements 'diffuse' only", b);
+        if (desc->spectral && (bd.type == MTSAMD_BSDF_CONDUCTOR || bd.type == MTSAMD_BSDF_ROUGHCONDUCTOR) &&
+            (bd.eta[0] != bd.eta[1] || bd.eta[0] != bd.eta[2] || bd.k[0] != bd.k[1] || bd.k[0] != bd.k[2]))
+            return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u: the spectral variant needs uniform (constant) eta and k spectra", b);
         if (bd.texture >= 0 && bd.type != MTSAMD_BSDF_DIFFUSE) return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u: bitmap textures are implemented for diffuse.reflectance only", b);
         if ((bd.type == MTSAMD_BSDF_DIELECTRIC || bd.type == MTSAMD_BSDF_PLASTIC) && (bd.int_ior < 0.0f || bd.ext_ior < 0.0f || bd.ext_ior == 0.0f))
             return fail(MTSAMD_ERR_INVALID, "The interior and exterior indices of refraction must be positive!");      // dielectric.cpp:183-185
@@ -397,16 +400,27 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         d.r = desc->bsdfs[b].reflectance[0]; d.g = desc->bsdfs[b].reflectance[1]; d.b = desc->bsdfs[b].reflectance[2];
         d.type = desc->bsdfs[b].type; d.texture = desc->bsdfs[b].texture < 0 ? -1 : desc->bsdfs[b].texture;
         fill_bsdf_model(desc->bsdfs[b], d);
-        if (d.type != kBsdfDiffuse || d.flags) s->general_bsdfs = true;
+        if (d.type != kBsdfDiffuse || (d.flags & kBsdfTwoSided)) s->general_bsdfs = true;
         if (desc->spectral) {
-            const float *c = desc->bsdfs[b].reflectance;
-            if (c[0] < 0 || c[1] < 0 || c[2] < 0 || c[0] > 1 || c[1] > 1 || c[2] > 1) {
-                delete s;
-                return fail(MTSAMD_ERR_INVALID, "Invalid RGB reflectance value [%g, %g, %g], must be in the range [0, 1]!", c[0], c[1], c[2]);
+            // every colour-valued parameter is a `uniform` constant or an `srgb` texture: range check + coefficient fetch
+            // (srgb.cpp:31-41); Texture::mean() of either kind feeds the plastic lobe-selection weight (plastic.cpp:170-175)
+            const mtsamd_bsdf_desc &bd = desc->bsdfs[b];
+            const float *vals[3] = { bd.reflectance, bd.specular_reflectance, bd.specular_transmittance };
+            float *coeffs[3] = { &d.c0, &d.sc0, &d.tc0 };
+            float means[3] = { 0.0f, 0.0f, 0.0f };
+            for (int p = 0; p < 3; ++p) {
+                if (bd.uniform_mask & (1 << p)) { means[p] = vals[p][0]; continue; }
+                const float *c = vals[p];
+                if (c[0] < 0 || c[1] < 0 || c[2] < 0 || c[0] > 1 || c[1] > 1 || c[2] > 1) {
+                    delete s;
+                    return fail(MTSAMD_ERR_INVALID, "Invalid RGB reflectance value [%g, %g, %g], must be in the range [0, 1]!", c[0], c[1], c[2]);
+                }
+                float coeff[3];
+                srgb_model_fetch(model, c, coeff);
+                coeffs[p][0] = coeff[0]; coeffs[p][1] = coeff[1]; coeffs[p][2] = coeff[2];
+                means[p] = srgb_model_mean(coeff);
             }
-            float coeff[3];
-            srgb_model_fetch(model, c, coeff);
-            d.c0 = coeff[0]; d.c1 = coeff[1]; d.c2 = coeff[2];
+            if (d.type == kBsdfPlastic) d.kr = means[1] / (means[0] + means[1]);
         }
     }
 

@@ -15,6 +15,8 @@ namespace mtsamd {
 
 constexpr int kBsdfDiffuse = 0, kBsdfConductor = 1, kBsdfRoughConductor = 2, kBsdfDielectric = 3, kBsdfPlastic = 4;
 constexpr uint32_t kBsdfTwoSided = 1u, kBsdfGGX = 2u, kBsdfSampleVisible = 4u, kBsdfNonlinear = 8u;
+// spectral variant: the parameter is a `uniform` spectrum (its constant sits in the first colour channel) instead of `srgb`
+constexpr uint32_t kBsdfUniformRefl = 16u, kBsdfUniformSpec = 32u, kBsdfUniformTrans = 64u;
 constexpr float kInvSqrtPi = 0.56418958354775628695f, kEps = kEpsilon;
 
 MTS_DEV float sqr(float x) { return x * x; }
@@ -178,7 +180,7 @@ MTS_DEV f3 mdf_sample(const Mdf &d, f3 wi, f2 sample, float &pdf) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Device-side BSDF record (80 B).  Roles of the generic fields per model:
+// Device-side BSDF record (112 B).  Roles of the generic fields per model:
 //   conductor / roughconductor   e = eta (rgb), k = extinction (rgb), s = specular_reflectance
 //   dielectric                   e.x = eta = int_ior / ext_ior, k = specular_transmittance, s = specular_reflectance
 //   plastic                      e.x = eta, e.y = 1 / eta^2, e.z = fdr_int, k.x = specular sampling weight,
@@ -189,6 +191,8 @@ struct DevBsdf {
     float sr, sg, sb; uint32_t flags;
     float er, eg, eb, alpha_u;
     float kr, kg, kb, alpha_v;
+    float sc0, sc1, sc2, pad0;               // spectral variant: srgb_model coefficients of specular_reflectance
+    float tc0, tc1, tc2, pad1;               //                   ... of specular_transmittance
 };
 
 struct BsdfSample { f3 wo; float pdf, eta; bool delta; };
@@ -197,16 +201,31 @@ MTS_DEV bool bsdf_is_smooth(const DevBsdf &b) {          // BSDFFlags::Smooth: a
     return b.type == kBsdfDiffuse || b.type == kBsdfRoughConductor || b.type == kBsdfPlastic;
 }
 
-MTS_DEV f3 plastic_diffuse(const DevBsdf &b, f3 refl) {
-    const bool nl = (b.flags & kBsdfNonlinear) != 0u;
-    return mk3(refl.x / (1.0f - (nl ? (refl.x * b.eb) : b.eb)), refl.y / (1.0f - (nl ? (refl.y * b.eb) : b.eb)),
-               refl.z / (1.0f - (nl ? (refl.z * b.eb) : b.eb)));
+// Per-channel inputs of a BSDF evaluation: N = 3 colour channels (RGB variant) or N = 4 wavelengths (spectral variant).
+//   refl  diffuse reflectance (diffuse.reflectance / plastic.diffuse_reflectance) at the hit point
+//   spec  specular_reflectance, trans  specular_transmittance, eta / k  complex IOR of conductors
+template <int N> struct BsdfChannels { float refl[N], spec[N], trans[N], eta[N], k[N]; };
+
+MTS_DEV BsdfChannels<3> rgb_channels(const DevBsdf &b, f3 refl) {
+    BsdfChannels<3> c;
+    c.refl[0] = refl.x; c.refl[1] = refl.y; c.refl[2] = refl.z;
+    c.spec[0] = b.sr; c.spec[1] = b.sg; c.spec[2] = b.sb;
+    c.trans[0] = b.kr; c.trans[1] = b.kg; c.trans[2] = b.kb;      // dielectric: k.* holds the transmittance
+    c.eta[0] = b.er; c.eta[1] = b.eg; c.eta[2] = b.eb;
+    c.k[0] = b.kr; c.k[1] = b.kg; c.k[2] = b.kb;
+    return c;
 }
 
-// BSDF::sample; `refl` = diffuse reflectance at the hit point.  Returns false (weight 0) for an invalid sample.
-MTS_DEV bool bsdf_sample(const DevBsdf &b, f3 refl, f3 wi, float sample1, f2 sample2, BsdfSample &bs, f3 &weight) {
+MTS_DEV float plastic_diffuse(const DevBsdf &b, float refl) {        // plastic.cpp:233-234,260-261
+    return refl / (1.0f - ((b.flags & kBsdfNonlinear) ? (refl * b.eb) : b.eb));
+}
+
+// BSDF::sample.  Returns false (weight 0) for an invalid sample.
+template <int N>
+MTS_DEV bool bsdf_sample_n(const DevBsdf &b, const BsdfChannels<N> &c, f3 wi, float sample1, f2 sample2, BsdfSample &bs, float (&weight)[N]) {
     bs.wo = mk3(0.0f, 0.0f, 0.0f); bs.pdf = 0.0f; bs.eta = 0.0f; bs.delta = false;
-    weight = mk3(0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int i = 0; i < N; ++i) weight[i] = 0.0f;
     const bool two = (b.flags & kBsdfTwoSided) != 0u;
     if (two && wi.z == 0.0f) return false;
     const bool flip = two && wi.z < 0.0f;
@@ -217,13 +236,17 @@ MTS_DEV bool bsdf_sample(const DevBsdf &b, f3 refl, f3 wi, float sample1, f2 sam
         if (wi.z > 0.0f) {
             bs.wo = square_to_cosine_hemisphere(sample2);
             bs.pdf = kInvPi * bs.wo.z;
-            if (bs.pdf > 0.0f) { weight = refl; ok = true; }
+            if (bs.pdf > 0.0f) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) weight[i] = c.refl[i];
+                ok = true;
+            }
         }
     } else if (b.type == kBsdfConductor) {
         if (wi.z > 0.0f) {
             bs.wo = reflect_z(wi); bs.eta = 1.0f; bs.pdf = 1.0f; bs.delta = true;
-            weight = mk3(b.sr * fresnel_conductor(wi.z, b.er, b.kr), b.sg * fresnel_conductor(wi.z, b.eg, b.kg),
-                         b.sb * fresnel_conductor(wi.z, b.eb, b.kb));
+#pragma unroll
+            for (int i = 0; i < N; ++i) weight[i] = c.spec[i] * fresnel_conductor(wi.z, c.eta[i], c.k[i]);
             ok = true;
         }
     } else if (b.type == kBsdfRoughConductor) {
@@ -239,9 +262,10 @@ MTS_DEV bool bsdf_sample(const DevBsdf &b, f3 refl, f3 wi, float sample1, f2 sam
             else w = mdf_G(d, wi, bs.wo, m) * dot(wi, m) / (cos_theta_i * m.z);
             bs.pdf /= 4.0f * dot(bs.wo, m);
             const float dwm = dot(wi, m);
-            if (active)
-                weight = mk3(fresnel_conductor(dwm, b.er, b.kr) * (w * b.sr), fresnel_conductor(dwm, b.eg, b.kg) * (w * b.sg),
-                             fresnel_conductor(dwm, b.eb, b.kb) * (w * b.sb));
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) weight[i] = fresnel_conductor(dwm, c.eta[i], c.k[i]) * (w * c.spec[i]);
+            }
             ok = active;
         }
     } else if (b.type == kBsdfDielectric) {
@@ -252,8 +276,9 @@ MTS_DEV bool bsdf_sample(const DevBsdf &b, f3 refl, f3 wi, float sample1, f2 sam
         bs.wo = selected_r ? reflect_z(wi) : mk3(-f.eta_ti * wi.x, -f.eta_ti * wi.y, f.cos_theta_t);
         bs.eta = selected_r ? 1.0f : f.eta_it;
         bs.delta = true;
-        if (selected_r) weight = mk3(1.0f * b.sr, 1.0f * b.sg, 1.0f * b.sb);
-        else { const float q = sqr(f.eta_ti); weight = mk3((1.0f * b.kr) * q, (1.0f * b.kg) * q, (1.0f * b.kb) * q); }
+        const float q = sqr(f.eta_ti);
+#pragma unroll
+        for (int i = 0; i < N; ++i) weight[i] = selected_r ? 1.0f * c.spec[i] : (1.0f * c.trans[i]) * q;
         ok = true;
     } else if (b.type == kBsdfPlastic) {
         const float cos_theta_i = wi.z;
@@ -266,26 +291,33 @@ MTS_DEV bool bsdf_sample(const DevBsdf &b, f3 refl, f3 wi, float sample1, f2 sam
             if (sample1 < prob_specular) {
                 bs.wo = reflect_z(wi); bs.pdf = prob_specular; bs.delta = true;
                 const float v = f_i / bs.pdf;
-                weight = mk3(v * b.sr, v * b.sg, v * b.sb);
+#pragma unroll
+                for (int i = 0; i < N; ++i) weight[i] = v * c.spec[i];
             } else {
                 bs.wo = square_to_cosine_hemisphere(sample2);
                 bs.pdf = prob_diffuse * (kInvPi * bs.wo.z);
                 const float f_o = fresnel(bs.wo.z, b.er).r;
-                const f3 value = plastic_diffuse(b, refl);
                 const float k = b.eg * (1.0f - f_i) * (1.0f - f_o) / prob_diffuse;
-                weight = mk3(value.x * k, value.y * k, value.z * k);
+#pragma unroll
+                for (int i = 0; i < N; ++i) weight[i] = plastic_diffuse(b, c.refl[i]) * k;
             }
             ok = true;
         }
     }
-    if (!ok) weight = mk3(0.0f, 0.0f, 0.0f);
+    if (!ok) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) weight[i] = 0.0f;
+    }
     if (flip) bs.wo.z = -bs.wo.z;
     return ok;
 }
 
 // BSDF::eval and BSDF::pdf
-MTS_DEV void bsdf_eval_pdf(const DevBsdf &b, f3 refl, f3 wi, f3 wo, f3 &value, float &pdf) {
-    value = mk3(0.0f, 0.0f, 0.0f); pdf = 0.0f;
+template <int N>
+MTS_DEV void bsdf_eval_pdf_n(const DevBsdf &b, const BsdfChannels<N> &c, f3 wi, f3 wo, float (&value)[N], float &pdf) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) value[i] = 0.0f;
+    pdf = 0.0f;
     if (b.flags & kBsdfTwoSided) {
         if (wi.z == 0.0f) return;
         if (wi.z < 0.0f) { wi.z = -wi.z; wo.z = -wo.z; }
@@ -293,7 +325,8 @@ MTS_DEV void bsdf_eval_pdf(const DevBsdf &b, f3 refl, f3 wi, f3 wo, f3 &value, f
     const float cos_theta_i = wi.z, cos_theta_o = wo.z;
     if (!(cos_theta_i > 0.0f && cos_theta_o > 0.0f)) return;      // every reflective model here is one-sided
     if (b.type == kBsdfDiffuse) {
-        value = mk3((refl.x * kInvPi) * wo.z, (refl.y * kInvPi) * wo.z, (refl.z * kInvPi) * wo.z);
+#pragma unroll
+        for (int i = 0; i < N; ++i) value[i] = (c.refl[i] * kInvPi) * wo.z;
         pdf = kInvPi * wo.z;
     } else if (b.type == kBsdfRoughConductor) {
         const f3 H = normalize(wo + wi);
@@ -304,8 +337,8 @@ MTS_DEV void bsdf_eval_pdf(const DevBsdf &b, f3 refl, f3 wi, f3 wo, f3 &value, f
             const float G = mdf_G(d, wi, wo, H);
             const float result = D * G / (4.0f * cos_theta_i);
             const float dwh = dot(wi, H);
-            value = mk3(fresnel_conductor(dwh, b.er, b.kr) * (result * b.sr), fresnel_conductor(dwh, b.eg, b.kg) * (result * b.sg),
-                        fresnel_conductor(dwh, b.eb, b.kb) * (result * b.sb));
+#pragma unroll
+            for (int i = 0; i < N; ++i) value[i] = fresnel_conductor(dwh, c.eta[i], c.k[i]) * (result * c.spec[i]);
         }
         if (dot(wi, H) > 0.0f && dot(wo, H) > 0.0f) {
             if (vis) pdf = mdf_eval(d, H) * mdf_smith_g1(d, wi, H) / (4.0f * cos_theta_i);
@@ -313,14 +346,27 @@ MTS_DEV void bsdf_eval_pdf(const DevBsdf &b, f3 refl, f3 wi, f3 wo, f3 &value, f
         }
     } else if (b.type == kBsdfPlastic) {
         const float f_i = fresnel(cos_theta_i, b.er).r, f_o = fresnel(cos_theta_o, b.er).r;
-        const f3 diff = plastic_diffuse(b, refl);
         const float k2 = (kInvPi * wo.z) * b.eg * (1.0f - f_i) * (1.0f - f_o);
-        value = mk3(diff.x * k2, diff.y * k2, diff.z * k2);
+#pragma unroll
+        for (int i = 0; i < N; ++i) value[i] = plastic_diffuse(b, c.refl[i]) * k2;
         const float prob_specular = f_i * b.kr;
         float prob_diffuse = (1.0f - f_i) * (1.0f - b.kr);
         prob_diffuse = prob_diffuse / (prob_specular + prob_diffuse);
         pdf = (kInvPi * wo.z) * prob_diffuse;
     }
+}
+
+// RGB variant
+MTS_DEV bool bsdf_sample(const DevBsdf &b, f3 refl, f3 wi, float sample1, f2 sample2, BsdfSample &bs, f3 &weight) {
+    float w[3];
+    const bool ok = bsdf_sample_n<3>(b, rgb_channels(b, refl), wi, sample1, sample2, bs, w);
+    weight = mk3(w[0], w[1], w[2]);
+    return ok;
+}
+MTS_DEV void bsdf_eval_pdf(const DevBsdf &b, f3 refl, f3 wi, f3 wo, f3 &value, float &pdf) {
+    float v[3];
+    bsdf_eval_pdf_n<3>(b, rgb_channels(b, refl), wi, wo, v, pdf);
+    value = mk3(v[0], v[1], v[2]);
 }
 
 } // namespace mtsamd

@@ -354,7 +354,21 @@ MTS_DEV void store_state(const PoolView &p, size_t i, const PathStateS &s) {
     p.misc[i] = make_uint2(s.ordinal, (s.depth & 0xffffu) | (s.flags << 16));
 }
 
-template <bool FLAT, bool DEFER = false>
+// spectral variant: `srgb` parameters evaluate the upsampled colour at each wavelength (srgb.cpp:45-52), `uniform` ones are
+// constants; conductors carry uniform eta / k
+MTS_DEV BsdfChannels<kWav> spectral_channels(const DevBsdf &b, const Spec4 &wav) {
+    BsdfChannels<kWav> c;
+#pragma unroll
+    for (int k = 0; k < kWav; ++k) {
+        c.refl[k] = (b.flags & kBsdfUniformRefl) ? b.r : srgb_model_eval(b.c0, b.c1, b.c2, wav.v[k]);
+        c.spec[k] = (b.flags & kBsdfUniformSpec) ? b.sr : srgb_model_eval(b.sc0, b.sc1, b.sc2, wav.v[k]);
+        c.trans[k] = (b.flags & kBsdfUniformTrans) ? b.kr : srgb_model_eval(b.tc0, b.tc1, b.tc2, wav.v[k]);
+        c.eta[k] = b.er; c.k[k] = b.kr;
+    }
+    return c;
+}
+
+template <bool FLAT, bool DEFER = false, bool GENERAL = false>
 MTS_DEV bool bounce_step_spectral(const RenderParams &P, const LdsView &lds, PathStateS &s, Counters &c, Deferred *df = nullptr) {
     const SceneView &sv = P.sv;
     const Geo<FLAT> geo{ sv, lds };
@@ -376,7 +390,8 @@ MTS_DEV bool bounce_step_spectral(const RenderParams &P, const LdsView &lds, Pat
                 f3 dd = si.p - s.o;
                 float dist = sqrtf(sqnorm(dd));
                 dd = div_s(dd, dist);
-                ew = mis_weight(s.bs_pdf, pdf_emitter_direction(sv.n_emitters, e.area_norm, dd, si.sh.n, dist));
+                const float pe = pdf_emitter_direction(sv.n_emitters, e.area_norm, dd, si.sh.n, dist);
+                ew = mis_weight(s.bs_pdf, (GENERAL && (s.flags & kFlagDelta)) ? 0.0f : pe);
             }
             if (si.wi.z > 0.0f) {
 #pragma unroll
@@ -402,9 +417,12 @@ MTS_DEV bool bounce_step_spectral(const RenderParams &P, const LdsView &lds, Pat
     const DevBsdf bsdf = geo.bsdf((uint32_t) si.shape_rec.bsdf);
     Spec4 refl;
 #pragma unroll
-    for (int k = 0; k < kWav; ++k) refl.v[k] = srgb_model_eval(bsdf.c0, bsdf.c1, bsdf.c2, s.wav.v[k]);   // srgb.cpp:45-52
+    for (int k = 0; k < kWav; ++k)       // srgb.cpp:45-52 / uniform.cpp
+        refl.v[k] = (bsdf.flags & kBsdfUniformRefl) ? bsdf.r : srgb_model_eval(bsdf.c0, bsdf.c1, bsdf.c2, s.wav.v[k]);
+    BsdfChannels<kWav> chan;
+    if (GENERAL) chan = spectral_channels(bsdf, s.wav);
 
-    {
+    if (!GENERAL || bsdf_is_smooth(bsdf)) {
         f2 s2; s2.x = pcg_next_f32(s.rng); s2.y = pcg_next_f32(s.rng);
         DirectionSample ds; float r1, r2;
         sample_emitter_direction(geo, si.p, s2, ds, r1, r2);
@@ -413,6 +431,8 @@ MTS_DEV bool bounce_step_spectral(const RenderParams &P, const LdsView &lds, Pat
             f3 wo = to_local(si.sh, ds.d);
             bool front = si.wi.z > 0.0f && wo.z > 0.0f;
             float bp = front ? kInvPi * wo.z : 0.0f;
+            float bvs[kWav];
+            if (GENERAL) bsdf_eval_pdf_n<kWav>(bsdf, chan, si.wi, wo, bvs, bp);
             float mis = mis_weight(ds.pdf, bp);
             Spec4 contrib; bool nz = false;
 #pragma unroll
@@ -420,7 +440,7 @@ MTS_DEV bool bounce_step_spectral(const RenderParams &P, const LdsView &lds, Pat
                 float le = table_eval(g_spectral.d65, e.d65_scale, s.wav.v[k]) * srgb_model_eval(e.c0, e.c1, e.c2, s.wav.v[k]);
                 float spec = le * r1;
                 if (sv.n_emitters > 1) spec *= r2;
-                float bv = front ? (refl.v[k] * kInvPi) * wo.z : 0.0f;
+                float bv = GENERAL ? bvs[k] : (front ? (refl.v[k] * kInvPi) * wo.z : 0.0f);
                 contrib.v[k] = ((mis * s.thr.v[k]) * bv) * spec;
                 nz = nz || contrib.v[k] != 0.0f;
             }
@@ -445,17 +465,27 @@ MTS_DEV bool bounce_step_spectral(const RenderParams &P, const LdsView &lds, Pat
         }
     }
 
-    (void) pcg_next_f32(s.rng);
+    const float s1 = pcg_next_f32(s.rng);
     f2 s2; s2.x = pcg_next_f32(s.rng); s2.y = pcg_next_f32(s.rng);
     f3 wo = mk3(0.0f, 0.0f, 0.0f); float pdf = 0.0f; bool ok = false;
-    if (si.wi.z > 0.0f) {
-        wo = square_to_cosine_hemisphere(s2);
-        pdf = kInvPi * wo.z;
-        ok = pdf > 0.0f;
-    }
     bool nz = false;
+    if (GENERAL) {
+        BsdfSample bs; float w[kWav];
+        bsdf_sample_n<kWav>(bsdf, chan, si.wi, s1, s2, bs, w);
+        wo = bs.wo; pdf = bs.pdf;
+        s.eta *= bs.eta;
+        s.flags = bs.delta ? (s.flags | kFlagDelta) : (s.flags & ~kFlagDelta);
 #pragma unroll
-    for (int k = 0; k < kWav; ++k) { s.thr.v[k] = s.thr.v[k] * (ok ? refl.v[k] : 0.0f); nz = nz || s.thr.v[k] != 0.0f; }
+        for (int k = 0; k < kWav; ++k) { s.thr.v[k] = s.thr.v[k] * w[k]; nz = nz || s.thr.v[k] != 0.0f; }
+    } else {
+        if (si.wi.z > 0.0f) {
+            wo = square_to_cosine_hemisphere(s2);
+            pdf = kInvPi * wo.z;
+            ok = pdf > 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < kWav; ++k) { s.thr.v[k] = s.thr.v[k] * (ok ? refl.v[k] : 0.0f); nz = nz || s.thr.v[k] != 0.0f; }
+    }
     if (!nz) return false;
     s.o = si.p;
     s.d = to_world(si.sh, wo);
@@ -496,7 +526,7 @@ MTS_DEV void store_result_spectral(const RenderParams &P, const PathStateS &s) {
     P.out_rgba[s.ordinal] = make_float4(xyz.x, xyz.y, xyz.z, (valid || !P.store_xyz) ? alpha : -1.0f);
 }
 
-template <bool FLAT>
+template <bool FLAT, bool GENERAL>
 __global__ __launch_bounds__(kBlock) void k_bounce_spectral(const RenderParams P) {
     extern __shared__ float4 smem[];
     const LdsView lds = lds_stage<FLAT>(P.sv, smem);
@@ -512,7 +542,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce_spectral(const RenderParams P
         bool alive = false;
         if (i0 + lane < n_in) {
             load_state(P.in, base + i0 + lane, s);
-            alive = bounce_step_spectral<FLAT>(P, lds, s, c);
+            alive = bounce_step_spectral<FLAT, false, GENERAL>(P, lds, s, c);
             if (!alive) store_result_spectral(P, s);
         }
         const uint64_t m = __ballot(alive);
@@ -689,7 +719,7 @@ MTS_DEV bool step_deferred(const RenderParams &P, const LdsView &lds, PathState 
 }
 template <bool GENERAL>
 MTS_DEV bool step_deferred(const RenderParams &P, const LdsView &lds, PathStateS &s, Counters &c, Deferred &df) {
-    return bounce_step_spectral<false, true>(P, lds, s, c, &df);
+    return bounce_step_spectral<false, true, GENERAL>(P, lds, s, c, &df);
 }
 MTS_DEV void finish_path(const RenderParams &P, const PathState &s) { store_result(P, s); }
 MTS_DEV void finish_path(const RenderParams &P, const PathStateS &s) { store_result_spectral(P, s); }
@@ -838,7 +868,8 @@ hipError_t launch_bounce(const RenderParams &p, hipStream_t s) {
     if (p.split) {
         const uint32_t shade_blocks = (p.n_waves * 64u + kBlock - 1) / kBlock;
         hipLaunchKernelGGL(k_trace<false>, dim3(p.n_waves), dim3(kBlock), trace_lds_bytes(p.sv), s, p);
-        if (p.spectral) hipLaunchKernelGGL((k_shade<PathStateS, false>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
+        if (p.spectral && p.sv.general) hipLaunchKernelGGL((k_shade<PathStateS, true>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
+        else if (p.spectral) hipLaunchKernelGGL((k_shade<PathStateS, false>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
         else if (p.sv.general) hipLaunchKernelGGL((k_shade<PathState, true>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
         else hipLaunchKernelGGL((k_shade<PathState, false>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
         hipLaunchKernelGGL(k_trace<true>, dim3((p.n_waves + kShadowGroup - 1) / kShadowGroup), dim3(kBlock), trace_lds_bytes(p.sv), s, p);
@@ -846,8 +877,13 @@ hipError_t launch_bounce(const RenderParams &p, hipStream_t s) {
     }
     uint32_t blocks = (p.n_waves * 64u + kBlock - 1) / kBlock;
     if (p.spectral) {
-        if (p.sv.flat) hipLaunchKernelGGL(k_bounce_spectral<true>, dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);
-        else hipLaunchKernelGGL(k_bounce_spectral<false>, dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);
+        if (p.sv.general) {
+            if (p.sv.flat) hipLaunchKernelGGL((k_bounce_spectral<true, true>), dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);
+            else hipLaunchKernelGGL((k_bounce_spectral<false, true>), dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);
+        } else {
+            if (p.sv.flat) hipLaunchKernelGGL((k_bounce_spectral<true, false>), dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);
+            else hipLaunchKernelGGL((k_bounce_spectral<false, false>), dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);
+        }
         return hipGetLastError();
     }
     if (p.sv.general) {

@@ -237,4 +237,17 @@ void srgb_model_fetch(const Rgb2Spec &m, const float rgb[3], float out[3]) {
     rgb2spec_fetch(m, rgb, out);
 }
 
+float srgb_model_mean(const float c[3]) {
+    float sum = 0.0f;
+    for (int i = 0; i < 16; ++i) {
+        const float l = 360.0f + (float) i * ((830.0f - 360.0f) / 15.0f);
+        const float v = std::fma(std::fma(c[0], l, c[1]), l, c[2]);
+        float r;
+        if (std::isinf(c[2])) r = std::fma(std::copysign(1.0f, c[2]), 0.5f, 0.5f);
+        else r = std::fmax(0.0f, std::fma(0.5f * v, 1.0f / std::sqrt(std::fma(v, v, 1.0f)), 0.5f));
+        sum += r;
+    }
+    return sum * (1.0f / 16.0f);
+}
+
 } // namespace mtsamd

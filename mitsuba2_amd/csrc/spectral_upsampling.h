@@ -16,5 +16,7 @@ bool rgb2spec_save(const char *path, const Rgb2Spec &m);
 bool rgb2spec_load(const char *path, Rgb2Spec &m);
 void rgb2spec_fetch(const Rgb2Spec &m, const float rgb[3], float out[3]);
 void srgb_model_fetch(const Rgb2Spec &m, const float rgb[3], float out[3]);
+// srgb_model_mean (include/mitsuba/render/srgb.h:25-35): mean of the model over 16 equidistant wavelengths in [360, 830] nm
+float srgb_model_mean(const float coeff[3]);
 
 } // namespace mtsamd

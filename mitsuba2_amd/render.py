@@ -413,8 +413,6 @@ class Scene:
         for i, b in enumerate(bsdfs):
             n = B.normalize(b)             # plugin defaults / validation (src/bsdfs/*.cpp constructors)
             self._bsdf_records.append(n)
-            if variant == "spectral" and (n["type"] != B.DIFFUSE or n["twosided"]):
-                raise RuntimeError("BSDF plugin '%s' is not supported by the spectral variant of this backend (diffuse only)" % b.get("type"))
             bd[i].type, bd[i].twosided = n["type"], int(n["twosided"])
             refl = n["reflectance"]
             if isinstance(refl, dict):
@@ -434,6 +432,7 @@ class Scene:
                 setattr(bd[i], name, (C.c_float * 3)(*n[name]))
             bd[i].int_ior, bd[i].ext_ior, bd[i].alpha_u, bd[i].alpha_v = n["int_ior"], n["ext_ior"], n["alpha_u"], n["alpha_v"]
             bd[i].distribution, bd[i].sample_visible, bd[i].nonlinear = n["distribution"], int(n["sample_visible"]), int(n["nonlinear"])
+            bd[i].uniform_mask = n["uniform_mask"]
         td = (L.TextureDesc * max(len(tex), 1))()
         for i, t in enumerate(tex):
             td[i].width, td[i].height = t.shape[1], t.shape[0]

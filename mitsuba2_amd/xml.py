@@ -403,8 +403,10 @@ def _bsdf_plugin_dict(ctx, node, base_dir):
                 nested += 1
             else:
                 raise XMLError('bsdf: unexpected nested object "%s"' % v.tag)
-        elif isinstance(v, tuple) and v and v[0] in ("rgb", "spectrum"):
+        elif isinstance(v, tuple) and v and v[0] == "rgb":
             d[k] = _colour(v, k)
+        elif isinstance(v, tuple) and v and v[0] == "spectrum":
+            d[k] = float(v[1])                           # a constant: `uniform` spectrum in the spectral variant
         else:
             d[k] = v
     for c in node.children:

@@ -46,6 +46,9 @@ typedef struct {
     int32_t distribution;              /* 0 beckmann, 1 ggx */
     int32_t sample_visible;
     int32_t nonlinear;                 /* plastic */
+    int32_t uniform_mask;              /* spectral variant: bit 0 / 1 / 2 set = reflectance / specular_reflectance /
+                                          specular_transmittance is a `uniform` spectrum (given as a constant: xml.cpp:1069-1083)
+                                          instead of an upsampled RGB colour (`srgb`); conductors need uniform eta and k */
 } mo_bsdf_desc;
 /* Replaces the BSDF of a shape (keeps an attached reflectance texture). */
 int mo_scene_set_bsdf(mo_scene *s, uint32_t shape, const mo_bsdf_desc *desc);

@@ -224,29 +224,49 @@ int mo_bsdf_is_smooth(const mo_bsdf *b) {
     return b->d.type == MO_BSDF_DIFFUSE || b->d.type == MO_BSDF_ROUGHCONDUCTOR || b->d.type == MO_BSDF_PLASTIC;
 }
 
-static void plastic_diffuse(const mo_bsdf *b, const float refl[3], float out[3]) {      /* plastic.cpp:233-234,260-261 */
-    for (int k = 0; k < 3; ++k)
-        out[k] = refl[k] / (1.0f - (b->d.nonlinear ? (refl[k] * b->fdr_int) : b->fdr_int));
+static float plastic_diffuse(const mo_bsdf *b, float refl) {      /* plastic.cpp:233-234,260-261 */
+    return refl / (1.0f - (b->d.nonlinear ? (refl * b->fdr_int) : b->fdr_int));
 }
 
-/* BSDF::sample -> returns 0 if the sample is invalid (weight 0).  refl = diffuse reflectance at the hit point. */
-int mo_bsdf_sample(const mo_bsdf *b, const float refl[3], mo_v3 wi, float sample1, mo_v2 sample2, mo_bsample *bs, float weight[3]) {
+static void rgb_channels(const mo_bsdf *b, const float refl[3], mo_bsdf_chan *c) {
+    for (int k = 0; k < 3; ++k) {
+        c->refl[k] = refl[k]; c->spec[k] = b->d.specular_reflectance[k]; c->trans[k] = b->d.specular_transmittance[k];
+        c->eta[k] = b->d.eta[k]; c->k[k] = b->d.k[k];
+    }
+}
+
+/* spectral variant: `srgb` textures evaluate the upsampled colour at each wavelength (srgb.cpp:45-52), `uniform` ones are
+ * constants (uniform.cpp); conductors carry uniform eta / k */
+void mo_bsdf_spectral_channels(const mo_bsdf *b, const float *wav, mo_bsdf_chan *c) {
+    for (int k = 0; k < MO_WAV; ++k) {
+        c->refl[k] = (b->d.uniform_mask & 1) ? b->d.reflectance[0] : mo_srgb_model_eval(b->refl_coeff, wav[k]);
+        c->spec[k] = (b->d.uniform_mask & 2) ? b->d.specular_reflectance[0] : mo_srgb_model_eval(b->spec_coeff, wav[k]);
+        c->trans[k] = (b->d.uniform_mask & 4) ? b->d.specular_transmittance[0] : mo_srgb_model_eval(b->trans_coeff, wav[k]);
+        c->eta[k] = b->d.eta[0]; c->k[k] = b->d.k[0];
+    }
+}
+
+/* BSDF::sample for n channels -> returns 0 if the sample is invalid (weight 0). */
+int mo_bsdf_sample_n(const mo_bsdf *b, int n, const mo_bsdf_chan *c, mo_v3 wi, float sample1, mo_v2 sample2, mo_bsample *bs, float *weight) {
     memset(bs, 0, sizeof(*bs));
-    weight[0] = weight[1] = weight[2] = 0.0f;
+    for (int k = 0; k < n; ++k) weight[k] = 0.0f;
     int flip = b->d.twosided && wi.z < 0.0f;                /* twosided.cpp:105-124 */
     if (b->d.twosided && wi.z == 0.0f) return 0;
     if (flip) wi.z = -wi.z;
     int ok = 0;
     switch (b->d.type) {
-    case MO_BSDF_DIFFUSE:
-        ok = mo_diffuse_sample(refl, wi, sample2, &bs->wo, &bs->pdf, weight);
+    case MO_BSDF_DIFFUSE:                                    /* diffuse.cpp:78-106 */
         bs->eta = 1.0f; bs->delta = 0;
+        if (wi.z > 0.0f) {
+            bs->wo = mo_square_to_cosine_hemisphere(sample2);
+            bs->pdf = mo_square_to_cosine_hemisphere_pdf(bs->wo);
+            if (bs->pdf > 0.0f) { for (int k = 0; k < n; ++k) weight[k] = c->refl[k]; ok = 1; }
+        }
         break;
     case MO_BSDF_CONDUCTOR: {                                /* conductor.cpp:203-252 */
         if (!(wi.z > 0.0f)) break;
         bs->wo = reflect_z(wi); bs->eta = 1.0f; bs->pdf = 1.0f; bs->delta = 1;
-        for (int k = 0; k < 3; ++k)
-            weight[k] = b->d.specular_reflectance[k] * mo_fresnel_conductor(wi.z, b->d.eta[k], b->d.k[k]);
+        for (int k = 0; k < n; ++k) weight[k] = c->spec[k] * mo_fresnel_conductor(wi.z, c->eta[k], c->k[k]);
         ok = 1;
     } break;
     case MO_BSDF_ROUGHCONDUCTOR: {                           /* roughconductor.cpp:196-272 */
@@ -261,9 +281,9 @@ int mo_bsdf_sample(const mo_bsdf *b, const float refl[3], mo_v3 wi, float sample
         else w = mdf_G(&d, wi, bs->wo, m) * mo_dot(wi, m) / (cos_theta_i * m.z);
         bs->pdf /= 4.0f * mo_dot(bs->wo, m);
         float dwm = mo_dot(wi, m);
-        for (int k = 0; k < 3; ++k) {
-            float F = mo_fresnel_conductor(dwm, b->d.eta[k], b->d.k[k]);
-            float wk = w * b->d.specular_reflectance[k];
+        for (int k = 0; k < n; ++k) {
+            float F = mo_fresnel_conductor(dwm, c->eta[k], c->k[k]);
+            float wk = w * c->spec[k];
             weight[k] = active ? F * wk : 0.0f;
         }
         ok = active;
@@ -277,9 +297,9 @@ int mo_bsdf_sample(const mo_bsdf *b, const float refl[3], mo_v3 wi, float sample
         bs->wo = selected_r ? reflect_z(wi) : refract_z(wi, f[1], f[3]);
         bs->eta = selected_r ? 1.0f : f[2];
         bs->delta = 1;
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < n; ++k) {
             float wk = 1.0f;
-            wk *= selected_r ? b->d.specular_reflectance[k] : b->d.specular_transmittance[k];
+            wk *= selected_r ? c->spec[k] : c->trans[k];
             if (!selected_r) wk *= sqr(f[3]);
             weight[k] = wk;
         }
@@ -296,39 +316,40 @@ int mo_bsdf_sample(const mo_bsdf *b, const float refl[3], mo_v3 wi, float sample
         bs->eta = 1.0f;
         if (sample1 < prob_specular) {
             bs->wo = reflect_z(wi); bs->pdf = prob_specular; bs->delta = 1;
-            for (int k = 0; k < 3; ++k) weight[k] = (f_i / bs->pdf) * b->d.specular_reflectance[k];
+            for (int k = 0; k < n; ++k) weight[k] = (f_i / bs->pdf) * c->spec[k];
         } else {
             bs->wo = mo_square_to_cosine_hemisphere(sample2);
             bs->pdf = prob_diffuse * mo_square_to_cosine_hemisphere_pdf(bs->wo);
             bs->delta = 0;
             mo_fresnel(bs->wo.z, b->eta_rel, f);
-            float f_o = f[0], value[3];
-            plastic_diffuse(b, refl, value);
-            for (int k = 0; k < 3; ++k) weight[k] = value[k] * (b->inv_eta_2 * (1.0f - f_i) * (1.0f - f_o) / prob_diffuse);
+            float f_o = f[0];
+            for (int k = 0; k < n; ++k) weight[k] = plastic_diffuse(b, c->refl[k]) * (b->inv_eta_2 * (1.0f - f_i) * (1.0f - f_o) / prob_diffuse);
         }
         ok = 1;
     } break;
     default: break;
     }
-    if (!ok) { weight[0] = weight[1] = weight[2] = 0.0f; }
+    if (!ok) for (int k = 0; k < n; ++k) weight[k] = 0.0f;
     if (flip) bs->wo.z = -bs->wo.z;
     return ok;
 }
 
-/* BSDF::eval and BSDF::pdf */
-void mo_bsdf_eval_pdf(const mo_bsdf *b, const float refl[3], mo_v3 wi, mo_v3 wo, float value[3], float *pdf) {
-    value[0] = value[1] = value[2] = 0.0f; *pdf = 0.0f;
+/* BSDF::eval and BSDF::pdf for n channels */
+void mo_bsdf_eval_pdf_n(const mo_bsdf *b, int n, const mo_bsdf_chan *c, mo_v3 wi, mo_v3 wo, float *value, float *pdf) {
+    for (int k = 0; k < n; ++k) value[k] = 0.0f;
+    *pdf = 0.0f;
     if (b->d.twosided) {                                     /* twosided.cpp:127-175 */
         if (wi.z == 0.0f) return;
         if (wi.z < 0.0f) { wi.z = -wi.z; wo.z = -wo.z; }
     }
+    float cos_theta_i = wi.z, cos_theta_o = wo.z;
+    if (!(cos_theta_i > 0.0f && cos_theta_o > 0.0f)) return;
     switch (b->d.type) {
-    case MO_BSDF_DIFFUSE:
-        mo_diffuse_eval_pdf(refl, wi, wo, value, pdf);
+    case MO_BSDF_DIFFUSE:                                    /* diffuse.cpp:108-135 */
+        for (int k = 0; k < n; ++k) value[k] = (c->refl[k] * MO_INV_PI) * cos_theta_o;
+        *pdf = mo_square_to_cosine_hemisphere_pdf(wo);
         break;
     case MO_BSDF_ROUGHCONDUCTOR: {                           /* roughconductor.cpp:274-391 */
-        float cos_theta_i = wi.z, cos_theta_o = wo.z;
-        if (!(cos_theta_i > 0.0f && cos_theta_o > 0.0f)) break;
         mo_v3 H = mo_normalize(mo_add(wo, wi));
         mdf d = mdf_make(b->d.distribution, b->d.alpha_u, b->d.alpha_v, b->d.sample_visible);
         float D = mdf_eval(&d, H);
@@ -336,8 +357,7 @@ void mo_bsdf_eval_pdf(const mo_bsdf *b, const float refl[3], mo_v3 wi, mo_v3 wo,
             float G = mdf_G(&d, wi, wo, H);
             float result = D * G / (4.0f * cos_theta_i);
             float dwh = mo_dot(wi, H);
-            for (int k = 0; k < 3; ++k)
-                value[k] = mo_fresnel_conductor(dwh, b->d.eta[k], b->d.k[k]) * (result * b->d.specular_reflectance[k]);
+            for (int k = 0; k < n; ++k) value[k] = mo_fresnel_conductor(dwh, c->eta[k], c->k[k]) * (result * c->spec[k]);
         }
         if (mo_dot(wi, H) > 0.0f && mo_dot(wo, H) > 0.0f) {
             if (b->d.sample_visible) *pdf = mdf_eval(&d, H) * mdf_smith_g1(&d, wi, H) / (4.0f * cos_theta_i);
@@ -345,21 +365,27 @@ void mo_bsdf_eval_pdf(const mo_bsdf *b, const float refl[3], mo_v3 wi, mo_v3 wo,
         }
     } break;
     case MO_BSDF_PLASTIC: {                                  /* plastic.cpp:243-297 */
-        float cos_theta_i = wi.z, cos_theta_o = wo.z;
-        if (!(cos_theta_i > 0.0f && cos_theta_o > 0.0f)) break;
         float f[4];
         mo_fresnel(cos_theta_i, b->eta_rel, f); float f_i = f[0];
         mo_fresnel(cos_theta_o, b->eta_rel, f); float f_o = f[0];
-        float diff[3];
-        plastic_diffuse(b, refl, diff);
         float k2 = mo_square_to_cosine_hemisphere_pdf(wo) * b->inv_eta_2 * (1.0f - f_i) * (1.0f - f_o);
-        for (int k = 0; k < 3; ++k) value[k] = diff[k] * k2;
+        for (int k = 0; k < n; ++k) value[k] = plastic_diffuse(b, c->refl[k]) * k2;
         float prob_specular = f_i * b->spec_weight, prob_diffuse = (1.0f - f_i) * (1.0f - b->spec_weight);
         prob_diffuse = prob_diffuse / (prob_specular + prob_diffuse);
         *pdf = mo_square_to_cosine_hemisphere_pdf(wo) * prob_diffuse;
     } break;
     default: break;      /* conductor / dielectric: delta lobes only, eval = pdf = 0 */
     }
+}
+
+/* RGB variant */
+int mo_bsdf_sample(const mo_bsdf *b, const float refl[3], mo_v3 wi, float sample1, mo_v2 sample2, mo_bsample *bs, float weight[3]) {
+    mo_bsdf_chan c; rgb_channels(b, refl, &c);
+    return mo_bsdf_sample_n(b, 3, &c, wi, sample1, sample2, bs, weight);
+}
+void mo_bsdf_eval_pdf(const mo_bsdf *b, const float refl[3], mo_v3 wi, mo_v3 wo, float value[3], float *pdf) {
+    mo_bsdf_chan c; rgb_channels(b, refl, &c);
+    mo_bsdf_eval_pdf_n(b, 3, &c, wi, wo, value, pdf);
 }
 
 /* ------------------------------------------------------------------ known-answer entry points */

@@ -17,7 +17,12 @@ typedef struct {
 typedef struct { mo_v3 p, n, d; float dist, pdf; uint32_t emitter; float pdf_single; } mo_dsample;   /* pdf_single: before the emitter-selection probability */
 
 /* a BSDF instance: the descriptor plus the constants its constructor derives (plastic.cpp:162-176) */
-typedef struct { mo_bsdf_desc d; float eta_rel, inv_eta_2, fdr_int, fdr_ext, spec_weight; } mo_bsdf;
+typedef struct {
+    mo_bsdf_desc d; float eta_rel, inv_eta_2, fdr_int, fdr_ext, spec_weight;
+    float refl_coeff[3], spec_coeff[3], trans_coeff[3];      /* spectral variant: srgb_model coefficients */
+} mo_bsdf;
+/* per-channel inputs of a BSDF evaluation: 3 colour channels or MO_WAV wavelengths */
+typedef struct { float refl[4], spec[4], trans[4], eta[4], k[4]; } mo_bsdf_chan;
 /* BSDFSample3 (bsdf.h:193-252): delta = has_flag(sampled_type, BSDFFlags::Delta) */
 typedef struct { mo_v3 wo; float pdf, eta; int delta; } mo_bsample;
 
@@ -73,6 +78,10 @@ void mo_bsdf_prepare(mo_bsdf *b);
 int mo_bsdf_is_smooth(const mo_bsdf *b);
 int mo_bsdf_sample(const mo_bsdf *b, const float refl[3], mo_v3 wi, float sample1, mo_v2 sample2, mo_bsample *bs, float weight[3]);
 void mo_bsdf_eval_pdf(const mo_bsdf *b, const float refl[3], mo_v3 wi, mo_v3 wo, float value[3], float *pdf);
+int mo_bsdf_sample_n(const mo_bsdf *b, int n, const mo_bsdf_chan *c, mo_v3 wi, float sample1, mo_v2 sample2, mo_bsample *bs, float *weight);
+void mo_bsdf_eval_pdf_n(const mo_bsdf *b, int n, const mo_bsdf_chan *c, mo_v3 wi, mo_v3 wo, float *value, float *pdf);
+void mo_bsdf_spectral_channels(const mo_bsdf *b, const float *wav, mo_bsdf_chan *c);
+float mo_srgb_model_mean(const float coeff[3]);
 
 /* spectral variant (mo_spectral.c) */
 #define MO_WAV 4

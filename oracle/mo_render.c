@@ -557,9 +557,10 @@ static void path_sample_spectral(const mo_scene *s, mo_pcg32 *rng, const mo_ray 
         }
         if ((uint32_t) depth >= (uint32_t) max_depth || !active) break;
         const mo_mesh *mesh = &s->meshes[si.shape];
-        float refl[MO_WAV];
-        for (int k = 0; k < MO_WAV; ++k) refl[k] = mo_srgb_model_eval(mesh->refl_coeff, wav[k]);
-        {
+        const mo_bsdf *bsdf = &mesh->bsdf;
+        mo_bsdf_chan chan;
+        mo_bsdf_spectral_channels(bsdf, wav, &chan);
+        if (mo_bsdf_is_smooth(bsdf)) {
             mo_v2 s2; s2.x = mo_pcg32_next_f32(rng); s2.y = mo_pcg32_next_f32(rng);
             mo_dsample ds; float rgb_spec[3];
             mo_sample_emitter_direction(s, si.p, s2, &ds, rgb_spec);
@@ -577,28 +578,28 @@ static void path_sample_spectral(const mo_scene *s, mo_pcg32 *rng, const mo_ray 
                 st->any++;
                 int occluded = mo_intersect(s, &sr, 1, 0, NULL);
                 mo_v3 wo = mo_to_local(&si.sh, ds.d);
-                int front = si.wi.z > 0.0f && wo.z > 0.0f;
-                float bsdf_pdf = front ? mo_square_to_cosine_hemisphere_pdf(wo) : 0.0f;
+                float bv[MO_WAV], bsdf_pdf;
+                mo_bsdf_eval_pdf_n(bsdf, MO_WAV, &chan, si.wi, wo, bv, &bsdf_pdf);
                 float mis = mis_weight(ds.pdf, bsdf_pdf);
                 for (int k = 0; k < MO_WAV; ++k) {
                     float le = mo_d65_eval(e->d65_scale, wav[k]) * mo_srgb_model_eval(e->coeff, wav[k]);
                     float spec = le * r1;
                     if (s->n_emitters > 1) spec *= r2;
                     if (occluded) spec = 0.0f;
-                    float bv = front ? (refl[k] * MO_INV_PI) * wo.z : 0.0f;
-                    result[k] += ((mis * throughput[k]) * bv) * spec;
+                    result[k] += ((mis * throughput[k]) * bv[k]) * spec;
                 }
             }
         }
-        float s1 = mo_pcg32_next_f32(rng); (void) s1;
+        float s1 = mo_pcg32_next_f32(rng);
         mo_v2 s2; s2.x = mo_pcg32_next_f32(rng); s2.y = mo_pcg32_next_f32(rng);
-        mo_v3 bs_wo; float bs_pdf, dummy_w[3]; const float one[3] = { 1.0f, 1.0f, 1.0f };
-        int sampled = mo_diffuse_sample(one, si.wi, s2, &bs_wo, &bs_pdf, dummy_w) && bs_pdf > 0.0f;
+        mo_bsample bs; float bsdf_w[MO_WAV];
+        mo_bsdf_sample_n(bsdf, MO_WAV, &chan, si.wi, s1, s2, &bs, bsdf_w);
         int nz = 0;
-        for (int k = 0; k < MO_WAV; ++k) { throughput[k] = throughput[k] * (sampled ? refl[k] : 0.0f); nz = nz || throughput[k] != 0.0f; }
+        for (int k = 0; k < MO_WAV; ++k) { throughput[k] = throughput[k] * bsdf_w[k]; nz = nz || throughput[k] != 0.0f; }
         active = active && nz;
         if (!active) break;
-        ray.o = si.p; ray.d = mo_to_world(&si.sh, bs_wo);
+        eta *= bs.eta;
+        ray.o = si.p; ray.d = mo_to_world(&si.sh, bs.wo);
         ray.mint = (1.0f + mo_hmax_abs(si.p)) * MO_RAY_EPSILON;
         ray.maxt = INFINITY;
         mo_si si_bsdf;
@@ -608,7 +609,8 @@ static void path_sample_spectral(const mo_scene *s, mo_pcg32 *rng, const mo_ray 
             mo_v3 d = mo_sub(si_bsdf.p, si.p);
             float dist = mo_norm(d);
             d = mo_div_s(d, dist);
-            emission_weight = mis_weight(bs_pdf, mo_pdf_emitter_direction(s, (uint32_t) emitter, d, si_bsdf.sh.n, dist));
+            float emitter_pdf = bs.delta ? 0.0f : mo_pdf_emitter_direction(s, (uint32_t) emitter, d, si_bsdf.sh.n, dist);
+            emission_weight = mis_weight(bs.pdf, emitter_pdf);
         }
         si = si_bsdf; si_valid = v2;
     }

@@ -36,6 +36,16 @@ float mo_srgb_model_eval(const float c[3], float l) {
     return fmaxf(0.0f, fmaf(0.5f * v, 1.0f / sqrtf(fmaf(v, v, 1.0f)), 0.5f));
 }
 
+/* srgb_model_mean (srgb.h:25-35): mean of the model over 16 equidistant wavelengths in [360, 830] */
+float mo_srgb_model_mean(const float c[3]) {
+    float sum = 0.0f;
+    for (int i = 0; i < 16; ++i) {
+        float l = 360.0f + (float) i * ((830.0f - 360.0f) / 15.0f);
+        sum += mo_srgb_model_eval(c, l);
+    }
+    return sum * (1.0f / 16.0f);
+}
+
 /* D65 table scaled by `scale` (d65.cpp:58-61) evaluated like RegularSpectrum (distr_1d.h:378-394) */
 float mo_d65_eval(float scale, float l) {
     if (!(l >= 360.0f && l <= 830.0f)) return 0.0f;
@@ -113,9 +123,25 @@ int mo_scene_set_spectral(mo_scene *s, const char *coeff_path) {
     if (!s || table_load(coeff_path, &t)) return -1;
     for (uint32_t i = 0; i < s->n_meshes; ++i) {
         mo_mesh *m = &s->meshes[i];
+        mo_bsdf *b = &m->bsdf;
         if (m->texture >= 0) { free(t.scale); free(t.data); return -2; }
-        for (int k = 0; k < 3; ++k) if (m->refl[k] < 0.0f || m->refl[k] > 1.0f) { free(t.scale); free(t.data); return -3; }   /* srgb.cpp:34-35 */
-        model_fetch(&t, m->refl, m->refl_coeff);
+        /* every colour-valued parameter is either `uniform` (a constant) or an `srgb` texture, whose constructor rejects
+         * values outside [0, 1] (srgb.cpp:34-35) and fetches the model coefficients */
+        const float *vals[3] = { m->refl, b->d.specular_reflectance, b->d.specular_transmittance };
+        float *coeffs[3] = { b->refl_coeff, b->spec_coeff, b->trans_coeff };
+        float means[3] = { 0.0f, 0.0f, 0.0f };
+        for (int p = 0; p < 3; ++p) {
+            if (b->d.uniform_mask & (1 << p)) { means[p] = vals[p][0]; continue; }
+            for (int k = 0; k < 3; ++k) if (vals[p][k] < 0.0f || vals[p][k] > 1.0f) { free(t.scale); free(t.data); return -3; }
+            model_fetch(&t, vals[p], coeffs[p]);
+            means[p] = mo_srgb_model_mean(coeffs[p]);
+        }
+        for (int k = 0; k < 3; ++k) m->refl_coeff[k] = b->refl_coeff[k];
+        if ((b->d.type == MO_BSDF_CONDUCTOR || b->d.type == MO_BSDF_ROUGHCONDUCTOR) &&
+            (b->d.eta[0] != b->d.eta[1] || b->d.eta[0] != b->d.eta[2] || b->d.k[0] != b->d.k[1] || b->d.k[0] != b->d.k[2])) {
+            free(t.scale); free(t.data); return -4;          /* RGB eta / k cannot be upsampled (values > 1): uniform spectra only */
+        }
+        if (b->d.type == MO_BSDF_PLASTIC) b->spec_weight = means[1] / (means[0] + means[1]);     /* plastic.cpp:170-175 with Texture::mean() */
     }
     for (uint32_t e = 0; e < s->n_emitters; ++e) {
         mo_emitter *em = &s->emitters[e];

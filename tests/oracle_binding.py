@@ -27,7 +27,7 @@ class BsdfDesc(C.Structure):
     _fields_ = [("type", C.c_int32), ("twosided", C.c_int32), ("reflectance", C.c_float * 3), ("specular_reflectance", C.c_float * 3),
                 ("specular_transmittance", C.c_float * 3), ("eta", C.c_float * 3), ("k", C.c_float * 3), ("int_ior", C.c_float),
                 ("ext_ior", C.c_float), ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("distribution", C.c_int32),
-                ("sample_visible", C.c_int32), ("nonlinear", C.c_int32)]
+                ("sample_visible", C.c_int32), ("nonlinear", C.c_int32), ("uniform_mask", C.c_int32)]
 
 
 def bsdf_desc(plugin_dict):
@@ -42,6 +42,7 @@ def bsdf_desc(plugin_dict):
         setattr(d, name, (C.c_float * 3)(*v))
     d.int_ior, d.ext_ior, d.alpha_u, d.alpha_v = n["int_ior"], n["ext_ior"], n["alpha_u"], n["alpha_v"]
     d.distribution, d.sample_visible, d.nonlinear = n["distribution"], int(n["sample_visible"]), int(n["nonlinear"])
+    d.uniform_mask = n["uniform_mask"]
     return d, n
 
 
@@ -155,7 +156,7 @@ class OracleScene:
                                      uv.ctypes.data_as(f32p) if uv is not None else None, faces.shape[0], faces.ctypes.data_as(u32p), 0,
                                      refl.ctypes.data_as(f32p), em.ctypes.data_as(f32p) if em is not None else None)
             assert rc >= 0, rc
-            if bn["type"] != 0 or bn["twosided"]:
+            if bn["type"] != 0 or bn["twosided"] or bn["uniform_mask"]:
                 assert L.mo_scene_set_bsdf(self.h, rc, C.byref(bd)) == 0
             if m["bsdf"] in self.tex_of_bsdf:
                 assert L.mo_scene_set_texture(self.h, rc, self.tex_of_bsdf[m["bsdf"]]) == 0

@@ -59,3 +59,44 @@ def test_spectral_vs_rgb_and_errors(gpu):
         gpu.Scene(scenes.cornell_box(texture=np.full((4, 4, 3), 0.5, np.float32)), variant="spectral")
     with pytest.raises(RuntimeError):
         gpu.Scene(sd, variant="polarized")
+
+
+SPECTRAL_MATERIALS = {
+    "uniform_diffuse": {"type": "diffuse", "reflectance": 0.4},
+    "twosided_diffuse": {"type": "twosided", "bsdf": {"type": "diffuse", "reflectance": [0.6, 0.3, 0.2]}},
+    "conductor": {"type": "conductor", "eta": 0.2, "k": 3.9, "specular_reflectance": [0.9, 0.7, 0.3]},
+    "rough_ggx": {"type": "roughconductor", "alpha": 0.2, "distribution": "ggx", "eta": 0.2, "k": 3.9},
+    "rough_beckmann": {"type": "roughconductor", "alpha_u": 0.3, "alpha_v": 0.1, "distribution": "beckmann", "eta": 0.0, "k": 1.0,
+                       "specular_reflectance": 0.8},
+    "glass": {"type": "dielectric", "int_ior": "bk7", "specular_transmittance": [0.9, 0.95, 1.0]},
+    "plastic": {"type": "plastic", "diffuse_reflectance": [0.1, 0.27, 0.36], "int_ior": 1.9},
+    "plastic_uniform": {"type": "plastic", "diffuse_reflectance": 0.3, "specular_reflectance": 0.7, "nonlinear": True},
+}
+
+
+@pytest.mark.parametrize("material", sorted(SPECTRAL_MATERIALS))
+def test_spectral_materials_match_oracle(gpu, oracle, material):
+    """the BSDF models of row f-2 in the spectral variant: `srgb` parameters upsampled per wavelength, `uniform` ones constant
+    (src/spectra/srgb.cpp:45-52, uniform.cpp), conductors with uniform eta / k; fused and split pipeline"""
+    path = gpu.srgb_coeff_path()
+    cb = scenes.cornell_box()
+    cb["bsdfs"] = list(cb["bsdfs"]) + [SPECTRAL_MATERIALS[material]]
+    cb["meshes"][6] = dict(cb["meshes"][6], bsdf=len(cb["bsdfs"]) - 1)
+    p = dict(scenes.cornell_box_sensor(48, 48, 8, seed=12), max_depth=6)
+    scene, sensor = gpu.Scene(cb, variant="spectral"), gpu.make_sensor(p)
+    n = 48 * 48 * 8
+    xyz, mask, pos = gpu.PathIntegrator(max_depth=6, pipeline=1).sample(scene, sensor, 0, n)
+    xyz2, _, _ = gpu.PathIntegrator(max_depth=6, pipeline=2).sample(scene, sensor, 0, n)
+    assert (xyz == xyz2).all()
+    ref, ref_pos = oracle.OracleScene(cb, spectral_path=path).sample_radiance(oracle.make_desc(p), 0, n)
+    assert (pos.cpu().numpy() == ref_pos).all() and ((ref[:, 3] > 0.5) == mask.cpu().numpy()).all()
+    close = np.isclose(xyz.cpu().numpy(), ref[:, :3], rtol=5e-3, atol=2e-4).all(axis=1)
+    assert close.mean() > 0.995, (material, close.mean())
+
+
+def test_spectral_conductor_needs_uniform_ior(gpu):
+    cb = scenes.cornell_box()
+    cb["bsdfs"] = list(cb["bsdfs"]) + [{"type": "conductor", "eta": [0.2, 0.9, 1.1], "k": [3.9, 2.4, 2.1]}]
+    cb["meshes"][6] = dict(cb["meshes"][6], bsdf=len(cb["bsdfs"]) - 1)
+    with pytest.raises(RuntimeError, match="uniform"):
+        gpu.Scene(cb, variant="spectral")

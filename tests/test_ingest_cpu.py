@@ -216,7 +216,7 @@ def test_xml_scene_subset(tmp_path):
     sd = d.scene_dict
     assert d.integrator == dict(type="path", max_depth=6, rr_depth=5)
     assert [b["id"] for b in sd["bsdfs"]] == ["white", "light"]
-    assert np.allclose(sd["bsdfs"][0]["reflectance"], [0.885809, 0.698859, 0.666422]) and sd["bsdfs"][1]["reflectance"] == [0.0] * 3
+    assert np.allclose(sd["bsdfs"][0]["reflectance"], [0.885809, 0.698859, 0.666422]) and sd["bsdfs"][1]["reflectance"] == 0.0
     floor, lamp = sd["meshes"]
     assert floor["bsdf"] == 0 and floor["emitter"] == -1 and floor["faces"].tolist() == [[0, 1, 2], [0, 2, 3]]
     assert lamp["bsdf"] == 1 and lamp["emitter"] == 0 and np.allclose(sd["emitters"][0]["radiance"], [18.387, 13.9873, 6.75357])
