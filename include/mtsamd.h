@@ -61,9 +61,9 @@ typedef struct {
 
 /* BSDF plugins (constructor parameters after the host resolved defaults and named IORs):
  *   diffuse src/bsdfs/diffuse.cpp, conductor conductor.cpp, roughconductor roughconductor.cpp + microfacet.h,
- *   dielectric dielectric.cpp, plastic plastic.cpp; `twosided` = wrapped in the TwoSidedBRDF adapter (twosided.cpp). */
+ *   dielectric dielectric.cpp, plastic plastic.cpp, roughplastic roughplastic.cpp (isotropic alpha_u); `twosided` = wrapped in the TwoSidedBRDF adapter (twosided.cpp). */
 typedef enum { MTSAMD_BSDF_DIFFUSE = 0, MTSAMD_BSDF_CONDUCTOR = 1, MTSAMD_BSDF_ROUGHCONDUCTOR = 2, MTSAMD_BSDF_DIELECTRIC = 3,
-               MTSAMD_BSDF_PLASTIC = 4 } mtsamd_bsdf_type;
+               MTSAMD_BSDF_PLASTIC = 4, MTSAMD_BSDF_ROUGHPLASTIC = 5 } mtsamd_bsdf_type;
 typedef struct {
     int32_t type;              /* mtsamd_bsdf_type */
     float reflectance[3];      /* diffuse.reflectance / plastic.diffuse_reflectance: constant `srgb` value (src/spectra/srgb.cpp:27-52) */
@@ -238,6 +238,9 @@ int mtsamd_sample_radiance(mtsamd_scene *scene, const mtsamd_render_desc *desc, 
 int mtsamd_render_adjoint(mtsamd_scene *scene, const mtsamd_render_desc *desc, const float *dloss_dimage_dev,
                           const float *film_dev, float *grad_bsdf_dev, float *grad_textures_dev, void *stream);
 /* Size of a bitmap texture and its float offset inside the concatenated texture-gradient buffer. */
+/* RoughPlastic precomputation (roughplastic.cpp:380-399) of BSDF `bsdf`: out65[0..63] = external transmittance at
+ * cos(theta) = i / 63, out65[64] = internal diffuse reflectance.  Host pointer. */
+int mtsamd_scene_roughplastic_tables(const mtsamd_scene *scene, uint32_t bsdf, float *out65);
 int mtsamd_scene_texture_info(const mtsamd_scene *scene, uint32_t texture, int32_t *width, int32_t *height,
                               uint64_t *grad_offset);
 

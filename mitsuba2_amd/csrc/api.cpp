@@ -200,12 +200,54 @@ static void fill_bsdf_model(const mtsamd_bsdf_desc &bd, DevBsdf &d) {
     } else if (bd.type == MTSAMD_BSDF_DIELECTRIC) {
         d.er = bd.int_ior / bd.ext_ior;
         d.kr = bd.specular_transmittance[0]; d.kg = bd.specular_transmittance[1]; d.kb = bd.specular_transmittance[2];
-    } else if (bd.type == MTSAMD_BSDF_PLASTIC) {
+    } else if (bd.type == MTSAMD_BSDF_PLASTIC || bd.type == MTSAMD_BSDF_ROUGHPLASTIC) {
         const float eta = bd.int_ior / bd.ext_ior;
-        d.er = eta; d.eg = 1.0f / (eta * eta); d.eb = fresnel_diffuse_reflectance(1.0f / eta);
+        d.er = eta; d.eg = 1.0f / (eta * eta);
+        d.eb = bd.type == MTSAMD_BSDF_PLASTIC ? fresnel_diffuse_reflectance(1.0f / eta) : 0.0f;     // roughplastic: set by the table kernel
         const float d_mean = (bd.reflectance[0] + bd.reflectance[1] + bd.reflectance[2]) * (1.0f / 3.0f);
         const float s_mean = (bd.specular_reflectance[0] + bd.specular_reflectance[1] + bd.specular_reflectance[2]) * (1.0f / 3.0f);
         d.kr = s_mean / (d_mean + s_mean);
+    }
+}
+
+// quad::gauss_legendre (src/libcore/quad.cpp:7-66, legendre_pd: math.h:127-154): nodes / weights on [-1, 1]
+static void gauss_legendre(int n, float *nodes, float *weights) {
+    auto legendre_pd = [](int l, double x, double &lv, double &dv) {
+        double l_cur = 0.0, d_cur = 0.0;
+        if (l > 1) {
+            double l_p_pred = 1.0, l_pred = x, d_p_pred = 0.0, d_pred = 1.0, k0 = 3.0, k1 = 2.0, k2 = 1.0;
+            for (int ki = 2; ki <= l; ++ki) {
+                l_cur = (k0 * x * l_pred - k2 * l_p_pred) / k1;
+                d_cur = d_p_pred + k0 * l_pred;
+                l_p_pred = l_pred; l_pred = l_cur; d_p_pred = d_pred; d_pred = d_cur;
+                k2 = k1; k0 += 2.0; k1 += 1.0;
+            }
+        } else if (l == 0) { l_cur = 1.0; d_cur = 0.0; }
+        else { l_cur = x; d_cur = 1.0; }
+        lv = l_cur; dv = d_cur;
+    };
+    n--;
+    if (n == 0) { nodes[0] = 0.0f; weights[0] = 2.0f; }
+    else if (n == 1) { nodes[0] = (float) -std::sqrt(1.0 / 3.0); nodes[1] = -nodes[0]; weights[0] = weights[1] = 1.0f; }
+    const int m = (n + 1) / 2;
+    for (int i = 0; i < m; ++i) {
+        double x = -std::cos((double) (2 * i + 1) / (double) (2 * n + 2) * 3.14159265358979323846);
+        double l, d;
+        for (int it = 0; it < 20; ++it) {
+            legendre_pd(n + 1, x, l, d);
+            const double step = l / d;
+            x -= step;
+            if (std::fabs(step) <= 4 * std::fabs(x) * 2.220446049250313e-16) break;
+        }
+        legendre_pd(n + 1, x, l, d);
+        weights[i] = weights[n - i] = (float) (2 / ((1 - x * x) * (d * d)));
+        nodes[i] = (float) x; nodes[n - i] = (float) -x;
+    }
+    if ((n % 2) == 0) {
+        double l, d;
+        legendre_pd(n + 1, 0.0, l, d);
+        weights[n / 2] = (float) (2.0 / (d * d));
+        nodes[n / 2] = 0.0f;
     }
 }
 
@@ -223,6 +265,7 @@ struct mtsamd_scene {
     uint32_t *d_prim_shape = nullptr;
     DevShape *d_shapes = nullptr; DevBsdf *d_bsdfs = nullptr; DevEmitter *d_emitters = nullptr;
     float *d_area_pmf = nullptr, *d_area_cdf = nullptr;
+    float *d_rough_tables = nullptr;     // roughplastic: 64 floats per BSDF that needs them
     float4 *d_flat = nullptr, *d_pairs = nullptr;
     std::vector<DevTexture> textures;       // device data pointers, owned
     DevTexture *d_textures = nullptr;
@@ -250,7 +293,7 @@ void mtsamd_scene_destroy(mtsamd_scene *s) {
     s->ws.release();
     (void) hipFree(s->d_nodes); (void) hipFree(s->d_tris); (void) hipFree(s->d_tri_pos); (void) hipFree(s->d_tri_nrm); (void) hipFree(s->d_tri_uv);
     (void) hipFree(s->d_prim_shape); (void) hipFree(s->d_shapes); (void) hipFree(s->d_bsdfs); (void) hipFree(s->d_emitters);
-    (void) hipFree(s->d_area_pmf); (void) hipFree(s->d_area_cdf); (void) hipFree(s->d_flat); (void) hipFree(s->d_pairs);
+    (void) hipFree(s->d_area_pmf); (void) hipFree(s->d_area_cdf); (void) hipFree(s->d_rough_tables); (void) hipFree(s->d_flat); (void) hipFree(s->d_pairs);
     for (auto &t : s->textures) (void) hipFree((void *) t.data);
     (void) hipFree(s->d_textures);
     delete s;
@@ -302,12 +345,16 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     }
     for (uint32_t b = 0; b < desc->bsdf_count; ++b) {
         const mtsamd_bsdf_desc &bd = desc->bsdfs[b];
-        if (bd.type < MTSAMD_BSDF_DIFFUSE || bd.type > MTSAMD_BSDF_PLASTIC) return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u: unknown BSDF type %d", b, bd.type);
+        if (bd.type < MTSAMD_BSDF_DIFFUSE || bd.type > MTSAMD_BSDF_ROUGHPLASTIC) return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u: unknown BSDF type %d", b, bd.type);
         if (desc->spectral && (bd.type == MTSAMD_BSDF_CONDUCTOR || bd.type == MTSAMD_BSDF_ROUGHCONDUCTOR) &&
             (bd.eta[0] != bd.eta[1] || bd.eta[0] != bd.eta[2] || bd.k[0] != bd.k[1] || bd.k[0] != bd.k[2]))
             return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u: the spectral variant needs uniform (constant) eta and k spectra", b);
         if (bd.texture >= 0 && bd.type != MTSAMD_BSDF_DIFFUSE) return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u: bitmap textures are implemented for diffuse.reflectance only", b);
-        if ((bd.type == MTSAMD_BSDF_DIELECTRIC || bd.type == MTSAMD_BSDF_PLASTIC) && (bd.int_ior < 0.0f || bd.ext_ior < 0.0f || bd.ext_ior == 0.0f))
+        if (bd.type == MTSAMD_BSDF_ROUGHPLASTIC && (bd.int_ior == bd.ext_ior || bd.alpha_u != bd.alpha_v))
+            return fail(MTSAMD_ERR_INVALID, bd.int_ior == bd.ext_ior ? "The interior and exterior indices of refraction must be positive and differ!"
+                                                                      : "The 'roughplastic' plugin currently does not support anisotropic microfacet distributions!");
+        if ((bd.type == MTSAMD_BSDF_DIELECTRIC || bd.type == MTSAMD_BSDF_PLASTIC || bd.type == MTSAMD_BSDF_ROUGHPLASTIC) &&
+            (bd.int_ior < 0.0f || bd.ext_ior < 0.0f || bd.ext_ior == 0.0f))
             return fail(MTSAMD_ERR_INVALID, "The interior and exterior indices of refraction must be positive!");      // dielectric.cpp:183-185
         if (bd.type == MTSAMD_BSDF_DIELECTRIC && bd.twosided)
             return fail(MTSAMD_ERR_INVALID, "Only materials without a transmission component can be nested!");          // twosided.cpp:90-91
@@ -420,7 +467,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
                 coeffs[p][0] = coeff[0]; coeffs[p][1] = coeff[1]; coeffs[p][2] = coeff[2];
                 means[p] = srgb_model_mean(coeff);
             }
-            if (d.type == kBsdfPlastic) d.kr = means[1] / (means[0] + means[1]);
+            if (d.type == kBsdfPlastic || d.type == kBsdfRoughPlastic) d.kr = means[1] / (means[0] + means[1]);
         }
     }
 
@@ -501,6 +548,33 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         mtsamd_scene_destroy(s);
         return rc;
     }
+    // roughplastic: transmittance tables and internal reflectance are integrated on the device (roughplastic.cpp:380-399)
+    {
+        std::vector<uint32_t> rough;
+        for (uint32_t b = 0; b < (uint32_t) s->bsdfs.size(); ++b) if (s->bsdfs[b].type == kBsdfRoughPlastic) rough.push_back(b);
+        if (!rough.empty()) {
+            float *d_gl = nullptr;
+            if (hipMalloc((void **) &s->d_rough_tables, rough.size() * kRoughTableRes * sizeof(float)) != hipSuccess ||
+                hipMalloc((void **) &d_gl, 512 * sizeof(float)) != hipSuccess) {
+                mtsamd_scene_destroy(s);
+                return fail(MTSAMD_ERR_NOMEM, "roughplastic tables: allocation failed");
+            }
+            hipError_t err = hipSuccess;
+            for (size_t k = 0; k < rough.size() && err == hipSuccess; ++k) {
+                const float eta = s->bsdfs[rough[k]].er;
+                const int res_t = eta > 1.0f ? 32 : 128, res_r = (1.0f / eta) > 1.0f ? 32 : 128;      // microfacet.h:476-478,520-522
+                float gl[512] = {};
+                gauss_legendre(res_t, gl, gl + 128);
+                gauss_legendre(res_r, gl + 256, gl + 384);
+                err = hipMemcpy(d_gl, gl, sizeof(gl), hipMemcpyHostToDevice);
+                if (err == hipSuccess) err = launch_roughplastic_tables(s->d_bsdfs, rough[k], s->d_rough_tables + k * kRoughTableRes, d_gl, res_t, res_r, nullptr);
+                if (err == hipSuccess) err = hipDeviceSynchronize();
+            }
+            if (err == hipSuccess) err = hipMemcpy(s->bsdfs.data(), s->d_bsdfs, s->bsdfs.size() * sizeof(DevBsdf), hipMemcpyDeviceToHost);
+            (void) hipFree(d_gl);
+            if (err != hipSuccess) { mtsamd_scene_destroy(s); return fail(MTSAMD_ERR_DEVICE, "roughplastic tables: %s", hipGetErrorString(err)); }
+        }
+    }
     SceneView &v = s->view;
     v.nodes = s->d_nodes; v.tris = s->d_tris; v.root = s->bvh.root;
     v.n_nodes = s->bvh.n_nodes; v.n_slots = s->bvh.n_slots; v.n_prims = s->n_prims;
@@ -545,12 +619,22 @@ int mtsamd_scene_set_bsdf_reflectance(mtsamd_scene *s, uint32_t bsdf, const floa
     if (!s || !rgb || bsdf >= s->bsdfs.size()) return fail(MTSAMD_ERR_INVALID, "invalid bsdf index");
     HIP_TRY(hipSetDevice(s->device));
     s->bsdfs[bsdf].r = rgb[0]; s->bsdfs[bsdf].g = rgb[1]; s->bsdfs[bsdf].b = rgb[2];
-    if (s->bsdfs[bsdf].type == kBsdfPlastic) {       // parameters_changed(): specular sampling weight (plastic.cpp:170-175)
+    if (s->bsdfs[bsdf].type == kBsdfPlastic || s->bsdfs[bsdf].type == kBsdfRoughPlastic) {       // parameters_changed(): specular sampling weight (plastic.cpp:170-175)
         DevBsdf &d = s->bsdfs[bsdf];
         const float d_mean = (d.r + d.g + d.b) * (1.0f / 3.0f), s_mean = (d.sr + d.sg + d.sb) * (1.0f / 3.0f);
         d.kr = s_mean / (d_mean + s_mean);
     }
     HIP_TRY(hipMemcpy(s->d_bsdfs + bsdf, &s->bsdfs[bsdf], sizeof(DevBsdf), hipMemcpyHostToDevice));
+    return MTSAMD_OK;
+}
+
+int mtsamd_scene_roughplastic_tables(const mtsamd_scene *s, uint32_t bsdf, float *out65) {
+    if (!s || !out65 || bsdf >= s->bsdfs.size()) return fail(MTSAMD_ERR_INVALID, "invalid bsdf index");
+    const DevBsdf &b = s->bsdfs[bsdf];
+    if (b.type != kBsdfRoughPlastic || !b.table) return fail(MTSAMD_ERR_INVALID, "bsdf %u is not a roughplastic", bsdf);
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMemcpy(out65, b.table, kRoughTableRes * sizeof(float), hipMemcpyDeviceToHost));
+    out65[kRoughTableRes] = b.eb;
     return MTSAMD_OK;
 }
 

@@ -4,6 +4,7 @@
 //   MicrofacetDistribution (Beckmann, GGX, visible normals)   include/mitsuba/render/microfacet.h:187-440
 //   SmoothConductor   src/bsdfs/conductor.cpp:203-262        RoughConductor  src/bsdfs/roughconductor.cpp:196-391
 //   SmoothDielectric  src/bsdfs/dielectric.cpp:201-318       SmoothPlastic   src/bsdfs/plastic.cpp:178-297
+//   RoughPlastic      src/bsdfs/roughplastic.cpp:180-399 (tables built on the device by k_roughplastic_tables)
 //   TwoSidedBRDF      src/bsdfs/twosided.cpp:94-175 (one nested BSDF for both sides)
 //
 // Arithmetic is written out operation by operation (explicit fmaf where the reference fuses) so that the results agree
@@ -13,7 +14,7 @@
 
 namespace mtsamd {
 
-constexpr int kBsdfDiffuse = 0, kBsdfConductor = 1, kBsdfRoughConductor = 2, kBsdfDielectric = 3, kBsdfPlastic = 4;
+constexpr int kBsdfDiffuse = 0, kBsdfConductor = 1, kBsdfRoughConductor = 2, kBsdfDielectric = 3, kBsdfPlastic = 4, kBsdfRoughPlastic = 5;
 constexpr uint32_t kBsdfTwoSided = 1u, kBsdfGGX = 2u, kBsdfSampleVisible = 4u, kBsdfNonlinear = 8u;
 // spectral variant: the parameter is a `uniform` spectrum (its constant sits in the first colour channel) instead of `srgb`
 constexpr uint32_t kBsdfUniformRefl = 16u, kBsdfUniformSpec = 32u, kBsdfUniformTrans = 64u;
@@ -52,6 +53,10 @@ MTS_DEV f3 reflect_z(f3 wi) { return mk3(-wi.x, -wi.y, wi.z); }
 MTS_DEV f3 reflect_m(f3 wi, f3 m) {
     const float k = 2.0f * dot(wi, m);
     return mk3(fmaf(m.x, k, -wi.x), fmaf(m.y, k, -wi.y), fmaf(m.z, k, -wi.z));
+}
+MTS_DEV f3 refract_m(f3 wi, f3 m, float cos_theta_t, float eta_ti) {          // fresnel.h:318-322
+    const float k = fmaf(dot(wi, m), eta_ti, cos_theta_t);
+    return mk3(fmaf(m.x, k, -(wi.x * eta_ti)), fmaf(m.y, k, -(wi.y * eta_ti)), fmaf(m.z, k, -(wi.z * eta_ti)));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -127,7 +132,7 @@ MTS_DEV f2 mdf_sample_visible_11(const Mdf &d, float cos_theta_i, f2 sample) {
     f2 p = square_to_uniform_disk_concentric(sample);
     const float s = 0.5f * (1.0f + cos_theta_i);
     const float a = safe_sqrt(1.0f - sqr(p.x));
-    p.y = fmaf(p.y - a, s, a);
+    p.y = fmaf(p.y, s, fmaf(-a, s, a));          // enoki::lerp(a, b, t) = fmadd(b, t, fnmadd(a, t, a))
     const float x = p.x, y = p.y, z = safe_sqrt(1.0f - (sqr(p.x) + sqr(p.y)));
     const float sin_theta_i = safe_sqrt(1.0f - sqr(cos_theta_i));
     const float norm = rcp(fmaf(sin_theta_i, y, cos_theta_i * z));
@@ -180,11 +185,13 @@ MTS_DEV f3 mdf_sample(const Mdf &d, f3 wi, f2 sample, float &pdf) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Device-side BSDF record (112 B).  Roles of the generic fields per model:
+// Device-side BSDF record (128 B).  Roles of the generic fields per model:
 //   conductor / roughconductor   e = eta (rgb), k = extinction (rgb), s = specular_reflectance
 //   dielectric                   e.x = eta = int_ior / ext_ior, k = specular_transmittance, s = specular_reflectance
 //   plastic                      e.x = eta, e.y = 1 / eta^2, e.z = fdr_int, k.x = specular sampling weight,
 //                                (r, g, b) = diffuse_reflectance, s = specular_reflectance
+//   roughplastic                 as plastic with e.z = internal diffuse reflectance, alpha_u = roughness and
+//                                table = 64 external transmittances over cos(theta) in [0, 1]
 struct DevBsdf {
     float r, g, b; int32_t type;
     int32_t texture; float c0, c1, c2;       // c*: srgb_model coefficients of (r, g, b) (spectral variant)
@@ -193,12 +200,21 @@ struct DevBsdf {
     float kr, kg, kb, alpha_v;
     float sc0, sc1, sc2, pad0;               // spectral variant: srgb_model coefficients of specular_reflectance
     float tc0, tc1, tc2, pad1;               //                   ... of specular_transmittance
+    const float *table; uint64_t pad2;       // roughplastic: external transmittance table (device memory)
 };
+constexpr int kRoughTableRes = 64;           // MTS_ROUGH_TRANSMITTANCE_RES
+
+MTS_DEV float lerp_gather(const float *data, float x, int size) {             // roughplastic.cpp:291-302
+    x *= (float) (size - 1);
+    const uint32_t index = min((uint32_t) x, (uint32_t) (size - 2));
+    const float v0 = data[index], v1 = data[index + 1], t = x - (float) index;
+    return fmaf(v1, t, fmaf(-v0, t, v0));
+}
 
 struct BsdfSample { f3 wo; float pdf, eta; bool delta; };
 
 MTS_DEV bool bsdf_is_smooth(const DevBsdf &b) {          // BSDFFlags::Smooth: any diffuse / glossy component
-    return b.type == kBsdfDiffuse || b.type == kBsdfRoughConductor || b.type == kBsdfPlastic;
+    return b.type == kBsdfDiffuse || b.type == kBsdfRoughConductor || b.type == kBsdfPlastic || b.type == kBsdfRoughPlastic;
 }
 
 // Per-channel inputs of a BSDF evaluation: N = 3 colour channels (RGB variant) or N = 4 wavelengths (spectral variant).
@@ -219,6 +235,9 @@ MTS_DEV BsdfChannels<3> rgb_channels(const DevBsdf &b, f3 refl) {
 MTS_DEV float plastic_diffuse(const DevBsdf &b, float refl) {        // plastic.cpp:233-234,260-261
     return refl / (1.0f - ((b.flags & kBsdfNonlinear) ? (refl * b.eb) : b.eb));
 }
+
+template <int N>
+MTS_DEV void bsdf_eval_pdf_n(const DevBsdf &b, const BsdfChannels<N> &c, f3 wi, f3 wo, float (&value)[N], float &pdf);
 
 // BSDF::sample.  Returns false (weight 0) for an invalid sample.
 template <int N>
@@ -303,6 +322,32 @@ MTS_DEV bool bsdf_sample_n(const DevBsdf &b, const BsdfChannels<N> &c, f3 wi, fl
             }
             ok = true;
         }
+    } else if (b.type == kBsdfRoughPlastic) {                  // roughplastic.cpp:180-232
+        const float cos_theta_i = wi.z;
+        if (cos_theta_i > 0.0f) {
+            const float t_i = lerp_gather(b.table, cos_theta_i, kRoughTableRes);
+            float prob_specular = (1.0f - t_i) * b.kr;
+            const float prob_diffuse = t_i * (1.0f - b.kr);
+            prob_specular = prob_specular / (prob_specular + prob_diffuse);
+            bs.eta = 1.0f;
+            if (sample1 < prob_specular) {
+                const Mdf d = mdf_make((b.flags & kBsdfGGX) != 0u, b.alpha_u, b.alpha_u, (b.flags & kBsdfSampleVisible) != 0u);
+                float unused;
+                const f3 m = mdf_sample(d, wi, sample2, unused);
+                bs.wo = reflect_m(wi, m);
+            } else {
+                bs.wo = square_to_cosine_hemisphere(sample2);
+            }
+            DevBsdf one_sided = b;
+            one_sided.flags &= ~kBsdfTwoSided;               // wi is already on the front side
+            float value[N];
+            bsdf_eval_pdf_n<N>(one_sided, c, wi, bs.wo, value, bs.pdf);
+            if (bs.pdf > 0.0f) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) weight[i] = value[i] / bs.pdf;
+                ok = true;
+            }
+        }
     }
     if (!ok) {
 #pragma unroll
@@ -353,7 +398,61 @@ MTS_DEV void bsdf_eval_pdf_n(const DevBsdf &b, const BsdfChannels<N> &c, f3 wi, 
         float prob_diffuse = (1.0f - f_i) * (1.0f - b.kr);
         prob_diffuse = prob_diffuse / (prob_specular + prob_diffuse);
         pdf = (kInvPi * wo.z) * prob_diffuse;
+    } else if (b.type == kBsdfRoughPlastic) {                  // roughplastic.cpp:234-289 (eval), :304-352 (pdf)
+        const bool vis = (b.flags & kBsdfSampleVisible) != 0u;
+        const Mdf d = mdf_make((b.flags & kBsdfGGX) != 0u, b.alpha_u, b.alpha_u, vis);
+        const f3 H = normalize(wo + wi);
+        const float D = mdf_eval(d, H);
+        const float F = fresnel(dot(wi, H), b.er).r;
+        const float G = mdf_G(d, wi, wo, H);
+        const float spec_v = F * D * G / (4.0f * cos_theta_i);
+        const float t_i = lerp_gather(b.table, cos_theta_i, kRoughTableRes), t_o = lerp_gather(b.table, cos_theta_o, kRoughTableRes);
+        const float kd = kInvPi * b.eg * cos_theta_o * t_i * t_o;
+#pragma unroll
+        for (int i = 0; i < N; ++i) value[i] = spec_v * c.spec[i] + plastic_diffuse(b, c.refl[i]) * kd;
+        float prob_specular = (1.0f - t_i) * b.kr, prob_diffuse = t_i * (1.0f - b.kr);
+        prob_specular = prob_specular / (prob_specular + prob_diffuse);
+        prob_diffuse = 1.0f - prob_specular;
+        float result;
+        if (vis) result = mdf_eval(d, H) * mdf_smith_g1(d, wi, H) / (4.0f * cos_theta_i);
+        else result = mdf_pdf(d, wi, H) / (4.0f * dot(wo, H));
+        result *= prob_specular;
+        result += prob_diffuse * (kInvPi * wo.z);
+        pdf = result;
     }
+}
+
+// Tables of RoughPlastic::parameters_changed (roughplastic.cpp:380-399, microfacet.h:462-553) for one incident cosine:
+// Gauss-Legendre quadrature over the visible-normal sampling domain of the transmitted / internally reflected energy.
+MTS_DEV float rough_transmittance(const Mdf &d, f3 wi, float eta, int res, const float *nodes, const float *weights) {
+    float accum = 0.0f;
+    for (int a = 0; a < res; ++a)
+        for (int b = 0; b < res; ++b) {
+            f2 node; node.x = fmaf(nodes[b], 0.5f, 0.5f); node.y = fmaf(nodes[a], 0.5f, 0.5f);
+            float pdf;
+            const f3 m = mdf_sample(d, wi, node, pdf);
+            const Fresnel f = fresnel(dot(wi, m), eta);
+            const f3 wo = refract_m(wi, m, f.cos_theta_t, f.eta_ti);
+            float smith = mdf_smith_g1(d, wo, m) * (1.0f - f.r);
+            if (wo.z * wi.z >= 0.0f) smith = 0.0f;
+            accum += smith * (weights[b] * weights[a]);
+        }
+    return accum * 0.25f;
+}
+MTS_DEV float rough_reflectance(const Mdf &d, f3 wi, float eta, int res, const float *nodes, const float *weights) {
+    float accum = 0.0f;
+    for (int a = 0; a < res; ++a)
+        for (int b = 0; b < res; ++b) {
+            f2 node; node.x = fmaf(nodes[b], 0.5f, 0.5f); node.y = fmaf(nodes[a], 0.5f, 0.5f);
+            float pdf;
+            const f3 m = mdf_sample(d, wi, node, pdf);
+            const f3 wo = reflect_m(wi, m);
+            const Fresnel f = fresnel(dot(wi, m), eta);
+            float smith = mdf_smith_g1(d, wo, m) * f.r;
+            if (wo.z <= 0.0f || wi.z <= 0.0f) smith = 0.0f;
+            accum += smith * (weights[b] * weights[a]);
+        }
+    return accum * 0.25f;
 }
 
 // RGB variant

@@ -128,6 +128,9 @@ hipError_t launch_put_block(const float *src, int32_t sw, int32_t sh, int32_t so
 // (values, squared values) into the 11-channel film of moment.cpp (accumulating)
 hipError_t launch_square_stream(float4 *rgba, uint64_t n, hipStream_t s);
 hipError_t launch_moment_pack(const float *values5, const float *squares5, float *film11, uint64_t n_pixels, hipStream_t s);
+// roughplastic: fills the 64-entry external transmittance table of bsdfs[index] and its internal diffuse reflectance
+// (DevBsdf::eb).  gl = Gauss-Legendre nodes / weights: [nodes_t(128) | weights_t(128) | nodes_r(128) | weights_r(128)]
+hipError_t launch_roughplastic_tables(DevBsdf *bsdfs, uint32_t index, float *table, const float *gl, int res_t, int res_r, hipStream_t s);
 hipError_t launch_film_develop(const float *xyzaw, uint64_t n, float *rgba, hipStream_t s);
 
 } // namespace mtsamd

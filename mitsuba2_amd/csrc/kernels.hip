@@ -1400,6 +1400,31 @@ hipError_t launch_put_block(const float *src, int32_t sw, int32_t sh, int32_t so
 }
 
 // HDRFilm::bitmap: (X,Y,Z,A) / W, RGB = M * XYZ (hdrfilm.cpp:278-299, struct.cpp:1761-1811)
+// RoughPlastic::parameters_changed (roughplastic.cpp:380-399): one thread per table entry
+__global__ __launch_bounds__(kRoughTableRes) void k_roughplastic_tables(DevBsdf *bsdfs, uint32_t index, float *table, const float *gl,
+                                                                      int res_t, int res_r) {
+    __shared__ float part[kRoughTableRes];
+    const DevBsdf b = bsdfs[index];
+    const Mdf d = mdf_make((b.flags & kBsdfGGX) != 0u, b.alpha_u, b.alpha_u, true);
+    const int i = (int) threadIdx.x;
+    const float mu = fmaxf(1e-6f, (float) i / (float) (kRoughTableRes - 1));
+    const f3 wi = mk3(sqrtf(1.0f - mu * mu), 0.0f, mu);
+    const float eta = b.er, inv_eta = 1.0f / eta;
+    table[i] = rough_transmittance(d, wi, eta, res_t, gl, gl + 128);
+    part[i] = rough_reflectance(d, wi, inv_eta, res_r, gl + 256, gl + 384) * wi.z;
+    __syncthreads();
+    if (i == 0) {
+        float sum = 0.0f;
+        for (int k = 0; k < kRoughTableRes; ++k) sum += part[k];
+        bsdfs[index].eb = (sum * (1.0f / (float) kRoughTableRes)) * 2.0f;
+        bsdfs[index].table = table;
+    }
+}
+hipError_t launch_roughplastic_tables(DevBsdf *bsdfs, uint32_t index, float *table, const float *gl, int res_t, int res_r, hipStream_t s) {
+    hipLaunchKernelGGL(k_roughplastic_tables, dim3(1), dim3(kRoughTableRes), 0, s, bsdfs, index, table, gl, res_t, res_r);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(kBlock) void k_square_stream(float4 *rgba, uint64_t n) {
     const uint64_t i = (uint64_t) blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;

@@ -34,7 +34,8 @@ int mo_scene_set_texture(mo_scene *s, uint32_t shape, int texture);
 int mo_scene_update_texture(mo_scene *s, uint32_t texture, const float *rgb);
 int mo_scene_set_reflectance(mo_scene *s, uint32_t shape, const float *rgb);
 /* BSDF models beyond `diffuse` (oracle/mo_bsdf.c).  `twosided` wraps the model in the TwoSidedBRDF adapter. */
-enum { MO_BSDF_DIFFUSE = 0, MO_BSDF_CONDUCTOR = 1, MO_BSDF_ROUGHCONDUCTOR = 2, MO_BSDF_DIELECTRIC = 3, MO_BSDF_PLASTIC = 4 };
+enum { MO_BSDF_DIFFUSE = 0, MO_BSDF_CONDUCTOR = 1, MO_BSDF_ROUGHCONDUCTOR = 2, MO_BSDF_DIELECTRIC = 3, MO_BSDF_PLASTIC = 4,
+       MO_BSDF_ROUGHPLASTIC = 5 };
 typedef struct {
     int32_t type, twosided;
     float reflectance[3];              /* diffuse.reflectance / plastic.diffuse_reflectance (constant part) */
@@ -58,6 +59,10 @@ float mo_kat_fresnel_diffuse(float eta);
 void mo_kat_microfacet(int ggx, float alpha_u, float alpha_v, int visible, int which, uint64_t n, const float *v3, const float *wi3, float *out);
 void mo_kat_microfacet_sample(int ggx, float alpha_u, float alpha_v, int visible, uint64_t n, const float *wi3, const float *sample2, float *m3, float *pdf);
 void mo_kat_bsdf(const mo_bsdf_desc *desc, uint64_t n, const float *wi3, const float *wo3, const float *sample3, float *out14);
+/* quad::gauss_legendre (src/libcore/quad.cpp:7-66) */
+void mo_kat_gauss_legendre(int n, float *nodes, float *weights);
+/* roughplastic tables (roughplastic.cpp:380-399): external transmittance at 64 cosines + internal reflectance (out[64]) */
+void mo_kat_roughplastic_tables(const mo_bsdf_desc *desc, float *out65);
 
 /* Switches the scene to the spectral variant: every RGB reflectance / radiance is upsampled through the coefficient
  * table at `coeff_path` ("data/srgb.coeff": srgb_model_fetch, src/librender/srgb.cpp:14-40; rgb2spec_fetch,

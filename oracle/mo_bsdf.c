@@ -150,7 +150,7 @@ static mo_v2 mdf_sample_visible_11(const mdf *d, float cos_theta_i, mo_v2 sample
     mo_v2 p = mo_square_to_uniform_disk_concentric(sample);
     float s = 0.5f * (1.0f + cos_theta_i);
     float a = mo_safe_sqrt(1.0f - sqr(p.x));
-    p.y = fmaf(p.y - a, s, a);                               /* enoki::lerp(a, b, t) = fmadd(b - a, t, a) */
+    p.y = fmaf(p.y, s, fnmadd(a, s, a));                     /* enoki::lerp(a, b, t) = fmadd(b, t, fnmadd(a, t, a)) */
     float x = p.x, y = p.y, z = mo_safe_sqrt(1.0f - (sqr(p.x) + sqr(p.y)));
     float sin_theta_i = mo_safe_sqrt(1.0f - sqr(cos_theta_i));
     float norm = mo_rcp(fmaf(sin_theta_i, y, cos_theta_i * z));
@@ -205,11 +205,14 @@ static mo_v3 mdf_sample(const mdf *d, mo_v3 wi, mo_v2 sample, float *pdf) {
 }
 
 /* ------------------------------------------------------------------ BSDFs */
-/* derived constants (plastic.cpp:162-176) */
+static void roughplastic_tables(mo_bsdf *b);
+
+/* derived constants (plastic.cpp:162-176, roughplastic.cpp:365-399) */
 void mo_bsdf_prepare(mo_bsdf *b) {
     b->eta_rel = 1.0f;
-    if (b->d.type == MO_BSDF_DIELECTRIC || b->d.type == MO_BSDF_PLASTIC) b->eta_rel = b->d.int_ior / b->d.ext_ior;
-    if (b->d.type == MO_BSDF_PLASTIC) {
+    if (b->d.type == MO_BSDF_DIELECTRIC || b->d.type == MO_BSDF_PLASTIC || b->d.type == MO_BSDF_ROUGHPLASTIC) b->eta_rel = b->d.int_ior / b->d.ext_ior;
+    if (b->d.type == MO_BSDF_ROUGHPLASTIC) roughplastic_tables(b);
+    if (b->d.type == MO_BSDF_PLASTIC || b->d.type == MO_BSDF_ROUGHPLASTIC) {
         b->inv_eta_2 = 1.0f / (b->eta_rel * b->eta_rel);
         b->fdr_int = mo_fresnel_diffuse_reflectance(1.0f / b->eta_rel);
         b->fdr_ext = mo_fresnel_diffuse_reflectance(b->eta_rel);
@@ -219,9 +222,106 @@ void mo_bsdf_prepare(mo_bsdf *b) {
     }
 }
 
+/* ------------------------------------------------------------------ roughplastic tables */
+/* quad::gauss_legendre (src/libcore/quad.cpp:7-66; legendre_pd: math.h:127-154) */
+static void legendre_pd(int l, double x, double *lv, double *dv) {
+    double l_cur = 0.0, d_cur = 0.0;
+    if (l > 1) {
+        double l_p_pred = 1.0, l_pred = x, d_p_pred = 0.0, d_pred = 1.0, k0 = 3.0, k1 = 2.0, k2 = 1.0;
+        for (int ki = 2; ki <= l; ++ki) {
+            l_cur = (k0 * x * l_pred - k2 * l_p_pred) / k1;
+            d_cur = d_p_pred + k0 * l_pred;
+            l_p_pred = l_pred; l_pred = l_cur; d_p_pred = d_pred; d_pred = d_cur;
+            k2 = k1; k0 += 2.0; k1 += 1.0;
+        }
+    } else if (l == 0) { l_cur = 1.0; d_cur = 0.0; }
+    else { l_cur = x; d_cur = 1.0; }
+    *lv = l_cur; *dv = d_cur;
+}
+static void gauss_legendre(int n, float *nodes, float *weights) {
+    n--;
+    if (n == 0) { nodes[0] = 0.0f; weights[0] = 2.0f; }
+    else if (n == 1) { nodes[0] = (float) -sqrt(1.0 / 3.0); nodes[1] = -nodes[0]; weights[0] = weights[1] = 1.0f; }
+    int m = (n + 1) / 2;
+    for (int i = 0; i < m; ++i) {
+        double x = -cos((double) (2 * i + 1) / (double) (2 * n + 2) * 3.14159265358979323846);
+        for (int it = 0; it < 20; ++it) {
+            double l, d; legendre_pd(n + 1, x, &l, &d);
+            double step = l / d;
+            x -= step;
+            if (fabs(step) <= 4 * fabs(x) * 2.220446049250313e-16) break;
+        }
+        double l, d; legendre_pd(n + 1, x, &l, &d);
+        weights[i] = weights[n - i] = (float) (2 / ((1 - x * x) * (d * d)));
+        nodes[i] = (float) x; nodes[n - i] = (float) -x;
+    }
+    if ((n % 2) == 0) {
+        double l, d; legendre_pd(n + 1, 0.0, &l, &d);
+        weights[n / 2] = (float) (2.0 / (d * d));
+        nodes[n / 2] = 0.0f;
+    }
+}
+static inline mo_v3 refract_m(mo_v3 wi, mo_v3 m, float cos_theta_t, float eta_ti) {      /* fresnel.h:318-322 */
+    float k = fmaf(mo_dot(wi, m), eta_ti, cos_theta_t);
+    return mo_v3_make(fmsub(m.x, k, wi.x * eta_ti), fmsub(m.y, k, wi.y * eta_ti), fmsub(m.z, k, wi.z * eta_ti));
+}
+/* eval_transmittance / eval_reflectance (microfacet.h:462-553) for one direction, visible-normal sampling */
+static float rough_transmittance(const mdf *d, mo_v3 wi, float eta, int res, const float *nodes, const float *weights) {
+    float accum = 0.0f;
+    for (int a = 0; a < res; ++a)
+        for (int b = 0; b < res; ++b) {
+            mo_v2 node = { fmaf(nodes[b], 0.5f, 0.5f), fmaf(nodes[a], 0.5f, 0.5f) };
+            float pdf; mo_v3 m = mdf_sample(d, wi, node, &pdf);
+            float f[4]; mo_fresnel(mo_dot(wi, m), eta, f);
+            mo_v3 wo = refract_m(wi, m, f[1], f[3]);
+            float smith = mdf_smith_g1(d, wo, m) * (1.0f - f[0]);
+            if (wo.z * wi.z >= 0.0f) smith = 0.0f;
+            accum += smith * (weights[b] * weights[a]);
+        }
+    return accum * 0.25f;
+}
+static float rough_reflectance(const mdf *d, mo_v3 wi, float eta, int res, const float *nodes, const float *weights) {
+    float accum = 0.0f;
+    for (int a = 0; a < res; ++a)
+        for (int b = 0; b < res; ++b) {
+            mo_v2 node = { fmaf(nodes[b], 0.5f, 0.5f), fmaf(nodes[a], 0.5f, 0.5f) };
+            float pdf; mo_v3 m = mdf_sample(d, wi, node, &pdf);
+            mo_v3 wo = reflect_m(wi, m);
+            float f[4]; mo_fresnel(mo_dot(wi, m), eta, f);
+            float smith = mdf_smith_g1(d, wo, m) * f[0];
+            if (wo.z <= 0.0f || wi.z <= 0.0f) smith = 0.0f;
+            accum += smith * (weights[b] * weights[a]);
+        }
+    return accum * 0.25f;
+}
+/* RoughPlastic::parameters_changed (roughplastic.cpp:380-399) */
+static void roughplastic_tables(mo_bsdf *b) {
+    mdf d = mdf_make(b->d.distribution, b->d.alpha_u, b->d.alpha_u, 1);
+    float nodes_t[128], weights_t[128], nodes_r[128], weights_r[128];
+    float eta = b->eta_rel, inv_eta = 1.0f / eta;
+    int res_t = eta > 1.0f ? 32 : 128, res_r = inv_eta > 1.0f ? 32 : 128;
+    gauss_legendre(res_t, nodes_t, weights_t);
+    gauss_legendre(res_r, nodes_r, weights_r);
+    float sum = 0.0f;
+    for (int i = 0; i < 64; ++i) {
+        float mu = fmaxf(1e-6f, (float) i / 63.0f);
+        mo_v3 wi = mo_v3_make(sqrtf(1.0f - mu * mu), 0.0f, mu);
+        b->ext_trans[i] = rough_transmittance(&d, wi, eta, res_t, nodes_t, weights_t);
+        sum += rough_reflectance(&d, wi, inv_eta, res_r, nodes_r, weights_r) * wi.z;
+    }
+    b->internal_reflectance = (sum * (1.0f / 64.0f)) * 2.0f;
+}
+static inline float lerp_gather(const float *data, float x, int size) {                 /* roughplastic.cpp:291-302 */
+    x *= (float) (size - 1);
+    uint32_t index = (uint32_t) x;
+    if (index > (uint32_t) (size - 2)) index = (uint32_t) (size - 2);
+    float v0 = data[index], v1 = data[index + 1], t = x - (float) index;
+    return fmaf(v1, t, fnmadd(v0, t, v0));
+}
+
 /* BSDFFlags::Smooth = any diffuse / glossy component (bsdf.h:106-112) */
 int mo_bsdf_is_smooth(const mo_bsdf *b) {
-    return b->d.type == MO_BSDF_DIFFUSE || b->d.type == MO_BSDF_ROUGHCONDUCTOR || b->d.type == MO_BSDF_PLASTIC;
+    return b->d.type == MO_BSDF_DIFFUSE || b->d.type == MO_BSDF_ROUGHCONDUCTOR || b->d.type == MO_BSDF_PLASTIC || b->d.type == MO_BSDF_ROUGHPLASTIC;
 }
 
 static float plastic_diffuse(const mo_bsdf *b, float refl) {      /* plastic.cpp:233-234,260-261 */
@@ -245,6 +345,8 @@ void mo_bsdf_spectral_channels(const mo_bsdf *b, const float *wav, mo_bsdf_chan 
         c->eta[k] = b->d.eta[0]; c->k[k] = b->d.k[0];
     }
 }
+
+void mo_bsdf_eval_pdf_n(const mo_bsdf *b, int n, const mo_bsdf_chan *c, mo_v3 wi, mo_v3 wo, float *value, float *pdf);
 
 /* BSDF::sample for n channels -> returns 0 if the sample is invalid (weight 0). */
 int mo_bsdf_sample_n(const mo_bsdf *b, int n, const mo_bsdf_chan *c, mo_v3 wi, float sample1, mo_v2 sample2, mo_bsample *bs, float *weight) {
@@ -327,6 +429,25 @@ int mo_bsdf_sample_n(const mo_bsdf *b, int n, const mo_bsdf_chan *c, mo_v3 wi, f
         }
         ok = 1;
     } break;
+    case MO_BSDF_ROUGHPLASTIC: {                             /* roughplastic.cpp:180-232 */
+        float cos_theta_i = wi.z;
+        if (!(cos_theta_i > 0.0f)) break;
+        float t_i = lerp_gather(b->ext_trans, cos_theta_i, 64);
+        float prob_specular = (1.0f - t_i) * b->spec_weight, prob_diffuse = t_i * (1.0f - b->spec_weight);
+        prob_specular = prob_specular / (prob_specular + prob_diffuse);
+        bs->eta = 1.0f; bs->delta = 0;
+        if (sample1 < prob_specular) {
+            mdf d = mdf_make(b->d.distribution, b->d.alpha_u, b->d.alpha_u, b->d.sample_visible);
+            float unused; mo_v3 m = mdf_sample(&d, wi, sample2, &unused);
+            bs->wo = reflect_m(wi, m);
+        } else {
+            bs->wo = mo_square_to_cosine_hemisphere(sample2);
+        }
+        float value[4];
+        mo_bsdf twin = *b; twin.d.twosided = 0;              /* wi is already on the front side */
+        mo_bsdf_eval_pdf_n(&twin, n, c, wi, bs->wo, value, &bs->pdf);
+        if (bs->pdf > 0.0f) { for (int k = 0; k < n; ++k) weight[k] = value[k] / bs->pdf; ok = 1; }
+    } break;
     default: break;
     }
     if (!ok) for (int k = 0; k < n; ++k) weight[k] = 0.0f;
@@ -374,6 +495,29 @@ void mo_bsdf_eval_pdf_n(const mo_bsdf *b, int n, const mo_bsdf_chan *c, mo_v3 wi
         prob_diffuse = prob_diffuse / (prob_specular + prob_diffuse);
         *pdf = mo_square_to_cosine_hemisphere_pdf(wo) * prob_diffuse;
     } break;
+    case MO_BSDF_ROUGHPLASTIC: {                             /* roughplastic.cpp:234-289 (eval), :304-352 (pdf) */
+        mdf d = mdf_make(b->d.distribution, b->d.alpha_u, b->d.alpha_u, b->d.sample_visible);
+        mo_v3 H = mo_normalize(mo_add(wo, wi));
+        float D = mdf_eval(&d, H);
+        float f[4]; mo_fresnel(mo_dot(wi, H), b->eta_rel, f);
+        float G = mdf_G(&d, wi, wo, H);
+        float spec_v = f[0] * D * G / (4.0f * cos_theta_i);
+        float t_i = lerp_gather(b->ext_trans, cos_theta_i, 64), t_o = lerp_gather(b->ext_trans, cos_theta_o, 64);
+        float kd = MO_INV_PI * b->inv_eta_2 * cos_theta_o * t_i * t_o;
+        for (int k = 0; k < n; ++k) {
+            float diff = c->refl[k] / (1.0f - (b->d.nonlinear ? (c->refl[k] * b->internal_reflectance) : b->internal_reflectance));
+            value[k] = spec_v * c->spec[k] + diff * kd;
+        }
+        float prob_specular = (1.0f - t_i) * b->spec_weight, prob_diffuse = t_i * (1.0f - b->spec_weight);
+        prob_specular = prob_specular / (prob_specular + prob_diffuse);
+        prob_diffuse = 1.0f - prob_specular;
+        float result;
+        if (b->d.sample_visible) result = mdf_eval(&d, H) * mdf_smith_g1(&d, wi, H) / (4.0f * cos_theta_i);
+        else result = mdf_pdf(&d, wi, H) / (4.0f * mo_dot(wo, H));
+        result *= prob_specular;
+        result += prob_diffuse * mo_square_to_cosine_hemisphere_pdf(wo);
+        *pdf = result;
+    } break;
     default: break;      /* conductor / dielectric: delta lobes only, eval = pdf = 0 */
     }
 }
@@ -408,10 +552,15 @@ void mo_kat_microfacet_sample(int ggx, float alpha_u, float alpha_v, int visible
         m3[3 * i] = m.x; m3[3 * i + 1] = m.y; m3[3 * i + 2] = m.z;
     }
 }
+void mo_kat_gauss_legendre(int n, float *nodes, float *weights) { gauss_legendre(n, nodes, weights); }
+void mo_kat_roughplastic_tables(const mo_bsdf_desc *desc, float *out65) {
+    mo_bsdf b; memset(&b, 0, sizeof(b)); b.d = *desc; mo_bsdf_prepare(&b);
+    memcpy(out65, b.ext_trans, sizeof(float) * 64); out65[64] = b.internal_reflectance;
+}
 /* generic BSDF evaluation for n (wi, wo, sample1, sample2) tuples.
  * out per tuple: eval(3) pdf | sampled wo(3) pdf eta delta weight(3) valid = 14 floats */
 void mo_kat_bsdf(const mo_bsdf_desc *desc, uint64_t n, const float *wi3, const float *wo3, const float *sample3, float *out14) {
-    mo_bsdf b; b.d = *desc; mo_bsdf_prepare(&b);
+    mo_bsdf b; memset(&b, 0, sizeof(b)); b.d = *desc; mo_bsdf_prepare(&b);
     for (uint64_t i = 0; i < n; ++i) {
         mo_v3 wi = mo_v3_make(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]), wo = mo_v3_make(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]);
         float *o = out14 + 14 * i;

@@ -20,6 +20,7 @@ typedef struct { mo_v3 p, n, d; float dist, pdf; uint32_t emitter; float pdf_sin
 typedef struct {
     mo_bsdf_desc d; float eta_rel, inv_eta_2, fdr_int, fdr_ext, spec_weight;
     float refl_coeff[3], spec_coeff[3], trans_coeff[3];      /* spectral variant: srgb_model coefficients */
+    float ext_trans[64], internal_reflectance;               /* roughplastic (roughplastic.cpp:380-399) */
 } mo_bsdf;
 /* per-channel inputs of a BSDF evaluation: 3 colour channels or MO_WAV wavelengths */
 typedef struct { float refl[4], spec[4], trans[4], eta[4], k[4]; } mo_bsdf_chan;

@@ -141,7 +141,7 @@ int mo_scene_set_spectral(mo_scene *s, const char *coeff_path) {
             (b->d.eta[0] != b->d.eta[1] || b->d.eta[0] != b->d.eta[2] || b->d.k[0] != b->d.k[1] || b->d.k[0] != b->d.k[2])) {
             free(t.scale); free(t.data); return -4;          /* RGB eta / k cannot be upsampled (values > 1): uniform spectra only */
         }
-        if (b->d.type == MO_BSDF_PLASTIC) b->spec_weight = means[1] / (means[0] + means[1]);     /* plastic.cpp:170-175 with Texture::mean() */
+        if (b->d.type == MO_BSDF_PLASTIC || b->d.type == MO_BSDF_ROUGHPLASTIC) b->spec_weight = means[1] / (means[0] + means[1]);     /* plastic.cpp:170-175 with Texture::mean() */
     }
     for (uint32_t e = 0; e < s->n_emitters; ++e) {
         mo_emitter *em = &s->emitters[e];

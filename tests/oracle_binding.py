@@ -115,6 +115,8 @@ def lib():
         L.mo_kat_microfacet.argtypes = [C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_uint64, vp, vp, vp]
         L.mo_kat_microfacet_sample.argtypes = [C.c_int, C.c_float, C.c_float, C.c_int, C.c_uint64, vp, vp, vp, vp]
         L.mo_kat_bsdf.argtypes = [C.POINTER(BsdfDesc), C.c_uint64, vp, vp, vp, vp]
+        L.mo_kat_gauss_legendre.argtypes = [C.c_int, vp, vp]
+        L.mo_kat_roughplastic_tables.argtypes = [C.POINTER(BsdfDesc), vp]
         L.mo_kat_srgb_model_fetch.argtypes = [C.c_char_p, vp, vp]
         L.mo_kat_spectral.argtypes = [C.c_float, vp, C.c_float, vp]
         _lib = L
@@ -357,3 +359,16 @@ def bsdf_kat(plugin_dict, wi, wo, sample3):
     lib().mo_kat_bsdf(C.byref(d), wi.shape[0], _p(wi), _p(wo), _p(s), _p(out))
     return dict(eval=out[:, 0:3], pdf=out[:, 3], s_wo=out[:, 4:7], s_pdf=out[:, 7], s_eta=out[:, 8], s_delta=out[:, 9] > 0.5,
                 s_weight=out[:, 10:13], s_valid=out[:, 13] > 0.5)
+
+
+def gauss_legendre(n):
+    nodes, weights = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    lib().mo_kat_gauss_legendre(n, _p(nodes), _p(weights))
+    return nodes, weights
+
+
+def roughplastic_tables(plugin_dict):
+    d, _ = bsdf_desc(plugin_dict)
+    out = np.zeros(65, np.float32)
+    lib().mo_kat_roughplastic_tables(C.byref(d), _p(out))
+    return out[:64], float(out[64])

@@ -239,9 +239,12 @@ def test_twosided(nested):
                                {"type": "roughconductor", "alpha_u": 0.2, "alpha_v": 0.05, "distribution": "ggx", "sample_visible": False, "eta": 0.0, "k": 1.0},
                                {"type": "roughconductor", "alpha_u": 0.2, "alpha_v": 0.05, "distribution": "ggx", "sample_visible": True, "eta": 0.0, "k": 1.0},
                                {"type": "plastic", "diffuse_reflectance": [0.5, 0.2, 0.1], "nonlinear": True},
+                               {"type": "roughplastic", "alpha": 0.05, "specular_reflectance": 0.7, "diffuse_reflectance": 0.1},
+                               {"type": "roughplastic", "alpha": 0.25, "specular_reflectance": 0.7, "diffuse_reflectance": 0.1},
+                               {"type": "roughplastic", "alpha": 0.3, "distribution": "ggx", "diffuse_reflectance": [0.5, 0.2, 0.1], "nonlinear": True},
                                {"type": "diffuse", "reflectance": [0.5, 0.2, 0.1]}])
 def test_bsdf_sample_eval_pdf_consistency(b):
-    """the configurations of test_rough_conductor.py:6-97 (chi^2 tests of sample vs pdf for wi = normalize(1,1,1)):
+    """the configurations of test_rough_conductor.py:6-97 and test_rough_plastic.py:4-34 (chi^2 tests of sample vs pdf):
     weight * pdf == eval and the sampled pdf == pdf() at the sampled direction; white-furnace bound on the mean weight"""
     rng = np.random.default_rng(5)
     n = 50000
@@ -270,3 +273,30 @@ def test_bsdf_parameter_errors():
         bsdfs.normalize({"type": "dielectric", "int_ior": "unobtainium"})
     assert bsdfs.normalize({"type": "dielectric"})["int_ior"] == pytest.approx(1.5046) and bsdfs.normalize({"type": "plastic"})["int_ior"] == pytest.approx(1.49)
     assert bsdfs.normalize({"type": "dielectric", "int_ior": "water"})["ext_ior"] == pytest.approx(1.000277)
+
+
+def test_gauss_legendre():
+    """src/libcore/tests/test_quad.py:16-22"""
+    assert np.allclose(ob.gauss_legendre(1), [[0], [2]])
+    assert np.allclose(ob.gauss_legendre(2), [[-math.sqrt(1 / 3), math.sqrt(1 / 3)], [1, 1]])
+    assert np.allclose(ob.gauss_legendre(3), [[-math.sqrt(3 / 5), 0, math.sqrt(3 / 5)], [5 / 9, 8 / 9, 5 / 9]])
+    assert np.allclose(ob.gauss_legendre(4), [[-0.861136, -0.339981, 0.339981, 0.861136], [0.347855, 0.652145, 0.652145, 0.347855]], atol=1e-6)
+    n, w = ob.gauss_legendre(128)
+    assert np.isclose(w.sum(), 2) and np.isclose((w * n ** 2).sum(), 2 / 3, atol=1e-6)
+
+
+def test_roughplastic_tables():
+    """RoughPlastic::parameters_changed (roughplastic.cpp:380-399): for vanishing roughness the external transmittance tends
+    to 1 - F(mu) of the smooth interface and the internal diffuse reflectance to fresnel_diffuse_reflectance(1 / eta)"""
+    trans, r_int = ob.roughplastic_tables({"type": "roughplastic", "alpha": 0.002, "int_ior": 1.5, "ext_ior": 1.0})
+    mu = np.maximum(1e-6, np.arange(64) / 63.0)
+    smooth = np.array([1 - ob.fresnel(m, 1.5)[0] for m in mu])
+    assert np.allclose(trans[8:], smooth[8:], atol=3e-3)
+    from mitsuba2_amd import bsdfs
+    assert abs(r_int - ob.lib().mo_kat_fresnel_diffuse(1 / 1.5)) < 1e-2
+    rough, r_rough = ob.roughplastic_tables({"type": "roughplastic", "alpha": 0.4, "distribution": "ggx"})
+    assert (rough >= 0).all() and (rough <= 1).all() and (np.diff(rough[4:]) > -1e-3).all() and 0.3 < r_rough < 0.8
+    with pytest.raises(RuntimeError, match="anisotropic"):
+        bsdfs.normalize({"type": "roughplastic", "alpha_u": 0.1, "alpha_v": 0.2})
+    with pytest.raises(RuntimeError, match="positive and differ"):
+        bsdfs.normalize({"type": "roughplastic", "int_ior": 1.2, "ext_ior": 1.2})

@@ -21,6 +21,9 @@ MATERIALS = {
     "glass": {"type": "dielectric", "int_ior": "bk7", "ext_ior": "air", "specular_transmittance": [0.9, 0.95, 1.0]},
     "plastic": {"type": "plastic", "diffuse_reflectance": [0.1, 0.27, 0.36], "int_ior": 1.9},
     "plastic_nl": {"type": "plastic", "diffuse_reflectance": [0.5, 0.2, 0.1], "nonlinear": True, "specular_reflectance": 0.8},
+    "roughplastic": {"type": "roughplastic", "alpha": 0.15, "diffuse_reflectance": [0.1, 0.27, 0.36], "int_ior": 1.9},
+    "roughplastic_ggx": {"type": "roughplastic", "alpha": 0.3, "distribution": "ggx", "diffuse_reflectance": 0.4, "specular_reflectance": 0.7,
+                         "nonlinear": True},
     "twosided_diffuse": {"type": "twosided", "bsdf": {"type": "diffuse", "reflectance": [0.6, 0.3, 0.2]}},
     "twosided_rough": {"type": "twosided", "bsdf": {"type": "roughconductor", "alpha": 0.15, "distribution": "ggx", "eta": 0.0, "k": 1.0}},
 }
@@ -77,3 +80,17 @@ def test_unsupported_combinations():
         R.Scene(cb, variant="spectral")
     with pytest.raises(RuntimeError, match="not supported by this backend"):
         R.Scene(dict(cb, bsdfs=[{"type": "roughdielectric"}] * len(cb["bsdfs"])))
+
+
+def test_roughplastic_tables_match_oracle():
+    """the transmittance table / internal reflectance integrated on the device against the oracle's (roughplastic.cpp:380-399)"""
+    import ctypes as C
+    from mitsuba2_amd import render as R, scenes, _lib as L
+    for mat in ({"type": "roughplastic", "alpha": 0.15, "int_ior": 1.9}, {"type": "roughplastic", "alpha": 0.4, "distribution": "ggx"}):
+        cb = scenes.cornell_box()
+        cb["bsdfs"] = [mat] + list(cb["bsdfs"][1:])
+        scene = R.Scene(cb)
+        got = np.zeros(65, np.float32)
+        L.check(L.lib().mtsamd_scene_roughplastic_tables(scene._handle, 0, got.ctypes.data_as(L.f32p)))
+        want, r_int = ob.roughplastic_tables(mat)
+        assert np.allclose(got[:64], want, rtol=1e-4, atol=1e-5) and abs(got[64] - r_int) < 1e-4
