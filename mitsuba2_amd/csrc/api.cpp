@@ -863,22 +863,28 @@ int setup_job(Job &j, mtsamd_scene *s, const mtsamd_render_desc *d, hipStream_t 
     j.s = s; j.d = d; j.stream = stream;
     if (int rc = make_camera(*d, j.cam)) return rc;
     if (int rc = make_filter(d->rfilter, d->rfilter_param, d->rfilter_analytic, j.filter)) return rc;
-    j.target = d->paths_per_wave > 0 ? (uint32_t) d->paths_per_wave : 256u;
-    j.target = std::min<uint32_t>(std::max<uint32_t>(j.target, 64u), 4096u);
+    // One pass holds up to 2^28 camera samples (6 GiB of sample stream): every pass ends with a drain phase in which the
+    // pool empties, so fewer, larger passes waste less (cbox 1024^2 @ 256 spp: 4 passes of 2^26 -> 1 pass: +7 %).
+    uint64_t pass_limit = 1ull << 28;
+    if (const char *e = getenv("MTSAMD_PASS_LOG2")) pass_limit = 1ull << std::min(31, std::max(10, atoi(e)));      // experiment switch
     // pipeline 0: fused kernel for LDS-resident (flat) scenes, split kernels for hierarchy scenes; 1 / 2 force one of them
     if (s->spectral && d->integrator != 0) return fail(MTSAMD_ERR_UNSUPPORTED, "the direct and depth integrators are implemented for the RGB variant only");
     j.split = d->integrator == 0 && (d->pipeline == 2 || (d->pipeline == 0 && !s->view.flat));
-    // Paths in flight.  Fused kernel: 16 scheduling waves per CU (one resident generation; the pool stays inside the
-    // Infinity Cache).  Split pipeline: its three launches per iteration are latency-bound walks whose tails and launch
-    // gaps only amortise over much larger launches -- measured on the 261 k-triangle mesh: 16 / 32 / 64 / 128 / 256 waves
-    // per CU -> 705 / 954 / 1162 / 1269 / 1309 Msample/s.
-    j.n_waves = (uint32_t) s->cu_count * 16u;
-    if (j.split) {      // no more scheduling waves than the pass can fill
-        const uint64_t want = (std::min<uint64_t>(max_pass, 1ull << 26) + j.target - 1) / j.target;
-        j.n_waves = (uint32_t) std::min<uint64_t>(std::max<uint64_t>(want, j.n_waves), (uint64_t) s->cu_count * 128u);
+    // Paths in flight.  A launch advances every in-flight path by one segment and ends with a tail in which the CUs run
+    // dry one by one; the tails (and, for the split pipeline, the gaps between its three launches) only amortise over large
+    // launches.  Measured on MI355X -- fused kernel, cbox 1024^2 @ 256 spp, scheduling waves per CU x slots per wave:
+    // 16 x 256 -> 1753, 48 x 256 -> 1953, 72 x 512 -> 2366, 104 x 512 -> 2459, 208 x 1024 -> 2507 Msample/s (power-of-two
+    // wave counts alias in the memory channels: 64 x 256 is slower than 72 x 256); split pipeline, 261 k-triangle mesh:
+    // 16 / 64 / 128 / 208 waves per CU x 256 slots -> 705 / 1162 / 1339 / 1407 Msample/s.
+    j.target = d->paths_per_wave > 0 ? (uint32_t) d->paths_per_wave : (j.split ? 256u : 512u);
+    j.target = std::min<uint32_t>(std::max<uint32_t>(j.target, 64u), 4096u);
+    {   // no more scheduling waves than the pass can fill
+        const uint64_t want = (std::min<uint64_t>(max_pass, pass_limit) + j.target - 1) / j.target;
+        const uint64_t lo = (uint64_t) s->cu_count * 16u, hi = (uint64_t) s->cu_count * (j.split ? 208u : 104u);
+        j.n_waves = (uint32_t) std::min<uint64_t>(std::max<uint64_t>(want, lo), hi);
     }
     if (const char *e = getenv("MTSAMD_WAVES_PER_CU")) j.n_waves = (uint32_t) s->cu_count * (uint32_t) std::max(1, atoi(e));    // experiment switch
-    j.pass_cap = std::max<uint64_t>(std::min<uint64_t>(max_pass, 1ull << 26), 1);
+    j.pass_cap = std::max<uint64_t>(std::min<uint64_t>(max_pass, pass_limit), 1);
     if (int rc = ensure_workspace(s, j.n_waves, j.target, j.pass_cap, j.split)) return rc;
     j.pass_cap = s->ws.pass_cap;
     HIP_TRY(hipMemsetAsync(s->ws.wave_stats, 0, 4 * (size_t) j.n_waves * sizeof(uint64_t), stream));
