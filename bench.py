@@ -143,14 +143,15 @@ def main():
         alg_bytes = 2 * STATE_BYTES * acc["segments"] + 24 * acc["samples"]
         bounce_s = acc["bounce_ns"] * 1e-9
         achieved = alg_bytes / max(bounce_s, 1e-12) / 1e9
-        # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3 passes):
-        # measured offline with scripts/collect_profiles.sh and committed under profiles/.
+        # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3 passes), measured
+        # offline with scripts/collect_profiles.sh on the same kernel at 32 spp and committed under profiles/ as the ratio of
+        # counted to algorithmic bytes; scaled here to this run's bytes per launch (launch sizes differ with the sample count).
         traffic, traffic_src = None, None
         import glob
         pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_k_bounce.json")))
         if pmc:
             try:
-                traffic = json.load(open(pmc[-1]))["hbm_bytes_per_launch"]
+                traffic = json.load(open(pmc[-1]))["traffic_over_algorithmic"] * (alg_bytes / launches)
                 traffic_src = os.path.relpath(pmc[-1], ROOT)
             except (OSError, ValueError, KeyError):
                 pass

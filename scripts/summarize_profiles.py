@@ -51,7 +51,7 @@ sq, n_s, b_s = counters("sq")
 alg_per_launch = b_f["roofline"]["alg_bytes_per_launch"]
 out = {
     "command": "rocprofv3 --pmc <counter> -- python3 bench.py --steps 1 --warmup 0 --spp 32 --no-cpu-baseline (one pass per TCC counter)",
-    "kernel": "k_bounce<true>",
+    "kernel": "k_bounce<true, false>",
     "launches": n_f,
     "fetch_size_kib_raw": fetch.get("FETCH_SIZE", 0.0),
     "write_size_kib_raw": write.get("WRITE_SIZE", 0.0),
