@@ -82,11 +82,18 @@ typedef struct {
                                   conductors need the same eta and k in all three channels (uniform) */
 } mtsamd_bsdf_desc;
 
-/* area: src/emitters/area.cpp (attached to a mesh); constant: src/emitters/constant.cpp (environment, RGB variant) */
-typedef enum { MTSAMD_EMITTER_AREA = 0, MTSAMD_EMITTER_CONSTANT = 1 } mtsamd_emitter_type;
+/* area: src/emitters/area.cpp (attached to a mesh); constant: src/emitters/constant.cpp and envmap: src/emitters/envmap.cpp
+ * (environment emitters, at most one per scene, RGB variant) */
+typedef enum { MTSAMD_EMITTER_AREA = 0, MTSAMD_EMITTER_CONSTANT = 1, MTSAMD_EMITTER_ENVMAP = 2 } mtsamd_emitter_type;
 typedef struct {
     int32_t type;              /* mtsamd_emitter_type; AreaLight = src/emitters/area.cpp */
-    float radiance[3];
+    float radiance[3];         /* area, constant */
+    /* envmap: latitude-longitude image, linear RGB, host pointer (height * width * 3), `scale`, and the emitter's to_world
+     * (row-major 4x4; the linear part is used) */
+    const float *envmap_data;
+    int32_t envmap_width, envmap_height;
+    float envmap_scale;
+    float to_world[16];
 } mtsamd_emitter_desc;
 
 typedef struct {

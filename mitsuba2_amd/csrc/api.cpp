@@ -9,6 +9,7 @@
 //   HDRFilm::prepare/put                                       src/films/hdrfilm.cpp:188-209
 #include "../../include/mtsamd.h"
 #include "bvh.h"
+#include "envmap.h"
 #include "kernels.h"
 #include "spectral_upsampling.h"
 #include "cie_data.h"
@@ -266,6 +267,7 @@ struct mtsamd_scene {
     DevShape *d_shapes = nullptr; DevBsdf *d_bsdfs = nullptr; DevEmitter *d_emitters = nullptr;
     float *d_area_pmf = nullptr, *d_area_cdf = nullptr;
     float *d_rough_tables = nullptr;     // roughplastic: 64 floats per BSDF that needs them
+    float *d_env_texels = nullptr, *d_env_warp = nullptr; DevEnvmap *d_envmap = nullptr;      // envmap emitter
     float4 *d_flat = nullptr, *d_pairs = nullptr;
     std::vector<DevTexture> textures;       // device data pointers, owned
     DevTexture *d_textures = nullptr;
@@ -293,7 +295,8 @@ void mtsamd_scene_destroy(mtsamd_scene *s) {
     s->ws.release();
     (void) hipFree(s->d_nodes); (void) hipFree(s->d_tris); (void) hipFree(s->d_tri_pos); (void) hipFree(s->d_tri_nrm); (void) hipFree(s->d_tri_uv);
     (void) hipFree(s->d_prim_shape); (void) hipFree(s->d_shapes); (void) hipFree(s->d_bsdfs); (void) hipFree(s->d_emitters);
-    (void) hipFree(s->d_area_pmf); (void) hipFree(s->d_area_cdf); (void) hipFree(s->d_rough_tables); (void) hipFree(s->d_flat); (void) hipFree(s->d_pairs);
+    (void) hipFree(s->d_area_pmf); (void) hipFree(s->d_area_cdf); (void) hipFree(s->d_rough_tables);
+    (void) hipFree(s->d_env_texels); (void) hipFree(s->d_env_warp); (void) hipFree(s->d_envmap); (void) hipFree(s->d_flat); (void) hipFree(s->d_pairs);
     for (auto &t : s->textures) (void) hipFree((void *) t.data);
     (void) hipFree(s->d_textures);
     delete s;
@@ -333,14 +336,16 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     int32_t environment = -1;
     for (uint32_t e = 0; e < desc->emitter_count; ++e) {
         const int32_t et = desc->emitters[e].type;
-        if (et == MTSAMD_EMITTER_CONSTANT) {
+        if (et == MTSAMD_EMITTER_CONSTANT || et == MTSAMD_EMITTER_ENVMAP) {
             if (emitter_shape[e] >= 0) return fail(MTSAMD_ERR_INVALID, "emitter %u: an environment emitter cannot be attached to a shape", e);
             if (environment >= 0) return fail(MTSAMD_ERR_INVALID, "Only one environment emitter can be specified per scene.");      // scene.cpp:45-46
-            if (desc->spectral) return fail(MTSAMD_ERR_UNSUPPORTED, "emitter %u: the constant emitter is implemented for the RGB variant only", e);
+            if (desc->spectral) return fail(MTSAMD_ERR_UNSUPPORTED, "emitter %u: environment emitters are implemented for the RGB variant only", e);
+            if (et == MTSAMD_EMITTER_ENVMAP && (!desc->emitters[e].envmap_data || desc->emitters[e].envmap_width < 2 || desc->emitters[e].envmap_height < 2))
+                return fail(MTSAMD_ERR_INVALID, "emitter %u: the environment map must be at least 2x2 pixels in size", e);
             environment = (int32_t) e;
             continue;
         }
-        if (et != MTSAMD_EMITTER_AREA) return fail(MTSAMD_ERR_UNSUPPORTED, "emitter %u: only 'area' and 'constant' emitters are implemented", e);
+        if (et != MTSAMD_EMITTER_AREA) return fail(MTSAMD_ERR_UNSUPPORTED, "emitter %u: only 'area', 'constant' and 'envmap' emitters are implemented", e);
         if (emitter_shape[e] < 0) return fail(MTSAMD_ERR_INVALID, "emitter %u is not attached to a shape", e);
     }
     for (uint32_t b = 0; b < desc->bsdf_count; ++b) {
@@ -499,7 +504,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         std::memset(&e, 0, sizeof(e));
         const mtsamd_emitter_desc &ed = desc->emitters[s->environment];
         e.r = ed.radiance[0]; e.g = ed.radiance[1]; e.b = ed.radiance[2];
-        e.shape = 0xffffffffu; e.pad0 = kEmitterConstant;
+        e.shape = 0xffffffffu; e.pad0 = ed.type == MTSAMD_EMITTER_ENVMAP ? kEmitterEnvmap : kEmitterConstant;
         const float *bb = s->bvh.bbox;
         e.cx = (bb[3] + bb[0]) * 0.5f; e.cy = (bb[4] + bb[1]) * 0.5f; e.cz = (bb[5] + bb[2]) * 0.5f;
         const float dx = e.cx - bb[3], dy = e.cy - bb[4], dz = e.cz - bb[5];
@@ -548,6 +553,33 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         mtsamd_scene_destroy(s);
         return rc;
     }
+    // envmap emitter: texels + sampling hierarchy (envmap.cpp:66-125, distr_2d.h:200-312)
+    if (s->environment >= 0 && desc->emitters[s->environment].type == MTSAMD_EMITTER_ENVMAP) {
+        const mtsamd_emitter_desc &ed = desc->emitters[s->environment];
+        EnvmapHost eh;
+        if (!build_envmap(ed.envmap_data, ed.envmap_width, ed.envmap_height, eh) || eh.lv_offset.size() > (size_t) kEnvMaxLevels) {
+            mtsamd_scene_destroy(s);
+            return fail(MTSAMD_ERR_INVALID, "envmap: unsupported image size %d x %d", ed.envmap_width, ed.envmap_height);
+        }
+        DevEnvmap de{};
+        std::vector<DevEnvmap> one(1);
+        if ((rc = upload(&s->d_env_texels, eh.texels)) || (rc = upload(&s->d_env_warp, eh.warp))) { mtsamd_scene_destroy(s); return rc; }
+        de.data = reinterpret_cast<const float4 *>(s->d_env_texels); de.warp = s->d_env_warp;
+        de.w = ed.envmap_width; de.h = ed.envmap_height; de.n_levels = (int32_t) eh.lv_offset.size(); de.scale = ed.envmap_scale;
+        for (size_t k = 0; k < eh.lv_offset.size(); ++k) { de.lv_offset[k] = eh.lv_offset[k]; de.lv_width[k] = eh.lv_width[k]; }
+        for (int k = 0; k < 2; ++k) { de.patch_size[k] = eh.patch_size[k]; de.inv_patch_size[k] = eh.inv_patch_size[k]; de.max_patch_index[k] = eh.max_patch_index[k]; }
+        const float *m = ed.to_world;
+        const double a = m[0], b = m[1], c = m[2], d2 = m[4], e2 = m[5], f = m[6], g = m[8], h2 = m[9], i2 = m[10];
+        const float lin[9] = { m[0], m[1], m[2], m[4], m[5], m[6], m[8], m[9], m[10] };
+        const double det = a * (e2 * i2 - f * h2) - b * (d2 * i2 - f * g) + c * (d2 * h2 - e2 * g);
+        if (det == 0.0) { mtsamd_scene_destroy(s); return fail(MTSAMD_ERR_INVALID, "envmap: singular to_world transformation"); }
+        const double inv[9] = { (e2 * i2 - f * h2) / det, (c * h2 - b * i2) / det, (b * f - c * e2) / det,
+                                (f * g - d2 * i2) / det, (a * i2 - c * g) / det, (c * d2 - a * f) / det,
+                                (d2 * h2 - e2 * g) / det, (b * g - a * h2) / det, (a * e2 - b * d2) / det };
+        for (int k = 0; k < 9; ++k) { de.to_world[k] = lin[k]; de.to_local[k] = (float) inv[k]; }
+        one[0] = de;
+        if ((rc = upload(&s->d_envmap, one))) { mtsamd_scene_destroy(s); return rc; }
+    }
     // roughplastic: transmittance tables and internal reflectance are integrated on the device (roughplastic.cpp:380-399)
     {
         std::vector<uint32_t> rough;
@@ -587,7 +619,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     v.tri_pos = s->d_tri_pos; v.tri_nrm = any_nrm ? s->d_tri_nrm : nullptr; v.tri_uv = any_uv ? s->d_tri_uv : nullptr;
     v.prim_shape = s->d_prim_shape; v.shapes = s->d_shapes; v.bsdfs = s->d_bsdfs;
     v.emitters = s->d_emitters; v.n_emitters = desc->emitter_count;
-    v.env_emitter = s->environment;
+    v.env_emitter = s->environment; v.envmap = s->d_envmap;
     v.area_pmf = s->d_area_pmf; v.area_cdf = s->d_area_cdf;
     v.n_shapes = desc->mesh_count; v.n_bsdfs = desc->bsdf_count;
     v.textures = s->d_textures; v.n_textures = desc->texture_count;

@@ -16,6 +16,7 @@
 #pragma once
 #include "device_math.h"
 #include "device_bsdf.h"
+#include "device_envmap.h"
 
 namespace mtsamd {
 
@@ -40,7 +41,7 @@ struct DevEmitter {
     float c0, c1, c2, d65_scale;       // spectral variant: SRGBEmitterSpectrum = D65 * d65_scale * srgb_model(c) (srgb_d65.cpp:27-63)
     float cx, cy, cz, radius;          // constant emitter (pad0 == 1): the scene's bounding sphere (constant.cpp:47-51)
 };
-constexpr uint32_t kEmitterConstant = 1u;     // DevEmitter::pad0
+constexpr uint32_t kEmitterConstant = 1u, kEmitterEnvmap = 2u;     // DevEmitter::pad0
 constexpr float kInvFourPi = 0.07957747154594766788f;
 
 struct SceneView {
@@ -70,6 +71,7 @@ struct SceneView {
     const float4 *flat_pairs;
     uint32_t flat, n_pairs;
     int32_t env_emitter;       // index of the environment emitter or -1 (scene.cpp:44-48)
+    const DevEnvmap *envmap;   // its image + sampling hierarchy if it is an `envmap`
     uint32_t general;          // some BSDF is not a one-sided `diffuse`: kernels instantiated with the BSDF switch are used
 };
 constexpr uint32_t kFlatMaxPrims = 64;
@@ -424,7 +426,7 @@ MTS_DEV void fill_si(const Geo<FLAT> &g, f3 ray_d, uint32_t prim, float b1, floa
 }
 
 // ---------------------------------------------------------------------------
-struct DirectionSample { f3 p, n, d; float dist, pdf; uint32_t emitter; };
+struct DirectionSample { f3 p, n, d; float dist, pdf; uint32_t emitter; f3 value; };      // value: radiance of an envmap sample
 
 // Scene::sample_emitter_direction without the visibility test.  The emitted spectrum is returned in factored
 // form: spec = (radiance * r1) * r2 with r1 = 1/pdf (0 when the sample is masked) and r2 = emitter count.
@@ -445,6 +447,17 @@ MTS_DEV void sample_emitter_direction(const Geo<FLAT> &g, f3 ref_p, f2 sample, D
         sample.x = (sample.x - (float) index * emitter_pdf) * nf;
     }
     const DevEmitter e = g.emitter(index);
+    if (e.pad0 == kEmitterEnvmap) {
+        // EnvironmentMapEmitter::sample_direction (envmap.cpp:154-190); r1 = 1 / pdf, the radiance is looked up by the caller
+        f3 d, value; float pdf;
+        envmap_sample(*sv.envmap, sample, d, pdf, value);
+        ds.dist = 2.0f * e.radius;
+        ds.p = ref_p + d * ds.dist;
+        ds.n = -d; ds.d = d; ds.pdf = pdf; ds.emitter = index; ds.value = value;
+        r1 = rcp(pdf);
+        if (sv.n_emitters > 1) { ds.pdf *= emitter_pdf; r2 = rcp(emitter_pdf); }
+        return;
+    }
     if (e.pad0 == kEmitterConstant) {
         // ConstantBackgroundEmitter::sample_direction (constant.cpp:82-107), square_to_uniform_sphere (warp.h:262-267)
         const float z = fmaf(-2.0f, sample.y, 1.0f), r = safe_sqrt(fmaf(-z, z, 1.0f));
@@ -513,14 +526,21 @@ MTS_DEV void sample_emitter_direction(const Geo<FLAT> &g, f3 ref_p, f2 sample, D
     spec = mk3(0, 0, 0);
     if (g.sv.n_emitters == 0) return;
     const DevEmitter e = g.emitter(ds.emitter);
-    spec = mk3(e.r * r1, e.g * r1, e.b * r1);
+    f3 rad = mk3(e.r, e.g, e.b);
+    if (e.pad0 == kEmitterEnvmap) rad = ds.value;                             // eval_spectrum at the sampled (u, v)
+    spec = mk3(rad.x * r1, rad.y * r1, rad.z * r1);
     if (g.sv.n_emitters > 1) spec = spec * r2;
 }
 
-MTS_DEV float pdf_environment(uint32_t n_emitters) {        // ConstantBackgroundEmitter::pdf_direction + Scene (scene.cpp:191-206)
-    float pdf = kInvFourPi;
-    if (n_emitters > 1) pdf *= 1.0f / (float) n_emitters;
+// pdf_direction of the environment emitter for world direction d (constant.cpp:109-114, envmap.cpp:192-208) + Scene (scene.cpp:191-206)
+MTS_DEV float pdf_environment(const SceneView &sv, const DevEmitter &e, f3 d) {
+    float pdf = e.pad0 == kEmitterEnvmap ? envmap_pdf(*sv.envmap, d) : kInvFourPi;
+    if (sv.n_emitters > 1) pdf *= 1.0f / (float) sv.n_emitters;
     return pdf;
+}
+// radiance an escaped ray travelling along d picks up from the environment emitter (constant.cpp:53-57, envmap.cpp:132-146)
+MTS_DEV f3 environment_radiance(const SceneView &sv, const DevEmitter &e, f3 d) {
+    return e.pad0 == kEmitterEnvmap ? envmap_eval(*sv.envmap, d) : mk3(e.r, e.g, e.b);
 }
 MTS_DEV float pdf_emitter_direction(uint32_t n_emitters, float area_norm, f3 d, f3 n, float dist) {
     float pdf = 0.0f;

@@ -116,8 +116,9 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
     if (!REC && !found && sv.env_emitter >= 0) {             // si.emitter(scene) of an escaped ray: the environment
         const DevEmitter e = geo.emitter((uint32_t) sv.env_emitter);
         float ew = 1.0f;
-        if (s.depth > 1u) ew = mis_weight(s.bs_pdf, (GENERAL && (s.flags & kFlagDelta)) ? 0.0f : pdf_environment(sv.n_emitters));
-        s.res.x += (ew * s.thr.x) * e.r; s.res.y += (ew * s.thr.y) * e.g; s.res.z += (ew * s.thr.z) * e.b;
+        if (s.depth > 1u) ew = mis_weight(s.bs_pdf, (GENERAL && (s.flags & kFlagDelta)) ? 0.0f : pdf_environment(sv, e, s.d));
+        const f3 le = environment_radiance(sv, e, s.d);
+        s.res.x += (ew * s.thr.x) * le.x; s.res.y += (ew * s.thr.y) * le.y; s.res.z += (ew * s.thr.z) * le.z;
     }
     bool active = found;
 
@@ -605,7 +606,8 @@ __global__ __launch_bounds__(kBlock) void k_direct(const RenderParams P, uint64_
         } else if (!found) {
             if (!P.hide_emitters && sv.env_emitter >= 0) {
                 const DevEmitter e = geo.emitter((uint32_t) sv.env_emitter);
-                s.res = mk3(s.res.x + e.r, s.res.y + e.g, s.res.z + e.b);
+                const f3 le = environment_radiance(sv, e, s.d);
+                s.res = mk3(s.res.x + le.x, s.res.y + le.y, s.res.z + le.z);
             }
         } else {
             int32_t ne = P.emitter_samples, nb = P.bsdf_samples;
@@ -662,8 +664,8 @@ __global__ __launch_bounds__(kBlock) void k_direct(const RenderParams P, uint64_
                 if (!traverse<FLAT, false>(sv, lds, si.p, d2, (1.0f + hmax_abs(si.p)) * kRayEpsilon, __builtin_inff(), h2, c.tri_tests)) {
                     if (sv.env_emitter < 0) continue;
                     const DevEmitter e = geo.emitter((uint32_t) sv.env_emitter);
-                    le = mk3(e.r, e.g, e.b);
-                    pe = delta ? 0.0f : pdf_environment(sv.n_emitters);
+                    le = environment_radiance(sv, e, d2);
+                    pe = delta ? 0.0f : pdf_environment(sv, e, d2);
                 } else {
                     SurfaceInteraction si2;
                     fill_si(geo, d2, h2.prim, h2.u, h2.v, si2);

@@ -441,9 +441,21 @@ class Scene:
         ed = (L.EmitterDesc * max(len(emitters), 1))()
         for i, e in enumerate(emitters):
             et = e.get("type", "area")
-            if et not in ("area", "constant"):
-                raise RuntimeError("Emitter plugin '%s' is not supported by this backend (area, constant)" % et)
-            ed[i].type = 0 if et == "area" else 1
+            if et not in ("area", "constant", "envmap"):
+                raise RuntimeError("Emitter plugin '%s' is not supported by this backend (area, constant, envmap)" % et)
+            ed[i].type = {"area": 0, "constant": 1, "envmap": 2}[et]
+            if et == "envmap":          # src/emitters/envmap.cpp: lat-long image (linear RGB), scale, to_world
+                img = _f32(e["data"])
+                if img.ndim != 3 or img.shape[2] != 3:
+                    raise RuntimeError("envmap: expected (H, W, 3) linear RGB data")
+                keep.append(img)
+                ed[i].envmap_data = img.ctypes.data_as(L.f32p)
+                ed[i].envmap_height, ed[i].envmap_width = img.shape[0], img.shape[1]
+                ed[i].envmap_scale = float(e.get("scale", 1.0))
+                tw = np.eye(4, dtype=np.float32) if e.get("to_world") is None else _f32(e["to_world"]).reshape(4, 4)
+                ed[i].to_world = (C.c_float * 16)(*tw.reshape(-1).tolist())
+                ed[i].radiance = (C.c_float * 3)(0.0, 0.0, 0.0)
+                continue
             ed[i].radiance = (C.c_float * 3)(*[float(x) for x in e["radiance"]])
         sd = L.SceneDesc(md, len(meshes), bd, len(bsdfs), ed, len(emitters), td, len(tex), 0, None)
         if variant == "spectral":

@@ -577,11 +577,22 @@ def _instantiate(ctx, root, base_dir):
         elif it.tag == "texture":
             continue                                 # instantiated where referenced
         elif it.tag == "emitter":
-            if it.type != "constant":
-                raise XMLError('Emitter plugin "%s" is not supported by this backend (area emitters attached to shapes, constant)' % it.type)
-            rad = _colour(_resolve(ctx, it.get("radiance", ("spectrum", 1.0))), "constant.radiance", True)
-            it.check_unqueried()
-            desc.scene_dict["emitters"].append(dict(type="constant", radiance=rad))
+            if it.type == "constant":
+                rad = _colour(_resolve(ctx, it.get("radiance", ("spectrum", 1.0))), "constant.radiance", True)
+                it.check_unqueried()
+                desc.scene_dict["emitters"].append(dict(type="constant", radiance=rad))
+            elif it.type == "envmap":
+                from . import bitmap
+                fn = it.get("filename", kind="string")
+                path = fn if os.path.isabs(fn) else os.path.join(base_dir, fn)
+                if not os.path.exists(path):
+                    raise XMLError('"%s": file does not exist!' % path)
+                entry = dict(type="envmap", data=bitmap.read_rgb(path), scale=it.get("scale", 1.0, "float"),
+                             to_world=it.get("to_world", np.eye(4, dtype=F32), "transform"))
+                it.check_unqueried()
+                desc.scene_dict["emitters"].append(entry)
+            else:
+                raise XMLError('Emitter plugin "%s" is not supported by this backend (area emitters attached to shapes, constant, envmap)' % it.type)
         else:
             raise XMLError('scene: unsupported child "%s"' % it.tag)
     return desc
@@ -641,7 +652,7 @@ def load_file(path, device=0, variant="rgb", **params):
 
 # -------------------------------------------------------------------------------------------- load_dict
 _PLUGIN_CLASS = {"twosided": "bsdf", "conductor": "bsdf", "roughconductor": "bsdf", "dielectric": "bsdf", "plastic": "bsdf", "roughplastic": "bsdf", "path": "integrator", "perspective": "sensor", "hdrfilm": "film", "independent": "sampler", "gaussian": "rfilter", "box": "rfilter",
-                 "direct": "integrator", "depth": "integrator", "moment": "integrator", "obj": "shape", "ply": "shape", "rectangle": "shape", "diffuse": "bsdf", "area": "emitter", "constant": "emitter", "bitmap": "texture", "scene": "scene"}
+                 "direct": "integrator", "depth": "integrator", "moment": "integrator", "obj": "shape", "ply": "shape", "rectangle": "shape", "diffuse": "bsdf", "area": "emitter", "constant": "emitter", "envmap": "emitter", "bitmap": "texture", "scene": "scene"}
 
 
 def _node_from_dict(d, ctx):

@@ -24,6 +24,14 @@ int mo_scene_add_mesh(mo_scene *s, uint32_t n_verts, const float *positions,
                       const float *emitter_rgb);
 /* `constant` environment emitter (src/emitters/constant.cpp); RGB variant only.  Returns the emitter index. */
 int mo_scene_add_constant_emitter(mo_scene *s, const float *radiance_rgb);
+/* `envmap` emitter (src/emitters/envmap.cpp): linear RGB latitude-longitude image (h * w * 3), `scale`, linear part of
+ * to_world (row-major 3x3, NULL = identity); RGB variant only.  Returns the emitter index. */
+int mo_scene_add_envmap_emitter(mo_scene *s, int w, int h, const float *rgb, float scale, const float *to_world9);
+/* Hierarchical2D0 (distr_2d.h): which = 0 sample / 1 invert / 2 eval for n points -> (x, y, pdf) each */
+void mo_kat_hier2d(const float *data, uint32_t w, uint32_t h, int normalize, int which, uint64_t n, const float *in2, float *out3);
+void mo_kat_bilinear_to_square(float v00, float v10, float v01, float v11, float x, float y, float *out3);
+/* envmap: per sample d(3) pdf spec(3) eval(d)(3) pdf_direction(d) = 11 floats */
+void mo_kat_envmap(int w, int h, const float *rgb, float scale, const float *to_world9, uint64_t n, const float *sample2, float *out11);
 /* Re-orders the emitter list: new emitter i = old emitter order[i] (Scene::m_emitters follows the order of the scene's
  * children, scene.cpp:31-56). */
 int mo_scene_set_emitter_order(mo_scene *s, uint32_t n, const uint32_t *order);

@@ -37,9 +37,23 @@ typedef struct {
     float *area_pmf, *area_cdf; float area_sum, area_norm; uint32_t valid_lo, valid_hi;
 } mo_mesh;
 
+/* Hierarchical2D<Float, 0> (distr_2d.h:180-600) and the `envmap` emitter built on it (mo_envmap.c) */
+typedef struct { uint32_t size, width; float *data; } mo_h2_level;
+typedef struct { int n_levels; mo_h2_level lv[34]; float patch_size[2], inv_patch_size[2]; uint32_t max_patch_index[2]; } mo_hier2d;
+typedef struct { int w, h; float *data; float scale; mo_hier2d warp; float to_world[9], to_local[9]; } mo_envmap;
+int mo_hier2d_build(mo_hier2d *h, const float *data, uint32_t w, uint32_t hgt, int normalize);
+void mo_hier2d_free(mo_hier2d *h);
+void mo_hier2d_sample(const mo_hier2d *h, float sx, float sy, float *ox, float *oy, float *pdf);
+float mo_hier2d_eval(const mo_hier2d *h, float px, float py);
+int mo_envmap_init(mo_envmap *e, int w, int h, const float *rgb, float scale, const float *to_world9);
+void mo_envmap_free(mo_envmap *e);
+void mo_envmap_eval(const mo_envmap *e, mo_v3 d, float out[3]);
+void mo_envmap_sample(const mo_envmap *e, mo_v2 sample, mo_v3 *d_out, float *pdf_out, float spec[3]);
+float mo_envmap_pdf(const mo_envmap *e, mo_v3 d_world);
+
 /* type 0: `area` (src/emitters/area.cpp) attached to `shape`; type 1: `constant` environment (src/emitters/constant.cpp)
- * with the scene's bounding sphere (set_scene, constant.cpp:47-51) */
-typedef struct { uint32_t shape; float radiance[3]; float coeff[3], d65_scale; int type; mo_v3 center; float radius; } mo_emitter;
+ * with the scene's bounding sphere (set_scene, constant.cpp:47-51); type 2: `envmap` (src/emitters/envmap.cpp) */
+typedef struct { uint32_t shape; float radiance[3]; float coeff[3], d65_scale; int type; mo_v3 center; float radius; mo_envmap *env; } mo_emitter;
 typedef struct { int w, h; float *data; } mo_texture;
 typedef struct { double lo[3], hi[3]; uint32_t left, right, first, count; } mo_bvh_node;
 

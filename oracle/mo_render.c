@@ -373,9 +373,11 @@ static void path_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, 
     for (int depth = 1;; ++depth) {
         /* ---------------- Intersection with emitters ---------------- */
         if (emitter >= 0 && active) {
-            /* AreaLight::eval (area.cpp:71-79); ConstantBackgroundEmitter::eval (constant.cpp:53-57) */
-            if (s->emitters[emitter].type == 1 || si.wi.z > 0.0f) {
+            /* AreaLight::eval (area.cpp:71-79); ConstantBackgroundEmitter::eval (constant.cpp:53-57); envmap.cpp:132-146 */
+            if (s->emitters[emitter].type != 0 || si.wi.z > 0.0f) {
+                float le_env[3];
                 const float *le = s->emitters[emitter].radiance;
+                if (s->emitters[emitter].type == 2) { mo_envmap_eval(s->emitters[emitter].env, mo_neg(si.wi), le_env); le = le_env; }
                 for (int k = 0; k < 3; ++k) result[k] += (emission_weight * throughput[k]) * le[k];
             }
         }
@@ -463,7 +465,12 @@ static void direct_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray, i
     int valid = scene_intersect(s, ray, &si, st);
     *valid_ray = valid;
     if (!valid) {                                                                              /* environment seen directly */
-        if (!hide_emitters && s->environment >= 0) for (int k = 0; k < 3; ++k) result[k] += s->emitters[s->environment].radiance[k];
+        if (!hide_emitters && s->environment >= 0) {
+            float le_env[3];
+            const float *le = s->emitters[s->environment].radiance;
+            if (s->emitters[s->environment].type == 2) { mo_envmap_eval(s->emitters[s->environment].env, mo_neg(si.wi), le_env); le = le_env; }
+            for (int k = 0; k < 3; ++k) result[k] += le[k];
+        }
         return;
     }
     const mo_mesh *mesh = &s->meshes[si.shape];
@@ -508,7 +515,8 @@ static void direct_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray, i
         int emitter = v2 ? s->meshes[si_bsdf.shape].emitter : s->environment;
         if (emitter < 0) continue;
         float emitter_val[3] = { 0.0f, 0.0f, 0.0f };
-        if (!v2 || si_bsdf.wi.z > 0.0f) for (int k = 0; k < 3; ++k) emitter_val[k] = s->emitters[emitter].radiance[k];
+        if (!v2 && s->emitters[emitter].type == 2) mo_envmap_eval(s->emitters[emitter].env, mo_neg(si_bsdf.wi), emitter_val);
+        else if (!v2 || si_bsdf.wi.z > 0.0f) for (int k = 0; k < 3; ++k) emitter_val[k] = s->emitters[emitter].radiance[k];
         mo_v3 d = mo_sub(si_bsdf.p, si.p);
         float dist = mo_norm(d);
         d = mo_div_s(d, dist);

@@ -97,6 +97,17 @@ int mo_scene_add_constant_emitter(mo_scene *s, const float *rgb) {
     s->environment = (int) s->n_emitters;
     return (int) s->n_emitters++;
 }
+int mo_scene_add_envmap_emitter(mo_scene *s, int w, int h, const float *rgb, float scale, const float *to_world9) {
+    if (!s || !rgb || s->environment >= 0) return -1;
+    mo_envmap *env = (mo_envmap *) malloc(sizeof(mo_envmap));
+    if (mo_envmap_init(env, w, h, rgb, scale, to_world9)) { free(env); return -2; }
+    s->emitters = (mo_emitter *) realloc(s->emitters, sizeof(mo_emitter) * (s->n_emitters + 1));
+    mo_emitter *e = &s->emitters[s->n_emitters];
+    memset(e, 0, sizeof(*e));
+    e->type = 2; e->shape = 0xffffffffu; e->env = env; e->radius = 1.0f;
+    s->environment = (int) s->n_emitters;
+    return (int) s->n_emitters++;
+}
 int mo_scene_set_emitter_order(mo_scene *s, uint32_t n, const uint32_t *order) {
     if (!s || n != s->n_emitters) return -1;
     mo_emitter *ne = (mo_emitter *) malloc(sizeof(mo_emitter) * (n ? n : 1));
@@ -104,7 +115,7 @@ int mo_scene_set_emitter_order(mo_scene *s, uint32_t n, const uint32_t *order) {
     free(s->emitters); s->emitters = ne;
     s->environment = -1;
     for (uint32_t i = 0; i < n; ++i) {
-        if (ne[i].type == 1) s->environment = (int) i;
+        if (ne[i].type != 0) s->environment = (int) i;
         else s->meshes[ne[i].shape].emitter = (int) i;
     }
     return 0;
@@ -330,7 +341,7 @@ int mo_scene_finalize(mo_scene *s) {
      * (bbox.h:329-332), radius * (1 + RayEpsilon) */
     for (uint32_t i = 0; i < s->n_emitters; ++i) {
         mo_emitter *e = &s->emitters[i];
-        if (e->type != 1) continue;
+        if (e->type == 0) continue;
         mo_v3 mn = mo_v3_make((float) lo[0], (float) lo[1], (float) lo[2]), mx = mo_v3_make((float) hi[0], (float) hi[1], (float) hi[2]);
         e->center = mo_scale(mo_add(mx, mn), 0.5f);
         float r = mo_norm(mo_sub(e->center, mx));
@@ -515,6 +526,21 @@ void mo_sample_emitter_direction(const mo_scene *s, mo_v3 ref_p, mo_v2 sample, m
     }
     const mo_emitter *e = &s->emitters[index];
     int active;
+    if (e->type == 2) {
+        /* EnvironmentMapEmitter::sample_direction (envmap.cpp:154-190) */
+        mo_v3 d; float pdf, val[3];
+        mo_envmap_sample(e->env, sample, &d, &pdf, val);
+        ds->dist = 2.0f * e->radius;
+        ds->p = mo_add(ref_p, mo_scale(d, ds->dist));
+        ds->n = mo_neg(d); ds->d = d; ds->pdf = pdf; ds->emitter = index; ds->pdf_single = pdf;
+        for (int k = 0; k < 3; ++k) spec[k] = val[k];
+        if (s->n_emitters > 1) {
+            ds->pdf *= emitter_pdf;
+            float r = mo_rcp(emitter_pdf);
+            for (int k = 0; k < 3; ++k) spec[k] *= r;
+        }
+        return;
+    }
     if (e->type == 1) {
         /* ConstantBackgroundEmitter::sample_direction (constant.cpp:82-107); square_to_uniform_sphere (warp.h:262-267) */
         float z = fmaf(-2.0f, sample.y, 1.0f), r = mo_safe_sqrt(fmaf(-z, z, 1.0f));
@@ -554,6 +580,11 @@ void mo_sample_emitter_direction(const mo_scene *s, mo_v3 ref_p, mo_v2 sample, m
 
 /* scene.cpp:191-206; area.cpp:119-125; shape.cpp:272-283 */
 float mo_pdf_emitter_direction(const mo_scene *s, uint32_t emitter, mo_v3 d, mo_v3 n, float dist) {
+    if (s->emitters[emitter].type == 2) {                    /* envmap.cpp:192-208 */
+        float pdf = mo_envmap_pdf(s->emitters[emitter].env, d);
+        if (s->n_emitters > 1) pdf *= 1.0f / (float) s->n_emitters;
+        return pdf;
+    }
     if (s->emitters[emitter].type == 1) {                    /* constant.cpp:109-114 */
         float pdf = MO_INV_FOUR_PI;
         if (s->n_emitters > 1) pdf *= 1.0f / (float) s->n_emitters;

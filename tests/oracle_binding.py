@@ -107,6 +107,10 @@ def lib():
         L.mo_scene_set_bsdf.argtypes = [vp, C.c_uint32, C.POINTER(BsdfDesc)]
         L.mo_scene_add_constant_emitter.argtypes = [vp, f32p]
         L.mo_scene_set_emitter_order.argtypes = [vp, C.c_uint32, vp]
+        L.mo_scene_add_envmap_emitter.argtypes = [vp, C.c_int, C.c_int, vp, C.c_float, vp]
+        L.mo_kat_hier2d.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_uint64, vp, vp]
+        L.mo_kat_bilinear_to_square.argtypes = [C.c_float] * 6 + [vp]
+        L.mo_kat_envmap.argtypes = [C.c_int, C.c_int, vp, C.c_float, vp, C.c_uint64, vp, vp]
         L.mo_kat_fresnel.argtypes = [C.c_float, C.c_float, vp]
         L.mo_kat_fresnel_conductor.argtypes = [C.c_float] * 3
         L.mo_kat_fresnel_conductor.restype = C.c_float
@@ -169,6 +173,11 @@ class OracleScene:
             if e.get("type", "area") == "constant":
                 rad = _f(e["radiance"])
                 assert L.mo_scene_add_constant_emitter(self.h, rad.ctypes.data_as(f32p)) == len(created)
+                created.append(ei)
+            elif e.get("type", "area") == "envmap":
+                img = _f(e["data"])
+                tw = _f(np.asarray(e["to_world"], np.float32).reshape(4, 4)[:3, :3]) if e.get("to_world") is not None else None
+                assert L.mo_scene_add_envmap_emitter(self.h, img.shape[1], img.shape[0], _p(img), float(e.get("scale", 1.0)), _p(tw)) == len(created)
                 created.append(ei)
         if created != list(range(len(created))):
             order = np.array([created.index(i) for i in range(len(created))], dtype=np.uint32)
@@ -372,3 +381,25 @@ def roughplastic_tables(plugin_dict):
     out = np.zeros(65, np.float32)
     lib().mo_kat_roughplastic_tables(C.byref(d), _p(out))
     return out[:64], float(out[64])
+
+
+def hier2d(data, which, points, normalize=True):
+    """Hierarchical2D0: which in ('sample', 'invert', 'eval') -> (N, 3) = (x, y, pdf)"""
+    data, pts = _f(data), _f(points).reshape(-1, 2)
+    out = np.zeros((pts.shape[0], 3), np.float32)
+    lib().mo_kat_hier2d(_p(data), data.shape[1], data.shape[0], int(normalize), {"sample": 0, "invert": 1, "eval": 2}[which], pts.shape[0], _p(pts), _p(out))
+    return out
+
+
+def bilinear_to_square(v00, v10, v01, v11, x, y):
+    out = np.zeros(3, np.float32)
+    lib().mo_kat_bilinear_to_square(v00, v10, v01, v11, x, y, _p(out))
+    return out
+
+
+def envmap_kat(rgb, sample2, scale=1.0, to_world=None):
+    rgb, s = _f(rgb), _f(sample2).reshape(-1, 2)
+    tw = _f(np.asarray(to_world, np.float32).reshape(4, 4)[:3, :3]) if to_world is not None else None
+    out = np.zeros((s.shape[0], 11), np.float32)
+    lib().mo_kat_envmap(rgb.shape[1], rgb.shape[0], _p(rgb), scale, _p(tw), s.shape[0], _p(s), _p(out))
+    return dict(d=out[:, 0:3], pdf=out[:, 3], spec=out[:, 4:7], eval=out[:, 7:10], pdf_again=out[:, 10])
