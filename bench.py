@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--paths-per-wave", type=int, default=0)
+    ap.add_argument("--pipeline", type=int, default=0, help="0 automatic, 1 fused, 2 split, 3 fused closest + queued shadow rays")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real path) or gloo (rehearsal of N ranks on fewer GPUs)")
     args = ap.parse_args()
@@ -99,7 +100,7 @@ def main():
     p = scenes.cornell_box_sensor(width, height, spp_total)
     scene = render.Scene(sd, device=local_rank)
     sensor = render.make_sensor(p)
-    integ = render.PathIntegrator(paths_per_wave=args.paths_per_wave)
+    integ = render.PathIntegrator(paths_per_wave=args.paths_per_wave, pipeline=args.pipeline)
     partition = mdist.film_partition(rank, n)
 
     def step():

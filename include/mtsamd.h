@@ -200,8 +200,9 @@ typedef struct {
     /* scheduler knobs (0 = library default) */
     int32_t paths_per_wave;    /* in-flight path slots per scheduling wave */
     int32_t pipeline;          /* 0 = automatic: fused bounce kernel for LDS-resident scenes (<= 64 primitives), split
-                                  trace / shade / trace kernels for hierarchy scenes; 1 = force fused; 2 = force split.
-                                  All three produce identical samples. */
+                                  trace / shade / trace kernels for hierarchy scenes; 1 = force fused; 2 = force split;
+                                  3 = LDS-resident scenes only: closest hit fused with shading, shadow rays queued and
+                                  resolved in dense batches by a second kernel.  All produce identical samples. */
     int32_t film_rgb;          /* 0: film channels X,Y,Z,A,W (integrator.cpp:72-74, 254-268);
                                   1: R,G,B,A,W -- linear RGB as mitsuba.python.autodiff._render_helper accumulates (autodiff.py:53-72) */
     int32_t integrator;        /* 0 = path (src/integrators/path.cpp), 1 = direct (direct.cpp), 2 = depth (depth.cpp) */

@@ -746,7 +746,7 @@ static int check_desc(const mtsamd_render_desc *d) {
     if (d->sample_count <= 0) return fail(MTSAMD_ERR_INVALID, "sample_count must be positive");
     if (d->integrator < 0 || d->integrator > 2) return fail(MTSAMD_ERR_UNSUPPORTED, "integrator %d is not implemented (0 path, 1 direct, 2 depth)", d->integrator);
     if (d->emitter_samples < 0 || d->bsdf_samples < 0) return fail(MTSAMD_ERR_INVALID, "Must have at least 1 BSDF or emitter sample!");
-    if (d->pipeline < 0 || d->pipeline > 2) return fail(MTSAMD_ERR_UNSUPPORTED, "pipeline %d is not available in this build", d->pipeline);
+    if (d->pipeline < 0 || d->pipeline > 3) return fail(MTSAMD_ERR_UNSUPPORTED, "pipeline %d is not available in this build", d->pipeline);
     return 0;
 }
 
@@ -802,7 +802,7 @@ struct Job {
     RowMap rows{};
     int store_xyz = 1;
     uint32_t plane_pix0 = 0, plane_pixels = 0;
-    bool split = false;
+    bool split = false, shadow_queue = false;
 };
 
 // Traces the local sample ordinals [first, first+n) of this render's rows to completion; results land in
@@ -836,7 +836,7 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     p.spp = j.d->sample_count; p.crop_x = j.d->crop_x; p.crop_y = j.d->crop_y; p.crop_w = j.d->crop_width; p.crop_h = j.d->crop_height;
     p.max_depth = j.d->max_depth; p.rr_depth = j.d->rr_depth;
     p.spectral = j.s->spectral ? 1 : 0;
-    p.split = j.split ? 1 : 0;
+    p.split = j.shadow_queue ? 2 : (j.split ? 1 : 0);
     p.integrator = j.d->integrator; p.emitter_samples = j.d->emitter_samples; p.bsdf_samples = j.d->bsdf_samples;
     p.hide_emitters = j.d->hide_emitters;
     if (j.d->integrator != 0) {          // direct / depth: one launch finishes the whole pass
@@ -902,6 +902,8 @@ int setup_job(Job &j, mtsamd_scene *s, const mtsamd_render_desc *d, hipStream_t 
     // pipeline 0: fused kernel for LDS-resident (flat) scenes, split kernels for hierarchy scenes; 1 / 2 force one of them
     if (s->spectral && d->integrator != 0) return fail(MTSAMD_ERR_UNSUPPORTED, "the direct and depth integrators are implemented for the RGB variant only");
     j.split = d->integrator == 0 && (d->pipeline == 2 || (d->pipeline == 0 && !s->view.flat));
+    j.shadow_queue = d->integrator == 0 && s->view.flat && d->pipeline == 3;
+    if (d->pipeline == 3 && !s->view.flat) return fail(MTSAMD_ERR_INVALID, "pipeline 3 (queued shadow rays) applies to LDS-resident scenes only");
     // Paths in flight.  A launch advances every in-flight path by one segment and ends with a tail in which the CUs run
     // dry one by one; the tails (and, for the split pipeline, the gaps between its three launches) only amortise over large
     // launches.  Measured on MI355X -- fused kernel, cbox 1024^2 @ 256 spp, scheduling waves per CU x slots per wave:
@@ -917,7 +919,7 @@ int setup_job(Job &j, mtsamd_scene *s, const mtsamd_render_desc *d, hipStream_t 
     }
     if (const char *e = getenv("MTSAMD_WAVES_PER_CU")) j.n_waves = (uint32_t) s->cu_count * (uint32_t) std::max(1, atoi(e));    // experiment switch
     j.pass_cap = std::max<uint64_t>(std::min<uint64_t>(max_pass, pass_limit), 1);
-    if (int rc = ensure_workspace(s, j.n_waves, j.target, j.pass_cap, j.split)) return rc;
+    if (int rc = ensure_workspace(s, j.n_waves, j.target, j.pass_cap, j.split || j.shadow_queue)) return rc;
     j.pass_cap = s->ws.pass_cap;
     HIP_TRY(hipMemsetAsync(s->ws.wave_stats, 0, 4 * (size_t) j.n_waves * sizeof(uint64_t), stream));
     s->cancel.store(0);

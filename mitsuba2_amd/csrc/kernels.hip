@@ -75,7 +75,9 @@ struct Deferred {
 // GENERAL = true: switch over the BSDF models of device_bsdf.h (delta lobes, eta, twosided).
 constexpr uint32_t kFlagDelta = 4u;       // the ray was spawned by a delta lobe: no emitter-sampling counterpart (path.cpp:198-203)
 
-template <bool FLAT, bool REC = false, bool DEFER = false, bool GENERAL = false>
+// DEFER: 0 = both ray queries inline (fused kernel); 1 = closest hit precomputed + shadow ray queued (split pipeline of
+// hierarchy scenes); 2 = closest hit inline, shadow ray queued (flat scenes: the any-hit loop then runs on dense batches)
+template <bool FLAT, bool REC = false, int DEFER = 0, bool GENERAL = false>
 MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s, Counters &c, VertexRec *rec = nullptr,
                          Deferred *df = nullptr) {
     static_assert(!(REC && GENERAL), "the adjoint replay handles diffuse BSDFs only");
@@ -88,7 +90,8 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
     Hit hit;
     ++c.closest; ++c.segments;
     bool found;
-    if (DEFER) { hit = df->hit; found = df->found; df->pending = false; }
+    if (DEFER) df->pending = false;
+    if (DEFER == 1) { hit = df->hit; found = df->found; }
     else found = traverse<FLAT, false>(sv, lds, s.o, s.d, s.mint, s.maxt, hit, c.tri_tests);
     if (s.depth == 1u) s.flags = found ? 1u : 0u;          // valid_ray (path.cpp:121)
 
@@ -369,14 +372,15 @@ MTS_DEV BsdfChannels<kWav> spectral_channels(const DevBsdf &b, const Spec4 &wav)
     return c;
 }
 
-template <bool FLAT, bool DEFER = false, bool GENERAL = false>
+template <bool FLAT, int DEFER = 0, bool GENERAL = false>
 MTS_DEV bool bounce_step_spectral(const RenderParams &P, const LdsView &lds, PathStateS &s, Counters &c, Deferred *df = nullptr) {
     const SceneView &sv = P.sv;
     const Geo<FLAT> geo{ sv, lds };
     Hit hit;
     ++c.closest; ++c.segments;
     bool found;
-    if (DEFER) { hit = df->hit; found = df->found; df->pending = false; }
+    if (DEFER) df->pending = false;
+    if (DEFER == 1) { hit = df->hit; found = df->found; }
     else found = traverse<FLAT, false>(sv, lds, s.o, s.d, s.mint, s.maxt, hit, c.tri_tests);
     if (s.depth == 1u) s.flags = found ? 1u : 0u;
 
@@ -715,22 +719,27 @@ hipError_t launch_direct(const RenderParams &p, uint64_t n, hipStream_t s) {
 // floating-point additions into the radiance is the fused kernel's, so both pipelines produce identical samples.
 constexpr uint32_t kFlagZombie = 2u;      // path already terminated, kept one iteration for its pending shadow ray
 
-template <bool GENERAL>
+template <bool GENERAL, bool FLAT>
 MTS_DEV bool step_deferred(const RenderParams &P, const LdsView &lds, PathState &s, Counters &c, Deferred &df) {
-    return bounce_step<false, false, true, GENERAL>(P, lds, s, c, nullptr, &df);
+    return bounce_step<FLAT, false, FLAT ? 2 : 1, GENERAL>(P, lds, s, c, nullptr, &df);
 }
-template <bool GENERAL>
+template <bool GENERAL, bool FLAT>
 MTS_DEV bool step_deferred(const RenderParams &P, const LdsView &lds, PathStateS &s, Counters &c, Deferred &df) {
-    return bounce_step_spectral<false, true, GENERAL>(P, lds, s, c, &df);
+    return bounce_step_spectral<FLAT, FLAT ? 2 : 1, GENERAL>(P, lds, s, c, &df);
 }
 MTS_DEV void finish_path(const RenderParams &P, const PathState &s) { store_result(P, s); }
 MTS_DEV void finish_path(const RenderParams &P, const PathStateS &s) { store_result_spectral(P, s); }
 MTS_DEV void start_path(const RenderParams &P, uint64_t ordinal, uint32_t lp, uint32_t j, PathState &s) { generate_path(P, ordinal, lp, j, s); }
 MTS_DEV void start_path(const RenderParams &P, uint64_t ordinal, uint32_t lp, uint32_t j, PathStateS &s) { generate_path_spectral(P, ordinal, lp, j, s); }
 
-template <typename State, bool GENERAL>
-__global__ __launch_bounds__(kBlock) void k_shade(const RenderParams P) {
+// FLAT = false: hierarchy scene, closest hits precomputed by k_trace<false>; FLAT = true: LDS-resident scene, closest hit
+// inline (wave-uniform primitive loop), only the shadow rays are queued
+template <typename State, bool GENERAL, bool FLAT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FLAT ? MTS_BOUNCE_WAVES : 1, FLAT ? MTS_BOUNCE_WAVES : 8)))
+void k_shade(const RenderParams P) {
+    extern __shared__ float4 smem[];
     LdsView lds = {};                      // Geo<false> reads the scene tables from global memory
+    if (FLAT) lds = lds_stage<true>(P.sv, smem);
     const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
     if (wave >= P.n_waves) return;
     const uint32_t lane = lane_id();
@@ -751,10 +760,12 @@ __global__ __launch_bounds__(kBlock) void k_shade(const RenderParams P) {
             if (s.flags & kFlagZombie) {
                 finish_path(P, s);
             } else {
-                const float4 h = P.in.hit[i];
-                df.hit.t = h.x; df.hit.prim = __float_as_uint(h.y); df.hit.u = h.z; df.hit.v = h.w;
-                df.found = df.hit.prim != kNoPrim;
-                alive = step_deferred<GENERAL>(P, lds, s, c, df);
+                if (!FLAT) {
+                    const float4 h = P.in.hit[i];
+                    df.hit.t = h.x; df.hit.prim = __float_as_uint(h.y); df.hit.u = h.z; df.hit.v = h.w;
+                    df.found = df.hit.prim != kNoPrim;
+                }
+                alive = step_deferred<GENERAL, FLAT>(P, lds, s, c, df);
                 if (!alive) {
                     if (df.pending) { s.flags |= kFlagZombie; alive = true; }
                     else finish_path(P, s);
@@ -797,9 +808,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(const RenderParams P) {
         cpix += q; crem = r - q * spp;
     }
 
-    uint32_t tot[3] = { c.closest, c.any, c.segments };
+    uint32_t tot[4] = { c.closest, c.any, c.segments, c.tri_tests };
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < 4; ++k)
         for (int off = 32; off > 0; off >>= 1) tot[k] += __shfl_xor(tot[k], off);
     if (lane == 0) {
         P.count_out[wave] = n_out;
@@ -807,6 +818,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(const RenderParams P) {
         P.cursor[wave] = cursor; P.cursor_pix[wave] = cpix; P.cursor_rem[wave] = crem;
         uint64_t *ws = P.wave_stats + 4u * (size_t) wave;
         ws[0] += tot[0]; ws[1] += tot[1]; ws[2] += tot[2];
+        if (FLAT) ws[3] += tot[3];
     }
 }
 
@@ -816,12 +828,16 @@ __global__ __launch_bounds__(kBlock) void k_shade(const RenderParams P) {
 // waves back to back to keep its lanes filled.  (64-thread workgroups sized to the queues were measured slower.)
 constexpr uint32_t kShadowGroup = 8;
 
-template <bool ANY>
+template <bool ANY, bool FLAT = false>
 __global__ __launch_bounds__(kBlock) void k_trace(const RenderParams P) {
     extern __shared__ float4 smem[];
     LdsView lds = {};
-    lds.stride = blockDim.x;
-    lds.stack = reinterpret_cast<uint32_t *>(smem);
+    if (FLAT) {
+        lds = lds_stage<true>(P.sv, smem);
+    } else {
+        lds.stride = blockDim.x;
+        lds.stack = reinterpret_cast<uint32_t *>(smem);
+    }
     uint32_t tri_tests = 0;
     Hit h;
     if (ANY) {
@@ -837,7 +853,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(const RenderParams P) {
                 if (wave == w0 + g && i >= cnt[g]) { i -= cnt[g]; ++wave; }
             const size_t base = (size_t) wave * P.seg_cap, k = base + i;
             const float4 o = pool.sh_o[k], d = pool.sh_d[k];
-            if (!traverse_bvh<true>(P.sv, lds, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), o.w, d.w, h, tri_tests)) {
+            if (!traverse<FLAT, true>(P.sv, lds, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), o.w, d.w, h, tri_tests)) {
                 const size_t slot = base + pool.sh_slot[k];
                 float4 r = pool.res[slot];
                 const float4 e = pool.nee[k];
@@ -867,14 +883,24 @@ __global__ __launch_bounds__(kBlock) void k_trace(const RenderParams P) {
 size_t trace_lds_bytes(const SceneView &sv) { return (size_t) 4 * sv.stack_depth * kBlock; }
 
 hipError_t launch_bounce(const RenderParams &p, hipStream_t s) {
+    if (p.split == 2) {       // LDS-resident scene: closest hit + shading fused, shadow rays queued and resolved in dense batches
+        const uint32_t shade_blocks = (p.n_waves * 64u + kBlock - 1) / kBlock;
+        const size_t lds = bounce_lds_bytes(p.sv);
+        if (p.spectral && p.sv.general) hipLaunchKernelGGL((k_shade<PathStateS, true, true>), dim3(shade_blocks), dim3(kBlock), lds, s, p);
+        else if (p.spectral) hipLaunchKernelGGL((k_shade<PathStateS, false, true>), dim3(shade_blocks), dim3(kBlock), lds, s, p);
+        else if (p.sv.general) hipLaunchKernelGGL((k_shade<PathState, true, true>), dim3(shade_blocks), dim3(kBlock), lds, s, p);
+        else hipLaunchKernelGGL((k_shade<PathState, false, true>), dim3(shade_blocks), dim3(kBlock), lds, s, p);
+        hipLaunchKernelGGL((k_trace<true, true>), dim3((p.n_waves + kShadowGroup - 1) / kShadowGroup), dim3(kBlock), lds, s, p);
+        return hipGetLastError();
+    }
     if (p.split) {
         const uint32_t shade_blocks = (p.n_waves * 64u + kBlock - 1) / kBlock;
-        hipLaunchKernelGGL(k_trace<false>, dim3(p.n_waves), dim3(kBlock), trace_lds_bytes(p.sv), s, p);
-        if (p.spectral && p.sv.general) hipLaunchKernelGGL((k_shade<PathStateS, true>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
-        else if (p.spectral) hipLaunchKernelGGL((k_shade<PathStateS, false>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
-        else if (p.sv.general) hipLaunchKernelGGL((k_shade<PathState, true>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
-        else hipLaunchKernelGGL((k_shade<PathState, false>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
-        hipLaunchKernelGGL(k_trace<true>, dim3((p.n_waves + kShadowGroup - 1) / kShadowGroup), dim3(kBlock), trace_lds_bytes(p.sv), s, p);
+        hipLaunchKernelGGL((k_trace<false, false>), dim3(p.n_waves), dim3(kBlock), trace_lds_bytes(p.sv), s, p);
+        if (p.spectral && p.sv.general) hipLaunchKernelGGL((k_shade<PathStateS, true, false>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
+        else if (p.spectral) hipLaunchKernelGGL((k_shade<PathStateS, false, false>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
+        else if (p.sv.general) hipLaunchKernelGGL((k_shade<PathState, true, false>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
+        else hipLaunchKernelGGL((k_shade<PathState, false, false>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
+        hipLaunchKernelGGL((k_trace<true, false>), dim3((p.n_waves + kShadowGroup - 1) / kShadowGroup), dim3(kBlock), trace_lds_bytes(p.sv), s, p);
         return hipGetLastError();
     }
     uint32_t blocks = (p.n_waves * 64u + kBlock - 1) / kBlock;

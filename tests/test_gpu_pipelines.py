@@ -23,7 +23,8 @@ def test_cbox_fused_equals_split(variant):
     cb, sp = scenes.cornell_box(), scenes.cornell_box_sensor(96, 96, spp=16, seed=3)
     a, sa = _render(cb, sp, 1, variant)
     b, sb = _render(cb, sp, 2, variant)
-    assert np.array_equal(a, b)
+    q, sq = _render(cb, sp, 3, variant)          # closest hit fused, shadow rays queued
+    assert np.array_equal(a, b) and np.array_equal(a, q) and sq["any_hit_rays"] == sa["any_hit_rays"] and sq["tri_tests"] == sa["tri_tests"]
     for k in ("closest_hit_rays", "any_hit_rays", "samples", "segments"):
         assert sa[k] == sb[k]
     assert a[..., 4].min() > 0 and np.isfinite(a).all() and a[..., :3].max() > 0
