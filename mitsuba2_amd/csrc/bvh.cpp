@@ -93,8 +93,20 @@ struct Builder {
         double leaf_cost = kIntersectCost * count;
         if (count <= max_leaf && (best_axis < 0 || leaf_cost <= best_cost)) return make_leaf();
 
+        // Depth guard: the traversal kernels keep a per-lane stack of `depth` entries in LDS (<= 64 KB per 256-thread workgroup).
+        // Past depth 40 the split is an object median along the widest centroid axis, which bounds the total depth by
+        // 40 + log2(n) whatever the SAH would have done on a pathological primitive distribution.
+        if (depth >= 40 && best_axis >= 0) {
+            int axis = 0;
+            for (int k = 1; k < 3; ++k) if (cb.hi[k] - cb.lo[k] > cb.hi[axis] - cb.lo[axis]) axis = k;
+            std::nth_element(perm.begin() + first, perm.begin() + first + count / 2, perm.begin() + first + count,
+                             [&](uint32_t a, uint32_t b) { return centroid[3 * a + axis] < centroid[3 * b + axis]; });
+            best_axis = -2;
+        }
         uint32_t mid;
-        if (best_axis >= 0) {
+        if (best_axis == -2) {
+            mid = first + count / 2;
+        } else if (best_axis >= 0) {
             double lo = cb.lo[best_axis], ext = cb.hi[best_axis] - cb.lo[best_axis];
             double scale = kBins / ext;
             auto it = std::partition(perm.begin() + first, perm.begin() + first + count, [&](uint32_t p) {
