@@ -156,6 +156,7 @@ class _Context:
         self.base_dir = base_dir
         self.instances = {}          # id -> Node
         self.aliases = {}            # alias id -> target id
+        self.tabulated = False       # a wavelength:value spectrum was seen (pre-integrated to RGB: RGB variants only)
         self.depth_includes = 0
 
 
@@ -326,12 +327,34 @@ def _parse_child(el, ctx, node):
             raise XMLError("'rgb' tag requires one or three values (got \"%s\")" % v)
         node.set(name, ("rgb", tuple(c)))
     elif tag == "spectrum":
-        if "filename" in a or ":" in v:
-            raise XMLError("tabulated spectra are not supported by this backend (constant <spectrum value='x'/> only)")
-        c = _floats(v)
-        if len(c) != 1:
-            raise XMLError("'spectrum' tag requires a single constant value in this backend (got \"%s\")" % v)
-        node.set(name, ("spectrum", c[0]))
+        if ("filename" in a) == ("value" in a):
+            raise XMLError("'spectrum' tag requires one of \"value\" or \"filename\" attributes")
+        toks = v.replace(",", " ").split()
+        if "filename" in a or len(toks) != 1:             # wavelength:value pairs, inline or from a file (xml.cpp:807-830)
+            from . import spectrum as S
+            if "filename" in a:
+                fn = a["filename"]
+                try:
+                    wl, vals = S.spectrum_from_file(fn if os.path.isabs(fn) else os.path.join(ctx.base_dir, fn))
+                except RuntimeError as e:
+                    raise XMLError(str(e))
+            else:
+                wl, vals = [], []
+                for tok in toks:
+                    pair = tok.split(":")
+                    if len(pair) != 2:
+                        raise XMLError("invalid spectrum (expected wavelength:value pairs)")
+                    try:
+                        wl.append(float(pair[0])); vals.append(float(pair[1]))
+                    except ValueError:
+                        raise XMLError('could not parse wavelength:value pair: "%s"' % tok)
+            node.set(name, ("tabulated", tuple(wl), tuple(vals)))
+            ctx.tabulated = True
+        else:
+            try:
+                node.set(name, ("spectrum", float(toks[0])))
+            except ValueError:
+                raise XMLError('could not parse constant spectrum "%s"' % toks[0])
 
 
 def _resolve(ctx, item):
@@ -355,6 +378,7 @@ class SceneDescription:
         self.scene_dict = dict(meshes=[], bsdfs=[], emitters=[])
         self.sensors = []            # dicts of PerspectiveCamera / HDRFilm / IndependentSampler arguments
         self.integrator = None       # dict(max_depth, rr_depth)
+        self.uses_tabulated_spectra = False
 
 
 def _colour(value, what, emitter=False):
@@ -364,6 +388,12 @@ def _colour(value, what, emitter=False):
         return [float(x) for x in value[1]]
     if isinstance(value, tuple) and value[0] == "spectrum":
         return [float(value[1])] * 3
+    if isinstance(value, tuple) and value[0] == "tabulated":      # RGB variants: pre-integrated against the CIE observer
+        from . import spectrum as S
+        try:
+            return S.tabulated_to_rgb(value[1], value[2], emitter, what.split(".")[-1])
+        except RuntimeError as e:
+            raise XMLError(str(e))
     if isinstance(value, (int, float)):
         return [float(value)] * 3
     raise XMLError("%s: expected an <rgb> or constant <spectrum> value" % what)
@@ -407,6 +437,8 @@ def _bsdf_plugin_dict(ctx, node, base_dir):
             d[k] = _colour(v, k)
         elif isinstance(v, tuple) and v and v[0] == "spectrum":
             d[k] = float(v[1])                           # a constant: `uniform` spectrum in the spectral variant
+        elif isinstance(v, tuple) and v and v[0] == "tabulated":
+            d[k] = _colour(v, k)
         else:
             d[k] = v
     for c in node.children:
@@ -559,6 +591,7 @@ def _instantiate(ctx, root, base_dir):
     if root.tag != "scene":
         raise XMLError('root element "%s" must be a scene in this backend' % root.tag)
     desc = SceneDescription()
+    desc.uses_tabulated_spectra = ctx.tabulated
     cache = {}
     for k, v in root.props.items():
         if not isinstance(v, (Node, tuple)) or (isinstance(v, tuple) and v[0] != "ref"):
@@ -625,6 +658,8 @@ def parse_file(path, **params):
 def instantiate(desc, device=0, variant="rgb"):
     """SceneDescription -> render.Scene with its sensors and integrator (needs the HIP library and a GPU)."""
     from . import render as R
+    if variant == "spectral" and desc.uses_tabulated_spectra:
+        raise XMLError("wavelength:value spectra are pre-integrated to RGB by this backend: RGB variant only")
     sensors = []
     for s in desc.sensors:
         f = s["film"]

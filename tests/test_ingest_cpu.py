@@ -286,3 +286,29 @@ def test_png_against_pillow(tmp_path):
     p2 = str(tmp_path / "ours.png")
     bitmap.write_png(p2, img)
     assert np.array_equal(np.asarray(Image.open(p2)), img)
+
+
+def test_tabulated_spectra_become_rgb():
+    """xml.cpp:1084-1140 + spectrum.cpp:41-86: wavelength:value spectra are integrated against the CIE observer in the RGB
+    variants; cie1931_xyz spot values from src/librender/tests/test_spectra.py:7-15"""
+    from mitsuba2_amd import spectrum as S
+    assert np.allclose(S.cie1931_xyz(600.0), [1.0622, 0.631, 0.0008], atol=1e-6)
+    assert np.allclose(S.cie1931_xyz([350.0, 840.0]), 0)
+    d = mxml.parse_string("""<scene version="2.0.0">
+        <bsdf type="diffuse" id="grey"><spectrum name="reflectance" value="360:0.5 600:0.5 830:0.5"/></bsdf>
+        <bsdf type="diffuse" id="redish"><spectrum name="reflectance" value="400:0.04, 500:0.05, 600:0.55, 700:0.63"/></bsdf>
+        <shape type="rectangle"><ref id="grey"/></shape>
+        <shape type="rectangle"><ref id="redish"/>
+            <emitter type="area"><spectrum name="radiance" value="400:0, 500:8, 600:15.6, 700:18.4"/></emitter></shape>
+    </scene>""")
+    grey, red = d.scene_dict["bsdfs"][0]["reflectance"], d.scene_dict["bsdfs"][1]["reflectance"]
+    e_white = S.spectrum_to_rgb([360, 830], [float(S.MTS_CIE_Y_NORMALIZATION)] * 2, False)      # equal-energy white in sRGB primaries
+    assert np.allclose(grey, np.minimum(0.5 * np.array(e_white), 1), atol=2e-3)
+    assert red[0] > 0.4 and red[0] > 2 * red[1] and red[1] > red[2] and max(red) <= 1.0 and min(red) >= 0.0
+    rad = d.scene_dict["emitters"][0]["radiance"]
+    assert rad[0] > rad[1] > rad[2] > 0 and rad[0] > 10                                           # the warm Cornell-box light
+    assert d.uses_tabulated_spectra
+    with pytest.raises(Exception, match="increasing order"):
+        mxml.parse_string('<scene version="2.0.0"><bsdf type="diffuse"><spectrum name="reflectance" value="500:1 400:1"/></bsdf></scene>')
+    with pytest.raises(Exception, match="expected wavelength:value pairs"):
+        mxml.parse_string('<scene version="2.0.0"><bsdf type="diffuse"><spectrum name="reflectance" value="500 400"/></bsdf></scene>')
