@@ -520,6 +520,9 @@ def _sensor(ctx, node):
         out["fov"] = node.get("fov", kind="float")
     if "focal_length" in node.props:
         out["focal_length"] = node.get("focal_length", kind="string")
+    node.get("focus_distance", 0.0, "float")       # ProjectiveCamera (sensor.cpp:96-103): irrelevant for a pinhole camera
+    if node.get("shutter_close", 0.0, "float") != node.get("shutter_open", 0.0, "float"):
+        raise XMLError("sensor: a non-zero shutter time (motion blur) is not supported by this backend")
     film = dict(width=768, height=576, crop_offset=None, crop_size=None, rfilter=("gaussian", 0.5))
     sampler = dict(sample_count=4, seed=0)
     for it in [_resolve(ctx, c) for c in node.children]:
