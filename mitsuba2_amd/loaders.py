@@ -211,6 +211,92 @@ def load_ply(path, to_world=None, face_normals=False):
     return dict(positions=positions, faces=faces, normals=normals, texcoords=texcoords)
 
 
+def load_serialized(path, shape_index=0, to_world=None, face_normals=False):
+    """SerializedMesh (src/shapes/serialized.cpp:190-336): Mitsuba's compressed binary mesh format.  Header 0x041C + version 3 / 4,
+    a zlib stream per sub-mesh (flags, [name], vertex / face counts, positions, [normals], [texcoords], [colours], indices) and an
+    end-of-file dictionary with the offset of every sub-mesh."""
+    import zlib
+    def fail(msg):
+        raise RuntimeError('Error while loading serialized file "%s": %s!' % (path, msg))
+    with open(path, "rb") as fh:
+        buf = fh.read()
+    if len(buf) < 4:
+        fail("encountered an invalid file format")
+    fmt, version = struct.unpack_from("<hh", buf, 0)
+    if fmt != 0x041C:
+        fail("encountered an invalid file format")
+    if version not in (3, 4):
+        fail("encountered an incompatible file version")
+    if shape_index < 0:
+        fail("shape index must be nonnegative")
+    offset = 0
+    if shape_index != 0:
+        count = struct.unpack_from("<I", buf, len(buf) - 4)[0]
+        if shape_index >= count:
+            fail("Unable to unserialize mesh, shape index is out of range! (requested %i out of 0..%i)" % (shape_index, count - 1))
+        if version == 4:
+            offset = struct.unpack_from("<Q", buf, len(buf) - 8 * (count - shape_index) - 4)[0]
+        else:
+            offset = struct.unpack_from("<I", buf, len(buf) - 4 * (count - shape_index + 1))[0]
+    data = zlib.decompressobj().decompress(buf[offset + 4:])
+    pos = 0
+    flags = struct.unpack_from("<I", data, pos)[0]; pos += 4
+    if version == 4:
+        end = data.index(b"\0", pos)
+        pos = end + 1
+    n_verts, n_faces = struct.unpack_from("<QQ", data, pos); pos += 16
+    dp = bool(flags & 0x2000)
+    ft, fs = ("<f8", 8) if dp else ("<f4", 4)
+
+    def block(dim):
+        nonlocal pos
+        a = np.frombuffer(data, dtype=ft, count=n_verts * dim, offset=pos).astype(F32).reshape(n_verts, dim)
+        pos += n_verts * dim * fs
+        return a
+    positions = block(3)
+    normals = block(3) if flags & 0x0001 else None
+    texcoords = block(2) if flags & 0x0002 else None
+    if flags & 0x0008:
+        block(3)                                             # vertex colours: skipped (serialized.cpp:290-291)
+    it = "<u8" if n_verts > 0xFFFFFFFF else "<u4"
+    faces = np.frombuffer(data, dtype=it, count=n_faces * 3, offset=pos).astype(np.uint32).reshape(n_faces, 3)
+    if faces.size and faces.max() >= n_verts:
+        fail("vertex index out of range")
+    positions = transform_points(to_world, positions)
+    if face_normals:
+        normals = None
+    elif normals is not None:
+        normals = transform_normals(to_world, normals)
+    else:
+        normals = compute_vertex_normals(positions, faces)
+    return dict(positions=np.ascontiguousarray(positions, F32), faces=np.ascontiguousarray(faces), normals=normals,
+                texcoords=None if texcoords is None else np.ascontiguousarray(texcoords, F32))
+
+
+def write_serialized(path, meshes, version=4):
+    """writes the same format (used by the tests and handy for exporting procedural scenes): `meshes` = list of dicts with
+    positions, faces and optionally normals / texcoords"""
+    import zlib
+    offsets, out = [], bytearray()
+    for m in meshes:
+        offsets.append(len(out))
+        p = np.asarray(m["positions"], F32).reshape(-1, 3)
+        f = np.asarray(m["faces"], np.uint32).reshape(-1, 3)
+        flags = 0x1000 | (0x0001 if m.get("normals") is not None else 0) | (0x0002 if m.get("texcoords") is not None else 0)
+        body = struct.pack("<I", flags) + (b"mesh\0" if version == 4 else b"") + struct.pack("<QQ", p.shape[0], f.shape[0]) + p.astype("<f4").tobytes()
+        if m.get("normals") is not None:
+            body += np.asarray(m["normals"], "<f4").tobytes()
+        if m.get("texcoords") is not None:
+            body += np.asarray(m["texcoords"], "<f4").tobytes()
+        body += f.astype("<u4").tobytes()
+        out += struct.pack("<hh", 0x041C, version) + zlib.compress(body, 6)
+    for o in offsets:
+        out += struct.pack("<Q" if version == 4 else "<I", o)
+    out += struct.pack("<I", len(meshes))
+    with open(path, "wb") as fh:
+        fh.write(bytes(out))
+
+
 def rectangle(to_world=None, flip_normals=False):
     """`rectangle` shape (src/shapes/rectangle.cpp:73-90: [-1,1]^2 in the xy plane, normal +z, uv = (p.xy+1)/2)
     tessellated into two triangles.  The reference intersects and samples it analytically; the tessellation has the same

@@ -466,7 +466,7 @@ def _bsdf(ctx, node, desc, cache, base_dir):
 
 def _shape(ctx, node, desc, cache, base_dir):
     to_world = node.get("to_world", np.eye(4, dtype=F32), "transform")
-    if node.type in ("obj", "ply"):
+    if node.type in ("obj", "ply", "serialized"):
         fn = node.get("filename", kind="string")
         path = fn if os.path.isabs(fn) else os.path.join(base_dir, fn)
         if not os.path.exists(path):
@@ -474,12 +474,14 @@ def _shape(ctx, node, desc, cache, base_dir):
         face_normals = node.get("face_normals", False, "bool")
         if node.type == "obj":
             mesh = loaders.load_obj(path, to_world, node.get("flip_tex_coords", True, "bool"), face_normals)
+        elif node.type == "serialized":
+            mesh = loaders.load_serialized(path, node.get("shape_index", 0, "int"), to_world, face_normals)
         else:
             mesh = loaders.load_ply(path, to_world, face_normals)
     elif node.type == "rectangle":
         mesh = loaders.rectangle(to_world, node.get("flip_normals", False, "bool"))
     else:
-        raise XMLError('Shape plugin "%s" is not supported by this backend (obj, ply, rectangle)' % node.type)
+        raise XMLError('Shape plugin "%s" is not supported by this backend (obj, ply, serialized, rectangle)' % node.type)
     bsdf, emitter = None, None
     items = [_resolve(ctx, c) for c in node.children] + [_resolve(ctx, v) for k, v in node.props.items() if isinstance(v, (Node, tuple)) and (isinstance(v, Node) or v[0] == "ref")]
     for k, v in node.props.items():
@@ -690,7 +692,7 @@ def load_file(path, device=0, variant="rgb", **params):
 
 # -------------------------------------------------------------------------------------------- load_dict
 _PLUGIN_CLASS = {"twosided": "bsdf", "conductor": "bsdf", "roughconductor": "bsdf", "dielectric": "bsdf", "plastic": "bsdf", "roughplastic": "bsdf", "path": "integrator", "perspective": "sensor", "hdrfilm": "film", "independent": "sampler", "gaussian": "rfilter", "box": "rfilter",
-                 "direct": "integrator", "depth": "integrator", "moment": "integrator", "obj": "shape", "ply": "shape", "rectangle": "shape", "diffuse": "bsdf", "area": "emitter", "constant": "emitter", "envmap": "emitter", "bitmap": "texture", "scene": "scene"}
+                 "direct": "integrator", "depth": "integrator", "moment": "integrator", "obj": "shape", "ply": "shape", "serialized": "shape", "rectangle": "shape", "diffuse": "bsdf", "area": "emitter", "constant": "emitter", "envmap": "emitter", "bitmap": "texture", "scene": "scene"}
 
 
 def _node_from_dict(d, ctx):

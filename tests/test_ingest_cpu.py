@@ -312,3 +312,31 @@ def test_tabulated_spectra_become_rgb():
         mxml.parse_string('<scene version="2.0.0"><bsdf type="diffuse"><spectrum name="reflectance" value="500:1 400:1"/></bsdf></scene>')
     with pytest.raises(Exception, match="expected wavelength:value pairs"):
         mxml.parse_string('<scene version="2.0.0"><bsdf type="diffuse"><spectrum name="reflectance" value="500 400"/></bsdf></scene>')
+
+
+@pytest.mark.parametrize("version", [3, 4])
+def test_serialized_meshes(tmp_path, version):
+    """src/shapes/serialized.cpp:190-336: multi-mesh files with the end-of-file dictionary, optional normals / texcoords,
+    computed normals when the file has none (test_mesh.py:137-170 covers the same feature matrix for 'serialized')"""
+    cb = scenes.cornell_box()
+    a = dict(positions=np.asarray(cb["meshes"][7]["positions"], np.float32).reshape(-1, 3), faces=np.asarray(cb["meshes"][7]["faces"]).reshape(-1, 3))
+    sphere = scenes.bumpy_sphere(8, 16)["meshes"][0]
+    b = dict(positions=np.asarray(sphere["positions"], np.float32).reshape(-1, 3), faces=np.asarray(sphere["faces"]).reshape(-1, 3),
+             normals=np.asarray(sphere["normals"], np.float32).reshape(-1, 3), texcoords=np.asarray(sphere["positions"], np.float32).reshape(-1, 3)[:, :2] * np.float32(0.1))
+    path = str(tmp_path / "two.serialized")
+    loaders.write_serialized(path, [a, b], version=version)
+    m0 = loaders.load_serialized(path, 0)
+    assert np.array_equal(m0["positions"], a["positions"]) and np.array_equal(m0["faces"], a["faces"]) and m0["texcoords"] is None
+    assert np.allclose(np.linalg.norm(m0["normals"], axis=1), 1, atol=1e-5)              # computed (the file has none)
+    assert loaders.load_serialized(path, 0, face_normals=True)["normals"] is None
+    m1 = loaders.load_serialized(path, 1, to_world=mxml.translate([1, 2, 3]))
+    assert np.allclose(m1["positions"], b["positions"] + [1, 2, 3]) and np.allclose(m1["normals"], b["normals"], atol=1e-6)
+    assert np.array_equal(m1["texcoords"], b["texcoords"]) and np.array_equal(m1["faces"], b["faces"])
+    with pytest.raises(RuntimeError, match="out of range"):
+        loaders.load_serialized(path, 2)
+    d = mxml.parse_string('<scene version="2.0.0"><shape type="serialized"><string name="filename" value="two.serialized"/>'
+                          '<integer name="shape_index" value="1"/></shape></scene>', base_dir=str(tmp_path))
+    assert d.scene_dict["meshes"][0]["faces"].shape == b["faces"].shape
+    open(str(tmp_path / "bad.serialized"), "wb").write(b"\x00\x00\x04\x00abcdef")
+    with pytest.raises(RuntimeError, match="invalid file format"):
+        loaders.load_serialized(str(tmp_path / "bad.serialized"))
