@@ -97,8 +97,11 @@ typedef struct {
 } mtsamd_emitter_desc;
 
 typedef struct {
-    int32_t width, height;     /* texels; channels = 3 (RGB) */
-    const float *data;         /* host, height*width*3 */
+    int32_t width, height;     /* bitmap (src/textures/bitmap.cpp): texels; channels = 3 (RGB) */
+    const float *data;         /* host, height*width*3 (NULL for a checkerboard) */
+    int32_t kind;              /* 0 = bitmap, 1 = checkerboard (src/textures/checkerboard.cpp) with constant colours */
+    float color0[3], color1[3];
+    float to_uv[6];            /* (m00, m01, m02, m10, m11, m12) of the extracted to_uv transform; all zero = identity */
 } mtsamd_texture_desc;
 
 typedef struct {

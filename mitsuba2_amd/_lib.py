@@ -35,7 +35,8 @@ class EmitterDesc(C.Structure):
 
 
 class TextureDesc(C.Structure):
-    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("data", f32p)]
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("data", f32p), ("kind", C.c_int32), ("color0", C.c_float * 3),
+                ("color1", C.c_float * 3), ("to_uv", C.c_float * 6)]
 
 
 class SceneDesc(C.Structure):

@@ -35,6 +35,8 @@ class ParameterMap:
                 continue
             name = b.get("id", "bsdf_%d" % i)
             refl = b["reflectance"]
+            if isinstance(refl, dict) and refl.get("type") != "bitmap":
+                continue                  # procedural textures have no differentiable texels
             if isinstance(refl, dict):
                 key = name + ".reflectance.data"
                 self.properties[key] = torch.as_tensor(refl["data"], dtype=torch.float32, device=dev).clone()

@@ -365,9 +365,13 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
             return fail(MTSAMD_ERR_INVALID, "Only materials without a transmission component can be nested!");          // twosided.cpp:90-91
         if (desc->bsdfs[b].texture >= (int32_t) desc->texture_count) return fail(MTSAMD_ERR_INVALID, "bsdf %u: invalid texture index %d", b, desc->bsdfs[b].texture);
     }
-    for (uint32_t t = 0; t < desc->texture_count; ++t)
-        if (!desc->textures || !desc->textures[t].data || desc->textures[t].width < 2 || desc->textures[t].height < 2)
+    for (uint32_t t = 0; t < desc->texture_count; ++t) {
+        if (!desc->textures) return fail(MTSAMD_ERR_INVALID, "null texture table");
+        const mtsamd_texture_desc &td = desc->textures[t];
+        if (td.kind != 0 && td.kind != 1) return fail(MTSAMD_ERR_UNSUPPORTED, "texture %u: unknown texture kind %d", t, td.kind);
+        if (td.kind == 0 && (!td.data || td.width < 2 || td.height < 2))
             return fail(MTSAMD_ERR_INVALID, "texture %u: image must be at least 2x2 pixels in size", t);      // bitmap.cpp:101-107
+    }
     if (total >= (1ull << 27)) return fail(MTSAMD_ERR_UNSUPPORTED, "too many primitives (%llu)", (unsigned long long) total);
 
     mtsamd_scene *s = new mtsamd_scene();
@@ -478,8 +482,15 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
 
     for (uint32_t t = 0; t < desc->texture_count; ++t) {
         const mtsamd_texture_desc &td = desc->textures[t];
-        DevTexture dt{ nullptr, td.width, td.height, 0u, 0u };
+        DevTexture dt{};
+        dt.kind = (uint32_t) td.kind;
+        dt.w = td.kind == 0 ? td.width : 0; dt.h = td.kind == 0 ? td.height : 0;
         dt.grad_offset = s->textures.empty() ? 0u : s->textures.back().grad_offset + 3u * (uint32_t) s->textures.back().w * (uint32_t) s->textures.back().h;
+        bool ident = true;
+        for (int k = 0; k < 6; ++k) { dt.uvm[k] = td.to_uv[k]; ident = ident && td.to_uv[k] == 0.0f; }
+        if (ident) { dt.uvm[0] = 1.0f; dt.uvm[4] = 1.0f; }
+        for (int k = 0; k < 3; ++k) { dt.c0[k] = td.color0[k]; dt.c1[k] = td.color1[k]; }
+        if (td.kind == 1) { s->textures.push_back(dt); continue; }
         size_t bytes = sizeof(float) * 3 * (size_t) td.width * td.height;
         float *ptr = nullptr;
         if (hipMalloc((void **) &ptr, bytes) != hipSuccess || hipMemcpy(ptr, td.data, bytes, hipMemcpyHostToDevice) != hipSuccess) {
@@ -674,6 +685,7 @@ int mtsamd_scene_update_texture(mtsamd_scene *s, uint32_t texture, const float *
     if (!s || !rgb || texture >= s->textures.size()) return fail(MTSAMD_ERR_INVALID, "invalid texture index");
     HIP_TRY(hipSetDevice(s->device));
     const DevTexture &t = s->textures[texture];
+    if (t.kind != 0) return fail(MTSAMD_ERR_INVALID, "texture %u is not a bitmap", texture);
     HIP_TRY(hipMemcpyAsync((void *) t.data, rgb, sizeof(float) * 3 * (size_t) t.w * t.h, hipMemcpyDefault, (hipStream_t) stream));
     return MTSAMD_OK;
 }

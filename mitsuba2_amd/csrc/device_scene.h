@@ -33,7 +33,11 @@ constexpr uint32_t kNoPrim = 0xffffffffu;
 
 struct DevShape { int32_t bsdf; int32_t emitter; uint32_t flags; uint32_t first_prim; };
 constexpr uint32_t kShapeHasNormals = 1u, kShapeHasUV = 2u;
-struct DevTexture { const float *data; int32_t w, h; uint32_t grad_offset, pad; };   // grad_offset: float offset in the concatenated gradient buffer       // linear RGB bitmap (src/textures/bitmap.cpp), identity to_uv
+struct DevTexture {
+    const float *data; int32_t w, h; uint32_t grad_offset, kind;        // kind 0: bitmap, 1: checkerboard (checkerboard.cpp)
+    float uvm[6];                                                       // to_uv: uv' = (m0 u + m1 v + m2, m3 u + m4 v + m5)
+    float c0[3], c1[3];                                                 // checkerboard colours
+};   // grad_offset: float offset in the concatenated gradient buffer       // linear RGB bitmap (src/textures/bitmap.cpp), identity to_uv
 struct DevEmitter {
     float r, g, b; uint32_t shape;
     uint32_t first_prim, n_prims; float area_sum, area_norm;
@@ -560,6 +564,14 @@ MTS_DEV f3 eval_reflectance(const SceneView &sv, const DevBsdf &b, f2 uv, uint32
     texel = kNoPrim; w1.x = w1.y = 0.0f;
     if (b.texture < 0) return mk3(b.r, b.g, b.b);
     const DevTexture t = sv.textures[b.texture];
+    {   // m_transform.transform_affine(si.uv) (bitmap.cpp:254, checkerboard.cpp:49)
+        const float u2 = fmaf(t.uvm[0], uv.x, fmaf(t.uvm[1], uv.y, t.uvm[2])), v2 = fmaf(t.uvm[3], uv.x, fmaf(t.uvm[4], uv.y, t.uvm[5]));
+        uv.x = u2; uv.y = v2;
+    }
+    if (t.kind == 1u) {                                      // checkerboard.cpp:46-63
+        const bool mx = (uv.x - floorf(uv.x)) > 0.5f, my = (uv.y - floorf(uv.y)) > 0.5f;
+        return mx == my ? mk3(t.c0[0], t.c0[1], t.c0[2]) : mk3(t.c1[0], t.c1[1], t.c1[2]);
+    }
     float ux = uv.x - floorf(uv.x), uy = uv.y - floorf(uv.y);
     ux *= (float) (uint32_t) (t.w - 1); uy *= (float) (uint32_t) (t.h - 1);
     uint32_t px = min((uint32_t) ux, (uint32_t) (t.w - 2)), py = min((uint32_t) uy, (uint32_t) (t.h - 2));

@@ -416,15 +416,19 @@ class Scene:
             bd[i].type, bd[i].twosided = n["type"], int(n["twosided"])
             refl = n["reflectance"]
             if isinstance(refl, dict):
-                if refl.get("type") != "bitmap":
-                    raise RuntimeError("Texture plugin '%s' is not supported by this backend (bitmap only)" % refl.get("type"))
-                data = _f32(refl["data"])
-                if data.ndim != 3 or data.shape[2] != 3:
-                    raise RuntimeError("bitmap texture: expected (H, W, 3) linear RGB data")
+                kind = refl.get("type")
+                if kind not in ("bitmap", "checkerboard"):
+                    raise RuntimeError("Texture plugin '%s' is not supported by this backend (bitmap, checkerboard)" % kind)
+                if kind == "bitmap":
+                    data = _f32(refl["data"])
+                    if data.ndim != 3 or data.shape[2] != 3:
+                        raise RuntimeError("bitmap texture: expected (H, W, 3) linear RGB data")
+                else:
+                    data = None
                 bd[i].reflectance = (C.c_float * 3)(0.5, 0.5, 0.5)
                 bd[i].texture = len(tex)
                 self._bsdf_texture[i] = len(tex)
-                tex.append(data)
+                tex.append((kind, data, refl))
             else:
                 bd[i].reflectance = (C.c_float * 3)(*[float(x) for x in refl])
                 bd[i].texture = -1
@@ -434,10 +438,18 @@ class Scene:
             bd[i].distribution, bd[i].sample_visible, bd[i].nonlinear = n["distribution"], int(n["sample_visible"]), int(n["nonlinear"])
             bd[i].uniform_mask = n["uniform_mask"]
         td = (L.TextureDesc * max(len(tex), 1))()
-        for i, t in enumerate(tex):
-            td[i].width, td[i].height = t.shape[1], t.shape[0]
-            td[i].data = t.ctypes.data_as(L.f32p)
-        self._texture_shapes = [t.shape for t in tex]
+        for i, (kind, t, spec) in enumerate(tex):
+            if kind == "bitmap":
+                td[i].kind, td[i].width, td[i].height = 0, t.shape[1], t.shape[0]
+                td[i].data = t.ctypes.data_as(L.f32p)
+            else:                       # src/textures/checkerboard.cpp: color0 = .4, color1 = .2 by default
+                td[i].kind = 1
+                td[i].color0 = (C.c_float * 3)(*B._rgb(spec.get("color0"), 0.4))
+                td[i].color1 = (C.c_float * 3)(*B._rgb(spec.get("color1"), 0.2))
+            if spec.get("to_uv") is not None:       # Transform4f::extract(): the upper-left 3x3 acts on (u, v, 1)
+                m = _f32(spec["to_uv"]).reshape(4, 4)
+                td[i].to_uv = (C.c_float * 6)(float(m[0, 0]), float(m[0, 1]), float(m[0, 2]), float(m[1, 0]), float(m[1, 1]), float(m[1, 2]))
+        self._texture_shapes = [t.shape if t is not None else (0, 0, 3) for (_, t, _) in tex]
         ed = (L.EmitterDesc * max(len(emitters), 1))()
         for i, e in enumerate(emitters):
             et = e.get("type", "area")

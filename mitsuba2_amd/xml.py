@@ -401,8 +401,18 @@ def _colour(value, what, emitter=False):
 
 def _texture(ctx, node, base_dir):
     from . import bitmap
+    to_uv = node.get("to_uv", np.eye(4, dtype=F32), "transform")
+    if node.type == "checkerboard":                     # src/textures/checkerboard.cpp:40-44
+        out = dict(type="checkerboard", to_uv=to_uv)
+        for key, default in (("color0", 0.4), ("color1", 0.2)):
+            v = _resolve(ctx, node.get(key, ("spectrum", default)))
+            if isinstance(v, Node):
+                raise XMLError("checkerboard: nested textures are not supported by this backend (constant colours only)")
+            out[key] = _colour(v, "checkerboard." + key)
+        node.check_unqueried()
+        return out
     if node.type != "bitmap":
-        raise XMLError('Texture plugin "%s" is not supported by this backend (bitmap only)' % node.type)
+        raise XMLError('Texture plugin "%s" is not supported by this backend (bitmap, checkerboard)' % node.type)
     fn = node.get("filename", kind="string")
     path = fn if os.path.isabs(fn) else os.path.join(base_dir, fn)
     raw = node.get("raw", False, "bool")
@@ -411,7 +421,7 @@ def _texture(ctx, node, base_dir):
     if ft != "bilinear" or wm != "repeat":
         raise XMLError("bitmap texture: only filter_type=bilinear / wrap_mode=repeat are supported by this backend")
     node.check_unqueried()
-    return dict(type="bitmap", data=bitmap.read_rgb(path, linearize=not raw))
+    return dict(type="bitmap", data=bitmap.read_rgb(path, linearize=not raw), to_uv=to_uv)
 
 
 def _bsdf_plugin_dict(ctx, node, base_dir):
@@ -692,7 +702,7 @@ def load_file(path, device=0, variant="rgb", **params):
 
 # -------------------------------------------------------------------------------------------- load_dict
 _PLUGIN_CLASS = {"twosided": "bsdf", "conductor": "bsdf", "roughconductor": "bsdf", "dielectric": "bsdf", "plastic": "bsdf", "roughplastic": "bsdf", "path": "integrator", "perspective": "sensor", "hdrfilm": "film", "independent": "sampler", "gaussian": "rfilter", "box": "rfilter",
-                 "direct": "integrator", "depth": "integrator", "moment": "integrator", "obj": "shape", "ply": "shape", "serialized": "shape", "rectangle": "shape", "diffuse": "bsdf", "area": "emitter", "constant": "emitter", "envmap": "emitter", "bitmap": "texture", "scene": "scene"}
+                 "direct": "integrator", "depth": "integrator", "moment": "integrator", "obj": "shape", "ply": "shape", "serialized": "shape", "rectangle": "shape", "diffuse": "bsdf", "area": "emitter", "constant": "emitter", "envmap": "emitter", "bitmap": "texture", "checkerboard": "texture", "scene": "scene"}
 
 
 def _node_from_dict(d, ctx):

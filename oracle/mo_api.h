@@ -38,6 +38,10 @@ int mo_scene_set_emitter_order(mo_scene *s, uint32_t n, const uint32_t *order);
 /* Bitmap texture (src/textures/bitmap.cpp, linear RGB data, identity to_uv): returns its index.  A texture is
  * attached to the reflectance of a shape's diffuse BSDF with mo_scene_set_texture (-1 detaches). */
 int mo_scene_add_texture(mo_scene *s, int width, int height, const float *rgb);
+/* to_uv of a texture: uvm6 = (m00, m01, m02, m10, m11, m12) of the extracted 3x3 transform (bitmap.cpp:62,254) */
+int mo_scene_set_texture_transform(mo_scene *s, uint32_t texture, const float *uvm6);
+/* Checkerboard texture with constant colours (src/textures/checkerboard.cpp:40-64): returns its index. */
+int mo_scene_add_checkerboard(mo_scene *s, const float *color0, const float *color1, const float *uvm6);
 int mo_scene_set_texture(mo_scene *s, uint32_t shape, int texture);
 int mo_scene_update_texture(mo_scene *s, uint32_t texture, const float *rgb);
 int mo_scene_set_reflectance(mo_scene *s, uint32_t shape, const float *rgb);

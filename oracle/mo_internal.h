@@ -54,7 +54,9 @@ float mo_envmap_pdf(const mo_envmap *e, mo_v3 d_world);
 /* type 0: `area` (src/emitters/area.cpp) attached to `shape`; type 1: `constant` environment (src/emitters/constant.cpp)
  * with the scene's bounding sphere (set_scene, constant.cpp:47-51); type 2: `envmap` (src/emitters/envmap.cpp) */
 typedef struct { uint32_t shape; float radiance[3]; float coeff[3], d65_scale; int type; mo_v3 center; float radius; mo_envmap *env; } mo_emitter;
-typedef struct { int w, h; float *data; } mo_texture;
+/* kind 0: bitmap (src/textures/bitmap.cpp), kind 1: checkerboard (src/textures/checkerboard.cpp); uvm = upper-left 2x3 of the
+ * extracted to_uv transform: uv' = (uvm[0] u + uvm[1] v + uvm[2], uvm[3] u + uvm[4] v + uvm[5]) */
+typedef struct { int w, h; float *data; int kind; float uvm[6]; float color0[3], color1[3]; } mo_texture;
 typedef struct { double lo[3], hi[3]; uint32_t left, right, first, count; } mo_bvh_node;
 
 struct mo_scene {

@@ -125,8 +125,26 @@ int mo_scene_add_texture(mo_scene *s, int width, int height, const float *rgb) {
     if (!s || width < 2 || height < 2 || !rgb) return -1;
     s->textures = (mo_texture *) realloc(s->textures, sizeof(mo_texture) * (s->n_textures + 1));
     mo_texture *t = &s->textures[s->n_textures];
+    memset(t, 0, sizeof(*t));
     t->w = width; t->h = height;
     t->data = (float *) dup_mem(rgb, sizeof(float) * 3 * (size_t) width * height);
+    t->uvm[0] = 1.0f; t->uvm[4] = 1.0f;
+    return (int) s->n_textures++;
+}
+int mo_scene_set_texture_transform(mo_scene *s, uint32_t texture, const float *uvm6) {
+    if (!s || texture >= s->n_textures || !uvm6) return -1;
+    memcpy(s->textures[texture].uvm, uvm6, sizeof(float) * 6);
+    return 0;
+}
+int mo_scene_add_checkerboard(mo_scene *s, const float *color0, const float *color1, const float *uvm6) {
+    if (!s || !color0 || !color1) return -1;
+    s->textures = (mo_texture *) realloc(s->textures, sizeof(mo_texture) * (s->n_textures + 1));
+    mo_texture *t = &s->textures[s->n_textures];
+    memset(t, 0, sizeof(*t));
+    t->kind = 1;
+    t->uvm[0] = 1.0f; t->uvm[4] = 1.0f;
+    if (uvm6) memcpy(t->uvm, uvm6, sizeof(float) * 6);
+    for (int k = 0; k < 3; ++k) { t->color0[k] = color0[k]; t->color1[k] = color1[k]; }
     return (int) s->n_textures++;
 }
 int mo_scene_set_texture(mo_scene *s, uint32_t shape, int texture) {
@@ -137,6 +155,7 @@ int mo_scene_set_texture(mo_scene *s, uint32_t shape, int texture) {
 int mo_scene_update_texture(mo_scene *s, uint32_t texture, const float *rgb) {
     if (!s || texture >= s->n_textures) return -1;
     mo_texture *t = &s->textures[texture];
+    if (t->kind != 0) return -2;
     memcpy(t->data, rgb, sizeof(float) * 3 * (size_t) t->w * t->h);
     return 0;
 }
@@ -165,6 +184,17 @@ void mo_reflectance(const mo_scene *s, const mo_mesh *m, mo_v2 uv, float out[3],
         return;
     }
     const mo_texture *t = &s->textures[m->texture];
+    {   /* m_transform.transform_affine(si.uv) (bitmap.cpp:254, checkerboard.cpp:49) */
+        float u2 = fmaf(t->uvm[0], uv.x, fmaf(t->uvm[1], uv.y, t->uvm[2])), v2 = fmaf(t->uvm[3], uv.x, fmaf(t->uvm[4], uv.y, t->uvm[5]));
+        uv.x = u2; uv.y = v2;
+    }
+    if (t->kind == 1) {                                      /* checkerboard.cpp:46-63 */
+        int mx = (uv.x - floorf(uv.x)) > 0.5f, my = (uv.y - floorf(uv.y)) > 0.5f;
+        const float *c = mx == my ? t->color0 : t->color1;
+        for (int k = 0; k < 3; ++k) out[k] = c[k];
+        if (texel) *texel = 0xffffffffu;
+        return;
+    }
     float ux = uv.x - floorf(uv.x), uy = uv.y - floorf(uv.y);
     ux *= (float) (uint32_t) (t->w - 1); uy *= (float) (uint32_t) (t->h - 1);
     uint32_t px = (uint32_t) ux, py = (uint32_t) uy;

@@ -65,6 +65,8 @@ def lib():
         L.mo_scene_finalize.argtypes = [C.c_void_p]
         L.mo_scene_add_texture.argtypes = [C.c_void_p, C.c_int, C.c_int, f32p]
         L.mo_scene_set_texture.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
+        L.mo_scene_set_texture_transform.argtypes = [C.c_void_p, C.c_uint32, f32p]
+        L.mo_scene_add_checkerboard.argtypes = [C.c_void_p, f32p, f32p, f32p]
         L.mo_scene_update_texture.argtypes = [C.c_void_p, C.c_uint32, f32p]
         L.mo_scene_set_reflectance.argtypes = [C.c_void_p, C.c_uint32, f32p]
         L.mo_scene_set_naive.argtypes = [C.c_void_p, C.c_int]
@@ -143,8 +145,21 @@ class OracleScene:
         for bi, b in enumerate(scene_dict["bsdfs"]):
             b = b.get("bsdf", b) if b.get("type") == "twosided" else b
             if isinstance(b.get("reflectance"), dict):
-                data = _f(b["reflectance"]["data"])
-                self.tex_of_bsdf[bi] = L.mo_scene_add_texture(self.h, data.shape[1], data.shape[0], data.ctypes.data_as(f32p))
+                spec = b["reflectance"]
+                uvm = None
+                if spec.get("to_uv") is not None:
+                    m = np.asarray(spec["to_uv"], np.float32).reshape(4, 4)
+                    uvm = _f([m[0, 0], m[0, 1], m[0, 2], m[1, 0], m[1, 1], m[1, 2]])
+                if spec.get("type") == "checkerboard":
+                    from mitsuba2_amd import bsdfs as B
+                    c0, c1 = _f(B._rgb(spec.get("color0"), 0.4)), _f(B._rgb(spec.get("color1"), 0.2))
+                    self.tex_of_bsdf[bi] = L.mo_scene_add_checkerboard(self.h, c0.ctypes.data_as(f32p), c1.ctypes.data_as(f32p),
+                                                                       uvm.ctypes.data_as(f32p) if uvm is not None else None)
+                else:
+                    data = _f(spec["data"])
+                    self.tex_of_bsdf[bi] = L.mo_scene_add_texture(self.h, data.shape[1], data.shape[0], data.ctypes.data_as(f32p))
+                    if uvm is not None:
+                        assert L.mo_scene_set_texture_transform(self.h, self.tex_of_bsdf[bi], uvm.ctypes.data_as(f32p)) == 0
                 assert self.tex_of_bsdf[bi] >= 0
         self.shapes_of_bsdf = {}
         for si, m in enumerate(scene_dict["meshes"]):

@@ -94,3 +94,29 @@ def test_roughplastic_tables_match_oracle():
         L.check(L.lib().mtsamd_scene_roughplastic_tables(scene._handle, 0, got.ctypes.data_as(L.f32p)))
         want, r_int = ob.roughplastic_tables(mat)
         assert np.allclose(got[:64], want, rtol=1e-4, atol=1e-5) and abs(got[64] - r_int) < 1e-4
+
+
+@pytest.mark.parametrize("kind", ["checkerboard", "bitmap_to_uv"])
+def test_procedural_and_transformed_textures(kind):
+    """src/textures/checkerboard.cpp:46-63 and the `to_uv` transform of textures (bitmap.cpp:62,254): per-sample parity"""
+    from mitsuba2_amd import render as R, scenes, xml as mxml
+    tex = np.random.default_rng(2).uniform(0.1, 0.9, size=(8, 8, 3)).astype(np.float32)
+    cb = scenes.cornell_box(texture=tex)
+    to_uv = mxml.scale([3.0, 5.0, 1.0])
+    to_uv[0, 2], to_uv[1, 2] = 0.25, 0.1                     # the third column of the 4x4 is the translation after extract()
+    for b in cb["bsdfs"]:
+        if isinstance(b.get("reflectance"), dict):
+            if kind == "checkerboard":
+                b["reflectance"] = {"type": "checkerboard", "color0": [0.8, 0.2, 0.1], "color1": 0.3, "to_uv": to_uv}
+            else:
+                b["reflectance"] = dict(b["reflectance"], to_uv=to_uv)
+    sp = dict(scenes.cornell_box_sensor(64, 64, spp=4, seed=9), max_depth=4)
+    scene, sensor = R.Scene(cb), R.make_sensor(sp)
+    n = 64 * 64 * 4
+    rgb, mask, pos = R.PathIntegrator(max_depth=4).sample(scene, sensor, 0, n)
+    want, wpos = ob.OracleScene(cb).sample_radiance(ob.make_desc(sp), 0, n)
+    assert np.array_equal(pos.cpu().numpy(), wpos)
+    close = np.isclose(rgb.cpu().numpy(), want[:, :3], rtol=2e-3, atol=1e-5).all(1)
+    assert close.mean() > 0.999, close.mean()
+    plain, _, _ = R.PathIntegrator(max_depth=4).sample(R.Scene(scenes.cornell_box(texture=tex)), sensor, 0, n)
+    assert not torch.equal(plain, rgb)                       # the transform / pattern really changes the picture
