@@ -527,7 +527,9 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     std::memcpy(nodes.data(), s->bvh.nodes.data(), s->bvh.nodes.size() * sizeof(float));
     std::memcpy(tris.data(), s->bvh.tris.data(), s->bvh.tris.size() * sizeof(float));
     // flat scenes: 64-byte records in primitive order (device_scene.h)
-    const bool flat = s->n_prims <= kFlatMaxPrims;
+    uint32_t flat_max = kFlatMaxPrims;
+    if (const char *e = std::getenv("MTSAMD_FLAT_MAX")) flat_max = std::min<uint32_t>(kFlatMaxPrims, (uint32_t) std::strtoul(e, nullptr, 10));   // experiment switch
+    const bool flat = s->n_prims <= flat_max;
     std::vector<float4> flat_recs(flat ? 4 * (size_t) s->n_prims : 0);
     for (uint32_t gp = 0; flat && gp < s->n_prims; ++gp) {
         const float *tp = &tri_pos[9 * (size_t) gp];

@@ -143,7 +143,8 @@ class OracleScene:
         self.h = C.c_void_p(L.mo_scene_new())
         self.tex_of_bsdf = {}
         for bi, b in enumerate(scene_dict["bsdfs"]):
-            b = b.get("bsdf", b) if b.get("type") == "twosided" else b
+            from mitsuba2_amd import bsdfs as B
+            b = B.normalize(b)                                # unwraps `twosided`, whatever the nested key is called
             if isinstance(b.get("reflectance"), dict):
                 spec = b["reflectance"]
                 uvm = None
@@ -151,7 +152,6 @@ class OracleScene:
                     m = np.asarray(spec["to_uv"], np.float32).reshape(4, 4)
                     uvm = _f([m[0, 0], m[0, 1], m[0, 2], m[1, 0], m[1, 1], m[1, 2]])
                 if spec.get("type") == "checkerboard":
-                    from mitsuba2_amd import bsdfs as B
                     c0, c1 = _f(B._rgb(spec.get("color0"), 0.4)), _f(B._rgb(spec.get("color1"), 0.2))
                     self.tex_of_bsdf[bi] = L.mo_scene_add_checkerboard(self.h, c0.ctypes.data_as(f32p), c1.ctypes.data_as(f32p),
                                                                        uvm.ctypes.data_as(f32p) if uvm is not None else None)

@@ -105,8 +105,64 @@ def test_hdrfilm_develop(tmp_path, file_format):
 
 def test_film_parameter_validation():
     """test_hdrfilm.py:22-32"""
-    from mitsuba2_amd import render as R
     with pytest.raises(RuntimeError):
         R.HDRFilm(component_format="uint8")
     with pytest.raises(RuntimeError):
         R.HDRFilm(pixel_format="brga")
+
+
+MATPREVIEW_XML = """<scene version="2.0.0">
+    <default name="spp" value="8"/>
+    <integrator type="path"><integer name="max_depth" value="6"/></integrator>
+    <sensor type="perspective">
+        <float name="fov" value="35"/>
+        <transform name="to_world"><lookat origin="0, 1.5, 4.5" target="0, 0.2, 0" up="0, 1, 0"/></transform>
+        <sampler type="independent"><integer name="sample_count" value="$spp"/><integer name="seed" value="3"/></sampler>
+        <film type="hdrfilm"><integer name="width" value="64"/><integer name="height" value="48"/><rfilter type="gaussian"/></film>
+    </sensor>
+    <bsdf type="roughplastic" id="object">
+        <float name="alpha" value="0.2"/><string name="distribution" value="ggx"/>
+        <rgb name="diffuse_reflectance" value="0.3, 0.1, 0.05"/><float name="int_ior" value="1.6"/>
+    </bsdf>
+    <shape type="serialized"><string name="filename" value="ball.serialized"/><ref id="object"/></shape>
+    <shape type="rectangle">
+        <transform name="to_world"><rotate x="1" angle="-90"/><scale value="4"/><translate y="-1.05"/></transform>
+        <bsdf type="twosided"><bsdf type="diffuse">
+            <texture type="checkerboard" name="reflectance"><rgb name="color0" value="0.6, 0.6, 0.6"/><spectrum name="color1" value="0.15"/>
+                <transform name="to_uv"><scale x="6" y="6"/></transform></texture>
+        </bsdf></bsdf>
+    </shape>
+    <emitter type="envmap"><string name="filename" value="sky.pfm"/><float name="scale" value="1.5"/>
+        <transform name="to_world"><rotate y="1" angle="40"/></transform></emitter>
+</scene>"""
+
+
+def test_matpreview_style_scene_from_files(tmp_path):
+    """a material-preview style scene assembled from files -- serialized mesh, roughplastic, checkerboard ground, envmap from a
+    PFM, XML with defaults -- renders like the oracle fed with the same parsed description"""
+    import oracle_binding as ob
+    from mitsuba2_amd import bitmap, loaders, scenes, xml as mxml
+    ball = scenes.bumpy_sphere(24, 48)["meshes"][0]
+    loaders.write_serialized(str(tmp_path / "ball.serialized"), [dict(positions=ball["positions"], faces=ball["faces"], normals=ball["normals"])])
+    yy, xx = np.mgrid[0:32, 0:64]
+    sky = np.stack([0.3 + 0.5 * (yy < 14), 0.4 + 0.4 * (yy < 14), 0.9 - 0.01 * yy], 2).astype(np.float32)
+    sky[6:9, 40:44] += 25.0
+    bitmap.write_pfm(str(tmp_path / "sky.pfm"), sky)
+    with open(str(tmp_path / "scene.xml"), "w") as fh:
+        fh.write(MATPREVIEW_XML)
+    desc = mxml.parse_file(str(tmp_path / "scene.xml"), spp=16)
+    scene = mxml.instantiate(desc)
+    sensor = scene.sensors()[0]
+    assert sensor.sampler().sample_count() == 16 and scene.integrator().max_depth == 6
+    n = 64 * 48 * 16
+    rgb, mask, pos = scene.integrator().sample(scene, sensor, 0, n)
+    sd = desc.sensors[0]
+    op = dict(to_world=sd["to_world"], fov=sensor.x_fov(), near_clip=sd["near_clip"], far_clip=sd["far_clip"], width=64, height=48,
+              crop=(0, 0, 64, 48), rfilter="gaussian", rfilter_param=0.5, sample_count=16, seed=3, max_depth=6, rr_depth=5)
+    want, wpos = ob.OracleScene(desc.scene_dict).sample_radiance(ob.make_desc(op), 0, n)
+    assert np.array_equal(pos.cpu().numpy(), wpos) and np.array_equal(mask.cpu().numpy(), want[:, 3] > 0.5)
+    close = np.isclose(rgb.cpu().numpy(), want[:, :3], rtol=5e-3, atol=2e-4).all(1)
+    assert close.mean() > 0.99, close.mean()
+    assert scene.integrator().render(scene, sensor)
+    img = sensor.film().bitmap().cpu().numpy()
+    assert np.isfinite(img).all() and img[..., :3].mean() > 0.05 and img[..., 3].min() >= 0
