@@ -83,7 +83,8 @@ typedef struct {
 } mtsamd_bsdf_desc;
 
 /* area: src/emitters/area.cpp (attached to a mesh); constant: src/emitters/constant.cpp and envmap: src/emitters/envmap.cpp
- * (environment emitters, at most one per scene, RGB variant) */
+ * (environment emitters, at most one per scene; spectral variant: `constant` radiance is upsampled like an area light's,
+ * `envmap` texels become (model coefficients, scale) as in envmap.cpp:96-109) */
 typedef enum { MTSAMD_EMITTER_AREA = 0, MTSAMD_EMITTER_CONSTANT = 1, MTSAMD_EMITTER_ENVMAP = 2 } mtsamd_emitter_type;
 typedef struct {
     int32_t type;              /* mtsamd_emitter_type; AreaLight = src/emitters/area.cpp */

@@ -339,7 +339,6 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         if (et == MTSAMD_EMITTER_CONSTANT || et == MTSAMD_EMITTER_ENVMAP) {
             if (emitter_shape[e] >= 0) return fail(MTSAMD_ERR_INVALID, "emitter %u: an environment emitter cannot be attached to a shape", e);
             if (environment >= 0) return fail(MTSAMD_ERR_INVALID, "Only one environment emitter can be specified per scene.");      // scene.cpp:45-46
-            if (desc->spectral) return fail(MTSAMD_ERR_UNSUPPORTED, "emitter %u: environment emitters are implemented for the RGB variant only", e);
             if (et == MTSAMD_EMITTER_ENVMAP && (!desc->emitters[e].envmap_data || desc->emitters[e].envmap_width < 2 || desc->emitters[e].envmap_height < 2))
                 return fail(MTSAMD_ERR_INVALID, "emitter %u: the environment map must be at least 2x2 pixels in size", e);
             environment = (int32_t) e;
@@ -512,7 +511,9 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     else { s->bvh = BvhOutput{}; s->bvh.root = 0x80000000u; }       // a leaf with no triangles
     if (s->environment >= 0) {       // ConstantBackgroundEmitter::set_scene (constant.cpp:47-51): bounding sphere of Scene::bbox()
         DevEmitter &e = s->emitters[s->environment];
+        const float sc[4] = { e.c0, e.c1, e.c2, e.d65_scale };            // spectral variant: filled above
         std::memset(&e, 0, sizeof(e));
+        e.c0 = sc[0]; e.c1 = sc[1]; e.c2 = sc[2]; e.d65_scale = sc[3];
         const mtsamd_emitter_desc &ed = desc->emitters[s->environment];
         e.r = ed.radiance[0]; e.g = ed.radiance[1]; e.b = ed.radiance[2];
         e.shape = 0xffffffffu; e.pad0 = ed.type == MTSAMD_EMITTER_ENVMAP ? kEmitterEnvmap : kEmitterConstant;
@@ -573,6 +574,18 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         if (!build_envmap(ed.envmap_data, ed.envmap_width, ed.envmap_height, eh) || eh.lv_offset.size() > (size_t) kEnvMaxLevels) {
             mtsamd_scene_destroy(s);
             return fail(MTSAMD_ERR_INVALID, "envmap: unsupported image size %d x %d", ed.envmap_width, ed.envmap_height);
+        }
+        if (desc->spectral) {
+            // envmap.cpp:96-109: every texel becomes (model coefficients of the colour scaled to a 50% maximum, scale); the
+            // sampling hierarchy stays the one built from the RGB luminance.  Black texels (a division by zero inside
+            // rgb2spec_fetch in the reference) get finite coefficients: they carry scale = 0.
+            for (size_t i = 0; i < eh.texels.size() / 4; ++i) {
+                float *px = eh.texels.data() + 4 * i;
+                const float sc = std::max(std::max(px[0], px[1]), px[2]) * 2.0f, dn = std::max(1e-8f, sc);
+                float rgb_norm[3] = { px[0] / dn, px[1] / dn, px[2] / dn }, coeff[3] = { 0.0f, 0.0f, 0.0f };
+                if (sc > 0.0f) srgb_model_fetch(model, rgb_norm, coeff);
+                px[0] = coeff[0]; px[1] = coeff[1]; px[2] = coeff[2]; px[3] = sc;
+            }
         }
         DevEnvmap de{};
         std::vector<DevEnvmap> one(1);

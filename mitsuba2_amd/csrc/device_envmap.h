@@ -1,4 +1,4 @@
-// device_envmap.h -- `envmap` emitter, RGB variant.
+// device_envmap.h -- `envmap` emitter, RGB and spectral variants.
 //
 //   Hierarchical2D<Float, 0>::sample / eval   include/mitsuba/core/distr_2d.h:320-400, :486-517
 //   square_to_bilinear / interval_to_linear   include/mitsuba/core/warp.h:367-441
@@ -11,7 +11,7 @@ namespace mtsamd {
 
 constexpr int kEnvMaxLevels = 34;
 struct DevEnvmap {
-    const float4 *data;                 // RGBA texels (alpha = 1), row-major
+    const float4 *data;                 // RGBA texels (alpha = 1), row-major; spectral variant: (srgb model coefficients, scale)
     const float *warp;                  // every level of the hierarchy, concatenated
     int32_t w, h, n_levels; float scale;
     uint32_t lv_offset[kEnvMaxLevels], lv_width[kEnvMaxLevels];
@@ -102,8 +102,8 @@ MTS_DEV f3 envmap_eval(const DevEnvmap &e, f3 d) {
     env_dir_to_uv(mat3_apply(e.to_local, d), u, v);
     return envmap_lookup(e, u, v);
 }
-// sample_direction (envmap.cpp:154-190): world direction, pdf, radiance (not yet divided by the pdf)
-MTS_DEV void envmap_sample(const DevEnvmap &e, f2 sample, f3 &d_out, float &pdf_out, f3 &value) {
+// sample_direction (envmap.cpp:154-190): world direction, pdf and the texture coordinates the radiance is looked up at
+MTS_DEV void envmap_sample(const DevEnvmap &e, f2 sample, f3 &d_out, float &pdf_out, f2 &uv) {
     float u, v, pdf;
     hier2d_sample(e, sample.x, sample.y, u, v, pdf);
     const float theta = v * kPi, phi = u * (2.0f * kPi);
@@ -113,7 +113,7 @@ MTS_DEV void envmap_sample(const DevEnvmap &e, f2 sample, f3 &d_out, float &pdf_
     const float inv_sin_theta = 1.0f / sqrtf(fmaxf(d.x * d.x + d.z * d.z, kEpsilon * kEpsilon));
     d = mat3_apply(e.to_world, d);
     pdf_out = pdf > 0.0f ? pdf * inv_sin_theta * (1.0f / (2.0f * (kPi * kPi))) : 0.0f;
-    value = envmap_lookup(e, u, v);
+    uv.x = u; uv.y = v;
     d_out = d;
 }
 MTS_DEV float envmap_pdf(const DevEnvmap &e, f3 d_world) {           // envmap.cpp:192-208

@@ -430,7 +430,7 @@ MTS_DEV void fill_si(const Geo<FLAT> &g, f3 ray_d, uint32_t prim, float b1, floa
 }
 
 // ---------------------------------------------------------------------------
-struct DirectionSample { f3 p, n, d; float dist, pdf; uint32_t emitter; f3 value; };      // value: radiance of an envmap sample
+struct DirectionSample { f3 p, n, d; float dist, pdf; uint32_t emitter; f2 uv; };      // uv: texture coordinates of an envmap sample
 
 // Scene::sample_emitter_direction without the visibility test.  The emitted spectrum is returned in factored
 // form: spec = (radiance * r1) * r2 with r1 = 1/pdf (0 when the sample is masked) and r2 = emitter count.
@@ -438,7 +438,7 @@ template <bool FLAT>
 MTS_DEV void sample_emitter_direction(const Geo<FLAT> &g, f3 ref_p, f2 sample, DirectionSample &ds, float &r1, float &r2) {
     const SceneView &sv = g.sv;
     ds.pdf = 0.0f; ds.dist = 0.0f; ds.emitter = 0;
-    ds.p = ds.n = ds.d = mk3(0, 0, 0);
+    ds.p = ds.n = ds.d = mk3(0, 0, 0); ds.uv.x = ds.uv.y = 0.0f;
     r1 = 0.0f; r2 = 1.0f;
     if (sv.n_emitters == 0) return;
     uint32_t index = 0;
@@ -453,11 +453,11 @@ MTS_DEV void sample_emitter_direction(const Geo<FLAT> &g, f3 ref_p, f2 sample, D
     const DevEmitter e = g.emitter(index);
     if (e.pad0 == kEmitterEnvmap) {
         // EnvironmentMapEmitter::sample_direction (envmap.cpp:154-190); r1 = 1 / pdf, the radiance is looked up by the caller
-        f3 d, value; float pdf;
-        envmap_sample(*sv.envmap, sample, d, pdf, value);
+        f3 d; f2 uv; float pdf;
+        envmap_sample(*sv.envmap, sample, d, pdf, uv);
         ds.dist = 2.0f * e.radius;
         ds.p = ref_p + d * ds.dist;
-        ds.n = -d; ds.d = d; ds.pdf = pdf; ds.emitter = index; ds.value = value;
+        ds.n = -d; ds.d = d; ds.pdf = pdf; ds.emitter = index; ds.uv = uv;
         r1 = rcp(pdf);
         if (sv.n_emitters > 1) { ds.pdf *= emitter_pdf; r2 = rcp(emitter_pdf); }
         return;
@@ -531,7 +531,7 @@ MTS_DEV void sample_emitter_direction(const Geo<FLAT> &g, f3 ref_p, f2 sample, D
     if (g.sv.n_emitters == 0) return;
     const DevEmitter e = g.emitter(ds.emitter);
     f3 rad = mk3(e.r, e.g, e.b);
-    if (e.pad0 == kEmitterEnvmap) rad = ds.value;                             // eval_spectrum at the sampled (u, v)
+    if (e.pad0 == kEmitterEnvmap) rad = envmap_lookup(*g.sv.envmap, ds.uv.x, ds.uv.y);      // eval_spectrum at the sampled (u, v)
     spec = mk3(rad.x * r1, rad.y * r1, rad.z * r1);
     if (g.sv.n_emitters > 1) spec = spec * r2;
 }

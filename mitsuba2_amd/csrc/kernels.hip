@@ -372,6 +372,38 @@ MTS_DEV BsdfChannels<kWav> spectral_channels(const DevBsdf &b, const Spec4 &wav)
     return c;
 }
 
+// radiance spectrum of an emitter at the path's 4 wavelengths: SRGBEmitterSpectrum::eval = d65 * srgb_model_eval
+// (srgb_d65.cpp:54-62) for `area` / `constant`; eval_spectrum's spectral branch (envmap.cpp:283-306) at texture
+// coordinates (u, v) for `envmap`, whose texels hold (model coefficients, scale) and whose whitepoint is D65 / 10568
+MTS_DEV Spec4 envmap_lookup_spectral(const DevEnvmap &e, float u, float v, const Spec4 &wav) {
+    u *= (float) (e.w - 1); v *= (float) (e.h - 1);
+    const uint32_t px = min((uint32_t) u, (uint32_t) (e.w - 2)), py = min((uint32_t) v, (uint32_t) (e.h - 2));
+    const float w1x = u - (float) px, w1y = v - (float) py, w0x = 1.0f - w1x, w0y = 1.0f - w1y;
+    const float4 *p = e.data + (size_t) py * e.w + px;
+    const float4 v00 = p[0], v10 = p[1], v01 = p[e.w], v11 = p[e.w + 1];
+    const float f0 = fmaf(w0x, v00.w, w1x * v10.w), f1 = fmaf(w0x, v01.w, w1x * v11.w);
+    const float f = fmaf(w0y, f0, w1y * f1);
+    Spec4 r;
+#pragma unroll
+    for (int k = 0; k < kWav; ++k) {
+        const float l = wav.v[k];
+        const float s00 = srgb_model_eval(v00.x, v00.y, v00.z, l), s10 = srgb_model_eval(v10.x, v10.y, v10.z, l);
+        const float s01 = srgb_model_eval(v01.x, v01.y, v01.z, l), s11 = srgb_model_eval(v11.x, v11.y, v11.z, l);
+        const float s0 = fmaf(w0x, s00, w1x * s10), s1 = fmaf(w0x, s01, w1x * s11);
+        const float sp = fmaf(w0y, s0, w1y * s1);
+        const float wp = table_eval(g_spectral.d65, 1.0f / 10568.0f, l);
+        r.v[k] = ((sp * wp) * f) * e.scale;
+    }
+    return r;
+}
+MTS_DEV Spec4 emitter_spectrum(const SceneView &sv, const DevEmitter &e, const Spec4 &wav, f2 uv) {
+    if (e.pad0 == kEmitterEnvmap) return envmap_lookup_spectral(*sv.envmap, uv.x, uv.y, wav);
+    Spec4 r;
+#pragma unroll
+    for (int k = 0; k < kWav; ++k) r.v[k] = table_eval(g_spectral.d65, e.d65_scale, wav.v[k]) * srgb_model_eval(e.c0, e.c1, e.c2, wav.v[k]);
+    return r;
+}
+
 template <bool FLAT, int DEFER = 0, bool GENERAL = false>
 MTS_DEV bool bounce_step_spectral(const RenderParams &P, const LdsView &lds, PathStateS &s, Counters &c, Deferred *df = nullptr) {
     const SceneView &sv = P.sv;
@@ -407,6 +439,16 @@ MTS_DEV bool bounce_step_spectral(const RenderParams &P, const LdsView &lds, Pat
             }
         }
     }
+    if (!found && sv.env_emitter >= 0) {                     // si.emitter(scene) of an escaped ray: the environment
+        const DevEmitter e = geo.emitter((uint32_t) sv.env_emitter);
+        float ew = 1.0f;
+        if (s.depth > 1u) ew = mis_weight(s.bs_pdf, (GENERAL && (s.flags & kFlagDelta)) ? 0.0f : pdf_environment(sv, e, s.d));
+        f2 uv; uv.x = uv.y = 0.0f;
+        if (e.pad0 == kEmitterEnvmap) env_dir_to_uv(mat3_apply(sv.envmap->to_local, s.d), uv.x, uv.y);      // envmap.cpp:135-144
+        const Spec4 le = emitter_spectrum(sv, e, s.wav, uv);
+#pragma unroll
+        for (int k = 0; k < kWav; ++k) s.res.v[k] += (ew * s.thr.v[k]) * le.v[k];
+    }
     bool active = found;
 
     if ((int32_t) s.depth > P.rr_depth) {
@@ -440,9 +482,10 @@ MTS_DEV bool bounce_step_spectral(const RenderParams &P, const LdsView &lds, Pat
             if (GENERAL) bsdf_eval_pdf_n<kWav>(bsdf, chan, si.wi, wo, bvs, bp);
             float mis = mis_weight(ds.pdf, bp);
             Spec4 contrib; bool nz = false;
+            const Spec4 le4 = emitter_spectrum(sv, e, s.wav, ds.uv);
 #pragma unroll
             for (int k = 0; k < kWav; ++k) {
-                float le = table_eval(g_spectral.d65, e.d65_scale, s.wav.v[k]) * srgb_model_eval(e.c0, e.c1, e.c2, s.wav.v[k]);
+                float le = le4.v[k];
                 float spec = le * r1;
                 if (sv.n_emitters > 1) spec *= r2;
                 float bv = GENERAL ? bvs[k] : (front ? (refl.v[k] * kInvPi) * wo.z : 0.0f);

@@ -237,7 +237,7 @@ void mo_envmap_eval(const mo_envmap *e, mo_v3 d, float out[3]) {
 }
 
 /* sample_direction (envmap.cpp:154-190): returns the world direction, its pdf and radiance / pdf */
-void mo_envmap_sample(const mo_envmap *e, mo_v2 sample, mo_v3 *d_out, float *pdf_out, float spec[3]) {
+void mo_envmap_sample(const mo_envmap *e, mo_v2 sample, mo_v3 *d_out, float *pdf_out, float spec[3], mo_v2 *uv_out) {
     float u, v, pdf;
     mo_hier2d_sample(&e->warp, sample.x, sample.y, &u, &v, &pdf);
     float theta = v * MO_PI_F, phi = u * (2.0f * MO_PI_F);
@@ -251,6 +251,33 @@ void mo_envmap_sample(const mo_envmap *e, mo_v2 sample, mo_v3 *d_out, float *pdf
     float r = mo_rcp(ds_pdf);
     for (int k = 0; k < 3; ++k) spec[k] = val[k] * r;
     *d_out = d; *pdf_out = ds_pdf;
+    if (uv_out) { uv_out->x = u; uv_out->y = v; }
+}
+
+/* eval_spectrum, spectral branch (envmap.cpp:283-306): texels hold (srgb model coefficients, scale) after
+ * mo_scene_set_spectral (envmap.cpp:100-109); whitepoint = Texture::D65(1.f), i.e. the D65 table / 10568 */
+void mo_envmap_lookup_spectral(const mo_envmap *e, float u, float v, const float *wav, float *out) {
+    u *= (float) (e->w - 1); v *= (float) (e->h - 1);
+    uint32_t px = (uint32_t) u, py = (uint32_t) v;
+    if (px > (uint32_t) (e->w - 2)) px = (uint32_t) (e->w - 2);
+    if (py > (uint32_t) (e->h - 2)) py = (uint32_t) (e->h - 2);
+    float w1x = u - (float) px, w1y = v - (float) py, w0x = 1.0f - w1x, w0y = 1.0f - w1y;
+    const float *v00 = e->data + 4 * ((size_t) py * e->w + px), *v10 = v00 + 4, *v01 = v00 + 4 * (size_t) e->w, *v11 = v01 + 4;
+    float f0 = fmaf(w0x, v00[3], w1x * v10[3]), f1 = fmaf(w0x, v01[3], w1x * v11[3]);
+    float f = fmaf(w0y, f0, w1y * f1);
+    for (int k = 0; k < MO_WAV; ++k) {
+        float s00 = mo_srgb_model_eval(v00, wav[k]), s10 = mo_srgb_model_eval(v10, wav[k]);
+        float s01 = mo_srgb_model_eval(v01, wav[k]), s11 = mo_srgb_model_eval(v11, wav[k]);
+        float s0 = fmaf(w0x, s00, w1x * s10), s1 = fmaf(w0x, s01, w1x * s11);
+        float sp = fmaf(w0y, s0, w1y * s1);
+        float wp = mo_d65_eval(1.0f / 10568.0f, wav[k]);
+        out[k] = ((sp * wp) * f) * e->scale;
+    }
+}
+void mo_envmap_eval_spectral(const mo_envmap *e, mo_v3 d, const float *wav, float *out) {
+    mo_v3 v = mat3_apply(e->to_local, d);
+    float u, vv; dir_to_uv(v, &u, &vv);
+    mo_envmap_lookup_spectral(e, u, vv, wav, out);
 }
 
 /* pdf_direction (envmap.cpp:192-208) */
@@ -286,7 +313,7 @@ void mo_kat_envmap(int w, int h, const float *rgb, float scale, const float *to_
     for (uint64_t i = 0; i < n; ++i) {
         float *o = out11 + 11 * i;
         mo_v2 s = { sample2[2 * i], sample2[2 * i + 1] };
-        mo_v3 d; mo_envmap_sample(&e, s, &d, &o[3], &o[4]);
+        mo_v3 d; mo_envmap_sample(&e, s, &d, &o[3], &o[4], NULL);
         o[0] = d.x; o[1] = d.y; o[2] = d.z;
         mo_envmap_eval(&e, d, &o[7]);
         o[10] = mo_envmap_pdf(&e, d);

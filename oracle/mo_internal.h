@@ -14,7 +14,7 @@ typedef struct {
 } mo_si;
 
 /* DirectionSample (include/mitsuba/render/records.h:121-174) */
-typedef struct { mo_v3 p, n, d; float dist, pdf; uint32_t emitter; float pdf_single; } mo_dsample;   /* pdf_single: before the emitter-selection probability */
+typedef struct { mo_v3 p, n, d; float dist, pdf; uint32_t emitter; float pdf_single; mo_v2 uv; } mo_dsample;   /* pdf_single: before the emitter-selection probability; uv: envmap samples */
 
 /* a BSDF instance: the descriptor plus the constants its constructor derives (plastic.cpp:162-176) */
 typedef struct {
@@ -48,7 +48,9 @@ float mo_hier2d_eval(const mo_hier2d *h, float px, float py);
 int mo_envmap_init(mo_envmap *e, int w, int h, const float *rgb, float scale, const float *to_world9);
 void mo_envmap_free(mo_envmap *e);
 void mo_envmap_eval(const mo_envmap *e, mo_v3 d, float out[3]);
-void mo_envmap_sample(const mo_envmap *e, mo_v2 sample, mo_v3 *d_out, float *pdf_out, float spec[3]);
+void mo_envmap_sample(const mo_envmap *e, mo_v2 sample, mo_v3 *d_out, float *pdf_out, float spec[3], mo_v2 *uv_out);
+void mo_envmap_lookup_spectral(const mo_envmap *e, float u, float v, const float *wav, float *out);   /* 4 wavelengths */
+void mo_envmap_eval_spectral(const mo_envmap *e, mo_v3 d, const float *wav, float *out);
 float mo_envmap_pdf(const mo_envmap *e, mo_v3 d_world);
 
 /* type 0: `area` (src/emitters/area.cpp) attached to `shape`; type 1: `constant` environment (src/emitters/constant.cpp)

@@ -535,6 +535,17 @@ static void depth_sample(const mo_scene *s, const mo_ray *ray, float result[3], 
     result[0] = result[1] = result[2] = valid ? si.t : 0.0f;
 }
 
+/* radiance spectrum of emitter `e` at 4 wavelengths: SRGBEmitterSpectrum (srgb_d65.cpp:54-62) for `area` / `constant`,
+ * eval_spectrum (envmap.cpp:283-306) for `envmap` -- by direction (`d`) or at known texture coordinates (`uv`) */
+static void emitter_spectrum(const mo_emitter *e, const float wav[MO_WAV], const mo_v3 *d, const mo_v2 *uv, float le[MO_WAV]) {
+    if (e->type == 2) {
+        if (uv) mo_envmap_lookup_spectral(e->env, uv->x, uv->y, wav, le);
+        else mo_envmap_eval_spectral(e->env, *d, wav, le);
+        return;
+    }
+    for (int k = 0; k < MO_WAV; ++k) le[k] = mo_d65_eval(e->d65_scale, wav[k]) * mo_srgb_model_eval(e->coeff, wav[k]);
+}
+
 /* PathIntegrator::sample for the spectral variant: identical control flow, 4 wavelength channels */
 static void path_sample_spectral(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, const float wav[MO_WAV],
                                  int max_depth, int rr_depth, float result[MO_WAV], int *valid_ray, ray_stats *st) {
@@ -545,15 +556,14 @@ static void path_sample_spectral(const mo_scene *s, mo_pcg32 *rng, const mo_ray 
     mo_si si;
     int si_valid = scene_intersect(s, &ray, &si, st);
     *valid_ray = si_valid;
-    int emitter = si_valid ? s->meshes[si.shape].emitter : -1;
+    int emitter = si_valid ? s->meshes[si.shape].emitter : s->environment;
     int active = 1;
     for (int depth = 1;; ++depth) {
-        if (emitter >= 0 && active && si.wi.z > 0.0f) {
-            const mo_emitter *e = &s->emitters[emitter];
-            for (int k = 0; k < MO_WAV; ++k) {
-                float le = mo_d65_eval(e->d65_scale, wav[k]) * mo_srgb_model_eval(e->coeff, wav[k]);
-                result[k] += (emission_weight * throughput[k]) * le;
-            }
+        if (emitter >= 0 && active && (s->emitters[emitter].type != 0 || si.wi.z > 0.0f)) {
+            float le[MO_WAV];
+            mo_v3 d = mo_neg(si.wi);
+            emitter_spectrum(&s->emitters[emitter], wav, &d, NULL, le);
+            for (int k = 0; k < MO_WAV; ++k) result[k] += (emission_weight * throughput[k]) * le[k];
         }
         active = active && si_valid;
         if (depth > rr_depth) {
@@ -574,10 +584,11 @@ static void path_sample_spectral(const mo_scene *s, mo_pcg32 *rng, const mo_ray 
             mo_sample_emitter_direction(s, si.p, s2, &ds, rgb_spec);
             if (ds.pdf != 0.0f && s->n_emitters > 0) {
                 const mo_emitter *e = &s->emitters[ds.emitter];
-                /* AreaLight::sample_direction: spec = radiance / pdf, masked (area.cpp:110-116); Scene: * emitter count */
+                /* sample_direction: spec = radiance / pdf, masked for area lights (area.cpp:110-116, constant.cpp:103-106,
+                 * envmap.cpp:186-189); Scene: * emitter count (scene.cpp:160-163) */
                 float r2 = s->n_emitters > 1 ? mo_rcp(1.0f / (float) s->n_emitters) : 1.0f;
                 float pdf_single = s->n_emitters > 1 ? ds.pdf_single : ds.pdf;
-                int act = mo_dot(ds.d, ds.n) < 0.0f && pdf_single != 0.0f;
+                int act = e->type != 0 || (mo_dot(ds.d, ds.n) < 0.0f && pdf_single != 0.0f);
                 float r1 = act ? mo_rcp(pdf_single) : 0.0f;
                 mo_ray sr;
                 sr.o = si.p; sr.d = ds.d;
@@ -586,12 +597,12 @@ static void path_sample_spectral(const mo_scene *s, mo_pcg32 *rng, const mo_ray 
                 st->any++;
                 int occluded = mo_intersect(s, &sr, 1, 0, NULL);
                 mo_v3 wo = mo_to_local(&si.sh, ds.d);
-                float bv[MO_WAV], bsdf_pdf;
+                float bv[MO_WAV], bsdf_pdf, le[MO_WAV];
                 mo_bsdf_eval_pdf_n(bsdf, MO_WAV, &chan, si.wi, wo, bv, &bsdf_pdf);
                 float mis = mis_weight(ds.pdf, bsdf_pdf);
+                emitter_spectrum(e, wav, &ds.d, &ds.uv, le);
                 for (int k = 0; k < MO_WAV; ++k) {
-                    float le = mo_d65_eval(e->d65_scale, wav[k]) * mo_srgb_model_eval(e->coeff, wav[k]);
-                    float spec = le * r1;
+                    float spec = le[k] * r1;
                     if (s->n_emitters > 1) spec *= r2;
                     if (occluded) spec = 0.0f;
                     result[k] += ((mis * throughput[k]) * bv[k]) * spec;
@@ -612,11 +623,12 @@ static void path_sample_spectral(const mo_scene *s, mo_pcg32 *rng, const mo_ray 
         ray.maxt = INFINITY;
         mo_si si_bsdf;
         int v2 = scene_intersect(s, &ray, &si_bsdf, st);
-        emitter = v2 ? s->meshes[si_bsdf.shape].emitter : -1;
+        emitter = v2 ? s->meshes[si_bsdf.shape].emitter : s->environment;
         if (emitter >= 0) {
             mo_v3 d = mo_sub(si_bsdf.p, si.p);
             float dist = mo_norm(d);
             d = mo_div_s(d, dist);
+            if (!v2) { d = mo_neg(si_bsdf.wi); dist = 0.0f; si_bsdf.sh.n = d; }
             float emitter_pdf = bs.delta ? 0.0f : mo_pdf_emitter_direction(s, (uint32_t) emitter, d, si_bsdf.sh.n, dist);
             emission_weight = mis_weight(bs.pdf, emitter_pdf);
         }

@@ -559,7 +559,7 @@ void mo_sample_emitter_direction(const mo_scene *s, mo_v3 ref_p, mo_v2 sample, m
     if (e->type == 2) {
         /* EnvironmentMapEmitter::sample_direction (envmap.cpp:154-190) */
         mo_v3 d; float pdf, val[3];
-        mo_envmap_sample(e->env, sample, &d, &pdf, val);
+        mo_envmap_sample(e->env, sample, &d, &pdf, val, &ds->uv);
         ds->dist = 2.0f * e->radius;
         ds->p = mo_add(ref_p, mo_scale(d, ds->dist));
         ds->n = mo_neg(d); ds->d = d; ds->pdf = pdf; ds->emitter = index; ds->pdf_single = pdf;

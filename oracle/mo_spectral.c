@@ -118,7 +118,6 @@ static void model_fetch(const coeff_table *t, const float c[3], float out[3]) {
 }
 
 int mo_scene_set_spectral(mo_scene *s, const char *coeff_path) {
-    if (s && s->environment >= 0) return -5;      /* the constant emitter is restated for the RGB variant only */
     coeff_table t = { 0, NULL, NULL };
     if (!s || table_load(coeff_path, &t)) return -1;
     for (uint32_t i = 0; i < s->n_meshes; ++i) {
@@ -152,6 +151,21 @@ int mo_scene_set_spectral(mo_scene *s, const char *coeff_path) {
         float m_scale = 1.0f * scale;
         m_scale *= 1.0f / 10568.0f;                                                  /* d65.cpp:48-49 */
         em->d65_scale = m_scale;
+        if (em->type == 2) {
+            /* envmap.cpp:96-109: every texel becomes (model coefficients of the colour scaled to a 50% maximum, scale);
+             * the sampling hierarchy stays the one built from the RGB luminance in the constructor (envmap.cpp:92-93,111) */
+            mo_envmap *env = em->env;
+            for (size_t i = 0; i < (size_t) env->w * env->h; ++i) {
+                float *px = env->data + 4 * i;
+                float sc = fmaxf(fmaxf(px[0], px[1]), px[2]) * 2.0f, dn = fmaxf(1e-8f, sc);
+                float rgb_norm[3] = { px[0] / dn, px[1] / dn, px[2] / dn };
+                /* a black texel makes rgb2spec_fetch divide by zero (NaN coefficients) in the reference; it carries scale = 0,
+                 * so any finite coefficients give the intended zero radiance */
+                if (sc > 0.0f) model_fetch(&t, rgb_norm, px);
+                else px[0] = px[1] = px[2] = 0.0f;
+                px[3] = sc;
+            }
+        }
     }
     s->spectral = 1;
     free(t.scale); free(t.data);

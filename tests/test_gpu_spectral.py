@@ -100,3 +100,38 @@ def test_spectral_conductor_needs_uniform_ior(gpu):
     cb["meshes"][6] = dict(cb["meshes"][6], bsdf=len(cb["bsdfs"]) - 1)
     with pytest.raises(RuntimeError, match="uniform"):
         gpu.Scene(cb, variant="spectral")
+
+
+@pytest.mark.parametrize("with_area", [False, True])
+@pytest.mark.parametrize("kind", ["constant", "envmap"])
+def test_spectral_environment_emitters(gpu, oracle, kind, with_area):
+    """`constant` (radiance upsampled like any emitter colour, srgb_d65.cpp) and `envmap` (per-texel model coefficients + scale,
+    D65 whitepoint: envmap.cpp:96-109, :283-306) in the spectral variant, alone and next to an area light; fused == split"""
+    from test_gpu_integrators import _open_scene, _envmap_image
+    path = gpu.srgb_coeff_path()
+    cb = _open_scene(with_area)
+    if kind == "envmap":
+        rot = scenes.look_at([0, 0, 0], [1, 0.2, 0.3], [0, 1, 0])
+        env = {"type": "envmap", "data": _envmap_image(), "scale": 0.7, "to_world": rot}
+        cb["emitters"] = [env] + [e for e in cb["emitters"] if e.get("type", "area") == "area"]
+    p = dict(scenes.cornell_box_sensor(64, 64, 4, seed=21), max_depth=5)
+    scene, sensor = gpu.Scene(cb, variant="spectral"), gpu.make_sensor(p)
+    n = 64 * 64 * 4
+    xyz, mask, pos = gpu.PathIntegrator(max_depth=5, pipeline=1).sample(scene, sensor, 0, n)
+    xyz2, _, _ = gpu.PathIntegrator(max_depth=5, pipeline=2).sample(scene, sensor, 0, n)
+    assert (xyz == xyz2).all()
+    ref, ref_pos = oracle.OracleScene(cb, spectral_path=path).sample_radiance(oracle.make_desc(p), 0, n)
+    m = mask.cpu().numpy()
+    assert (pos.cpu().numpy() == ref_pos).all() and ((ref[:, 3] > 0.5) == m).all() and (~m).any()
+    got = xyz.cpu().numpy()
+    assert np.isfinite(got).all() and (got[~m].sum(1) > 0).all()          # escaped camera rays see the environment
+    close = np.isclose(got, ref[:, :3], rtol=5e-3, atol=2e-4).all(axis=1)
+    assert close.mean() > 0.99, (kind, with_area, close.mean())
+    assert abs(got.mean() - ref[:, :3].mean()) < 0.02 * ref[:, :3].mean()
+    # the spectral rendering agrees with the RGB one up to the upsampling model (film: XYZ -> RGB on both sides)
+    out = {}
+    for variant in ("rgb", "spectral"):
+        sc, se = gpu.Scene(cb, variant=variant), gpu.make_sensor(dict(p, sample_count=32))
+        assert gpu.PathIntegrator(max_depth=5).render(sc, se)
+        out[variant] = se.film().bitmap().cpu().numpy()[..., :3]
+    assert abs(out["rgb"].mean() - out["spectral"].mean()) < 0.1 * out["rgb"].mean()

@@ -114,3 +114,31 @@ def test_spectral_oracle_render_is_close_to_rgb(oracle):
     # colours agree up to metamerism of multi-bounce transport + spectral sampling noise
     assert abs(a[..., :3].mean() - b[..., :3].mean()) / a[..., :3].mean() < 0.1
     assert np.all(np.abs(a[..., :3].mean(axis=(0, 1)) - b[..., :3].mean(axis=(0, 1))) / a[..., :3].mean(axis=(0, 1)) < 0.2)
+
+
+@pytest.mark.parametrize("kind", ["constant", "envmap"])
+def test_spectral_oracle_environment_emitters(oracle, kind):
+    """`constant` / `envmap` in the oracle's spectral path: escaped camera rays return the emitter's colour (XYZ of the
+    upsampled spectrum ~ XYZ of the RGB colour), and the rendering stays close to the RGB variant's"""
+    from mitsuba2_amd import scenes, render
+    cb = scenes.cornell_box()
+    cb["meshes"] = [dict(m) for i, m in enumerate(cb["meshes"]) if i not in (1, 2) and m.get("emitter", -1) < 0]
+    if kind == "constant":
+        cb["emitters"] = [{"type": "constant", "radiance": [0.4, 0.6, 1.0]}]
+    else:
+        img = np.random.default_rng(2).uniform(0.2, 1.0, size=(16, 32, 3)).astype(np.float32)
+        img[0:2, 3:5] = 0.0                                        # black texels: scale 0, finite coefficients
+        cb["emitters"] = [{"type": "envmap", "data": img, "scale": 1.5}]
+    p = dict(scenes.cornell_box_sensor(32, 32, 64, seed=4), max_depth=4)
+    d = oracle.make_desc(p)
+    n = 32 * 32 * 64
+    rgb, _ = oracle.OracleScene(cb).sample_radiance(d, 0, n)
+    xyz, _ = oracle.OracleScene(cb, spectral_path=render.srgb_coeff_path()).sample_radiance(d, 0, n)
+    assert np.isfinite(xyz).all() and np.array_equal(rgb[:, 3], xyz[:, 3])
+    M = np.float32([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]])
+    want = rgb[:, :3] @ M.T
+    esc = rgb[:, 3] < 0.5
+    assert esc.any()
+    # one sample is 4 wavelengths: its tristimulus value is noisy, the mean over many samples is not
+    assert np.all(np.abs(xyz[esc, :3].mean(0) - want[esc].mean(0)) < 0.05 * want[esc].mean(0))
+    assert np.all(np.abs(xyz[~esc, :3].mean(0) - want[~esc].mean(0)) < 0.15 * want[~esc].mean(0))
