@@ -129,7 +129,8 @@ def normalize(b):
         out["uniform_mask"] |= 4 if _is_uniform(b.get("specular_transmittance"), 1.0) else 0
         known |= {"specular_transmittance"}
     if tid in (PLASTIC, ROUGHPLASTIC):
-        out["reflectance"] = _rgb(b.get("diffuse_reflectance"), 0.5)
+        dr = b.get("diffuse_reflectance")                  # a colour, a constant or a texture (bitmap / checkerboard)
+        out["reflectance"] = dr if isinstance(dr, dict) else _rgb(dr, 0.5)
         out["uniform_mask"] |= 1 if _is_uniform(b.get("diffuse_reflectance"), 0.5) else 0
         out["nonlinear"] = bool(b.get("nonlinear", False))
         known |= {"diffuse_reflectance", "nonlinear"}

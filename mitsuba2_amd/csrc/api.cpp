@@ -270,6 +270,7 @@ struct mtsamd_scene {
     float *d_env_texels = nullptr, *d_env_warp = nullptr; DevEnvmap *d_envmap = nullptr;      // envmap emitter
     float4 *d_flat = nullptr, *d_pairs = nullptr;
     std::vector<DevTexture> textures;       // device data pointers, owned
+    std::vector<float> spec_mean;           // per BSDF: mean of specular_reflectance
     DevTexture *d_textures = nullptr;
     SceneView view{};
     bool spectral = false;
@@ -353,7 +354,8 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         if (desc->spectral && (bd.type == MTSAMD_BSDF_CONDUCTOR || bd.type == MTSAMD_BSDF_ROUGHCONDUCTOR) &&
             (bd.eta[0] != bd.eta[1] || bd.eta[0] != bd.eta[2] || bd.k[0] != bd.k[1] || bd.k[0] != bd.k[2]))
             return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u: the spectral variant needs uniform (constant) eta and k spectra", b);
-        if (bd.texture >= 0 && bd.type != MTSAMD_BSDF_DIFFUSE) return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u: bitmap textures are implemented for diffuse.reflectance only", b);
+        if (bd.texture >= 0 && bd.type != MTSAMD_BSDF_DIFFUSE && bd.type != MTSAMD_BSDF_PLASTIC && bd.type != MTSAMD_BSDF_ROUGHPLASTIC)
+            return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u: textures are implemented for diffuse.reflectance and (rough)plastic.diffuse_reflectance only", b);
         if (bd.type == MTSAMD_BSDF_ROUGHPLASTIC && (bd.int_ior == bd.ext_ior || bd.alpha_u != bd.alpha_v))
             return fail(MTSAMD_ERR_INVALID, bd.int_ior == bd.ext_ior ? "The interior and exterior indices of refraction must be positive and differ!"
                                                                       : "The 'roughplastic' plugin currently does not support anisotropic microfacet distributions!");
@@ -428,7 +430,6 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     // spectral variant: RGB -> spectrum coefficients on the host (srgb.cpp:31-41, srgb_d65.cpp:31-46)
     Rgb2Spec model;
     if (desc->spectral) {
-        if (desc->texture_count) { delete s; return fail(MTSAMD_ERR_UNSUPPORTED, "bitmap textures are not supported by the spectral variant"); }
         if (!desc->rgb2spec_path || !rgb2spec_load(desc->rgb2spec_path, model)) {
             delete s;
             return fail(MTSAMD_ERR_INVALID, "Could not load sRGB-to-spectrum upsampling model ('%s'); build it with mtsamd_rgb2spec_build",
@@ -449,8 +450,10 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         }
     }
     s->bsdfs.resize(desc->bsdf_count);
+    std::vector<float> spec_mean(desc->bsdf_count, 0.0f);          // Texture::mean() of specular_reflectance (plastic lobe weights)
     for (uint32_t b = 0; b < desc->bsdf_count; ++b) {
         DevBsdf &d = s->bsdfs[b];
+        spec_mean[b] = (desc->bsdfs[b].specular_reflectance[0] + desc->bsdfs[b].specular_reflectance[1] + desc->bsdfs[b].specular_reflectance[2]) * (1.0f / 3.0f);
         std::memset(&d, 0, sizeof(d));
         d.r = desc->bsdfs[b].reflectance[0]; d.g = desc->bsdfs[b].reflectance[1]; d.b = desc->bsdfs[b].reflectance[2];
         d.type = desc->bsdfs[b].type; d.texture = desc->bsdfs[b].texture < 0 ? -1 : desc->bsdfs[b].texture;
@@ -464,6 +467,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
             float *coeffs[3] = { &d.c0, &d.sc0, &d.tc0 };
             float means[3] = { 0.0f, 0.0f, 0.0f };
             for (int p = 0; p < 3; ++p) {
+                if (p == 0 && d.texture >= 0) continue;               // textured: coefficients per texel, mean from the texture (below)
                 if (bd.uniform_mask & (1 << p)) { means[p] = vals[p][0]; continue; }
                 const float *c = vals[p];
                 if (c[0] < 0 || c[1] < 0 || c[2] < 0 || c[0] > 1 || c[1] > 1 || c[2] > 1) {
@@ -476,6 +480,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
                 means[p] = srgb_model_mean(coeff);
             }
             if (d.type == kBsdfPlastic || d.type == kBsdfRoughPlastic) d.kr = means[1] / (means[0] + means[1]);
+            spec_mean[b] = means[1];
         }
     }
 
@@ -489,15 +494,58 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         for (int k = 0; k < 6; ++k) { dt.uvm[k] = td.to_uv[k]; ident = ident && td.to_uv[k] == 0.0f; }
         if (ident) { dt.uvm[0] = 1.0f; dt.uvm[4] = 1.0f; }
         for (int k = 0; k < 3; ++k) { dt.c0[k] = td.color0[k]; dt.c1[k] = td.color1[k]; }
-        if (td.kind == 1) { s->textures.push_back(dt); continue; }
+        if (td.kind == 1) {
+            // Texture::mean(): mean of the two colours' means (checkerboard.cpp:88-90, srgb.cpp:52-57); spectral variant: `srgb`
+            // spectra with the constructor's range check (srgb.cpp:34-35)
+            if (desc->spectral) {
+                for (int k = 0; k < 3; ++k)
+                    if (td.color0[k] < 0 || td.color0[k] > 1 || td.color1[k] < 0 || td.color1[k] > 1) {
+                        mtsamd_scene_destroy(s);
+                        return fail(MTSAMD_ERR_INVALID, "Invalid RGB reflectance value in checkerboard texture %u, must be in the range [0, 1]!", t);
+                    }
+                srgb_model_fetch(model, td.color0, dt.c0);
+                srgb_model_fetch(model, td.color1, dt.c1);
+                dt.mean = 0.5f * (srgb_model_mean(dt.c0) + srgb_model_mean(dt.c1));
+            } else {
+                dt.mean = 0.5f * ((td.color0[0] + td.color0[1] + td.color0[2]) * (1.0f / 3.0f) + (td.color1[0] + td.color1[1] + td.color1[2]) * (1.0f / 3.0f));
+            }
+            s->textures.push_back(dt);
+            continue;
+        }
         size_t bytes = sizeof(float) * 3 * (size_t) td.width * td.height;
         float *ptr = nullptr;
-        if (hipMalloc((void **) &ptr, bytes) != hipSuccess || hipMemcpy(ptr, td.data, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        // Texture::mean(): mean luminance (bitmap.cpp:124-136); spectral variant: texels become model coefficients, mean of
+        // srgb_model_mean (bitmap.cpp:116-123)
+        const size_t n_texels = (size_t) td.width * td.height;
+        std::vector<float> coeffs;
+        const float *src = td.data;
+        double mean = 0.0;
+        if (desc->spectral) {
+            coeffs.resize(3 * n_texels);
+            for (size_t i = 0; i < n_texels; ++i) {
+                srgb_model_fetch(model, td.data + 3 * i, coeffs.data() + 3 * i);
+                mean += (double) srgb_model_mean(coeffs.data() + 3 * i);
+            }
+            src = coeffs.data();
+        } else {
+            for (size_t i = 0; i < n_texels; ++i) {
+                const float *p = td.data + 3 * i;
+                mean += (double) (p[0] * 0.212671f + p[1] * 0.715160f + p[2] * 0.072169f);
+            }
+        }
+        dt.mean = (float) (mean / (double) n_texels);
+        if (hipMalloc((void **) &ptr, bytes) != hipSuccess || hipMemcpy(ptr, src, bytes, hipMemcpyHostToDevice) != hipSuccess) {
             mtsamd_scene_destroy(s);
             return fail(MTSAMD_ERR_NOMEM, "texture %u: upload failed", t);
         }
         dt.data = ptr;
         s->textures.push_back(dt);
+    }
+    // plastic.cpp:170-175: specular sampling weight from Texture::mean() of both reflectances
+    s->spec_mean = spec_mean;
+    for (uint32_t b = 0; b < desc->bsdf_count; ++b) {
+        DevBsdf &d = s->bsdfs[b];
+        if (d.texture >= 0 && (d.type == kBsdfPlastic || d.type == kBsdfRoughPlastic)) d.kr = spec_mean[b] / (s->textures[d.texture].mean + spec_mean[b]);
     }
 
     if (desc->spectral) {
@@ -577,13 +625,12 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         }
         if (desc->spectral) {
             // envmap.cpp:96-109: every texel becomes (model coefficients of the colour scaled to a 50% maximum, scale); the
-            // sampling hierarchy stays the one built from the RGB luminance.  Black texels (a division by zero inside
-            // rgb2spec_fetch in the reference) get finite coefficients: they carry scale = 0.
+            // sampling hierarchy stays the one built from the RGB luminance
             for (size_t i = 0; i < eh.texels.size() / 4; ++i) {
                 float *px = eh.texels.data() + 4 * i;
                 const float sc = std::max(std::max(px[0], px[1]), px[2]) * 2.0f, dn = std::max(1e-8f, sc);
-                float rgb_norm[3] = { px[0] / dn, px[1] / dn, px[2] / dn }, coeff[3] = { 0.0f, 0.0f, 0.0f };
-                if (sc > 0.0f) srgb_model_fetch(model, rgb_norm, coeff);
+                float rgb_norm[3] = { px[0] / dn, px[1] / dn, px[2] / dn }, coeff[3];
+                srgb_model_fetch(model, rgb_norm, coeff);             // black: (0, 0, -inf), evaluates to 0 (srgb.cpp:31-33)
                 px[0] = coeff[0]; px[1] = coeff[1]; px[2] = coeff[2]; px[3] = sc;
             }
         }
@@ -679,7 +726,7 @@ int mtsamd_scene_set_bsdf_reflectance(mtsamd_scene *s, uint32_t bsdf, const floa
     s->bsdfs[bsdf].r = rgb[0]; s->bsdfs[bsdf].g = rgb[1]; s->bsdfs[bsdf].b = rgb[2];
     if (s->bsdfs[bsdf].type == kBsdfPlastic || s->bsdfs[bsdf].type == kBsdfRoughPlastic) {       // parameters_changed(): specular sampling weight (plastic.cpp:170-175)
         DevBsdf &d = s->bsdfs[bsdf];
-        const float d_mean = (d.r + d.g + d.b) * (1.0f / 3.0f), s_mean = (d.sr + d.sg + d.sb) * (1.0f / 3.0f);
+        const float d_mean = d.texture >= 0 ? s->textures[d.texture].mean : (d.r + d.g + d.b) * (1.0f / 3.0f), s_mean = (d.sr + d.sg + d.sb) * (1.0f / 3.0f);
         d.kr = s_mean / (d_mean + s_mean);
     }
     HIP_TRY(hipMemcpy(s->d_bsdfs + bsdf, &s->bsdfs[bsdf], sizeof(DevBsdf), hipMemcpyHostToDevice));
@@ -701,7 +748,25 @@ int mtsamd_scene_update_texture(mtsamd_scene *s, uint32_t texture, const float *
     HIP_TRY(hipSetDevice(s->device));
     const DevTexture &t = s->textures[texture];
     if (t.kind != 0) return fail(MTSAMD_ERR_INVALID, "texture %u is not a bitmap", texture);
+    if (s->spectral) return fail(MTSAMD_ERR_UNSUPPORTED, "texture updates are implemented for the RGB variant only (the texels hold model coefficients)");
     HIP_TRY(hipMemcpyAsync((void *) t.data, rgb, sizeof(float) * 3 * (size_t) t.w * t.h, hipMemcpyDefault, (hipStream_t) stream));
+    // parameters_changed() (bitmap.cpp:308-322): the mean follows the data; only plastic lobe weights read it
+    bool used = false;
+    for (const DevBsdf &b : s->bsdfs) used = used || (b.texture == (int32_t) texture && (b.type == kBsdfPlastic || b.type == kBsdfRoughPlastic));
+    if (used) {
+        std::vector<float> host(3 * (size_t) t.w * t.h);
+        HIP_TRY(hipStreamSynchronize((hipStream_t) stream));
+        HIP_TRY(hipMemcpy(host.data(), t.data, host.size() * sizeof(float), hipMemcpyDeviceToHost));
+        double mean = 0.0;
+        for (size_t i = 0; i < host.size() / 3; ++i) mean += (double) (host[3 * i] * 0.212671f + host[3 * i + 1] * 0.715160f + host[3 * i + 2] * 0.072169f);
+        s->textures[texture].mean = (float) (mean / (double) (host.size() / 3));
+        for (size_t b = 0; b < s->bsdfs.size(); ++b) {
+            DevBsdf &d = s->bsdfs[b];
+            if (d.texture != (int32_t) texture || (d.type != kBsdfPlastic && d.type != kBsdfRoughPlastic)) continue;
+            d.kr = s->spec_mean[b] / (s->textures[texture].mean + s->spec_mean[b]);
+            HIP_TRY(hipMemcpy(s->d_bsdfs + b, &d, sizeof(DevBsdf), hipMemcpyHostToDevice));
+        }
+    }
     return MTSAMD_OK;
 }
 

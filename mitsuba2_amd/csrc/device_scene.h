@@ -36,7 +36,8 @@ constexpr uint32_t kShapeHasNormals = 1u, kShapeHasUV = 2u;
 struct DevTexture {
     const float *data; int32_t w, h; uint32_t grad_offset, kind;        // kind 0: bitmap, 1: checkerboard (checkerboard.cpp)
     float uvm[6];                                                       // to_uv: uv' = (m0 u + m1 v + m2, m3 u + m4 v + m5)
-    float c0[3], c1[3];                                                 // checkerboard colours
+    float c0[3], c1[3];                                                 // checkerboard colours (spectral variant: model coefficients)
+    float mean;                                                         // Texture::mean() (plastic lobe weights)
 };   // grad_offset: float offset in the concatenated gradient buffer       // linear RGB bitmap (src/textures/bitmap.cpp), identity to_uv
 struct DevEmitter {
     float r, g, b; uint32_t shape;

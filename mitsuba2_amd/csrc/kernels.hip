@@ -396,6 +396,38 @@ MTS_DEV Spec4 envmap_lookup_spectral(const DevEnvmap &e, float u, float v, const
     }
     return r;
 }
+// textured reflectance in the spectral variant: bitmap texels hold srgb model coefficients, evaluated at the four corners and
+// then interpolated (bitmap.cpp:274-286); checkerboard colours are `srgb` spectra (checkerboard.cpp:46-63)
+MTS_DEV Spec4 eval_reflectance_spectral(const SceneView &sv, const DevBsdf &b, f2 uv, const Spec4 &wav) {
+    const DevTexture t = sv.textures[b.texture];
+    {
+        const float u2 = fmaf(t.uvm[0], uv.x, fmaf(t.uvm[1], uv.y, t.uvm[2])), v2 = fmaf(t.uvm[3], uv.x, fmaf(t.uvm[4], uv.y, t.uvm[5]));
+        uv.x = u2; uv.y = v2;
+    }
+    Spec4 r;
+    if (t.kind == 1u) {
+        const bool mx = (uv.x - floorf(uv.x)) > 0.5f, my = (uv.y - floorf(uv.y)) > 0.5f;
+        const float *c = mx == my ? t.c0 : t.c1;
+        const float a0 = c[0], a1 = c[1], a2 = c[2];
+#pragma unroll
+        for (int k = 0; k < kWav; ++k) r.v[k] = srgb_model_eval(a0, a1, a2, wav.v[k]);
+        return r;
+    }
+    float ux = uv.x - floorf(uv.x), uy = uv.y - floorf(uv.y);
+    ux *= (float) (uint32_t) (t.w - 1); uy *= (float) (uint32_t) (t.h - 1);
+    const uint32_t px = min((uint32_t) ux, (uint32_t) (t.w - 2)), py = min((uint32_t) uy, (uint32_t) (t.h - 2));
+    const float w1x = ux - (float) px, w1y = uy - (float) py, w0x = 1.0f - w1x, w0y = 1.0f - w1y;
+    const float *v00 = t.data + 3u * (size_t) (px + py * (uint32_t) t.w), *v01 = v00 + 3u * (size_t) t.w;
+#pragma unroll
+    for (int k = 0; k < kWav; ++k) {
+        const float l = wav.v[k];
+        const float c00 = srgb_model_eval(v00[0], v00[1], v00[2], l), c10 = srgb_model_eval(v00[3], v00[4], v00[5], l);
+        const float c01 = srgb_model_eval(v01[0], v01[1], v01[2], l), c11 = srgb_model_eval(v01[3], v01[4], v01[5], l);
+        const float c0 = fmaf(w0x, c00, w1x * c10), c1 = fmaf(w0x, c01, w1x * c11);
+        r.v[k] = fmaf(w0y, c0, w1y * c1);
+    }
+    return r;
+}
 MTS_DEV Spec4 emitter_spectrum(const SceneView &sv, const DevEmitter &e, const Spec4 &wav, f2 uv) {
     if (e.pad0 == kEmitterEnvmap) return envmap_lookup_spectral(*sv.envmap, uv.x, uv.y, wav);
     Spec4 r;
@@ -466,8 +498,13 @@ MTS_DEV bool bounce_step_spectral(const RenderParams &P, const LdsView &lds, Pat
 #pragma unroll
     for (int k = 0; k < kWav; ++k)       // srgb.cpp:45-52 / uniform.cpp
         refl.v[k] = (bsdf.flags & kBsdfUniformRefl) ? bsdf.r : srgb_model_eval(bsdf.c0, bsdf.c1, bsdf.c2, s.wav.v[k]);
+    if (bsdf.texture >= 0) refl = eval_reflectance_spectral(sv, bsdf, si.uv, s.wav);
     BsdfChannels<kWav> chan;
-    if (GENERAL) chan = spectral_channels(bsdf, s.wav);
+    if (GENERAL) {
+        chan = spectral_channels(bsdf, s.wav);
+#pragma unroll
+        for (int k = 0; k < kWav; ++k) chan.refl[k] = refl.v[k];
+    }
 
     if (!GENERAL || bsdf_is_smooth(bsdf)) {
         f2 s2; s2.x = pcg_next_f32(s.rng); s2.y = pcg_next_f32(s.rng);

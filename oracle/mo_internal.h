@@ -58,7 +58,9 @@ float mo_envmap_pdf(const mo_envmap *e, mo_v3 d_world);
 typedef struct { uint32_t shape; float radiance[3]; float coeff[3], d65_scale; int type; mo_v3 center; float radius; mo_envmap *env; } mo_emitter;
 /* kind 0: bitmap (src/textures/bitmap.cpp), kind 1: checkerboard (src/textures/checkerboard.cpp); uvm = upper-left 2x3 of the
  * extracted to_uv transform: uv' = (uvm[0] u + uvm[1] v + uvm[2], uvm[3] u + uvm[4] v + uvm[5]) */
-typedef struct { int w, h; float *data; int kind; float uvm[6]; float color0[3], color1[3]; } mo_texture;
+typedef struct { int w, h; float *data; int kind; float uvm[6]; float color0[3], color1[3];
+                 float mean;        /* Texture::mean(): bitmap.cpp:112-136 / checkerboard.cpp:88-90 (feeds plastic's lobe weights) */
+                 float coeff0[3], coeff1[3]; } mo_texture;   /* spectral variant: checkerboard colours upsampled; bitmap `data` holds coefficients */
 typedef struct { double lo[3], hi[3]; uint32_t left, right, first, count; } mo_bvh_node;
 
 struct mo_scene {
@@ -104,6 +106,8 @@ float mo_srgb_model_mean(const float coeff[3]);
 
 /* spectral variant (mo_spectral.c) */
 #define MO_WAV 4
+void mo_reflectance_spectral(const struct mo_scene *s, const mo_mesh *m, mo_v2 uv, const float *wav, float *out);   /* textured reflectance, 4 wavelengths */
+void mo_texture_update_mean(struct mo_scene *s, int texture);
 void mo_sample_wavelengths(float sample, float wav[MO_WAV], float weight[MO_WAV]);
 float mo_srgb_model_eval(const float coeff[3], float lambda);
 float mo_d65_eval(float scale, float lambda);

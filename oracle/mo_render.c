@@ -578,6 +578,7 @@ static void path_sample_spectral(const mo_scene *s, mo_pcg32 *rng, const mo_ray 
         const mo_bsdf *bsdf = &mesh->bsdf;
         mo_bsdf_chan chan;
         mo_bsdf_spectral_channels(bsdf, wav, &chan);
+        if (mesh->texture >= 0) mo_reflectance_spectral(s, mesh, si.uv, wav, chan.refl);
         if (mo_bsdf_is_smooth(bsdf)) {
             mo_v2 s2; s2.x = mo_pcg32_next_f32(rng); s2.y = mo_pcg32_next_f32(rng);
             mo_dsample ds; float rgb_spec[3];

@@ -129,7 +129,25 @@ int mo_scene_add_texture(mo_scene *s, int width, int height, const float *rgb) {
     t->w = width; t->h = height;
     t->data = (float *) dup_mem(rgb, sizeof(float) * 3 * (size_t) width * height);
     t->uvm[0] = 1.0f; t->uvm[4] = 1.0f;
-    return (int) s->n_textures++;
+    mo_texture_update_mean(s, (int) s->n_textures++);
+    return (int) s->n_textures - 1;
+}
+/* Texture::mean() in the RGB variant: mean luminance of a bitmap (bitmap.cpp:124-136), mean of the two colours' channel
+ * means for a checkerboard (checkerboard.cpp:88-90, srgb.cpp:52-57); plastic BSDFs that use the texture follow */
+void mo_texture_update_mean(mo_scene *s, int texture) {
+    mo_texture *t = &s->textures[texture];
+    if (t->kind == 1) {
+        float m0 = (t->color0[0] + t->color0[1] + t->color0[2]) * (1.0f / 3.0f), m1 = (t->color1[0] + t->color1[1] + t->color1[2]) * (1.0f / 3.0f);
+        t->mean = 0.5f * (m0 + m1);
+    } else {
+        double mean = 0.0;
+        for (size_t i = 0; i < (size_t) t->w * t->h; ++i) {
+            const float *p = t->data + 3 * i;
+            mean += (double) (p[0] * 0.212671f + p[1] * 0.715160f + p[2] * 0.072169f);
+        }
+        t->mean = (float) (mean / (double) ((size_t) t->w * t->h));
+    }
+    for (uint32_t i = 0; i < s->n_meshes; ++i) if (s->meshes[i].texture == texture) mo_scene_set_texture(s, i, texture);
 }
 int mo_scene_set_texture_transform(mo_scene *s, uint32_t texture, const float *uvm6) {
     if (!s || texture >= s->n_textures || !uvm6) return -1;
@@ -145,18 +163,28 @@ int mo_scene_add_checkerboard(mo_scene *s, const float *color0, const float *col
     t->uvm[0] = 1.0f; t->uvm[4] = 1.0f;
     if (uvm6) memcpy(t->uvm, uvm6, sizeof(float) * 6);
     for (int k = 0; k < 3; ++k) { t->color0[k] = color0[k]; t->color1[k] = color1[k]; }
-    return (int) s->n_textures++;
+    mo_texture_update_mean(s, (int) s->n_textures++);
+    return (int) s->n_textures - 1;
 }
 int mo_scene_set_texture(mo_scene *s, uint32_t shape, int texture) {
     if (!s || shape >= s->n_meshes || texture >= (int) s->n_textures) return -1;
-    s->meshes[shape].texture = texture;
+    mo_mesh *m = &s->meshes[shape];
+    m->texture = texture;
+    if (texture >= 0 && (m->bsdf.d.type == MO_BSDF_PLASTIC || m->bsdf.d.type == MO_BSDF_ROUGHPLASTIC)) {
+        /* plastic.cpp:170-175: specular sampling weight from Texture::mean() of both reflectances */
+        const float *sr = m->bsdf.d.specular_reflectance;
+        float d_mean = s->textures[texture].mean, s_mean = (sr[0] + sr[1] + sr[2]) * (1.0f / 3.0f);
+        m->bsdf.spec_weight = s_mean / (d_mean + s_mean);
+    }
     return 0;
 }
 int mo_scene_update_texture(mo_scene *s, uint32_t texture, const float *rgb) {
     if (!s || texture >= s->n_textures) return -1;
     mo_texture *t = &s->textures[texture];
     if (t->kind != 0) return -2;
+    if (s->spectral) return -3;                                       /* the texels hold model coefficients */
     memcpy(t->data, rgb, sizeof(float) * 3 * (size_t) t->w * t->h);
+    mo_texture_update_mean(s, (int) texture);                         /* bitmap.cpp:308-322 */
     return 0;
 }
 int mo_scene_set_reflectance(mo_scene *s, uint32_t shape, const float *rgb) {
@@ -209,6 +237,34 @@ void mo_reflectance(const mo_scene *s, const mo_mesh *m, mo_v2 uv, float out[3],
     }
     if (texel) *texel = index;
     if (w1o) { w1o[0] = w1x; w1o[1] = w1y; }
+}
+
+/* spectral variant of the lookup: bitmap texels hold srgb model coefficients which are evaluated at the four corners and
+ * then interpolated (bitmap.cpp:274-286); checkerboard colours are `srgb` spectra (checkerboard.cpp:46-63) */
+void mo_reflectance_spectral(const mo_scene *s, const mo_mesh *m, mo_v2 uv, const float *wav, float *out) {
+    const mo_texture *t = &s->textures[m->texture];
+    float u2 = fmaf(t->uvm[0], uv.x, fmaf(t->uvm[1], uv.y, t->uvm[2])), v2 = fmaf(t->uvm[3], uv.x, fmaf(t->uvm[4], uv.y, t->uvm[5]));
+    uv.x = u2; uv.y = v2;
+    if (t->kind == 1) {
+        int mx = (uv.x - floorf(uv.x)) > 0.5f, my = (uv.y - floorf(uv.y)) > 0.5f;
+        const float *c = mx == my ? t->coeff0 : t->coeff1;
+        for (int k = 0; k < MO_WAV; ++k) out[k] = mo_srgb_model_eval(c, wav[k]);
+        return;
+    }
+    float ux = uv.x - floorf(uv.x), uy = uv.y - floorf(uv.y);
+    ux *= (float) (uint32_t) (t->w - 1); uy *= (float) (uint32_t) (t->h - 1);
+    uint32_t px = (uint32_t) ux, py = (uint32_t) uy;
+    if (px > (uint32_t) (t->w - 2)) px = (uint32_t) (t->w - 2);
+    if (py > (uint32_t) (t->h - 2)) py = (uint32_t) (t->h - 2);
+    float w1x = ux - (float) px, w1y = uy - (float) py, w0x = 1.0f - w1x, w0y = 1.0f - w1y;
+    uint32_t index = px + py * (uint32_t) t->w, width = (uint32_t) t->w;
+    const float *v00 = t->data + 3 * (size_t) index, *v10 = v00 + 3, *v01 = t->data + 3 * (size_t) (index + width), *v11 = v01 + 3;
+    for (int k = 0; k < MO_WAV; ++k) {
+        float c00 = mo_srgb_model_eval(v00, wav[k]), c10 = mo_srgb_model_eval(v10, wav[k]);
+        float c01 = mo_srgb_model_eval(v01, wav[k]), c11 = mo_srgb_model_eval(v11, wav[k]);
+        float c0 = fmaf(w0x, c00, w1x * c10), c1 = fmaf(w0x, c01, w1x * c11);
+        out[k] = fmaf(w0y, c0, w1y * c1);
+    }
 }
 
 static inline mo_v3 vtx(const mo_mesh *m, uint32_t i) {

@@ -120,16 +120,36 @@ static void model_fetch(const coeff_table *t, const float c[3], float out[3]) {
 int mo_scene_set_spectral(mo_scene *s, const char *coeff_path) {
     coeff_table t = { 0, NULL, NULL };
     if (!s || table_load(coeff_path, &t)) return -1;
+    /* textures: bitmap texels become model coefficients (bitmap.cpp:116-123), checkerboard colours are `srgb` spectra with the
+     * constructor's range check (srgb.cpp:34-35); Texture::mean() = mean of srgb_model_mean (bitmap.cpp:120, srgb.cpp:54) */
+    for (uint32_t i = 0; i < s->n_textures; ++i) {
+        mo_texture *tx = &s->textures[i];
+        if (tx->kind == 1) {
+            for (int k = 0; k < 3; ++k)
+                if (tx->color0[k] < 0.0f || tx->color0[k] > 1.0f || tx->color1[k] < 0.0f || tx->color1[k] > 1.0f) { free(t.scale); free(t.data); return -3; }
+            model_fetch(&t, tx->color0, tx->coeff0);
+            model_fetch(&t, tx->color1, tx->coeff1);
+            tx->mean = 0.5f * (mo_srgb_model_mean(tx->coeff0) + mo_srgb_model_mean(tx->coeff1));
+        } else {
+            double mean = 0.0;
+            for (size_t p = 0; p < (size_t) tx->w * tx->h; ++p) {
+                float rgb[3] = { tx->data[3 * p], tx->data[3 * p + 1], tx->data[3 * p + 2] };
+                model_fetch(&t, rgb, tx->data + 3 * p);
+                mean += (double) mo_srgb_model_mean(tx->data + 3 * p);
+            }
+            tx->mean = (float) (mean / (double) ((size_t) tx->w * tx->h));
+        }
+    }
     for (uint32_t i = 0; i < s->n_meshes; ++i) {
         mo_mesh *m = &s->meshes[i];
         mo_bsdf *b = &m->bsdf;
-        if (m->texture >= 0) { free(t.scale); free(t.data); return -2; }
         /* every colour-valued parameter is either `uniform` (a constant) or an `srgb` texture, whose constructor rejects
          * values outside [0, 1] (srgb.cpp:34-35) and fetches the model coefficients */
         const float *vals[3] = { m->refl, b->d.specular_reflectance, b->d.specular_transmittance };
         float *coeffs[3] = { b->refl_coeff, b->spec_coeff, b->trans_coeff };
         float means[3] = { 0.0f, 0.0f, 0.0f };
         for (int p = 0; p < 3; ++p) {
+            if (p == 0 && m->texture >= 0) { means[0] = s->textures[m->texture].mean; continue; }
             if (b->d.uniform_mask & (1 << p)) { means[p] = vals[p][0]; continue; }
             for (int k = 0; k < 3; ++k) if (vals[p][k] < 0.0f || vals[p][k] > 1.0f) { free(t.scale); free(t.data); return -3; }
             model_fetch(&t, vals[p], coeffs[p]);
@@ -159,10 +179,7 @@ int mo_scene_set_spectral(mo_scene *s, const char *coeff_path) {
                 float *px = env->data + 4 * i;
                 float sc = fmaxf(fmaxf(px[0], px[1]), px[2]) * 2.0f, dn = fmaxf(1e-8f, sc);
                 float rgb_norm[3] = { px[0] / dn, px[1] / dn, px[2] / dn };
-                /* a black texel makes rgb2spec_fetch divide by zero (NaN coefficients) in the reference; it carries scale = 0,
-                 * so any finite coefficients give the intended zero radiance */
-                if (sc > 0.0f) model_fetch(&t, rgb_norm, px);
-                else px[0] = px[1] = px[2] = 0.0f;
+                model_fetch(&t, rgb_norm, px);                 /* black: (0, 0, -inf), evaluates to 0 (srgb.cpp:31-33) */
                 px[3] = sc;
             }
         }

@@ -105,6 +105,7 @@ def test_hdrfilm_develop(tmp_path, file_format):
 
 def test_film_parameter_validation():
     """test_hdrfilm.py:22-32"""
+    from mitsuba2_amd import render as R
     with pytest.raises(RuntimeError):
         R.HDRFilm(component_format="uint8")
     with pytest.raises(RuntimeError):
