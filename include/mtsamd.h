@@ -61,9 +61,11 @@ typedef struct {
 
 /* BSDF plugins (constructor parameters after the host resolved defaults and named IORs):
  *   diffuse src/bsdfs/diffuse.cpp, conductor conductor.cpp, roughconductor roughconductor.cpp + microfacet.h,
- *   dielectric dielectric.cpp, plastic plastic.cpp, roughplastic roughplastic.cpp (isotropic alpha_u); `twosided` = wrapped in the TwoSidedBRDF adapter (twosided.cpp). */
+ *   dielectric dielectric.cpp, roughdielectric roughdielectric.cpp, plastic plastic.cpp, roughplastic roughplastic.cpp (isotropic alpha_u);
+ *   `twosided` = wrapped in the TwoSidedBRDF adapter (twosided.cpp). */
 typedef enum { MTSAMD_BSDF_DIFFUSE = 0, MTSAMD_BSDF_CONDUCTOR = 1, MTSAMD_BSDF_ROUGHCONDUCTOR = 2, MTSAMD_BSDF_DIELECTRIC = 3,
-               MTSAMD_BSDF_PLASTIC = 4, MTSAMD_BSDF_ROUGHPLASTIC = 5 } mtsamd_bsdf_type;
+               MTSAMD_BSDF_PLASTIC = 4, MTSAMD_BSDF_ROUGHPLASTIC = 5,
+               MTSAMD_BSDF_ROUGHDIELECTRIC = 6 } mtsamd_bsdf_type;
 typedef struct {
     int32_t type;              /* mtsamd_bsdf_type */
     float reflectance[3];      /* diffuse.reflectance / plastic.diffuse_reflectance: constant `srgb` value (src/spectra/srgb.cpp:27-52) */

@@ -1,16 +1,16 @@
 """Host-side BSDF plugin parameters: turns the plugin dictionaries / XML properties of
 `diffuse`, `conductor`, `roughconductor`, `dielectric`, `plastic` and the `twosided` adapter into the flat record the C ABI
-takes (``mtsamd_bsdf_desc``; also `roughplastic`, ``roughplastic.cpp:146-178``), with the reference constructors' defaults and error behaviour:
+takes (``mtsamd_bsdf_desc``; also `roughplastic`, ``roughplastic.cpp:146-178``, and `roughdielectric`, ``roughdielectric.cpp:141-196``), with the reference constructors' defaults and error behaviour:
 ``src/bsdfs/diffuse.cpp:72-76``, ``conductor.cpp:185-200``, ``roughconductor.cpp:143-192``, ``dielectric.cpp:175-198``,
 ``plastic.cpp:136-160``, ``twosided.cpp:63-92``, ``include/mitsuba/render/ior.h:20-101`` (named indices of refraction).
 """
 import numpy as np
 
-DIFFUSE, CONDUCTOR, ROUGHCONDUCTOR, DIELECTRIC, PLASTIC, ROUGHPLASTIC = range(6)
+DIFFUSE, CONDUCTOR, ROUGHCONDUCTOR, DIELECTRIC, PLASTIC, ROUGHPLASTIC, ROUGHDIELECTRIC = range(7)
 TYPE_IDS = {"diffuse": DIFFUSE, "conductor": CONDUCTOR, "roughconductor": ROUGHCONDUCTOR, "dielectric": DIELECTRIC, "plastic": PLASTIC,
-            "roughplastic": ROUGHPLASTIC}
-SMOOTH = {DIFFUSE: True, CONDUCTOR: False, ROUGHCONDUCTOR: True, DIELECTRIC: False, PLASTIC: True, ROUGHPLASTIC: True}      # BSDFFlags::Smooth
-TRANSMISSIVE = {DIELECTRIC}
+            "roughplastic": ROUGHPLASTIC, "roughdielectric": ROUGHDIELECTRIC}
+SMOOTH = {DIFFUSE: True, CONDUCTOR: False, ROUGHCONDUCTOR: True, DIELECTRIC: False, PLASTIC: True, ROUGHPLASTIC: True, ROUGHDIELECTRIC: True}      # BSDFFlags::Smooth
+TRANSMISSIVE = {DIELECTRIC, ROUGHDIELECTRIC}
 
 # ior.h:23-50
 IOR = {"vacuum": 1.0, "helium": 1.000036, "hydrogen": 1.000132, "air": 1.000277, "carbon dioxide": 1.00045, "water": 1.3330,
@@ -73,7 +73,7 @@ def normalize(b):
             out["id"] = b["id"]
         return out
     if t not in TYPE_IDS:
-        raise RuntimeError("BSDF plugin '%s' is not supported by this backend (diffuse, conductor, roughconductor, dielectric, plastic, roughplastic, twosided)" % t)
+        raise RuntimeError("BSDF plugin '%s' is not supported by this backend (diffuse, conductor, roughconductor, dielectric, roughdielectric, plastic, roughplastic, twosided)" % t)
     tid = TYPE_IDS[t]
     out = dict(type=tid, twosided=twosided, reflectance=[0.5, 0.5, 0.5], specular_reflectance=[1.0] * 3, specular_transmittance=[1.0] * 3,
                eta=[0.0] * 3, k=[1.0] * 3, int_ior=1.0, ext_ior=1.0, alpha_u=0.1, alpha_v=0.1, distribution=0, sample_visible=True,
@@ -97,7 +97,7 @@ def normalize(b):
         out["specular_reflectance"] = _rgb(b.get("specular_reflectance"), 1.0)
         out["uniform_mask"] |= 2 if _is_uniform(b.get("specular_reflectance"), 1.0) else 0
         known |= {"material", "eta", "k", "specular_reflectance"}
-    if tid in (ROUGHCONDUCTOR, ROUGHPLASTIC):
+    if tid in (ROUGHCONDUCTOR, ROUGHPLASTIC, ROUGHDIELECTRIC):
         distr = str(b.get("distribution", "beckmann")).lower()
         if distr not in ("beckmann", "ggx"):
             raise RuntimeError('Specified an invalid distribution "%s", must be "beckmann" or "ggx"!' % distr)
@@ -114,17 +114,17 @@ def normalize(b):
         known |= {"distribution", "sample_visible", "alpha", "alpha_u", "alpha_v"}
         if tid == ROUGHPLASTIC and out["alpha_u"] != out["alpha_v"]:
             raise RuntimeError("The 'roughplastic' plugin currently does not support anisotropic microfacet distributions!")
-    if tid in (DIELECTRIC, PLASTIC, ROUGHPLASTIC):
-        out["int_ior"] = lookup_ior(b.get("int_ior"), "bk7" if tid == DIELECTRIC else "polypropylene")
+    if tid in (DIELECTRIC, PLASTIC, ROUGHPLASTIC, ROUGHDIELECTRIC):
+        out["int_ior"] = lookup_ior(b.get("int_ior"), "bk7" if tid in (DIELECTRIC, ROUGHDIELECTRIC) else "polypropylene")
         out["ext_ior"] = lookup_ior(b.get("ext_ior"), "air")
         if out["int_ior"] < 0 or out["ext_ior"] < 0:
             raise RuntimeError("The interior and exterior indices of refraction must be positive!")
-        if tid == ROUGHPLASTIC and out["int_ior"] == out["ext_ior"]:
+        if tid in (ROUGHPLASTIC, ROUGHDIELECTRIC) and out["int_ior"] == out["ext_ior"]:
             raise RuntimeError("The interior and exterior indices of refraction must be positive and differ!")
         out["specular_reflectance"] = _rgb(b.get("specular_reflectance"), 1.0)
         out["uniform_mask"] |= 2 if _is_uniform(b.get("specular_reflectance"), 1.0) else 0
         known |= {"int_ior", "ext_ior", "specular_reflectance"}
-    if tid == DIELECTRIC:
+    if tid in (DIELECTRIC, ROUGHDIELECTRIC):
         out["specular_transmittance"] = _rgb(b.get("specular_transmittance"), 1.0)
         out["uniform_mask"] |= 4 if _is_uniform(b.get("specular_transmittance"), 1.0) else 0
         known |= {"specular_transmittance"}

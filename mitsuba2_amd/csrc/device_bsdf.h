@@ -14,7 +14,8 @@
 
 namespace mtsamd {
 
-constexpr int kBsdfDiffuse = 0, kBsdfConductor = 1, kBsdfRoughConductor = 2, kBsdfDielectric = 3, kBsdfPlastic = 4, kBsdfRoughPlastic = 5;
+constexpr int kBsdfDiffuse = 0, kBsdfConductor = 1, kBsdfRoughConductor = 2, kBsdfDielectric = 3, kBsdfPlastic = 4, kBsdfRoughPlastic = 5,
+              kBsdfRoughDielectric = 6;
 constexpr uint32_t kBsdfTwoSided = 1u, kBsdfGGX = 2u, kBsdfSampleVisible = 4u, kBsdfNonlinear = 8u;
 // spectral variant: the parameter is a `uniform` spectrum (its constant sits in the first colour channel) instead of `srgb`
 constexpr uint32_t kBsdfUniformRefl = 16u, kBsdfUniformSpec = 32u, kBsdfUniformTrans = 64u;
@@ -187,7 +188,7 @@ MTS_DEV f3 mdf_sample(const Mdf &d, f3 wi, f2 sample, float &pdf) {
 // ---------------------------------------------------------------------------------------------
 // Device-side BSDF record (128 B).  Roles of the generic fields per model:
 //   conductor / roughconductor   e = eta (rgb), k = extinction (rgb), s = specular_reflectance
-//   dielectric                   e.x = eta = int_ior / ext_ior, k = specular_transmittance, s = specular_reflectance
+//   dielectric, roughdielectric  e.x = eta = int_ior / ext_ior, k = specular_transmittance, s = specular_reflectance
 //   plastic                      e.x = eta, e.y = 1 / eta^2, e.z = fdr_int, k.x = specular sampling weight,
 //                                (r, g, b) = diffuse_reflectance, s = specular_reflectance
 //   roughplastic                 as plastic with e.z = internal diffuse reflectance, alpha_u = roughness and
@@ -214,7 +215,8 @@ MTS_DEV float lerp_gather(const float *data, float x, int size) {             //
 struct BsdfSample { f3 wo; float pdf, eta; bool delta; };
 
 MTS_DEV bool bsdf_is_smooth(const DevBsdf &b) {          // BSDFFlags::Smooth: any diffuse / glossy component
-    return b.type == kBsdfDiffuse || b.type == kBsdfRoughConductor || b.type == kBsdfPlastic || b.type == kBsdfRoughPlastic;
+    return b.type == kBsdfDiffuse || b.type == kBsdfRoughConductor || b.type == kBsdfPlastic || b.type == kBsdfRoughPlastic ||
+           b.type == kBsdfRoughDielectric;
 }
 
 // Per-channel inputs of a BSDF evaluation: N = 3 colour channels (RGB variant) or N = 4 wavelengths (spectral variant).
@@ -348,6 +350,45 @@ MTS_DEV bool bsdf_sample_n(const DevBsdf &b, const BsdfChannels<N> &c, f3 wi, fl
                 ok = true;
             }
         }
+    } else if (b.type == kBsdfRoughDielectric) {               // roughdielectric.cpp:202-300 (both lobes enabled, radiance transport)
+        const float cos_theta_i = wi.z;
+        bool active = cos_theta_i != 0.0f;                     // perfectly grazing configurations are ignored
+        const bool vis = (b.flags & kBsdfSampleVisible) != 0u;
+        const Mdf d = mdf_make((b.flags & kBsdfGGX) != 0u, b.alpha_u, b.alpha_v, vis);
+        Mdf sd = d;
+        if (!vis) {                                            // Walter et al.'s trick: widen the sampling distribution
+            const float sc = 1.2f - 0.2f * sqrtf(fabsf(cos_theta_i));
+            sd.au *= sc; sd.av *= sc;
+        }
+        const f3 wi_up = mk3(mulsign(wi.x, cos_theta_i), mulsign(wi.y, cos_theta_i), mulsign(wi.z, cos_theta_i));
+        const f3 m = mdf_sample(sd, wi_up, sample2, bs.pdf);
+        active = active && bs.pdf != 0.0f;
+        const Fresnel f = fresnel(dot(wi, m), b.er);
+        const bool selected_r = sample1 <= f.r && active, selected_t = !selected_r && active;
+        bs.pdf *= selected_r ? f.r : 1.0f - f.r;
+        bs.eta = selected_r ? 1.0f : f.eta_it;
+        float dwh_dwo = 0.0f;
+        if (selected_r) {
+            bs.wo = reflect_m(wi, m);
+            dwh_dwo = rcp(4.0f * dot(bs.wo, m));
+        }
+        if (selected_t) {
+            bs.wo = refract_m(wi, m, f.cos_theta_t, f.eta_ti);
+            dwh_dwo = (sqr(bs.eta) * dot(bs.wo, m)) / sqr(dot(wi, m) + bs.eta * dot(bs.wo, m));
+        }
+        float g;
+        if (vis) g = mdf_smith_g1(d, bs.wo, m);
+        else g = mdf_G(d, wi, bs.wo, m) * dot(wi, m) / (cos_theta_i * m.z);
+        bs.pdf *= fabsf(dwh_dwo);
+        const float q = sqr(f.eta_ti);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            float wk = 1.0f;
+            if (selected_r) wk *= c.spec[i];
+            if (selected_t) wk *= q * c.trans[i];
+            weight[i] = wk * g;
+        }
+        ok = active;
     }
     if (!ok) {
 #pragma unroll
@@ -368,6 +409,41 @@ MTS_DEV void bsdf_eval_pdf_n(const DevBsdf &b, const BsdfChannels<N> &c, f3 wi, 
         if (wi.z < 0.0f) { wi.z = -wi.z; wo.z = -wo.z; }
     }
     const float cos_theta_i = wi.z, cos_theta_o = wo.z;
+    if (b.type == kBsdfRoughDielectric) {                      // roughdielectric.cpp:302-375 (eval), :377-447 (pdf)
+        if (cos_theta_i == 0.0f) return;
+        const bool reflect = cos_theta_i * cos_theta_o > 0.0f;
+        const float m_inv_eta = 1.0f / b.er;                   // parameters_changed(): roughdielectric.cpp:198-200
+        const float eta = cos_theta_i > 0.0f ? b.er : m_inv_eta, inv_eta = cos_theta_i > 0.0f ? m_inv_eta : b.er;
+        f3 m = normalize(wi + wo * (reflect ? 1.0f : eta));
+        m = mk3(mulsign(m.x, m.z), mulsign(m.y, m.z), mulsign(m.z, m.z));
+        const bool vis = (b.flags & kBsdfSampleVisible) != 0u;
+        const Mdf d = mdf_make((b.flags & kBsdfGGX) != 0u, b.alpha_u, b.alpha_v, vis);
+        const float D = mdf_eval(d, m);
+        const float F = fresnel(dot(wi, m), b.er).r, G = mdf_G(d, wi, wo, m);
+        const float dwm = dot(wi, m), dom = dot(wo, m);
+        if (reflect) {
+            const float v = F * D * G / (4.0f * fabsf(cos_theta_i));
+#pragma unroll
+            for (int i = 0; i < N; ++i) value[i] = v * c.spec[i];
+        } else {
+            const float scale = sqr(inv_eta);                  // radiance transport: solid angle compression
+            const float v = fabsf((scale * (1.0f - F) * D * G * eta * eta * dwm * dom) / (cos_theta_i * sqr(dwm + eta * dom)));
+#pragma unroll
+            for (int i = 0; i < N; ++i) value[i] = v * c.trans[i];
+        }
+        const bool active = dwm * cos_theta_i > 0.0f && dom * cos_theta_o > 0.0f;
+        const float dwh_dwo = reflect ? rcp(4.0f * dom) : (eta * eta * dom) / sqr(dwm + eta * dom);
+        Mdf sd = d;
+        if (!vis) {
+            const float sc = 1.2f - 0.2f * sqrtf(fabsf(cos_theta_i));
+            sd.au *= sc; sd.av *= sc;
+        }
+        const f3 wi_up = mk3(mulsign(wi.x, cos_theta_i), mulsign(wi.y, cos_theta_i), mulsign(wi.z, cos_theta_i));
+        float prob = mdf_pdf(sd, wi_up, m);
+        prob *= reflect ? F : 1.0f - F;
+        pdf = active ? prob * fabsf(dwh_dwo) : 0.0f;
+        return;
+    }
     if (!(cos_theta_i > 0.0f && cos_theta_o > 0.0f)) return;      // every reflective model here is one-sided
     if (b.type == kBsdfDiffuse) {
 #pragma unroll

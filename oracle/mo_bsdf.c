@@ -210,7 +210,7 @@ static void roughplastic_tables(mo_bsdf *b);
 /* derived constants (plastic.cpp:162-176, roughplastic.cpp:365-399) */
 void mo_bsdf_prepare(mo_bsdf *b) {
     b->eta_rel = 1.0f;
-    if (b->d.type == MO_BSDF_DIELECTRIC || b->d.type == MO_BSDF_PLASTIC || b->d.type == MO_BSDF_ROUGHPLASTIC) b->eta_rel = b->d.int_ior / b->d.ext_ior;
+    if (b->d.type == MO_BSDF_DIELECTRIC || b->d.type == MO_BSDF_PLASTIC || b->d.type == MO_BSDF_ROUGHPLASTIC || b->d.type == MO_BSDF_ROUGHDIELECTRIC) b->eta_rel = b->d.int_ior / b->d.ext_ior;
     if (b->d.type == MO_BSDF_ROUGHPLASTIC) roughplastic_tables(b);
     if (b->d.type == MO_BSDF_PLASTIC || b->d.type == MO_BSDF_ROUGHPLASTIC) {
         b->inv_eta_2 = 1.0f / (b->eta_rel * b->eta_rel);
@@ -321,7 +321,8 @@ static inline float lerp_gather(const float *data, float x, int size) {         
 
 /* BSDFFlags::Smooth = any diffuse / glossy component (bsdf.h:106-112) */
 int mo_bsdf_is_smooth(const mo_bsdf *b) {
-    return b->d.type == MO_BSDF_DIFFUSE || b->d.type == MO_BSDF_ROUGHCONDUCTOR || b->d.type == MO_BSDF_PLASTIC || b->d.type == MO_BSDF_ROUGHPLASTIC;
+    return b->d.type == MO_BSDF_DIFFUSE || b->d.type == MO_BSDF_ROUGHCONDUCTOR || b->d.type == MO_BSDF_PLASTIC || b->d.type == MO_BSDF_ROUGHPLASTIC ||
+           b->d.type == MO_BSDF_ROUGHDIELECTRIC;
 }
 
 static float plastic_diffuse(const mo_bsdf *b, float refl) {      /* plastic.cpp:233-234,260-261 */
@@ -448,6 +449,45 @@ int mo_bsdf_sample_n(const mo_bsdf *b, int n, const mo_bsdf_chan *c, mo_v3 wi, f
         mo_bsdf_eval_pdf_n(&twin, n, c, wi, bs->wo, value, &bs->pdf);
         if (bs->pdf > 0.0f) { for (int k = 0; k < n; ++k) weight[k] = value[k] / bs->pdf; ok = 1; }
     } break;
+    case MO_BSDF_ROUGHDIELECTRIC: {                          /* roughdielectric.cpp:202-300 (both lobes enabled, radiance transport) */
+        float cos_theta_i = wi.z;
+        int active = cos_theta_i != 0.0f;                    /* perfectly grazing configurations are ignored */
+        mdf d = mdf_make(b->d.distribution, b->d.alpha_u, b->d.alpha_v, b->d.sample_visible), sd = d;
+        if (!b->d.sample_visible) {                          /* Walter et al.'s trick: widen the sampling distribution */
+            float sc = 1.2f - 0.2f * sqrtf(fabsf(cos_theta_i));
+            sd.au *= sc; sd.av *= sc;
+        }
+        mo_v3 wi_up = mo_v3_make(mo_mulsign(wi.x, cos_theta_i), mo_mulsign(wi.y, cos_theta_i), mo_mulsign(wi.z, cos_theta_i));
+        mo_v3 m = mdf_sample(&sd, wi_up, sample2, &bs->pdf);
+        active = active && bs->pdf != 0.0f;
+        float f[4];
+        mo_fresnel(mo_dot(wi, m), b->eta_rel, f);            /* F, cos_theta_t, eta_it, eta_ti */
+        float F = f[0];
+        int selected_r = sample1 <= F && active, selected_t = !selected_r && active;
+        bs->pdf *= selected_r ? F : 1.0f - F;
+        bs->eta = selected_r ? 1.0f : f[2];
+        bs->delta = 0;
+        float dwh_dwo = 0.0f;
+        if (selected_r) {
+            bs->wo = reflect_m(wi, m);
+            dwh_dwo = mo_rcp(4.0f * mo_dot(bs->wo, m));
+        }
+        if (selected_t) {
+            bs->wo = refract_m(wi, m, f[1], f[3]);
+            dwh_dwo = (sqr(bs->eta) * mo_dot(bs->wo, m)) / sqr(mo_dot(wi, m) + bs->eta * mo_dot(bs->wo, m));
+        }
+        float g;
+        if (b->d.sample_visible) g = mdf_smith_g1(&d, bs->wo, m);
+        else g = mdf_G(&d, wi, bs->wo, m) * mo_dot(wi, m) / (cos_theta_i * m.z);
+        bs->pdf *= fabsf(dwh_dwo);
+        for (int k = 0; k < n; ++k) {
+            float wk = 1.0f;
+            if (selected_r) wk *= c->spec[k];
+            if (selected_t) wk *= sqr(f[3]) * c->trans[k];
+            weight[k] = wk * g;
+        }
+        ok = active;
+    } break;
     default: break;
     }
     if (!ok) for (int k = 0; k < n; ++k) weight[k] = 0.0f;
@@ -464,6 +504,39 @@ void mo_bsdf_eval_pdf_n(const mo_bsdf *b, int n, const mo_bsdf_chan *c, mo_v3 wi
         if (wi.z < 0.0f) { wi.z = -wi.z; wo.z = -wo.z; }
     }
     float cos_theta_i = wi.z, cos_theta_o = wo.z;
+    if (b->d.type == MO_BSDF_ROUGHDIELECTRIC) {              /* roughdielectric.cpp:302-375 (eval), :377-447 (pdf) */
+        if (cos_theta_i == 0.0f) return;
+        int reflect = cos_theta_i * cos_theta_o > 0.0f;
+        float m_inv_eta = 1.0f / b->eta_rel;                 /* parameters_changed(): roughdielectric.cpp:198-200 */
+        float eta = cos_theta_i > 0.0f ? b->eta_rel : m_inv_eta, inv_eta = cos_theta_i > 0.0f ? m_inv_eta : b->eta_rel;
+        mo_v3 m = mo_normalize(mo_add(wi, mo_scale(wo, reflect ? 1.0f : eta)));
+        m = mo_v3_make(mo_mulsign(m.x, m.z), mo_mulsign(m.y, m.z), mo_mulsign(m.z, m.z));
+        mdf d = mdf_make(b->d.distribution, b->d.alpha_u, b->d.alpha_v, b->d.sample_visible);
+        float D = mdf_eval(&d, m);
+        float f[4]; mo_fresnel(mo_dot(wi, m), b->eta_rel, f);
+        float F = f[0], G = mdf_G(&d, wi, wo, m);
+        float dwm = mo_dot(wi, m), dom = mo_dot(wo, m);
+        if (reflect) {
+            float v = F * D * G / (4.0f * fabsf(cos_theta_i));
+            for (int k = 0; k < n; ++k) value[k] = v * c->spec[k];
+        } else {
+            float scale = sqr(inv_eta);                      /* radiance transport: solid angle compression */
+            float v = fabsf((scale * (1.0f - F) * D * G * eta * eta * dwm * dom) / (cos_theta_i * sqr(dwm + eta * dom)));
+            for (int k = 0; k < n; ++k) value[k] = v * c->trans[k];
+        }
+        int active = dwm * cos_theta_i > 0.0f && dom * cos_theta_o > 0.0f;
+        float dwh_dwo = reflect ? mo_rcp(4.0f * dom) : (eta * eta * dom) / sqr(dwm + eta * dom);
+        mdf sd = d;
+        if (!b->d.sample_visible) {
+            float sc = 1.2f - 0.2f * sqrtf(fabsf(cos_theta_i));
+            sd.au *= sc; sd.av *= sc;
+        }
+        mo_v3 wi_up = mo_v3_make(mo_mulsign(wi.x, cos_theta_i), mo_mulsign(wi.y, cos_theta_i), mo_mulsign(wi.z, cos_theta_i));
+        float prob = mdf_pdf(&sd, wi_up, m);
+        prob *= reflect ? F : 1.0f - F;
+        *pdf = active ? prob * fabsf(dwh_dwo) : 0.0f;
+        return;
+    }
     if (!(cos_theta_i > 0.0f && cos_theta_o > 0.0f)) return;
     switch (b->d.type) {
     case MO_BSDF_DIFFUSE:                                    /* diffuse.cpp:108-135 */

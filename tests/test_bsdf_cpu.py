@@ -300,3 +300,70 @@ def test_roughplastic_tables():
         bsdfs.normalize({"type": "roughplastic", "alpha_u": 0.1, "alpha_v": 0.2})
     with pytest.raises(RuntimeError, match="positive and differ"):
         bsdfs.normalize({"type": "roughplastic", "int_ior": 1.2, "ext_ior": 1.2})
+
+
+ROUGH_DIELECTRIC_CASES = [          # test_rough_dielectric.py:5-185 (chi^2 configurations test01 .. test09 and the anisotropic one)
+    ({"alpha": 0.05}, [0.8, 0.3, 0.05]),
+    ({"alpha": 0.5}, [0.8, 0.3, 0.05]),
+    ({"alpha": 0.5, "sample_visible": False, "distribution": "beckmann"}, [0.5, 0.0, 0.5]),
+    ({"alpha": 0.5, "sample_visible": True, "distribution": "beckmann"}, [0.5, 0.0, 0.5]),
+    ({"alpha": 0.5, "sample_visible": False, "distribution": "ggx"}, [0.5, 0.0, 0.5]),
+    ({"alpha": 0.5, "sample_visible": True, "distribution": "ggx"}, [0.5, 0.5, 0.001]),
+    ({"alpha": 0.5}, [0.2, -0.6, -0.5]),
+    ({"alpha": 0.5}, [0.8, 0.3, -0.05]),
+    ({"alpha": 0.5, "ext_ior": 1.5, "int_ior": 1.0}, [0.2, -0.6, 0.5]),
+    ({"alpha_u": 0.5, "alpha_v": 0.2}, [-0.5, -0.5, 0.1]),
+]
+
+
+@pytest.mark.parametrize("case", range(len(ROUGH_DIELECTRIC_CASES)))
+def test_rough_dielectric_sample_pdf_eval(case):
+    """src/bsdfs/roughdielectric.cpp in the configurations of its chi^2 tests: the pdf returned with a sample equals pdf() at
+    the sampled direction, weight * pdf == eval for visible-normal sampling (with sample_visible = false the reference
+    samples a widened distribution but weights with the original one), and sample() is distributed according to pdf():
+    expectations of test functions under the samples equal their integrals against pdf()"""
+    params, wi = ROUGH_DIELECTRIC_CASES[case]
+    b = dict(params, type="roughdielectric")
+    rng = np.random.default_rng(case)
+    n = 200000
+    w = np.float32(wi) / np.float32(np.linalg.norm(wi))
+    W = np.tile(w, (n, 1))
+    s3 = rng.uniform(size=(n, 3)).astype(np.float32)
+    r = ob.bsdf_kat(b, W, W, s3)
+    assert not r["s_delta"].any()
+    ok = r["s_valid"] & (r["s_pdf"] > 1e-4) & (r["s_weight"][:, 0] > 0)
+    assert ok.mean() > 0.8
+    e = ob.bsdf_kat(b, W[ok], r["s_wo"][ok], s3[ok])
+    # (a handful of samples at grazing angles are ill-conditioned in single precision)
+    assert np.isclose(r["s_pdf"][ok], e["pdf"], rtol=5e-3, atol=1e-5).mean() > 0.9995
+    if params.get("sample_visible", True):
+        assert np.isclose(r["s_weight"][ok] * r["s_pdf"][ok][:, None], e["eval"], rtol=5e-3, atol=1e-4).all(1).mean() > 0.9995
+    refl = np.sign(r["s_wo"][ok][:, 2]) == np.sign(w[2])
+    assert np.all(r["s_eta"][ok][refl] == 1.0)                      # bs.eta: 1 for reflection, eta_it for refraction
+    eta = params.get("int_ior", 1.5046) / params.get("ext_ior", 1.000277)
+    if (~refl).any():
+        assert np.allclose(r["s_eta"][ok][~refl], eta if w[2] > 0 else 1 / eta, rtol=1e-6)
+    assert np.allclose(np.linalg.norm(r["s_wo"][ok], axis=1), 1.0, atol=1e-4)
+    # distribution of the samples against pdf(): uniform sphere quadrature of pdf * g vs the sample mean of g
+    m = 400000
+    u = rng.uniform(size=(m, 2))
+    z = 1 - 2 * u[:, 0]
+    rr = np.sqrt(np.maximum(0, 1 - z * z))
+    dirs = np.stack([rr * np.cos(2 * math.pi * u[:, 1]), rr * np.sin(2 * math.pi * u[:, 1]), z], 1).astype(np.float32)
+    pdf_all = ob.bsdf_kat(b, np.tile(w, (m, 1)), dirs, np.zeros((m, 3), np.float32))["pdf"].astype(np.float64)
+    good = r["s_valid"] & (r["s_pdf"] > 0)
+    wo = r["s_wo"].astype(np.float64)
+    if params.get("alpha", 0.5) >= 0.5 or "alpha_u" in params:      # the smooth case is too peaked for uniform quadrature
+        for g in (lambda d: np.ones(len(d)), lambda d: d[:, 2] > 0, lambda d: d[:, 0], lambda d: d[:, 1], lambda d: d[:, 2] ** 2):
+            quad = 4 * math.pi * np.mean(pdf_all * g(dirs.astype(np.float64)))
+            mc = np.mean(np.where(good & (r["s_weight"][:, 0] > 0), g(wo), 0.0))
+            assert abs(quad - mc) < 0.03, (quad, mc)
+
+
+def test_rough_dielectric_parameters():
+    with pytest.raises(RuntimeError, match="positive and differ"):
+        ob.bsdf_desc({"type": "roughdielectric", "int_ior": 1.3, "ext_ior": 1.3})
+    with pytest.raises(RuntimeError, match="without a transmission component"):
+        ob.bsdf_desc({"type": "twosided", "bsdf": {"type": "roughdielectric"}})
+    d, n = ob.bsdf_desc({"type": "roughdielectric"})                # defaults: bk7 / air, beckmann, alpha = 0.1
+    assert n["int_ior"] == 1.5046 and n["ext_ior"] == 1.000277 and n["alpha_u"] == n["alpha_v"] == 0.1 and n["distribution"] == 0

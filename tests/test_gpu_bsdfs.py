@@ -24,6 +24,10 @@ MATERIALS = {
     "roughplastic": {"type": "roughplastic", "alpha": 0.15, "diffuse_reflectance": [0.1, 0.27, 0.36], "int_ior": 1.9},
     "roughplastic_ggx": {"type": "roughplastic", "alpha": 0.3, "distribution": "ggx", "diffuse_reflectance": 0.4, "specular_reflectance": 0.7,
                          "nonlinear": True},
+    "frosted_glass": {"type": "roughdielectric", "alpha": 0.2, "specular_transmittance": [0.9, 0.95, 1.0]},
+    "frosted_ggx_aniso": {"type": "roughdielectric", "alpha_u": 0.3, "alpha_v": 0.1, "distribution": "ggx", "int_ior": "diamond",
+                          "specular_reflectance": [0.9, 0.8, 0.7]},
+    "frosted_beckmann_all": {"type": "roughdielectric", "alpha": 0.3, "sample_visible": False, "int_ior": 1.0, "ext_ior": 1.5},
     "twosided_diffuse": {"type": "twosided", "bsdf": {"type": "diffuse", "reflectance": [0.6, 0.3, 0.2]}},
     "twosided_rough": {"type": "twosided", "bsdf": {"type": "roughconductor", "alpha": 0.15, "distribution": "ggx", "eta": 0.0, "k": 1.0}},
 }
@@ -59,7 +63,7 @@ def test_sample_radiance_matches_oracle(material, pipeline):
     assert abs(rgb.mean() - want[:, :3].mean()) < 2e-2 * max(want[:, :3].mean(), 1e-3)
 
 
-@pytest.mark.parametrize("material", ["rough_ggx", "glass", "plastic"])
+@pytest.mark.parametrize("material", ["rough_ggx", "glass", "plastic", "frosted_glass"])
 def test_film_relmse(material):
     from mitsuba2_amd import render as R, scenes
     cb, sp = _scene(material), scenes.cornell_box_sensor(48, 48, spp=32, seed=4)
@@ -79,7 +83,9 @@ def test_unsupported_combinations():
     with pytest.raises(RuntimeError, match="uniform"):
         R.Scene(cb, variant="spectral")
     with pytest.raises(RuntimeError, match="not supported by this backend"):
-        R.Scene(dict(cb, bsdfs=[{"type": "roughdielectric"}] * len(cb["bsdfs"])))
+        R.Scene(dict(cb, bsdfs=[{"type": "thindielectric"}] * len(cb["bsdfs"])))
+    with pytest.raises(RuntimeError, match="positive and differ"):
+        R.Scene(dict(cb, bsdfs=[{"type": "roughdielectric", "int_ior": 1.2, "ext_ior": 1.2}] * len(cb["bsdfs"])))
 
 
 def test_roughplastic_tables_match_oracle():
