@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MTSAMD_ABI_VERSION 2
+#define MTSAMD_ABI_VERSION 3
 
 typedef enum {
     MTSAMD_OK = 0,
@@ -175,7 +175,9 @@ int mtsamd_ray_intersect_si(const mtsamd_scene *scene, uint64_t n, const mtsamd_
                             void *stream);
 
 /* ---- sensor / film / sampler / integrator ----------------------------------- */
-typedef enum { MTSAMD_RFILTER_GAUSSIAN = 0, MTSAMD_RFILTER_BOX = 1 } mtsamd_rfilter_type;
+/* src/rfilters/{gaussian,box,tent,catmullrom,mitchell,lanczos}.cpp */
+typedef enum { MTSAMD_RFILTER_GAUSSIAN = 0, MTSAMD_RFILTER_BOX = 1, MTSAMD_RFILTER_TENT = 2, MTSAMD_RFILTER_CATMULLROM = 3,
+               MTSAMD_RFILTER_MITCHELL = 4, MTSAMD_RFILTER_LANCZOS = 5 } mtsamd_rfilter_type;
 
 typedef struct {
     /* PerspectiveCamera (src/sensors/perspective.cpp): to_world is row-major 4x4 */
@@ -185,9 +187,10 @@ typedef struct {
     /* Film (src/librender/film.cpp:7-64): size and crop window */
     int32_t film_width, film_height;
     int32_t crop_x, crop_y, crop_width, crop_height;
-    /* ReconstructionFilter: gaussian stddev (src/rfilters/gaussian.cpp) / box radius (box.cpp) */
+    /* ReconstructionFilter: gaussian stddev (src/rfilters/gaussian.cpp) / box radius (box.cpp) / mitchell B (mitchell.cpp:33) /
+     * lanczos lobes (lanczos.cpp:34); param2: mitchell C; tent and catmullrom take no parameter */
     int32_t rfilter;           /* mtsamd_rfilter_type */
-    float rfilter_param;
+    float rfilter_param, rfilter_param2;
     int32_t rfilter_analytic;  /* 0: eval_discretized (scalar/packet variants, imageblock.cpp:131);
                                   1: eval() as the reference's GPU variants do (:132) */
     /* IndependentSampler (src/samplers/independent.cpp): sample_count, seed */
@@ -278,7 +281,7 @@ int mtsamd_camera_sample_rays(const mtsamd_render_desc *desc, uint64_t n, const 
  * and is accumulated into (float atomics, as the reference's scatter_add).
  * pos_dev: n*2 floats, values_dev: n*channels floats. */
 int mtsamd_imageblock_put(int32_t width, int32_t height, int32_t offset_x, int32_t offset_y,
-                          int32_t channels, int32_t rfilter, float rfilter_param,
+                          int32_t channels, int32_t rfilter, float rfilter_param, float rfilter_param2,
                           int32_t rfilter_analytic, int32_t border, uint64_t n,
                           const float *pos_dev, const float *values_dev, float *data_dev,
                           void *stream);
@@ -289,7 +292,7 @@ int mtsamd_imageblock_put_block(const float *src_dev, int32_t src_w, int32_t src
                                 int32_t dst_h, int32_t dst_ox, int32_t dst_oy, int32_t dst_border,
                                 int32_t channels, void *stream);
 /* ReconstructionFilter discretisation (src/libcore/rfilter.cpp:9-20): host outputs. */
-int mtsamd_rfilter_info(int32_t rfilter, float rfilter_param, float *table32_host,
+int mtsamd_rfilter_info(int32_t rfilter, float rfilter_param, float rfilter_param2, float *table32_host,
                         float *radius_host, int32_t *border_host);
 /* HDRFilm::bitmap (src/films/hdrfilm.cpp:249-320): XYZAW -> RGBA float32, n pixels. */
 int mtsamd_film_develop(const float *xyzaw_dev, uint64_t n_pixels, float *rgba_dev, void *stream);

@@ -53,7 +53,7 @@ class Rays(C.Structure):
 class RenderDesc(C.Structure):
     _fields_ = [("to_world", C.c_float * 16), ("fov_x_deg", C.c_float), ("near_clip", C.c_float), ("far_clip", C.c_float),
                 ("film_width", C.c_int32), ("film_height", C.c_int32), ("crop_x", C.c_int32), ("crop_y", C.c_int32),
-                ("crop_width", C.c_int32), ("crop_height", C.c_int32), ("rfilter", C.c_int32), ("rfilter_param", C.c_float),
+                ("crop_width", C.c_int32), ("crop_height", C.c_int32), ("rfilter", C.c_int32), ("rfilter_param", C.c_float), ("rfilter_param2", C.c_float),
                 ("rfilter_analytic", C.c_int32), ("sample_count", C.c_int32), ("seed", C.c_uint64), ("max_depth", C.c_int32),
                 ("rr_depth", C.c_int32), ("row_begin", C.c_int32), ("row_end", C.c_int32), ("part_index", C.c_int32),
                 ("part_count", C.c_int32), ("part_tile_rows", C.c_int32), ("paths_per_wave", C.c_int32),
@@ -86,9 +86,9 @@ SYMBOLS = {
     "mtsamd_scene_texture_info": (C.c_int, [vp, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), u64p]),
     "mtsamd_sample_radiance": (C.c_int, [vp, C.POINTER(RenderDesc), C.c_uint64, C.c_uint64, vp, vp, vp]),
     "mtsamd_camera_sample_rays": (C.c_int, [C.POINTER(RenderDesc), C.c_uint64] + [vp] * 11),
-    "mtsamd_imageblock_put": (C.c_int, [C.c_int32] * 6 + [C.c_float, C.c_int32, C.c_int32, C.c_uint64, vp, vp, vp, vp]),
+    "mtsamd_imageblock_put": (C.c_int, [C.c_int32] * 6 + [C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_uint64, vp, vp, vp, vp]),
     "mtsamd_imageblock_put_block": (C.c_int, [vp] + [C.c_int32] * 5 + [vp] + [C.c_int32] * 6 + [vp]),
-    "mtsamd_rfilter_info": (C.c_int, [C.c_int32, C.c_float, f32p, f32p, C.POINTER(C.c_int32)]),
+    "mtsamd_rfilter_info": (C.c_int, [C.c_int32, C.c_float, C.c_float, f32p, f32p, C.POINTER(C.c_int32)]),
     "mtsamd_film_develop": (C.c_int, [vp, C.c_uint64, vp, vp]),
 }
 
@@ -108,7 +108,7 @@ def lib():
             fn = getattr(handle, name)      # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if handle.mtsamd_abi_version() != 2:
+        if handle.mtsamd_abi_version() != 3:
             raise RuntimeError("libmtsamd.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -106,7 +106,18 @@ int make_camera(const mtsamd_render_desc &d, CameraView &c) {
     return 0;
 }
 
-int make_filter(int32_t kind, float param, int32_t analytic, FilterView &f) {
+// B-spline family of mitchell.cpp:41-56 / catmullrom.cpp:29-43 (B = 0, C = 0.5)
+static float cubic_filter(float x, float B, float C) {
+    x = std::fabs(x);
+    const float x2 = x * x, x3 = x2 * x;
+    const float result = (1.0f / 6.0f) * (x < 1.0f
+        ? (12.0f - 9.0f * B - 6.0f * C) * x3 + (-18.0f + 12.0f * B + 6.0f * C) * x2 + (6.0f - 2.0f * B)
+        : (-B - 6.0f * C) * x3 + (6.0f * B + 30.0f * C) * x2 + (-12.0f * B - 48.0f * C) * x + (8.0f * B + 24.0f * C));
+    return x < 2.0f ? result : 0.0f;
+}
+
+// param / param2: gaussian stddev | box radius | mitchell B, C | lanczos lobes (tent and catmullrom take none)
+int make_filter(int32_t kind, float param, float param2, int32_t analytic, FilterView &f) {
     std::memset(&f, 0, sizeof(f));
     f.kind = kind; f.analytic = analytic;
     if (kind == MTSAMD_RFILTER_GAUSSIAN) {
@@ -117,12 +128,31 @@ int make_filter(int32_t kind, float param, int32_t analytic, FilterView &f) {
     } else if (kind == MTSAMD_RFILTER_BOX) {
         if (!(param > 0.0f)) return fail(MTSAMD_ERR_INVALID, "box rfilter: radius must be positive");
         f.radius = param + kRayEpsilon;
+    } else if (kind == MTSAMD_RFILTER_TENT) {
+        f.radius = 1.0f; f.alpha = 1.0f / f.radius;                    // alpha = m_inv_radius (tent.cpp:28-30)
+    } else if (kind == MTSAMD_RFILTER_CATMULLROM) {
+        f.radius = 2.0f;
+    } else if (kind == MTSAMD_RFILTER_MITCHELL) {
+        f.radius = 2.0f; f.alpha = param; f.bias = param2;            // alpha = B, bias = C
+    } else if (kind == MTSAMD_RFILTER_LANCZOS) {
+        if (!(param >= 1.0f) || param > 16.0f) return fail(MTSAMD_ERR_INVALID, "lanczos rfilter: 'lobes' must be in [1, 16]");
+        f.radius = (float) (int) param;
     } else {
-        return fail(MTSAMD_ERR_UNSUPPORTED, "unsupported reconstruction filter %d (gaussian and box are implemented)", kind);
+        return fail(MTSAMD_ERR_UNSUPPORTED, "unsupported reconstruction filter %d (gaussian, box, tent, catmullrom, mitchell, lanczos)", kind);
     }
     auto eval = [&](float x) -> float {
-        if (kind == MTSAMD_RFILTER_GAUSSIAN) return std::max(0.0f, std::exp(f.alpha * (x * x)) - f.bias);
-        return std::fabs(x) <= f.radius ? 1.0f : 0.0f;
+        switch (kind) {
+        case MTSAMD_RFILTER_GAUSSIAN: return std::max(0.0f, std::exp(f.alpha * (x * x)) - f.bias);
+        case MTSAMD_RFILTER_TENT: return std::max(0.0f, 1.0f - std::fabs(x * f.alpha));
+        case MTSAMD_RFILTER_CATMULLROM: return cubic_filter(x, 0.0f, 0.5f);
+        case MTSAMD_RFILTER_MITCHELL: return cubic_filter(x, f.alpha, f.bias);
+        case MTSAMD_RFILTER_LANCZOS: {
+            x = std::fabs(x);
+            const float x1 = kPi * x, x2 = x1 / f.radius, result = (std::sin(x1) * std::sin(x2)) / (x1 * x2);
+            return x < kEpsilon ? 1.0f : (x > f.radius ? 0.0f : result);
+        }
+        default: return std::fabs(x) <= f.radius ? 1.0f : 0.0f;
+        }
     };
     for (int i = 0; i < 31; ++i) f.table[i] = eval((f.radius * (float) i) / 31.0f);
     f.table[31] = 0.0f;
@@ -988,7 +1018,7 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
 int setup_job(Job &j, mtsamd_scene *s, const mtsamd_render_desc *d, hipStream_t stream, uint64_t max_pass) {
     j.s = s; j.d = d; j.stream = stream;
     if (int rc = make_camera(*d, j.cam)) return rc;
-    if (int rc = make_filter(d->rfilter, d->rfilter_param, d->rfilter_analytic, j.filter)) return rc;
+    if (int rc = make_filter(d->rfilter, d->rfilter_param, d->rfilter_param2, d->rfilter_analytic, j.filter)) return rc;
     // One pass holds up to 2^28 camera samples (6 GiB of sample stream): every pass ends with a drain phase in which the
     // pool empties, so fewer, larger passes waste less (cbox 1024^2 @ 256 spp: 4 passes of 2^26 -> 1 pass: +7 %).
     uint64_t pass_limit = 1ull << 28;
@@ -1141,7 +1171,7 @@ int mtsamd_render_adjoint(mtsamd_scene *s, const mtsamd_render_desc *d, const fl
     HIP_TRY(hipSetDevice(s->device));
     AdjointParams a{};
     if (int rc = make_camera(*d, a.rp.cam)) return rc;
-    if (int rc = make_filter(d->rfilter, d->rfilter_param, d->rfilter_analytic, a.filter)) return rc;
+    if (int rc = make_filter(d->rfilter, d->rfilter_param, d->rfilter_param2, d->rfilter_analytic, a.filter)) return rc;
     if (a.filter.taps > 8) return fail(MTSAMD_ERR_UNSUPPORTED, "reconstruction filter too wide for the adjoint pass");
     a.rp.sv = s->view;
     a.rp.base_seed = d->seed; a.rp.spp = d->sample_count;
@@ -1223,11 +1253,11 @@ int mtsamd_camera_sample_rays(const mtsamd_render_desc *d, uint64_t n, const flo
 
 // ---- ImageBlock / Film ------------------------------------------------------------------------
 int mtsamd_imageblock_put(int32_t width, int32_t height, int32_t offset_x, int32_t offset_y, int32_t channels, int32_t rfilter,
-                          float rfilter_param, int32_t analytic, int32_t border, uint64_t n, const float *pos, const float *values,
+                          float rfilter_param, float rfilter_param2, int32_t analytic, int32_t border, uint64_t n, const float *pos, const float *values,
                           float *data, void *stream) {
     if (width <= 0 || height <= 0 || channels <= 0 || channels > 16 || !pos || !values || !data) return fail(MTSAMD_ERR_INVALID, "invalid ImageBlock arguments");
     FilterView f;
-    if (int rc = make_filter(rfilter, rfilter_param, analytic, f)) return rc;
+    if (int rc = make_filter(rfilter, rfilter_param, rfilter_param2, analytic, f)) return rc;
     if (border != 0 && border != f.border) return fail(MTSAMD_ERR_INVALID, "border must be 0 or the filter's border_size (%d)", f.border);
     HIP_TRY(launch_imageblock_put(f, width, height, offset_x, offset_y, channels, border, n, pos, values, data, (hipStream_t) stream));
     return MTSAMD_OK;
@@ -1241,9 +1271,9 @@ int mtsamd_imageblock_put_block(const float *src, int32_t sw, int32_t sh, int32_
     return MTSAMD_OK;
 }
 
-int mtsamd_rfilter_info(int32_t rfilter, float param, float *table32, float *radius, int32_t *border) {
+int mtsamd_rfilter_info(int32_t rfilter, float param, float param2, float *table32, float *radius, int32_t *border) {
     FilterView f;
-    if (int rc = make_filter(rfilter, param, 0, f)) return rc;
+    if (int rc = make_filter(rfilter, param, param2, 0, f)) return rc;
     if (table32) std::memcpy(table32, f.table, sizeof(float) * 32);
     if (radius) *radius = f.radius;
     if (border) *border = f.border;

@@ -1004,10 +1004,29 @@ hipError_t launch_bounce(const RenderParams &p, hipStream_t s) {
     return hipGetLastError();
 }
 
-// reconstruction filter (rfilter.h:62-65, gaussian.cpp:45-47, box.cpp:34-36)
+// reconstruction filter (rfilter.h:62-65, gaussian.cpp:45-47, box.cpp:34-36, tent.cpp:33-35, catmullrom.cpp:29-43,
+// mitchell.cpp:41-56, lanczos.cpp:38-48); FilterView::alpha / bias carry tent's 1 / radius and mitchell's B / C
+MTS_DEV float cubic_filter(float x, float B, float C) {
+    x = fabsf(x);
+    const float x2 = x * x, x3 = x2 * x;
+    const float result = (1.0f / 6.0f) * (x < 1.0f
+        ? (12.0f - 9.0f * B - 6.0f * C) * x3 + (-18.0f + 12.0f * B + 6.0f * C) * x2 + (6.0f - 2.0f * B)
+        : (-B - 6.0f * C) * x3 + (6.0f * B + 30.0f * C) * x2 + (-12.0f * B - 48.0f * C) * x + (8.0f * B + 24.0f * C));
+    return x < 2.0f ? result : 0.0f;
+}
 MTS_DEV float filter_eval(const FilterView &f, float x) {
-    if (f.kind == 0) return fmaxf(0.0f, expf(f.alpha * (x * x)) - f.bias);
-    return fabsf(x) <= f.radius ? 1.0f : 0.0f;
+    switch (f.kind) {
+    case 0: return fmaxf(0.0f, expf(f.alpha * (x * x)) - f.bias);
+    case 2: return fmaxf(0.0f, 1.0f - fabsf(x * f.alpha));
+    case 3: return cubic_filter(x, 0.0f, 0.5f);
+    case 4: return cubic_filter(x, f.alpha, f.bias);
+    case 5: {
+        x = fabsf(x);
+        const float x1 = kPi * x, x2 = x1 / f.radius, result = (sinf(x1) * sinf(x2)) / (x1 * x2);
+        return x < kEpsilon ? 1.0f : (x > f.radius ? 0.0f : result);
+    }
+    default: return fabsf(x) <= f.radius ? 1.0f : 0.0f;
+    }
 }
 MTS_DEV float filter_weight(const FilterView &f, float x) {
     if (f.analytic) return filter_eval(f, x);

@@ -75,12 +75,12 @@ class ReconstructionFilter:
     """include/mitsuba/core/rfilter.h; discretisation from src/libcore/rfilter.cpp:9-20 via the C ABI."""
     kind = -1
 
-    def __init__(self, param):
-        self.param = float(param)
+    def __init__(self, param=0.0, param2=0.0):
+        self.param, self.param2 = float(param), float(param2)
         table = (C.c_float * 32)()
         radius = C.c_float()
         border = C.c_int32()
-        L.check(L.lib().mtsamd_rfilter_info(self.kind, self.param, table, C.byref(radius), C.byref(border)))
+        L.check(L.lib().mtsamd_rfilter_info(self.kind, self.param, self.param2, table, C.byref(radius), C.byref(border)))
         self._table = np.array(table, dtype=np.float32)
         self._radius = radius.value
         self._border = border.value
@@ -110,6 +110,41 @@ class BoxFilter(ReconstructionFilter):
 
     def __init__(self, radius=0.5):
         super().__init__(radius)
+
+
+class TentFilter(ReconstructionFilter):
+    """src/rfilters/tent.cpp (radius 1: ImageBlock::put treats it like a one-pixel footprint, imageblock.cpp:117)"""
+    kind = 2
+
+
+class CatmullRomFilter(ReconstructionFilter):
+    """src/rfilters/catmullrom.cpp"""
+    kind = 3
+
+
+class MitchellFilter(ReconstructionFilter):
+    """src/rfilters/mitchell.cpp"""
+    kind = 4
+
+    def __init__(self, B=1.0 / 3.0, C=1.0 / 3.0):
+        super().__init__(B, C)
+
+
+class LanczosFilter(ReconstructionFilter):
+    """src/rfilters/lanczos.cpp"""
+    kind = 5
+
+    def __init__(self, lobes=3):
+        super().__init__(int(lobes))
+
+
+def make_filter(name, *params):
+    """reconstruction filter plugin by name: gaussian(stddev) | box(radius) | tent | catmullrom | mitchell(B, C) | lanczos(lobes)"""
+    classes = {"gaussian": GaussianFilter, "box": BoxFilter, "tent": TentFilter, "catmullrom": CatmullRomFilter,
+               "mitchell": MitchellFilter, "lanczos": LanczosFilter}
+    if name not in classes:
+        raise RuntimeError('Reconstruction filter "%s" is not supported by this backend (%s)' % (name, ", ".join(classes)))
+    return classes[name](*params)
 
 
 class ImageBlock:
@@ -158,7 +193,7 @@ class ImageBlock:
             pos, values = pos[keep].contiguous(), values[keep].contiguous()
         f = self._filter
         L.check(lib.mtsamd_imageblock_put(self._size[0], self._size[1], self._offset[0], self._offset[1], self._channels, f.kind,
-                                          f.param, 0, self._border, pos.shape[0], _ptr(pos), _ptr(values), _ptr(self._data),
+                                          f.param, f.param2, 0, self._border, pos.shape[0], _ptr(pos), _ptr(values), _ptr(self._data),
                                           _stream()))
 
 
@@ -348,6 +383,7 @@ class PerspectiveCamera:
         d.crop_width, d.crop_height = f.crop_size()
         d.rfilter = f.reconstruction_filter().kind
         d.rfilter_param = f.reconstruction_filter().param
+        d.rfilter_param2 = f.reconstruction_filter().param2
         d.rfilter_analytic = 0
         d.sample_count = self._sampler.sample_count()
         d.seed = self._sampler.seed_value()
@@ -706,7 +742,8 @@ class MomentIntegrator(PathIntegrator):
 
 def make_sensor(params):
     """Build PerspectiveCamera/HDRFilm/IndependentSampler from a scenes.*_sensor() dict."""
-    flt = GaussianFilter(params["rfilter_param"]) if params["rfilter"] == "gaussian" else BoxFilter(params["rfilter_param"])
+    rp = params.get("rfilter_param")
+    flt = make_filter(params["rfilter"], *([] if rp is None else (list(rp) if isinstance(rp, (list, tuple)) else [rp])))
     cx, cy, cw, ch = params["crop"]
     film = HDRFilm(params["width"], params["height"], (cx, cy), (cw, ch), flt)
     sampler = IndependentSampler(params["sample_count"], params["seed"])

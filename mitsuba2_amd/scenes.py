@@ -123,7 +123,7 @@ def look_at(origin, target, up):
 def cornell_box_sensor(width=256, height=256, spp=16, seed=0, max_depth=-1, rr_depth=5,
                        rfilter="gaussian", rfilter_param=None):
     """Sensor/film/sampler/integrator parameters of the synthetic cbox (dict of plain values)."""
-    if rfilter_param is None:
+    if rfilter_param is None and rfilter in ("gaussian", "box"):
         rfilter_param = 0.5
     return dict(to_world=look_at([278, 273, -800], [278, 273, -799], [0, 1, 0]), fov=39.3077, near_clip=10.0, far_clip=2800.0,
                 width=width, height=height, crop=(0, 0, width, height), rfilter=rfilter, rfilter_param=rfilter_param,

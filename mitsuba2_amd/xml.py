@@ -1,6 +1,6 @@
 """Scene description loading: the subset of the reference's XML format
 (``src/libcore/xml.cpp``) and ``load_dict`` needed to drive the hot path -- ``scene`` / ``integrator`` (path) /
-``sensor`` (perspective) / ``sampler`` (independent) / ``film`` (hdrfilm) / ``rfilter`` (gaussian, box) / ``shape``
+``sensor`` (perspective) / ``sampler`` (independent) / ``film`` (hdrfilm) / ``rfilter`` (gaussian, box, tent, catmullrom, mitchell, lanczos) / ``shape``
 (obj, ply, rectangle) / ``bsdf`` (diffuse) / ``texture`` (bitmap) / ``emitter`` (area), with ``default`` + ``$param``
 substitution, ``ref``/``id`` resolution, ``alias``, ``include`` and the ``transform`` operations.
 
@@ -555,8 +555,14 @@ def _sensor(ctx, node):
                     film["rfilter"] = ("gaussian", f.get("stddev", 0.5, "float"))
                 elif f.type == "box":
                     film["rfilter"] = ("box", f.get("radius", 0.5, "float")) if "radius" in f.props else ("box", 0.5)
+                elif f.type in ("tent", "catmullrom"):
+                    film["rfilter"] = (f.type,)
+                elif f.type == "mitchell":                       # mitchell.cpp:33-37
+                    film["rfilter"] = ("mitchell", f.get("B", 1.0 / 3.0, "float"), f.get("C", 1.0 / 3.0, "float"))
+                elif f.type == "lanczos":                        # lanczos.cpp:34
+                    film["rfilter"] = ("lanczos", f.get("lobes", 3, "int"))
                 else:
-                    raise XMLError('Reconstruction filter "%s" is not supported by this backend (gaussian, box)' % f.type)
+                    raise XMLError('Reconstruction filter "%s" is not supported by this backend (gaussian, box, tent, catmullrom, mitchell, lanczos)' % f.type)
                 f.check_unqueried()
             it.check_unqueried()
         elif it.tag == "sampler":
@@ -678,7 +684,7 @@ def instantiate(desc, device=0, variant="rgb"):
     sensors = []
     for s in desc.sensors:
         f = s["film"]
-        flt = R.GaussianFilter(f["rfilter"][1]) if f["rfilter"][0] == "gaussian" else R.BoxFilter(f["rfilter"][1])
+        flt = R.make_filter(f["rfilter"][0], *f["rfilter"][1:])
         extra = {k: f[k] for k in ("file_format", "pixel_format", "component_format", "high_quality_edges") if k in f}
         film = R.HDRFilm(f["width"], f["height"], f["crop_offset"], f["crop_size"], flt, **extra)
         sampler = R.IndependentSampler(s["sampler"]["sample_count"], s["sampler"]["seed"])
@@ -701,7 +707,7 @@ def load_file(path, device=0, variant="rgb", **params):
 
 
 # -------------------------------------------------------------------------------------------- load_dict
-_PLUGIN_CLASS = {"twosided": "bsdf", "conductor": "bsdf", "roughconductor": "bsdf", "dielectric": "bsdf", "plastic": "bsdf", "roughplastic": "bsdf", "roughdielectric": "bsdf", "path": "integrator", "perspective": "sensor", "hdrfilm": "film", "independent": "sampler", "gaussian": "rfilter", "box": "rfilter",
+_PLUGIN_CLASS = {"twosided": "bsdf", "conductor": "bsdf", "roughconductor": "bsdf", "dielectric": "bsdf", "plastic": "bsdf", "roughplastic": "bsdf", "roughdielectric": "bsdf", "path": "integrator", "perspective": "sensor", "hdrfilm": "film", "independent": "sampler", "gaussian": "rfilter", "box": "rfilter", "tent": "rfilter", "catmullrom": "rfilter", "mitchell": "rfilter", "lanczos": "rfilter",
                  "direct": "integrator", "depth": "integrator", "moment": "integrator", "obj": "shape", "ply": "shape", "serialized": "shape", "rectangle": "shape", "diffuse": "bsdf", "area": "emitter", "constant": "emitter", "envmap": "emitter", "bitmap": "texture", "checkerboard": "texture", "scene": "scene"}
 
 

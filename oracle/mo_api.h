@@ -113,8 +113,9 @@ typedef struct {
     float near_clip, far_clip;
     int32_t film_w, film_h;     /* full film size */
     int32_t crop_x, crop_y, crop_w, crop_h;
-    int32_t rfilter;            /* 0 = gaussian, 1 = box */
-    float rfilter_param;        /* gaussian: stddev (0.5), box: radius (0.5) */
+    int32_t rfilter;            /* 0 gaussian, 1 box, 2 tent, 3 catmullrom, 4 mitchell, 5 lanczos */
+    float rfilter_param;        /* gaussian: stddev (0.5), box: radius (0.5), mitchell: B (1/3), lanczos: lobes (3) */
+    float rfilter_param2;       /* mitchell: C (1/3) */
     int32_t spp;
     uint64_t base_seed;         /* sampler "seed" property */
     int32_t max_depth, rr_depth;
@@ -158,11 +159,11 @@ void mo_camera_rays(const mo_render_desc *d, uint64_t n, const float *sx, const 
 /* Splat n samples (pos 2 floats, value ch floats) into a block of size (w,h) at offset (ox,oy)
  * with optional border; data: (h+2b)*(w+2b)*ch floats, accumulated in place.
  * returns the border size. */
-int mo_imageblock_put(int w, int h, int ox, int oy, int ch, int rfilter, float rfilter_param,
+int mo_imageblock_put(int w, int h, int ox, int oy, int ch, int rfilter, float rfilter_param, float rfilter_param2,
                       int border, int analytic, uint64_t n, const float *pos,
                       const float *values, float *data);
 /* ReconstructionFilter::eval_discretized table (32 entries), radius and border size */
-void mo_rfilter_table(int rfilter, float param, float *table32, float *radius, int *border);
+void mo_rfilter_table(int rfilter, float param, float param2, float *table32, float *radius, int *border);
 
 /* ---- unit-level entry points for known-answer tests --------------------- */
 uint32_t mo_kat_tea32(uint32_t v0, uint32_t v1, int rounds);

@@ -8,6 +8,7 @@
  *   Transform::perspective            include/mitsuba/core/transform.h:203-220
  *   ReconstructionFilter              include/mitsuba/core/rfilter.h:62-65, src/libcore/rfilter.cpp:9-20
  *   GaussianFilter / BoxFilter        src/rfilters/gaussian.cpp:33-47, src/rfilters/box.cpp:30-36
+ *   Tent / CatmullRom / Mitchell / Lanczos   src/rfilters/tent.cpp:27-35, catmullrom.cpp:23-43, mitchell.cpp:30-56, lanczos.cpp:33-48
  *   ImageBlock::put                   src/librender/imageblock.cpp:49-172
  *   accumulate_2d                     include/mitsuba/core/bitmap.h:657-716
  *   Spiral                            src/librender/spiral.cpp:8-74
@@ -152,20 +153,48 @@ typedef struct {
     float values[MO_FILTER_RES + 1];
 } rfilter;
 
-static float rfilter_eval(const rfilter *f, float x) {
-    if (f->kind == 0) return fmaxf(0.0f, expf(f->alpha * (x * x)) - f->bias);
-    return fabsf(x) <= f->radius ? 1.0f : 0.0f;
+/* B-spline family of mitchell.cpp:41-56 / catmullrom.cpp:29-43 (B = 0, C = 0.5) */
+static float cubic_filter(float x, float B, float C) {
+    x = fabsf(x);
+    float x2 = x * x, x3 = x2 * x;
+    float result = (1.0f / 6.0f) * (x < 1.0f
+        ? (12.0f - 9.0f * B - 6.0f * C) * x3 + (-18.0f + 12.0f * B + 6.0f * C) * x2 + (6.0f - 2.0f * B)
+        : (-B - 6.0f * C) * x3 + (6.0f * B + 30.0f * C) * x2 + (-12.0f * B - 48.0f * C) * x + (8.0f * B + 24.0f * C));
+    return x < 2.0f ? result : 0.0f;
 }
-static void rfilter_init(rfilter *f, int kind, float param) {
+static float rfilter_eval(const rfilter *f, float x) {
+    switch (f->kind) {
+    case 0: return fmaxf(0.0f, expf(f->alpha * (x * x)) - f->bias);
+    case 2: return fmaxf(0.0f, 1.0f - fabsf(x * f->alpha));                    /* tent.cpp:33-35, alpha = 1 / radius */
+    case 3: return cubic_filter(x, 0.0f, 0.5f);
+    case 4: return cubic_filter(x, f->alpha, f->bias);                         /* alpha = B, bias = C */
+    case 5: {                                                                  /* lanczos.cpp:38-48 */
+        x = fabsf(x);
+        float x1 = MO_PI_F * x, x2 = x1 / f->radius, result = (sinf(x1) * sinf(x2)) / (x1 * x2);
+        return x < MO_EPSILON ? 1.0f : (x > f->radius ? 0.0f : result);
+    }
+    default: return fabsf(x) <= f->radius ? 1.0f : 0.0f;
+    }
+}
+/* param / param2: gaussian stddev | box radius | mitchell B, C | lanczos lobes (the others take none) */
+static void rfilter_init(rfilter *f, int kind, float param, float param2) {
     f->kind = kind;
+    f->alpha = f->bias = 0;
     if (kind == 0) {
         float stddev = param;
         f->radius = 4 * stddev;
         f->alpha = -1.0f / (2.0f * stddev * stddev);
         f->bias = expf(f->alpha * (f->radius * f->radius));
+    } else if (kind == 2) {
+        f->radius = 1.0f; f->alpha = 1.0f / f->radius;
+    } else if (kind == 3) {
+        f->radius = 2.0f;
+    } else if (kind == 4) {
+        f->radius = 2.0f; f->alpha = param; f->bias = param2;
+    } else if (kind == 5) {
+        f->radius = (float) (int) param;
     } else {
         f->radius = param + MO_RAY_EPSILON;
-        f->alpha = f->bias = 0;
     }
     for (int i = 0; i < MO_FILTER_RES; ++i)
         f->values[i] = rfilter_eval(f, (f->radius * (float) i) / (float) MO_FILTER_RES);
@@ -178,8 +207,8 @@ static inline float rfilter_eval_discretized(const rfilter *f, float x) {
     if (idx > MO_FILTER_RES) idx = MO_FILTER_RES;
     return f->values[idx];
 }
-void mo_rfilter_table(int kind, float param, float *table32, float *radius, int *border) {
-    rfilter f; rfilter_init(&f, kind, param);
+void mo_rfilter_table(int kind, float param, float param2, float *table32, float *radius, int *border) {
+    rfilter f; rfilter_init(&f, kind, param, param2);
     memcpy(table32, f.values, sizeof(float) * 32);
     *radius = f.radius; *border = f.border;
 }
@@ -240,9 +269,9 @@ static int iblock_put(iblock *b, float px, float py, const float *value) {
     return 1;
 }
 
-int mo_imageblock_put(int w, int h, int ox, int oy, int ch, int kind, float param, int border,
+int mo_imageblock_put(int w, int h, int ox, int oy, int ch, int kind, float param, float param2, int border,
                       int analytic, uint64_t n, const float *pos, const float *values, float *data) {
-    rfilter f; rfilter_init(&f, kind, param);
+    rfilter f; rfilter_init(&f, kind, param, param2);
     iblock b = { w, h, ox, oy, ch, border ? f.border : 0, &f, analytic, data };
     for (uint64_t i = 0; i < n; ++i) iblock_put(&b, pos[2 * i], pos[2 * i + 1], values + (size_t) ch * i);
     return b.border;
@@ -717,7 +746,7 @@ int mo_sample_radiance(const mo_scene *s, const mo_render_desc *d, uint64_t firs
 static int render_wavefront_rows(const mo_scene *s, const mo_render_desc *d, int row0, int row1,
                                  float *film, uint64_t *stats) {
     camera cam; camera_init(d, &cam);
-    rfilter f; rfilter_init(&f, d->rfilter, d->rfilter_param);
+    rfilter f; rfilter_init(&f, d->rfilter, d->rfilter_param, d->rfilter_param2);
     /* ImageBlock(film_size, 5, filter, border = true) then film->put(block) (integrator.cpp:156-168) */
     iblock blk = { d->crop_w, d->crop_h, d->crop_x, d->crop_y, 5, f.border, &f, d->filter_analytic, NULL };
     blk.data = (float *) calloc(iblock_floats(&blk), sizeof(float));
@@ -759,7 +788,7 @@ int mo_render_rows(const mo_scene *s, const mo_render_desc *d, int row0, int row
 static int render_blocks(const mo_scene *s, const mo_render_desc *d, int n_threads, int block_size,
                          float *film, uint64_t *stats) {
     camera cam; camera_init(d, &cam);
-    rfilter f; rfilter_init(&f, d->rfilter, d->rfilter_param);
+    rfilter f; rfilter_init(&f, d->rfilter, d->rfilter_param, d->rfilter_param2);
     if (block_size == 0) {
         uint32_t bs = 32;
         while (1) {
@@ -928,7 +957,7 @@ int mo_render_adjoint(const mo_scene *s, const mo_render_desc *d, const float *d
                       float *grad_shape, float *grad_tex) {
     if (desc_check(d) || d->max_depth < 0 || d->max_depth > MO_ADJ_MAX_DEPTH) return -1;
     camera cam; camera_init(d, &cam);
-    rfilter f; rfilter_init(&f, d->rfilter, d->rfilter_param);
+    rfilter f; rfilter_init(&f, d->rfilter, d->rfilter_param, d->rfilter_param2);
     uint32_t taps = (uint32_t) ceilf((f.radius - 2.0f * MO_RAY_EPSILON) * 2.0f);
     /* texture gradient offsets: concatenated in index order */
     size_t *toff = (size_t *) calloc(s->n_textures + 1, sizeof(size_t));

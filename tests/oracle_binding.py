@@ -17,7 +17,7 @@ u32p = C.POINTER(C.c_uint32)
 class RenderDesc(C.Structure):
     _fields_ = [("to_world", C.c_float * 16), ("fov_x_deg", C.c_float), ("near_clip", C.c_float), ("far_clip", C.c_float),
                 ("film_w", C.c_int32), ("film_h", C.c_int32), ("crop_x", C.c_int32), ("crop_y", C.c_int32), ("crop_w", C.c_int32),
-                ("crop_h", C.c_int32), ("rfilter", C.c_int32), ("rfilter_param", C.c_float), ("spp", C.c_int32),
+                ("crop_h", C.c_int32), ("rfilter", C.c_int32), ("rfilter_param", C.c_float), ("rfilter_param2", C.c_float), ("spp", C.c_int32),
                 ("base_seed", C.c_uint64), ("max_depth", C.c_int32), ("rr_depth", C.c_int32), ("filter_analytic", C.c_int32),
                 ("film_rgb", C.c_int32), ("integrator", C.c_int32), ("emitter_samples", C.c_int32), ("bsdf_samples", C.c_int32),
                 ("hide_emitters", C.c_int32)]
@@ -84,8 +84,8 @@ def lib():
         L.mo_film_develop.argtypes = [vp, C.c_uint64, vp]
         L.mo_render_adjoint.argtypes = [vp, C.POINTER(RenderDesc), vp, vp, vp, vp]
         L.mo_camera_rays.argtypes = [C.POINTER(RenderDesc), C.c_uint64] + [vp] * 6
-        L.mo_imageblock_put.argtypes = [C.c_int] * 6 + [C.c_float, C.c_int, C.c_int, C.c_uint64, vp, vp, vp]
-        L.mo_rfilter_table.argtypes = [C.c_int, C.c_float, vp, f32p, C.POINTER(C.c_int)]
+        L.mo_imageblock_put.argtypes = [C.c_int] * 6 + [C.c_float, C.c_float, C.c_int, C.c_int, C.c_uint64, vp, vp, vp]
+        L.mo_rfilter_table.argtypes = [C.c_int, C.c_float, C.c_float, vp, f32p, C.POINTER(C.c_int)]
         L.mo_kat_tea32.restype = C.c_uint32
         L.mo_kat_tea32.argtypes = [C.c_uint32, C.c_uint32, C.c_int]
         L.mo_kat_tea64_u32.restype = C.c_uint64
@@ -292,8 +292,11 @@ def make_desc(params, analytic=False, film_rgb=False):
     d.near_clip, d.far_clip = params["near_clip"], params["far_clip"]
     d.film_w, d.film_h = params["width"], params["height"]
     d.crop_x, d.crop_y, d.crop_w, d.crop_h = params["crop"]
-    d.rfilter = 0 if params["rfilter"] == "gaussian" else 1
-    d.rfilter_param = params["rfilter_param"]
+    d.rfilter = RFILTERS[params["rfilter"]]
+    rp = params.get("rfilter_param")
+    rp = [] if rp is None else (list(rp) if isinstance(rp, (list, tuple)) else [rp])
+    rp = rp + RFILTER_DEFAULTS[params["rfilter"]][len(rp):]
+    d.rfilter_param, d.rfilter_param2 = float(rp[0]), float(rp[1])
     d.spp = params["sample_count"]
     d.base_seed = params["seed"]
     d.max_depth, d.rr_depth = params["max_depth"], params["rr_depth"]
@@ -322,19 +325,24 @@ def camera_rays(desc, sx, sy):
     return o, d, mint, maxt
 
 
-def imageblock_put(w, h, ox, oy, ch, rfilter, param, border, pos, values, analytic=False):
+RFILTERS = {"gaussian": 0, "box": 1, "tent": 2, "catmullrom": 3, "mitchell": 4, "lanczos": 5}
+RFILTER_DEFAULTS = {"gaussian": [0.5, 0.0], "box": [0.5, 0.0], "tent": [0.0, 0.0], "catmullrom": [0.0, 0.0], "mitchell": [1.0 / 3.0, 1.0 / 3.0],
+                    "lanczos": [3.0, 0.0]}
+
+
+def imageblock_put(w, h, ox, oy, ch, rfilter, param, border, pos, values, analytic=False, param2=0.0):
     pos, values = _f(pos).reshape(-1, 2), _f(values).reshape(-1, ch)
     tbl = np.empty(32, np.float32); radius = C.c_float(); b = C.c_int()
-    lib().mo_rfilter_table(rfilter, param, _p(tbl), C.byref(radius), C.byref(b))
+    lib().mo_rfilter_table(rfilter, param, param2, _p(tbl), C.byref(radius), C.byref(b))
     bs = b.value if border else 0
     data = np.zeros((h + 2 * bs, w + 2 * bs, ch), np.float32)
-    lib().mo_imageblock_put(w, h, ox, oy, ch, rfilter, param, 1 if border else 0, 1 if analytic else 0, pos.shape[0], _p(pos), _p(values), _p(data))
+    lib().mo_imageblock_put(w, h, ox, oy, ch, rfilter, param, param2, 1 if border else 0, 1 if analytic else 0, pos.shape[0], _p(pos), _p(values), _p(data))
     return data
 
 
-def rfilter_table(rfilter, param):
+def rfilter_table(rfilter, param=0.0, param2=0.0):
     tbl = np.empty(32, np.float32); radius = C.c_float(); b = C.c_int()
-    lib().mo_rfilter_table(rfilter, param, _p(tbl), C.byref(radius), C.byref(b))
+    lib().mo_rfilter_table(rfilter, param, param2, _p(tbl), C.byref(radius), C.byref(b))
     return tbl, radius.value, b.value
 
 

@@ -26,7 +26,7 @@ def test_header_symbols_are_exported():
     handle = C.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(handle, name), "libmtsamd.so does not export %s" % name
-    assert _lib.lib().mtsamd_abi_version() == 2
+    assert _lib.lib().mtsamd_abi_version() == 3
 
 
 def test_every_entry_point_cites_the_reference():
@@ -45,20 +45,23 @@ def test_argument_validation_without_gpu():
     assert b"null" in lib.mtsamd_last_error()
     table = (C.c_float * 32)()
     radius, border = C.c_float(), C.c_int32()
-    assert lib.mtsamd_rfilter_info(0, 0.5, table, C.byref(radius), C.byref(border)) == 0
+    assert lib.mtsamd_rfilter_info(0, 0.5, 0.0, table, C.byref(radius), C.byref(border)) == 0
     assert radius.value == 2.0 and border.value == 2 and table[31] == 0.0      # gaussian.cpp:33-47, rfilter.cpp:9-20
-    assert lib.mtsamd_rfilter_info(1, 0.5, table, C.byref(radius), C.byref(border)) == 0
+    assert lib.mtsamd_rfilter_info(1, 0.5, 0.0, table, C.byref(radius), C.byref(border)) == 0
     assert border.value == 0 and abs(radius.value - 0.5) < 1e-3                # box.cpp:30-36
-    assert lib.mtsamd_rfilter_info(7, 0.5, table, C.byref(radius), C.byref(border)) == -5
+    assert lib.mtsamd_rfilter_info(7, 0.5, 0.0, table, C.byref(radius), C.byref(border)) == -5
     with pytest.raises(RuntimeError, match="unsupported reconstruction filter"):
-        L.check(lib.mtsamd_rfilter_info(7, 0.5, table, C.byref(radius), C.byref(border)))
+        L.check(lib.mtsamd_rfilter_info(7, 0.5, 0.0, table, C.byref(radius), C.byref(border)))
 
 
 def test_rfilter_tables_match_oracle(oracle):
     from mitsuba2_amd import render
-    for cls, kind, param in ((render.GaussianFilter, 0, 0.5), (render.GaussianFilter, 0, 1.5), (render.BoxFilter, 1, 0.5), (render.BoxFilter, 1, 0.4)):
-        f = cls(param)
-        tbl, radius, border = oracle.rfilter_table(kind, param)
+    for cls, kind, params in ((render.GaussianFilter, 0, (0.5,)), (render.GaussianFilter, 0, (1.5,)), (render.BoxFilter, 1, (0.5,)),
+                              (render.BoxFilter, 1, (0.4,)), (render.TentFilter, 2, ()), (render.CatmullRomFilter, 3, ()),
+                              (render.MitchellFilter, 4, (1 / 3, 1 / 3)), (render.MitchellFilter, 4, (0.2, 0.6)),
+                              (render.LanczosFilter, 5, (3,)), (render.LanczosFilter, 5, (2,))):
+        f = cls(*params)
+        tbl, radius, border = oracle.rfilter_table(kind, *params)
         assert (f._table == tbl).all() and f.radius() == radius and f.border_size() == border
         for x in np.linspace(-radius * 1.2, radius * 1.2, 41):
             idx = min(int(abs(np.float32(x) * np.float32(31.0 / radius))), 31)

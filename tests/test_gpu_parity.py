@@ -179,6 +179,29 @@ def test_film_matches_oracle(gpu, oracle, rfilter):
     assert integ.stats["any_hit_rays"] <= stats[1]              # zero-contribution shadow rays are skipped
 
 
+@pytest.mark.parametrize("rfilter", [("tent", None), ("catmullrom", None), ("mitchell", None), ("mitchell", (0.2, 0.6)), ("lanczos", None),
+                                     ("lanczos", 2), ("gaussian", 1.2)])
+def test_film_with_other_reconstruction_filters(gpu, oracle, rfilter):
+    """src/rfilters/{tent,catmullrom,mitchell,lanczos}.cpp through ImageBlock::put: negative lobes, footprints of 1 (tent: radius
+    1 is not > 1, imageblock.cpp:117), 4 x 4 (tiled film kernel) and 6 x 6 / 10 x 10 pixels (general splat path); crop window
+    included so that the border logic is exercised"""
+    sd = scenes.cornell_box()
+    p = scenes.cornell_box_sensor(72, 56, 4, seed=6, rfilter=rfilter[0], rfilter_param=rfilter[1])
+    p["crop"] = (5, 3, 60, 50)
+    scene, sensor = gpu.Scene(sd), gpu.make_sensor(p)
+    assert gpu.PathIntegrator().render(scene, sensor)
+    film = sensor.film().bitmap(raw=True).cpu().numpy()
+    ref, _ = oracle.OracleScene(sd, naive=True).render(oracle.make_desc(p), mode=1)
+    assert film.shape == ref.shape
+    assert np.allclose(film[..., 4], ref[..., 4], rtol=1e-5, atol=2e-6)
+    assert np.allclose(film[..., 3], ref[..., 3], rtol=1e-5, atol=1e-5)
+    if rfilter[0] in ("catmullrom", "mitchell", "lanczos"):
+        assert ref[..., 4].min() > 0 and (ref[..., :3] < 0).any()           # negative lobes really occur
+    scale = np.abs(ref[..., :3]).mean()
+    assert np.abs(film[..., :3] - ref[..., :3]).max() < 2e-2 * scale
+    assert np.abs(film[..., :3] - ref[..., :3]).mean() < 1e-4 * scale
+
+
 def test_film_statistically_matches_scalar_block_mode(gpu, oracle):
     # scalar_rgb seeding (one PCG32 stream per spiral block) cannot be reproduced sample by sample on a
     # parallel machine; the estimates must agree statistically (z-test style, test_renders.py:60-78)

@@ -183,6 +183,22 @@ def test_rfilter_tables():
     assert radius == 60.0 and border == 60
 
 
+def test_rfilter_spot_values():
+    """src/rfilters/tests/test_rfilter.py:9-62 (test01 .. test06): eval_discretized spot checks of every filter"""
+    def disc(kind, x, param=0.0, param2=0.0):
+        tbl, radius, _ = ob.rfilter_table(kind, param, param2)
+        return float(tbl[min(int(abs(np.float32(x) * np.float32(31.0 / radius))), 31)])
+    assert disc(1, 0.49, 0.5) == 1 and disc(1, 0.51, 0.5) == 0                                        # box
+    assert abs(disc(0, 0.2, 0.5) - 0.9227) < 8e-3 and disc(0, 2.1, 0.5) == 0                         # gaussian
+    assert abs(disc(5, 1.4, 3) - (-0.14668)) < 1e-2 and disc(5, 3.1, 3) == 0                         # lanczos
+    assert abs(disc(4, 0.0, 1 / 3, 1 / 3) - 0.8888) < 1e-3 and disc(4, 2.1, 1 / 3, 1 / 3) == 0       # mitchell
+    assert abs(disc(3, 0.0) - 0.9765) < 5e-2 and disc(3, 2.1) == 0                                   # catmullrom
+    assert abs(disc(2, 0.1) - 0.903) < 5e-2 and disc(2, 1.1) == 0                                    # tent
+    for kind, radius, border in ((2, 1.0, 1), (3, 2.0, 2), (4, 2.0, 2), (5, 3.0, 3)):
+        _, r, b = ob.rfilter_table(kind, 3.0 if kind == 5 else 1 / 3, 1 / 3)
+        assert r == radius and b == border                                                            # rfilter.h:72-73
+
+
 def test_imageblock_box_put_lands_in_one_pixel():
     # src/librender/tests/test_imageblock.py:52-75 (test02): centre samples, box filter, 4 channels
     w, h, ch = 10, 5, 4
