@@ -220,6 +220,9 @@ typedef struct {
     int32_t hide_emitters;     /* direct: do not add directly visible emitters (integrator.cpp:39, direct.cpp:117-121) */
     int32_t moment;            /* != 0: `moment` integrator around the selected one (src/integrators/moment.cpp:56-99): the film
                                   has 11 channels X,Y,Z,A,W, nested.X,nested.Y,nested.Z, m2_nested.X,m2_nested.Y,m2_nested.Z */
+    /* ThinLensCamera (src/sensors/thinlens.cpp:110-118): aperture_radius > 0 selects the thin lens model -- two more sampler
+     * dimensions per camera sample (integrator.cpp:229-231) -- focused at focus_distance (sensor.cpp:104); 0: pinhole */
+    float aperture_radius, focus_distance;
 } mtsamd_render_desc;
 
 /* SamplingIntegrator::render for the `path` integrator (src/librender/integrator.cpp:52-176,
@@ -268,10 +271,11 @@ int mtsamd_rgb2spec_build(const char *path, int32_t resolution, int32_t threads)
 /* srgb_model_fetch (src/librender/srgb.cpp:14-40): coefficients of the smooth spectrum for a linear sRGB colour. */
 int mtsamd_srgb_model_fetch(const char *path, const float *rgb3, float *coeff3);
 
-/* PerspectiveCamera::sample_ray (perspective.cpp:153-188) for n film-plane samples in [0,1)^2
+/* PerspectiveCamera::sample_ray (perspective.cpp:153-188) / ThinLensCamera::sample_ray (thinlens.cpp:175-214) for n
+ * film-plane samples in [0,1)^2 and, for a thin lens, n aperture samples (NULL: 0.5, as integrator.cpp:229 initialises them)
  * (device SoA in, device SoA out). */
 int mtsamd_camera_sample_rays(const mtsamd_render_desc *desc, uint64_t n, const float *sx,
-                              const float *sy, float *ox, float *oy, float *oz, float *dx,
+                              const float *sy, const float *aperture_x, const float *aperture_y, float *ox, float *oy, float *oz, float *dx,
                               float *dy, float *dz, float *mint, float *maxt, void *stream);
 
 /* ---- ImageBlock / Film ------------------------------------------------------- */

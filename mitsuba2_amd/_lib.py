@@ -58,7 +58,8 @@ class RenderDesc(C.Structure):
                 ("rr_depth", C.c_int32), ("row_begin", C.c_int32), ("row_end", C.c_int32), ("part_index", C.c_int32),
                 ("part_count", C.c_int32), ("part_tile_rows", C.c_int32), ("paths_per_wave", C.c_int32),
                 ("pipeline", C.c_int32), ("film_rgb", C.c_int32), ("integrator", C.c_int32), ("emitter_samples", C.c_int32),
-                ("bsdf_samples", C.c_int32), ("hide_emitters", C.c_int32), ("moment", C.c_int32)]
+                ("bsdf_samples", C.c_int32), ("hide_emitters", C.c_int32), ("moment", C.c_int32),
+                ("aperture_radius", C.c_float), ("focus_distance", C.c_float)]
 
 
 # every symbol include/mtsamd.h declares: name -> (restype, argtypes)
@@ -85,7 +86,7 @@ SYMBOLS = {
     "mtsamd_scene_roughplastic_tables": (C.c_int, [vp, C.c_uint32, f32p]),
     "mtsamd_scene_texture_info": (C.c_int, [vp, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), u64p]),
     "mtsamd_sample_radiance": (C.c_int, [vp, C.POINTER(RenderDesc), C.c_uint64, C.c_uint64, vp, vp, vp]),
-    "mtsamd_camera_sample_rays": (C.c_int, [C.POINTER(RenderDesc), C.c_uint64] + [vp] * 11),
+    "mtsamd_camera_sample_rays": (C.c_int, [C.POINTER(RenderDesc), C.c_uint64] + [vp] * 13),
     "mtsamd_imageblock_put": (C.c_int, [C.c_int32] * 6 + [C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_uint64, vp, vp, vp, vp]),
     "mtsamd_imageblock_put_block": (C.c_int, [vp] + [C.c_int32] * 5 + [vp] + [C.c_int32] * 6 + [vp]),
     "mtsamd_rfilter_info": (C.c_int, [C.c_int32, C.c_float, C.c_float, f32p, f32p, C.POINTER(C.c_int32)]),

@@ -103,6 +103,9 @@ int make_camera(const mtsamd_render_desc &d, CameraView &c) {
     for (int r = 0; r < 4; ++r) for (int j = 0; j < 4; ++j) c.s2c[4 * r + j] = s2c.m[r][j];
     std::memcpy(c.c2w, d.to_world, sizeof(float) * 16);
     c.near_clip = d.near_clip; c.far_clip = d.far_clip;
+    if (d.aperture_radius < 0.0f) return fail(MTSAMD_ERR_INVALID, "The 'aperture_radius' parameter must not be negative");
+    c.aperture_radius = d.aperture_radius; c.focus_distance = d.focus_distance;
+    if (d.aperture_radius > 0.0f && !(d.focus_distance > 0.0f)) return fail(MTSAMD_ERR_INVALID, "thinlens: 'focus_distance' must be positive");
     return 0;
 }
 
@@ -1242,12 +1245,12 @@ int mtsamd_sample_radiance(mtsamd_scene *s, const mtsamd_render_desc *d, uint64_
     return MTSAMD_OK;
 }
 
-int mtsamd_camera_sample_rays(const mtsamd_render_desc *d, uint64_t n, const float *sx, const float *sy, float *ox, float *oy,
+int mtsamd_camera_sample_rays(const mtsamd_render_desc *d, uint64_t n, const float *sx, const float *sy, const float *apx, const float *apy, float *ox, float *oy,
                               float *oz, float *dx, float *dy, float *dz, float *mint, float *maxt, void *stream) {
     if (!d || !sx || !sy || !ox || !oy || !oz || !dx || !dy || !dz || !mint || !maxt) return fail(MTSAMD_ERR_INVALID, "null argument");
     CameraView cam;
     if (int rc = make_camera(*d, cam)) return rc;
-    HIP_TRY(launch_camera_rays(cam, n, sx, sy, ox, oy, oz, dx, dy, dz, mint, maxt, (hipStream_t) stream));
+    HIP_TRY(launch_camera_rays(cam, n, sx, sy, apx, apy, ox, oy, oz, dx, dy, dz, mint, maxt, (hipStream_t) stream));
     return MTSAMD_OK;
 }
 

@@ -610,13 +610,15 @@ MTS_DEV f3 srgb_to_xyz(f3 c) {
 }
 
 // ---------------------------------------------------------------------------
-// PerspectiveCamera::sample_ray_differential (perspective.cpp:190-222), ray part.
+// PerspectiveCamera::sample_ray_differential (perspective.cpp:190-222), ray part; with an aperture
+// (aperture_radius > 0): ThinLensCamera::sample_ray (thinlens.cpp:175-214).
 struct CameraView {
     float s2c[16];      // sample_to_camera, row-major
     float c2w[16];      // to_world, row-major
     float near_clip, far_clip;
+    float aperture_radius, focus_distance;
 };
-MTS_DEV void camera_ray(const CameraView &c, float sx, float sy, f3 &o, f3 &d, float &mint, float &maxt) {
+MTS_DEV void camera_ray(const CameraView &c, float sx, float sy, f2 aperture_sample, f3 &o, f3 &d, float &mint, float &maxt) {
     float r[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -627,11 +629,30 @@ MTS_DEV void camera_ray(const CameraView &c, float sx, float sy, f3 &o, f3 &d, f
         r[k] = acc;
     }
     float iw = rcp(r[3]);
-    f3 dl = normalize(mk3(r[0] * iw, r[1] * iw, r[2] * iw));
+    const f3 near_p = mk3(r[0] * iw, r[1] * iw, r[2] * iw);
+    f3 dl;
+    if (c.aperture_radius > 0.0f) {
+        const f2 t = square_to_uniform_disk_concentric(aperture_sample);
+        const f3 aperture_p = mk3(c.aperture_radius * t.x, c.aperture_radius * t.y, 0.0f);
+        const f3 focus_p = near_p * (c.focus_distance / near_p.z);
+        dl = normalize(focus_p - aperture_p);
+        float oo[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {                        // transform_affine(aperture_p)
+            float acc = c.c2w[4 * k + 3];
+            acc = fmaf(c.c2w[4 * k + 0], aperture_p.x, acc);
+            acc = fmaf(c.c2w[4 * k + 1], aperture_p.y, acc);
+            acc = fmaf(c.c2w[4 * k + 2], aperture_p.z, acc);
+            oo[k] = acc;
+        }
+        o = mk3(oo[0], oo[1], oo[2]);
+    } else {
+        dl = normalize(near_p);
+        o = mk3(c.c2w[3], c.c2w[7], c.c2w[11]);
+    }
     float inv_z = rcp(dl.z);
     mint = c.near_clip * inv_z;
     maxt = c.far_clip * inv_z;
-    o = mk3(c.c2w[3], c.c2w[7], c.c2w[11]);
     float dd[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {

@@ -115,7 +115,7 @@ hipError_t launch_ray_intersect(const SceneView &sv, uint64_t n, const RayStream
                                 uint32_t *prim, uint32_t *shape, float *u, float *v, float *si26,
                                 hipStream_t s);
 hipError_t launch_ray_test(const SceneView &sv, uint64_t n, const RayStreams &r, uint8_t *hit, hipStream_t s);
-hipError_t launch_camera_rays(const CameraView &cam, uint64_t n, const float *sx, const float *sy, float *ox,
+hipError_t launch_camera_rays(const CameraView &cam, uint64_t n, const float *sx, const float *sy, const float *apx, const float *apy, float *ox,
                               float *oy, float *oz, float *dx, float *dy, float *dz, float *mint, float *maxt,
                               hipStream_t s);
 hipError_t launch_imageblock_put(const FilterView &f, int32_t w, int32_t h, int32_t ox, int32_t oy, int32_t ch,

@@ -221,9 +221,11 @@ MTS_DEV void generate_path(const RenderParams &P, uint64_t ordinal, uint32_t lp,
     seed_sample(s.rng, index, P.base_seed);
     float jx = pcg_next_f32(s.rng), jy = pcg_next_f32(s.rng);
     float psx = ((float) px + (float) P.crop_x) + jx, psy = ((float) py + (float) P.crop_y) + jy;
+    f2 ap; ap.x = ap.y = 0.5f;                               // needs_aperture_sample(): integrator.cpp:229-231
+    if (P.cam.aperture_radius > 0.0f) { ap.x = pcg_next_f32(s.rng); ap.y = pcg_next_f32(s.rng); }
     (void) pcg_next_f32(s.rng);                              // wavelength sample (drawn even in RGB mode)
     float ax = (psx - (float) P.crop_x) / (float) P.crop_w, ay = (psy - (float) P.crop_y) / (float) P.crop_h;
-    camera_ray(P.cam, ax, ay, s.o, s.d, s.mint, s.maxt);
+    camera_ray(P.cam, ax, ay, ap, s.o, s.d, s.mint, s.maxt);
     s.thr = mk3(1.0f, 1.0f, 1.0f); s.bs_pdf = 0.0f;
     s.res = mk3(0.0f, 0.0f, 0.0f); s.eta = 1.0f;
     s.ordinal = P.plane_pixels ? j * P.plane_pixels + (lp - P.plane_pix0) : (uint32_t) (ordinal - P.first_ordinal);
@@ -589,10 +591,12 @@ MTS_DEV void generate_path_spectral(const RenderParams &P, uint64_t ordinal, uin
     seed_sample(s.rng, index, P.base_seed);
     float jx = pcg_next_f32(s.rng), jy = pcg_next_f32(s.rng);
     float psx = ((float) px + (float) P.crop_x) + jx, psy = ((float) py + (float) P.crop_y) + jy;
+    f2 ap; ap.x = ap.y = 0.5f;
+    if (P.cam.aperture_radius > 0.0f) { ap.x = pcg_next_f32(s.rng); ap.y = pcg_next_f32(s.rng); }
     Spec4 weight;
     sample_wavelengths(pcg_next_f32(s.rng), s.wav, weight);    // integrator.cpp:237, perspective.cpp:196
     float ax = (psx - (float) P.crop_x) / (float) P.crop_w, ay = (psy - (float) P.crop_y) / (float) P.crop_h;
-    camera_ray(P.cam, ax, ay, s.o, s.d, s.mint, s.maxt);
+    camera_ray(P.cam, ax, ay, ap, s.o, s.d, s.mint, s.maxt);
 #pragma unroll
     for (int k = 0; k < kWav; ++k) { s.thr.v[k] = 1.0f; s.res.v[k] = 0.0f; }
     s.bs_pdf = 0.0f; s.eta = 1.0f;
@@ -1442,18 +1446,19 @@ hipError_t launch_ray_test(const SceneView &sv, uint64_t n, const RayStreams &r,
 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_camera_rays(const CameraView cam, uint64_t n, const float *sx, const float *sy,
-                                                        float *ox, float *oy, float *oz, float *dx, float *dy, float *dz,
+                                                        const float *apx, const float *apy, float *ox, float *oy, float *oz, float *dx, float *dy, float *dz,
                                                         float *mint, float *maxt) {
     for (uint64_t i = (uint64_t) blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t) gridDim.x * kBlock) {
         f3 o, d; float t0, t1;
-        camera_ray(cam, sx[i], sy[i], o, d, t0, t1);
+        f2 ap; ap.x = apx ? apx[i] : 0.5f; ap.y = apy ? apy[i] : 0.5f;
+        camera_ray(cam, sx[i], sy[i], ap, o, d, t0, t1);
         ox[i] = o.x; oy[i] = o.y; oz[i] = o.z; dx[i] = d.x; dy[i] = d.y; dz[i] = d.z; mint[i] = t0; maxt[i] = t1;
     }
 }
-hipError_t launch_camera_rays(const CameraView &cam, uint64_t n, const float *sx, const float *sy, float *ox, float *oy,
+hipError_t launch_camera_rays(const CameraView &cam, uint64_t n, const float *sx, const float *sy, const float *apx, const float *apy, float *ox, float *oy,
                               float *oz, float *dx, float *dy, float *dz, float *mint, float *maxt, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_camera_rays, dim3(stream_grid(n)), dim3(kBlock), 0, s, cam, n, sx, sy, ox, oy, oz, dx, dy, dz, mint, maxt);
+    hipLaunchKernelGGL(k_camera_rays, dim3(stream_grid(n)), dim3(kBlock), 0, s, cam, n, sx, sy, apx, apy, ox, oy, oz, dx, dy, dz, mint, maxt);
     return hipGetLastError();
 }
 

@@ -387,18 +387,55 @@ class PerspectiveCamera:
         d.rfilter_analytic = 0
         d.sample_count = self._sampler.sample_count()
         d.seed = self._sampler.seed_value()
+        d.aperture_radius, d.focus_distance = 0.0, 0.0
 
-    def sample_ray(self, position_sample):
-        """perspective.cpp:153-188 for (N,2) film-plane samples in [0,1)^2 -> Ray3f."""
+    def needs_aperture_sample(self):
+        return False
+
+    def sample_ray(self, position_sample, aperture_sample=None):
+        """perspective.cpp:153-188 / thinlens.cpp:175-214 for (N,2) film-plane samples in [0,1)^2 (and (N,2) aperture samples)
+        -> Ray3f."""
         ps = torch.as_tensor(position_sample, dtype=torch.float32, device="cuda").reshape(-1, 2)
         n = ps.shape[0]
         sx, sy = ps[:, 0].contiguous(), ps[:, 1].contiguous()
+        apx = apy = None
+        if aperture_sample is not None:
+            ap = torch.as_tensor(aperture_sample, dtype=torch.float32, device="cuda").reshape(-1, 2)
+            if ap.shape[0] != n:
+                raise RuntimeError("aperture_sample must have one entry per position sample")
+            apx, apy = ap[:, 0].contiguous(), ap[:, 1].contiguous()
         out = torch.empty((8, n), dtype=torch.float32, device="cuda")
         d = L.RenderDesc()
         self._fill_desc(d)
         d.max_depth, d.rr_depth = -1, 5
-        L.check(L.lib().mtsamd_camera_sample_rays(C.byref(d), n, _ptr(sx), _ptr(sy), *[_ptr(out[k]) for k in range(8)], _stream()))
+        L.check(L.lib().mtsamd_camera_sample_rays(C.byref(d), n, _ptr(sx), _ptr(sy), _ptr(apx) if apx is not None else None,
+                                                  _ptr(apy) if apy is not None else None, *[_ptr(out[k]) for k in range(8)], _stream()))
         return Ray3f(o=out[0:3].t().contiguous(), d=out[3:6].t().contiguous(), mint=out[6].clone(), maxt=out[7].clone())
+
+
+class ThinLensCamera(PerspectiveCamera):
+    """src/sensors/thinlens.cpp: perspective camera with a circular aperture focused at `focus_distance`"""
+
+    def __init__(self, aperture_radius=None, focus_distance=None, **kwargs):
+        super().__init__(**kwargs)
+        if aperture_radius is None:
+            raise RuntimeError('Property "aperture_radius" has not been specified!')       # props.float_("aperture_radius"), thinlens.cpp:112
+        self._aperture_radius = float(aperture_radius)
+        if self._aperture_radius == 0.0:              # thinlens.cpp:114-117
+            self._aperture_radius = float(np.finfo(np.float32).eps) / 2
+        if self._aperture_radius < 0.0:
+            raise RuntimeError("The 'aperture_radius' parameter must not be negative")
+        self._focus_distance = float(focus_distance) if focus_distance is not None else self._far      # sensor.cpp:104
+
+    def aperture_radius(self): return self._aperture_radius
+    def focus_distance(self): return self._focus_distance
+
+    def needs_aperture_sample(self):
+        return True
+
+    def _fill_desc(self, d):
+        super()._fill_desc(d)
+        d.aperture_radius, d.focus_distance = self._aperture_radius, self._focus_distance
 
 
 def srgb_coeff_path(build=True):
@@ -747,5 +784,7 @@ def make_sensor(params):
     cx, cy, cw, ch = params["crop"]
     film = HDRFilm(params["width"], params["height"], (cx, cy), (cw, ch), flt)
     sampler = IndependentSampler(params["sample_count"], params["seed"])
-    return PerspectiveCamera(to_world=params["to_world"], fov=params["fov"], near_clip=params["near_clip"],
-                             far_clip=params["far_clip"], film=film, sampler=sampler)
+    kw = dict(to_world=params["to_world"], fov=params["fov"], near_clip=params["near_clip"], far_clip=params["far_clip"], film=film, sampler=sampler)
+    if params.get("aperture_radius") is not None:
+        return ThinLensCamera(aperture_radius=params["aperture_radius"], focus_distance=params.get("focus_distance"), **kw)
+    return PerspectiveCamera(**kw)

@@ -1,6 +1,6 @@
 """Scene description loading: the subset of the reference's XML format
 (``src/libcore/xml.cpp``) and ``load_dict`` needed to drive the hot path -- ``scene`` / ``integrator`` (path) /
-``sensor`` (perspective) / ``sampler`` (independent) / ``film`` (hdrfilm) / ``rfilter`` (gaussian, box, tent, catmullrom, mitchell, lanczos) / ``shape``
+``sensor`` (perspective, thinlens) / ``sampler`` (independent) / ``film`` (hdrfilm) / ``rfilter`` (gaussian, box, tent, catmullrom, mitchell, lanczos) / ``shape``
 (obj, ply, rectangle) / ``bsdf`` (diffuse) / ``texture`` (bitmap) / ``emitter`` (area), with ``default`` + ``$param``
 substitution, ``ref``/``id`` resolution, ``alias``, ``include`` and the ``transform`` operations.
 
@@ -524,15 +524,19 @@ def _shape(ctx, node, desc, cache, base_dir):
 
 
 def _sensor(ctx, node):
-    if node.type != "perspective":
-        raise XMLError('Sensor plugin "%s" is not supported by this backend (perspective only)' % node.type)
-    out = dict(to_world=node.get("to_world", np.eye(4, dtype=F32), "transform"), near_clip=node.get("near_clip", 1e-2, "float"),
+    if node.type not in ("perspective", "thinlens"):
+        raise XMLError('Sensor plugin "%s" is not supported by this backend (perspective, thinlens)' % node.type)
+    out = dict(type=node.type, to_world=node.get("to_world", np.eye(4, dtype=F32), "transform"), near_clip=node.get("near_clip", 1e-2, "float"),
                far_clip=node.get("far_clip", 1e4, "float"), fov_axis=node.get("fov_axis", "x", "string"), fov=None, focal_length=None)
     if "fov" in node.props:
         out["fov"] = node.get("fov", kind="float")
     if "focal_length" in node.props:
         out["focal_length"] = node.get("focal_length", kind="string")
-    node.get("focus_distance", 0.0, "float")       # ProjectiveCamera (sensor.cpp:96-103): irrelevant for a pinhole camera
+    out["focus_distance"] = node.get("focus_distance", out["far_clip"], "float")       # ProjectiveCamera (sensor.cpp:104); unused by a pinhole camera
+    if node.type == "thinlens":
+        if "aperture_radius" not in node.props:
+            raise XMLError('Property "aperture_radius" has not been specified!')          # thinlens.cpp:112
+        out["aperture_radius"] = node.get("aperture_radius", kind="float")
     if node.get("shutter_close", 0.0, "float") != node.get("shutter_open", 0.0, "float"):
         raise XMLError("sensor: a non-zero shutter time (motion blur) is not supported by this backend")
     film = dict(width=768, height=576, crop_offset=None, crop_size=None, rfilter=("gaussian", 0.5))
@@ -688,8 +692,12 @@ def instantiate(desc, device=0, variant="rgb"):
         extra = {k: f[k] for k in ("file_format", "pixel_format", "component_format", "high_quality_edges") if k in f}
         film = R.HDRFilm(f["width"], f["height"], f["crop_offset"], f["crop_size"], flt, **extra)
         sampler = R.IndependentSampler(s["sampler"]["sample_count"], s["sampler"]["seed"])
-        sensors.append(R.PerspectiveCamera(to_world=s["to_world"], fov=s["fov"], focal_length=s["focal_length"], fov_axis=s["fov_axis"],
-                                           near_clip=s["near_clip"], far_clip=s["far_clip"], film=film, sampler=sampler))
+        kw = dict(to_world=s["to_world"], fov=s["fov"], focal_length=s["focal_length"], fov_axis=s["fov_axis"],
+                  near_clip=s["near_clip"], far_clip=s["far_clip"], film=film, sampler=sampler)
+        if s.get("type", "perspective") == "thinlens":
+            sensors.append(R.ThinLensCamera(aperture_radius=s["aperture_radius"], focus_distance=s.get("focus_distance"), **kw))
+        else:
+            sensors.append(R.PerspectiveCamera(**kw))
     integ = _make_integrator(desc.integrator) if desc.integrator is not None else None
     scene = R.Scene(desc.scene_dict, device=device, integrator=integ, variant=variant)
     scene._sensors = sensors
@@ -707,7 +715,7 @@ def load_file(path, device=0, variant="rgb", **params):
 
 
 # -------------------------------------------------------------------------------------------- load_dict
-_PLUGIN_CLASS = {"twosided": "bsdf", "conductor": "bsdf", "roughconductor": "bsdf", "dielectric": "bsdf", "plastic": "bsdf", "roughplastic": "bsdf", "roughdielectric": "bsdf", "path": "integrator", "perspective": "sensor", "hdrfilm": "film", "independent": "sampler", "gaussian": "rfilter", "box": "rfilter", "tent": "rfilter", "catmullrom": "rfilter", "mitchell": "rfilter", "lanczos": "rfilter",
+_PLUGIN_CLASS = {"twosided": "bsdf", "conductor": "bsdf", "roughconductor": "bsdf", "dielectric": "bsdf", "plastic": "bsdf", "roughplastic": "bsdf", "roughdielectric": "bsdf", "path": "integrator", "perspective": "sensor", "thinlens": "sensor", "hdrfilm": "film", "independent": "sampler", "gaussian": "rfilter", "box": "rfilter", "tent": "rfilter", "catmullrom": "rfilter", "mitchell": "rfilter", "lanczos": "rfilter",
                  "direct": "integrator", "depth": "integrator", "moment": "integrator", "obj": "shape", "ply": "shape", "serialized": "shape", "rectangle": "shape", "diffuse": "bsdf", "area": "emitter", "constant": "emitter", "envmap": "emitter", "bitmap": "texture", "checkerboard": "texture", "scene": "scene"}
 
 

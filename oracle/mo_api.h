@@ -124,6 +124,8 @@ typedef struct {
     int32_t integrator;         /* 0: path (src/integrators/path.cpp), 1: direct (direct.cpp), 2: depth (depth.cpp) */
     int32_t emitter_samples, bsdf_samples;   /* direct: samples per technique (0, 0 = shading_samples default 1, 1) */
     int32_t hide_emitters;      /* direct (integrator.cpp:39, direct.cpp:117-121) */
+    float aperture_radius;      /* 0: `perspective` (src/sensors/perspective.cpp); > 0: `thinlens` (src/sensors/thinlens.cpp) */
+    float focus_distance;       /* thinlens: distance of the plane in focus (sensor.cpp:104, default far_clip) */
 } mo_render_desc;
 
 /* mode 0: scalar_rgb block mode (spiral blocks, Morton order, one PCG32 stream per block);
@@ -152,7 +154,7 @@ void mo_film_develop(const float *xyzaw, uint64_t n_pixels, float *rgba);
 
 /* ---- camera ------------------------------------------------------------ */
 /* PerspectiveCamera::sample_ray (perspective.cpp:106-188) for n film samples in [0,1)^2 */
-void mo_camera_rays(const mo_render_desc *d, uint64_t n, const float *sx, const float *sy,
+void mo_camera_rays(const mo_render_desc *d, uint64_t n, const float *sx, const float *sy, const float *aperture2 /* or NULL */,
                     float *o3, float *d3, float *mint, float *maxt);
 
 /* ---- ImageBlock (imageblock.cpp:8-172) ---------------------------------- */

@@ -83,6 +83,7 @@ static xform xf_perspective(float fov, float near_, float far_) {
 typedef struct {
     mat4 sample_to_camera, to_world;
     float near_clip, far_clip;
+    float aperture_radius, focus_distance;       /* thin lens (aperture_radius > 0) */
 } camera;
 
 /* perspective.cpp:106-131 */
@@ -102,10 +103,12 @@ static void camera_init(const mo_render_desc *d, camera *c) {
     c->sample_to_camera = mat_transpose(&c2s.inv_t);
     memcpy(c->to_world.m, d->to_world, sizeof(float) * 16);
     c->near_clip = d->near_clip; c->far_clip = d->far_clip;
+    c->aperture_radius = d->aperture_radius; c->focus_distance = d->focus_distance;
 }
 
-/* perspective.cpp:190-222 (ray part; differentials are unused by `path` with constant textures) */
-static void camera_sample_ray(const camera *c, float sx, float sy, mo_ray *ray) {
+/* perspective.cpp:190-222 (ray part; differentials are unused by `path` with constant textures); with an aperture:
+ * ThinLensCamera::sample_ray (thinlens.cpp:175-214) */
+static void camera_sample_ray(const camera *c, float sx, float sy, float ap_x, float ap_y, mo_ray *ray) {
     const mat4 *m = &c->sample_to_camera;
     float r[4];
     for (int k = 0; k < 4; ++k) {
@@ -117,12 +120,30 @@ static void camera_sample_ray(const camera *c, float sx, float sy, mo_ray *ray) 
     }
     float iw = mo_rcp(r[3]);
     mo_v3 near_p = mo_v3_make(r[0] * iw, r[1] * iw, r[2] * iw);
-    mo_v3 dl = mo_normalize(near_p);
+    mo_v3 dl;
+    const mat4 *w = &c->to_world;
+    if (c->aperture_radius > 0.0f) {
+        mo_v2 aps = { ap_x, ap_y };
+        mo_v2 t = mo_square_to_uniform_disk_concentric(aps);
+        mo_v3 aperture_p = mo_v3_make(c->aperture_radius * t.x, c->aperture_radius * t.y, 0.0f);
+        mo_v3 focus_p = mo_scale(near_p, c->focus_distance / near_p.z);
+        dl = mo_normalize(mo_sub(focus_p, aperture_p));
+        float o[3];
+        for (int k = 0; k < 3; ++k) {                   /* transform_affine(aperture_p) */
+            float acc = w->m[k][3];
+            acc = fmaf(w->m[k][0], aperture_p.x, acc);
+            acc = fmaf(w->m[k][1], aperture_p.y, acc);
+            acc = fmaf(w->m[k][2], aperture_p.z, acc);
+            o[k] = acc;
+        }
+        ray->o = mo_v3_make(o[0], o[1], o[2]);
+    } else {
+        dl = mo_normalize(near_p);
+        ray->o = mo_v3_make(w->m[0][3], w->m[1][3], w->m[2][3]);
+    }
     float inv_z = mo_rcp(dl.z);
     ray->mint = c->near_clip * inv_z;
     ray->maxt = c->far_clip * inv_z;
-    const mat4 *w = &c->to_world;
-    ray->o = mo_v3_make(w->m[0][3], w->m[1][3], w->m[2][3]);
     float dd[3];
     for (int k = 0; k < 3; ++k) {
         float acc = w->m[k][0] * dl.x;
@@ -133,11 +154,11 @@ static void camera_sample_ray(const camera *c, float sx, float sy, mo_ray *ray) 
     ray->d = mo_v3_make(dd[0], dd[1], dd[2]);
 }
 
-void mo_camera_rays(const mo_render_desc *d, uint64_t n, const float *sx, const float *sy, float *o3,
+void mo_camera_rays(const mo_render_desc *d, uint64_t n, const float *sx, const float *sy, const float *ap, float *o3,
                     float *d3, float *mint, float *maxt) {
     camera c; camera_init(d, &c);
     for (uint64_t i = 0; i < n; ++i) {
-        mo_ray r; camera_sample_ray(&c, sx[i], sy[i], &r);
+        mo_ray r; camera_sample_ray(&c, sx[i], sy[i], ap ? ap[2 * i] : 0.5f, ap ? ap[2 * i + 1] : 0.5f, &r);
         o3[3 * i] = r.o.x; o3[3 * i + 1] = r.o.y; o3[3 * i + 2] = r.o.z;
         d3[3 * i] = r.d.x; d3[3 * i + 1] = r.d.y; d3[3 * i + 2] = r.d.z;
         mint[i] = r.mint; maxt[i] = r.maxt;
@@ -681,9 +702,11 @@ static void render_sample(const mo_scene *s, const mo_render_desc *d, const came
                           int *valid_out, ray_stats *st) {
     float jx = mo_pcg32_next_f32(rng), jy = mo_pcg32_next_f32(rng);
     float psx = pos_x + jx, psy = pos_y + jy;
+    float apx = 0.5f, apy = 0.5f;                         /* needs_aperture_sample(): integrator.cpp:229-231 */
+    if (cam->aperture_radius > 0.0f) { apx = mo_pcg32_next_f32(rng); apy = mo_pcg32_next_f32(rng); }
     float wavelength_sample = mo_pcg32_next_f32(rng);
     float ax = (psx - (float) d->crop_x) / (float) d->crop_w, ay = (psy - (float) d->crop_y) / (float) d->crop_h;
-    mo_ray ray; camera_sample_ray(cam, ax, ay, &ray);
+    mo_ray ray; camera_sample_ray(cam, ax, ay, apx, apy, &ray);
     float L[3] = { 0, 0, 0 }; int valid;
     float xyz[3];
     if (s->spectral) {
@@ -969,9 +992,11 @@ int mo_render_adjoint(const mo_scene *s, const mo_render_desc *d, const float *d
         float px0 = (float) (uint32_t) (pixel % (uint64_t) d->crop_w) + (float) d->crop_x, py0 = (float) (uint32_t) (pixel / (uint64_t) d->crop_w) + (float) d->crop_y;
         float jx = mo_pcg32_next_f32(&rng), jy = mo_pcg32_next_f32(&rng);
         float psx = px0 + jx, psy = py0 + jy;
+        float apx = 0.5f, apy = 0.5f;
+        if (cam.aperture_radius > 0.0f) { apx = mo_pcg32_next_f32(&rng); apy = mo_pcg32_next_f32(&rng); }
         (void) mo_pcg32_next_f32(&rng);
         float ax = (psx - (float) d->crop_x) / (float) d->crop_w, ay = (psy - (float) d->crop_y) / (float) d->crop_h;
-        mo_ray ray; camera_sample_ray(&cam, ax, ay, &ray);
+        mo_ray ray; camera_sample_ray(&cam, ax, ay, apx, apy, &ray);
         /* delta = dLoss/dRadiance of this sample */
         float delta[3] = { 0, 0, 0 };
         float px = psx - ((float) d->crop_x + 0.5f), py = psy - ((float) d->crop_y + 0.5f);

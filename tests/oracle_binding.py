@@ -20,7 +20,7 @@ class RenderDesc(C.Structure):
                 ("crop_h", C.c_int32), ("rfilter", C.c_int32), ("rfilter_param", C.c_float), ("rfilter_param2", C.c_float), ("spp", C.c_int32),
                 ("base_seed", C.c_uint64), ("max_depth", C.c_int32), ("rr_depth", C.c_int32), ("filter_analytic", C.c_int32),
                 ("film_rgb", C.c_int32), ("integrator", C.c_int32), ("emitter_samples", C.c_int32), ("bsdf_samples", C.c_int32),
-                ("hide_emitters", C.c_int32)]
+                ("hide_emitters", C.c_int32), ("aperture_radius", C.c_float), ("focus_distance", C.c_float)]
 
 
 class BsdfDesc(C.Structure):
@@ -83,7 +83,7 @@ def lib():
         L.mo_render_rows.argtypes = [vp, C.POINTER(RenderDesc), C.c_int, C.c_int, vp]
         L.mo_film_develop.argtypes = [vp, C.c_uint64, vp]
         L.mo_render_adjoint.argtypes = [vp, C.POINTER(RenderDesc), vp, vp, vp, vp]
-        L.mo_camera_rays.argtypes = [C.POINTER(RenderDesc), C.c_uint64] + [vp] * 6
+        L.mo_camera_rays.argtypes = [C.POINTER(RenderDesc), C.c_uint64] + [vp] * 7
         L.mo_imageblock_put.argtypes = [C.c_int] * 6 + [C.c_float, C.c_float, C.c_int, C.c_int, C.c_uint64, vp, vp, vp]
         L.mo_rfilter_table.argtypes = [C.c_int, C.c_float, C.c_float, vp, f32p, C.POINTER(C.c_int)]
         L.mo_kat_tea32.restype = C.c_uint32
@@ -305,6 +305,9 @@ def make_desc(params, analytic=False, film_rgb=False):
     d.integrator = {"path": 0, "direct": 1, "depth": 2}[params.get("integrator", "path")]
     d.emitter_samples, d.bsdf_samples = params.get("emitter_samples", 0), params.get("bsdf_samples", 0)
     d.hide_emitters = 1 if params.get("hide_emitters", False) else 0
+    if params.get("aperture_radius") is not None:          # thinlens.cpp:112-117, sensor.cpp:104
+        d.aperture_radius = params["aperture_radius"] if params["aperture_radius"] != 0 else float(np.finfo(np.float32).eps) / 2
+        d.focus_distance = params["focus_distance"] if params.get("focus_distance") is not None else params["far_clip"]
     return d
 
 
@@ -316,12 +319,13 @@ def film_develop(xyzaw):
     return out
 
 
-def camera_rays(desc, sx, sy):
+def camera_rays(desc, sx, sy, aperture=None):
     sx, sy = _f(sx), _f(sy)
+    ap = _f(aperture).reshape(-1, 2) if aperture is not None else None
     n = sx.shape[0]
     o = np.empty((n, 3), np.float32); d = np.empty((n, 3), np.float32)
     mint = np.empty(n, np.float32); maxt = np.empty(n, np.float32)
-    lib().mo_camera_rays(C.byref(desc), n, _p(sx), _p(sy), _p(o), _p(d), _p(mint), _p(maxt))
+    lib().mo_camera_rays(C.byref(desc), n, _p(sx), _p(sy), _p(ap) if ap is not None else None, _p(o), _p(d), _p(mint), _p(maxt))
     return o, d, mint, maxt
 
 

@@ -167,3 +167,25 @@ def test_matpreview_style_scene_from_files(tmp_path):
     assert scene.integrator().render(scene, sensor)
     img = sensor.film().bitmap().cpu().numpy()
     assert np.isfinite(img).all() and img[..., :3].mean() > 0.05 and img[..., 3].min() >= 0
+
+
+def test_xml_thinlens_sensor():
+    """`thinlens` sensor from XML: aperture_radius is mandatory (thinlens.cpp:112), focus_distance defaults to far_clip"""
+    from mitsuba2_amd import xml as mxml
+    x = """<scene version="2.0.0"><sensor type="thinlens"><float name="aperture_radius" value="0.2"/>%s
+           <float name="far_clip" value="50"/><film type="hdrfilm"><integer name="width" value="16"/><integer name="height" value="8"/>
+           <rfilter type="mitchell"><float name="B" value="0.2"/></rfilter></film></sensor>
+           <shape type="rectangle"><emitter type="area"><rgb name="radiance" value="1,1,1"/></emitter>
+           <transform name="to_world"><rotate y="1" angle="180"/><translate z="4"/></transform></shape></scene>"""
+    scene = mxml.load_string(x % '<float name="focus_distance" value="4"/>')
+    cam = scene.sensors()[0]
+    assert cam.needs_aperture_sample() and abs(cam.aperture_radius() - 0.2) < 1e-7 and cam.focus_distance() == 4.0
+    assert cam.film().reconstruction_filter().kind == 4 and abs(cam.film().reconstruction_filter().param - 0.2) < 1e-7
+    assert mxml.load_string(x % "").sensors()[0].focus_distance() == 50.0
+    with pytest.raises(Exception, match="aperture_radius"):
+        mxml.load_string(x.replace('<float name="aperture_radius" value="0.2"/>', "") % "")
+    assert scene.integrator() is None
+    from mitsuba2_amd import render as R
+    assert R.PathIntegrator(max_depth=2).render(scene, cam)
+    img = cam.film().bitmap().cpu().numpy()
+    assert np.isfinite(img).all() and img[..., :3].max() > 0

@@ -132,6 +132,38 @@ def test_camera_rays_exact(gpu, oracle):
     assert np.allclose(np.linalg.norm(d, axis=1), 1, atol=1e-6)
 
 
+@pytest.mark.parametrize("aperture,focus", [(0.1, 15.0), (25.0, 900.0), (0.0, None)])
+def test_thinlens_rays_and_render(gpu, oracle, aperture, focus):
+    """src/sensors/thinlens.cpp: sample_ray with aperture samples (bit-exact up to sincos of the disk warp), and the two extra
+    sampler dimensions per camera sample in the path integrator (integrator.cpp:229-231), RGB and spectral, fused and split"""
+    p = dict(scenes.cornell_box_sensor(64, 48, 4, seed=11), aperture_radius=aperture, focus_distance=focus, max_depth=5)
+    sensor = gpu.make_sensor(p)
+    assert sensor.needs_aperture_sample() and not gpu.make_sensor(scenes.cornell_box_sensor(8, 8, 1)).needs_aperture_sample()
+    rng = np.random.RandomState(3)
+    s, ap = rng.rand(4000, 2).astype(np.float32), rng.rand(4000, 2).astype(np.float32)
+    ray = sensor.sample_ray(torch.from_numpy(s).cuda(), torch.from_numpy(ap).cuda())
+    o, d, mint, maxt = oracle.camera_rays(oracle.make_desc(p), s[:, 0].copy(), s[:, 1].copy(), ap)
+    assert np.allclose(ray.o.cpu().numpy(), o, rtol=1e-6, atol=1e-4) and np.allclose(ray.d.cpu().numpy(), d, atol=1e-6)
+    assert np.allclose(ray.mint.cpu().numpy(), mint, rtol=1e-6) and np.allclose(ray.maxt.cpu().numpy(), maxt, rtol=1e-6)
+    centred = sensor.sample_ray(torch.from_numpy(s).cuda())                # aperture sample (0.5, 0.5): the lens centre
+    assert np.allclose(centred.o.cpu().numpy(), np.float32([278, 273, -800]), atol=1e-3)
+    sd = scenes.cornell_box()
+    n = 64 * 48 * 4
+    for variant in ("rgb", "spectral"):
+        scene = gpu.Scene(sd, variant=variant)
+        a, mask, pos = gpu.PathIntegrator(max_depth=5, pipeline=1).sample(scene, sensor, 0, n)
+        b, _, _ = gpu.PathIntegrator(max_depth=5, pipeline=2).sample(scene, sensor, 0, n)
+        assert (a == b).all()
+        S = oracle.OracleScene(sd, spectral_path=gpu.srgb_coeff_path() if variant == "spectral" else None)
+        want, wpos = S.sample_radiance(oracle.make_desc(p), 0, n)
+        assert (pos.cpu().numpy() == wpos).all()
+        close = np.isclose(a.cpu().numpy(), want[:, :3], rtol=5e-3, atol=2e-4).all(1)
+        assert close.mean() > 0.995, (variant, close.mean())
+    if aperture == 25.0:                                                    # a wide lens really defocuses the picture
+        pin, _, _ = gpu.PathIntegrator(max_depth=5).sample(gpu.Scene(sd), gpu.make_sensor(dict(p, aperture_radius=None)), 0, n)
+        assert not torch.equal(pin, gpu.PathIntegrator(max_depth=5).sample(gpu.Scene(sd), sensor, 0, n)[0])
+
+
 @pytest.mark.parametrize("max_depth", [-1, 1, 2, 3, 6])
 def test_per_sample_radiance(gpu, oracle, max_depth):
     sd = scenes.cornell_box()
