@@ -87,16 +87,20 @@ typedef struct {
 /* area: src/emitters/area.cpp (attached to a mesh); constant: src/emitters/constant.cpp and envmap: src/emitters/envmap.cpp
  * (environment emitters, at most one per scene; spectral variant: `constant` radiance is upsampled like an area light's,
  * `envmap` texels become (model coefficients, scale) as in envmap.cpp:96-109) */
-typedef enum { MTSAMD_EMITTER_AREA = 0, MTSAMD_EMITTER_CONSTANT = 1, MTSAMD_EMITTER_ENVMAP = 2 } mtsamd_emitter_type;
+/* delta emitters: point src/emitters/point.cpp, spot spot.cpp (without projection texture), directional directional.cpp */
+typedef enum { MTSAMD_EMITTER_AREA = 0, MTSAMD_EMITTER_CONSTANT = 1, MTSAMD_EMITTER_ENVMAP = 2, MTSAMD_EMITTER_POINT = 3,
+               MTSAMD_EMITTER_SPOT = 4, MTSAMD_EMITTER_DIRECTIONAL = 5 } mtsamd_emitter_type;
 typedef struct {
     int32_t type;              /* mtsamd_emitter_type; AreaLight = src/emitters/area.cpp */
-    float radiance[3];         /* area, constant */
+    float radiance[3];         /* area / constant: radiance; point / spot: intensity; directional: irradiance */
     /* envmap: latitude-longitude image, linear RGB, host pointer (height * width * 3), `scale`, and the emitter's to_world
      * (row-major 4x4; the linear part is used) */
     const float *envmap_data;
     int32_t envmap_width, envmap_height;
     float envmap_scale;
-    float to_world[16];
+    float to_world[16];        /* envmap; point / spot: position = translation; spot / directional: orientation (the light points
+                                  along the local +z axis: spot.cpp:129-151, directional.cpp:104-129) */
+    float cutoff_angle, beam_width;   /* spot, degrees (spot.cpp:81-82: defaults 20 and 3/4 of the cutoff angle, resolved by the host) */
 } mtsamd_emitter_desc;
 
 typedef struct {

@@ -31,7 +31,8 @@ class BsdfDesc(C.Structure):
 
 class EmitterDesc(C.Structure):
     _fields_ = [("type", C.c_int32), ("radiance", C.c_float * 3), ("envmap_data", f32p), ("envmap_width", C.c_int32),
-                ("envmap_height", C.c_int32), ("envmap_scale", C.c_float), ("to_world", C.c_float * 16)]
+                ("envmap_height", C.c_int32), ("envmap_scale", C.c_float), ("to_world", C.c_float * 16),
+                ("cutoff_angle", C.c_float), ("beam_width", C.c_float)]
 
 
 class TextureDesc(C.Structure):

@@ -378,7 +378,13 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
             environment = (int32_t) e;
             continue;
         }
-        if (et != MTSAMD_EMITTER_AREA) return fail(MTSAMD_ERR_UNSUPPORTED, "emitter %u: only 'area', 'constant' and 'envmap' emitters are implemented", e);
+        if (et == MTSAMD_EMITTER_POINT || et == MTSAMD_EMITTER_SPOT || et == MTSAMD_EMITTER_DIRECTIONAL) {
+            if (emitter_shape[e] >= 0) return fail(MTSAMD_ERR_INVALID, "emitter %u: a point / spot / directional emitter cannot be attached to a shape", e);
+            if (et == MTSAMD_EMITTER_SPOT && !(desc->emitters[e].cutoff_angle >= desc->emitters[e].beam_width))
+                return fail(MTSAMD_ERR_INVALID, "emitter %u: spot: cutoff_angle must not be smaller than beam_width", e);      // spot.cpp:89
+            continue;
+        }
+        if (et != MTSAMD_EMITTER_AREA) return fail(MTSAMD_ERR_UNSUPPORTED, "emitter %u: unknown emitter type %d", e, et);
         if (emitter_shape[e] < 0) return fail(MTSAMD_ERR_INVALID, "emitter %u is not attached to a shape", e);
     }
     for (uint32_t b = 0; b < desc->bsdf_count; ++b) {
@@ -461,6 +467,30 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
             e.valid_lo = lo; e.valid_hi = hi;
         }
         off += m.face_count;
+    }
+    // delta emitters (point.cpp:52-65, spot.cpp:68-91, directional.cpp:43-63)
+    for (uint32_t ei = 0; ei < desc->emitter_count; ++ei) {
+        const mtsamd_emitter_desc &ed = desc->emitters[ei];
+        if (ed.type != MTSAMD_EMITTER_POINT && ed.type != MTSAMD_EMITTER_SPOT && ed.type != MTSAMD_EMITTER_DIRECTIONAL) continue;
+        DevEmitter &e = s->emitters[ei];
+        std::memset(&e, 0, sizeof(e));
+        e.r = ed.radiance[0]; e.g = ed.radiance[1]; e.b = ed.radiance[2];
+        e.shape = 0xffffffffu; e.pad0 = (uint32_t) ed.type;
+        const float *m = ed.to_world;
+        e.cx = m[3]; e.cy = m[7]; e.cz = m[11];
+        if (ed.type == MTSAMD_EMITTER_DIRECTIONAL) {             // d = to_world * (0, 0, 1)
+            e.aux[0] = m[2]; e.aux[1] = m[6]; e.aux[2] = m[10];
+        } else if (ed.type == MTSAMD_EMITTER_SPOT) {
+            const double a = m[0], b = m[1], c = m[2], d2 = m[4], e2 = m[5], f = m[6], g = m[8], h2 = m[9], i2 = m[10];
+            const double det = a * (e2 * i2 - f * h2) - b * (d2 * i2 - f * g) + c * (d2 * h2 - e2 * g);
+            if (det == 0.0) { delete s; return fail(MTSAMD_ERR_INVALID, "emitter %u: singular to_world transformation", ei); }
+            const double inv[9] = { (e2 * i2 - f * h2) / det, (c * h2 - b * i2) / det, (b * f - c * e2) / det,
+                                    (f * g - d2 * i2) / det, (a * i2 - c * g) / det, (c * d2 - a * f) / det,
+                                    (d2 * h2 - e2 * g) / det, (b * g - a * h2) / det, (a * e2 - b * d2) / det };
+            for (int k = 0; k < 9; ++k) e.aux[k] = (float) inv[k];
+            const float cutoff = ed.cutoff_angle * (kPi / 180.0f), beam = ed.beam_width * (kPi / 180.0f);
+            e.aux[9] = cutoff; e.aux[10] = std::cos(cutoff); e.aux[11] = std::cos(beam); e.aux[12] = 1.0f / (cutoff - beam);
+        }
     }
     // spectral variant: RGB -> spectrum coefficients on the host (srgb.cpp:31-41, srgb_d65.cpp:31-46)
     Rgb2Spec model;
@@ -603,6 +633,15 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         const float *bb = s->bvh.bbox;
         e.cx = (bb[3] + bb[0]) * 0.5f; e.cy = (bb[4] + bb[1]) * 0.5f; e.cz = (bb[5] + bb[2]) * 0.5f;
         const float dx = e.cx - bb[3], dy = e.cy - bb[4], dz = e.cz - bb[5];
+        const float r = std::sqrt(std::fma(dz, dz, std::fma(dy, dy, dx * dx)));
+        e.radius = std::max(kRayEpsilon, r * (1.0f + kRayEpsilon));
+    }
+
+    for (DevEmitter &e : s->emitters) {           // DirectionalEmitter::set_scene (directional.cpp:65-70)
+        if (e.pad0 != kEmitterDirectional) continue;
+        const float *bb = s->bvh.bbox;
+        const float cx = (bb[3] + bb[0]) * 0.5f, cy = (bb[4] + bb[1]) * 0.5f, cz = (bb[5] + bb[2]) * 0.5f;
+        const float dx = cx - bb[3], dy = cy - bb[4], dz = cz - bb[5];
         const float r = std::sqrt(std::fma(dz, dz, std::fma(dy, dy, dx * dx)));
         e.radius = std::max(kRayEpsilon, r * (1.0f + kRayEpsilon));
     }

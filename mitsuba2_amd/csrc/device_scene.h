@@ -44,9 +44,13 @@ struct DevEmitter {
     uint32_t first_prim, n_prims; float area_sum, area_norm;
     uint32_t valid_lo, valid_hi; uint32_t pad0, pad1;
     float c0, c1, c2, d65_scale;       // spectral variant: SRGBEmitterSpectrum = D65 * d65_scale * srgb_model(c) (srgb_d65.cpp:27-63)
-    float cx, cy, cz, radius;          // constant emitter (pad0 == 1): the scene's bounding sphere (constant.cpp:47-51)
+    float cx, cy, cz, radius;          // constant emitter (pad0 == 1): the scene's bounding sphere (constant.cpp:47-51);
+                                       // point / spot: position; directional: radius of the bounding sphere
+    // delta emitters -- spot: aux[0..8] = world-to-local rotation, aux[9] = cutoff angle, aux[10] = cos(cutoff), aux[11] = cos(beam width),
+    // aux[12] = 1 / (cutoff - beam width) (spot.cpp:81-90); directional: aux[0..2] = direction the light travels in
+    float aux[16];
 };
-constexpr uint32_t kEmitterConstant = 1u, kEmitterEnvmap = 2u;     // DevEmitter::pad0
+constexpr uint32_t kEmitterConstant = 1u, kEmitterEnvmap = 2u, kEmitterPoint = 3u, kEmitterSpot = 4u, kEmitterDirectional = 5u;     // DevEmitter::pad0
 constexpr float kInvFourPi = 0.07957747154594766788f;
 
 struct SceneView {
@@ -431,7 +435,7 @@ MTS_DEV void fill_si(const Geo<FLAT> &g, f3 ray_d, uint32_t prim, float b1, floa
 }
 
 // ---------------------------------------------------------------------------
-struct DirectionSample { f3 p, n, d; float dist, pdf; uint32_t emitter; f2 uv; };      // uv: texture coordinates of an envmap sample
+struct DirectionSample { f3 p, n, d; float dist, pdf; uint32_t emitter; f2 uv; bool delta; float falloff; };      // uv: texture coordinates of an envmap sample; delta emitters: spec = (L * falloff) * r1
 
 // Scene::sample_emitter_direction without the visibility test.  The emitted spectrum is returned in factored
 // form: spec = (radiance * r1) * r2 with r1 = 1/pdf (0 when the sample is masked) and r2 = emitter count.
@@ -439,7 +443,7 @@ template <bool FLAT>
 MTS_DEV void sample_emitter_direction(const Geo<FLAT> &g, f3 ref_p, f2 sample, DirectionSample &ds, float &r1, float &r2) {
     const SceneView &sv = g.sv;
     ds.pdf = 0.0f; ds.dist = 0.0f; ds.emitter = 0;
-    ds.p = ds.n = ds.d = mk3(0, 0, 0); ds.uv.x = ds.uv.y = 0.0f;
+    ds.p = ds.n = ds.d = mk3(0, 0, 0); ds.uv.x = ds.uv.y = 0.0f; ds.delta = false; ds.falloff = 1.0f;
     r1 = 0.0f; r2 = 1.0f;
     if (sv.n_emitters == 0) return;
     uint32_t index = 0;
@@ -460,6 +464,32 @@ MTS_DEV void sample_emitter_direction(const Geo<FLAT> &g, f3 ref_p, f2 sample, D
         ds.p = ref_p + d * ds.dist;
         ds.n = -d; ds.d = d; ds.pdf = pdf; ds.emitter = index; ds.uv = uv;
         r1 = rcp(pdf);
+        if (sv.n_emitters > 1) { ds.pdf *= emitter_pdf; r2 = rcp(emitter_pdf); }
+        return;
+    }
+    if (e.pad0 >= kEmitterPoint) {
+        // PointLight / SpotLight / DirectionalEmitter::sample_direction (point.cpp:76-101, spot.cpp:129-151,
+        // directional.cpp:104-129): pdf = 1, delta; spec = (L * falloff) * r1 with r1 = 1 / dist^2 (1 for `directional`)
+        ds.pdf = 1.0f; ds.delta = true; ds.emitter = index;
+        if (e.pad0 == kEmitterDirectional) {
+            const f3 dir = mk3(e.aux[0], e.aux[1], e.aux[2]);
+            ds.dist = 2.0f * e.radius;
+            ds.p = ref_p - dir * ds.dist;
+            ds.n = dir; ds.d = -dir;
+            r1 = 1.0f;
+        } else {
+            ds.p = mk3(e.cx, e.cy, e.cz);
+            ds.d = ds.p - ref_p;
+            ds.dist = sqrtf(sqnorm(ds.d));
+            const float inv_dist = rcp(ds.dist);
+            ds.d = ds.d * inv_dist;
+            if (e.pad0 == kEmitterSpot) {                      // falloff_curve (spot.cpp:95-113)
+                const float cos_theta = normalize(mat3_apply(e.aux, -ds.d)).z;
+                if (!(cos_theta >= e.aux[11])) ds.falloff = (e.aux[9] - acosf(cos_theta)) * e.aux[12];
+                if (cos_theta <= e.aux[10]) ds.falloff = 0.0f;
+            }
+            r1 = inv_dist * inv_dist;
+        }
         if (sv.n_emitters > 1) { ds.pdf *= emitter_pdf; r2 = rcp(emitter_pdf); }
         return;
     }
@@ -533,6 +563,7 @@ MTS_DEV void sample_emitter_direction(const Geo<FLAT> &g, f3 ref_p, f2 sample, D
     const DevEmitter e = g.emitter(ds.emitter);
     f3 rad = mk3(e.r, e.g, e.b);
     if (e.pad0 == kEmitterEnvmap) rad = envmap_lookup(*g.sv.envmap, ds.uv.x, ds.uv.y);      // eval_spectrum at the sampled (u, v)
+    if (ds.delta) rad = mk3(rad.x * ds.falloff, rad.y * ds.falloff, rad.z * ds.falloff);
     spec = mk3(rad.x * r1, rad.y * r1, rad.z * r1);
     if (g.sv.n_emitters > 1) spec = spec * r2;
 }

@@ -154,7 +154,7 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
             f3 bv; float bp;
             if (GENERAL) bsdf_eval_pdf(bsdf, refl, si.wi, wo, bv, bp);
             else diffuse_eval_pdf(refl, si.wi, wo, bv, bp);
-            float mis = mis_weight(ds.pdf, bp);
+            float mis = ds.delta ? 1.0f : mis_weight(ds.pdf, bp);      // path.cpp:170
             f3 contrib = mk3(((mis * s.thr.x) * bv.x) * spec.x, ((mis * s.thr.y) * bv.y) * spec.y,
                              ((mis * s.thr.z) * bv.z) * spec.z);
             // The visibility test only ever zeroes `spec` (scene.cpp:178-182): trace the shadow
@@ -519,12 +519,12 @@ MTS_DEV bool bounce_step_spectral(const RenderParams &P, const LdsView &lds, Pat
             float bp = front ? kInvPi * wo.z : 0.0f;
             float bvs[kWav];
             if (GENERAL) bsdf_eval_pdf_n<kWav>(bsdf, chan, si.wi, wo, bvs, bp);
-            float mis = mis_weight(ds.pdf, bp);
+            float mis = ds.delta ? 1.0f : mis_weight(ds.pdf, bp);
             Spec4 contrib; bool nz = false;
             const Spec4 le4 = emitter_spectrum(sv, e, s.wav, ds.uv);
 #pragma unroll
             for (int k = 0; k < kWav; ++k) {
-                float le = le4.v[k];
+                float le = ds.delta ? le4.v[k] * ds.falloff : le4.v[k];
                 float spec = le * r1;
                 if (sv.n_emitters > 1) spec *= r2;
                 float bv = GENERAL ? bvs[k] : (front ? (refl.v[k] * kInvPi) * wo.z : 0.0f);
@@ -722,7 +722,7 @@ __global__ __launch_bounds__(kBlock) void k_direct(const RenderParams P, uint64_
                     f3 bv; float bp;
                     if (GENERAL) bsdf_eval_pdf(bsdf, refl, si.wi, wo, bv, bp);
                     else diffuse_eval_pdf(refl, si.wi, wo, bv, bp);
-                    const float mis = mis_weight(ds.pdf * frac_lum, bp * frac_bsdf) * weight_lum;
+                    const float mis = ds.delta ? 1.0f : mis_weight(ds.pdf * frac_lum, bp * frac_bsdf) * weight_lum;      // direct.cpp:155-156
                     const f3 contrib = mk3((mis * bv.x) * spec.x, (mis * bv.y) * spec.y, (mis * bv.z) * spec.z);
                     if (contrib.x != 0.0f || contrib.y != 0.0f || contrib.z != 0.0f) {
                         Hit sh;

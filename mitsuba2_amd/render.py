@@ -524,24 +524,21 @@ class Scene:
                 td[i].to_uv = (C.c_float * 6)(float(m[0, 0]), float(m[0, 1]), float(m[0, 2]), float(m[1, 0]), float(m[1, 1]), float(m[1, 2]))
         self._texture_shapes = [t.shape if t is not None else (0, 0, 3) for (_, t, _) in tex]
         ed = (L.EmitterDesc * max(len(emitters), 1))()
+        from . import emitters as E
         for i, e in enumerate(emitters):
-            et = e.get("type", "area")
-            if et not in ("area", "constant", "envmap"):
-                raise RuntimeError("Emitter plugin '%s' is not supported by this backend (area, constant, envmap)" % et)
-            ed[i].type = {"area": 0, "constant": 1, "envmap": 2}[et]
-            if et == "envmap":          # src/emitters/envmap.cpp: lat-long image (linear RGB), scale, to_world
-                img = _f32(e["data"])
+            n = E.normalize(e)             # plugin defaults / validation (src/emitters/*.cpp constructors)
+            ed[i].type = n["type"]
+            ed[i].to_world = (C.c_float * 16)(*n["to_world"].reshape(-1).tolist())
+            ed[i].radiance = (C.c_float * 3)(*n["radiance"])
+            ed[i].cutoff_angle, ed[i].beam_width = n["cutoff_angle"], n["beam_width"]
+            if n["type"] == E.TYPE_IDS["envmap"]:          # src/emitters/envmap.cpp: lat-long image (linear RGB), scale, to_world
+                img = _f32(n["data"])
                 if img.ndim != 3 or img.shape[2] != 3:
                     raise RuntimeError("envmap: expected (H, W, 3) linear RGB data")
                 keep.append(img)
                 ed[i].envmap_data = img.ctypes.data_as(L.f32p)
                 ed[i].envmap_height, ed[i].envmap_width = img.shape[0], img.shape[1]
-                ed[i].envmap_scale = float(e.get("scale", 1.0))
-                tw = np.eye(4, dtype=np.float32) if e.get("to_world") is None else _f32(e["to_world"]).reshape(4, 4)
-                ed[i].to_world = (C.c_float * 16)(*tw.reshape(-1).tolist())
-                ed[i].radiance = (C.c_float * 3)(0.0, 0.0, 0.0)
-                continue
-            ed[i].radiance = (C.c_float * 3)(*[float(x) for x in e["radiance"]])
+                ed[i].envmap_scale = n["scale"]
         sd = L.SceneDesc(md, len(meshes), bd, len(bsdfs), ed, len(emitters), td, len(tex), 0, None)
         if variant == "spectral":
             sd.spectral = 1

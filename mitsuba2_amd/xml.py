@@ -649,8 +649,30 @@ def _instantiate(ctx, root, base_dir):
                              to_world=it.get("to_world", np.eye(4, dtype=F32), "transform"))
                 it.check_unqueried()
                 desc.scene_dict["emitters"].append(entry)
+            elif it.type in ("point", "spot", "directional"):       # point.cpp:52-65, spot.cpp:68-91, directional.cpp:43-63
+                key = "irradiance" if it.type == "directional" else "intensity"
+                entry = {"type": it.type, key: _colour(_resolve(ctx, it.get(key, ("spectrum", 1.0))), "%s.%s" % (it.type, key), True)}
+                if "to_world" in it.props:
+                    entry["to_world"] = it.get("to_world", kind="transform")
+                if it.type == "point" and "position" in it.props:
+                    entry["position"] = [float(x) for x in it.get("position")]
+                if it.type == "directional" and "direction" in it.props:
+                    entry["direction"] = [float(x) for x in it.get("direction")]
+                if it.type == "spot":
+                    for k in ("cutoff_angle", "beam_width"):
+                        if k in it.props:
+                            entry[k] = it.get(k, kind="float")
+                    if any(c[0] == "texture" if isinstance(c, tuple) else getattr(c, "tag", "") == "texture" for c in it.children) or "texture" in it.props:
+                        raise XMLError("spot: projection textures are not supported by this backend")
+                it.check_unqueried()
+                from . import emitters as E
+                try:
+                    E.normalize(entry)                              # the constructors' consistency checks
+                except RuntimeError as err:
+                    raise XMLError(str(err))
+                desc.scene_dict["emitters"].append(entry)
             else:
-                raise XMLError('Emitter plugin "%s" is not supported by this backend (area emitters attached to shapes, constant, envmap)' % it.type)
+                raise XMLError('Emitter plugin "%s" is not supported by this backend (area emitters attached to shapes, constant, envmap, point, spot, directional)' % it.type)
         else:
             raise XMLError('scene: unsupported child "%s"' % it.tag)
     return desc
@@ -716,7 +738,7 @@ def load_file(path, device=0, variant="rgb", **params):
 
 # -------------------------------------------------------------------------------------------- load_dict
 _PLUGIN_CLASS = {"twosided": "bsdf", "conductor": "bsdf", "roughconductor": "bsdf", "dielectric": "bsdf", "plastic": "bsdf", "roughplastic": "bsdf", "roughdielectric": "bsdf", "path": "integrator", "perspective": "sensor", "thinlens": "sensor", "hdrfilm": "film", "independent": "sampler", "gaussian": "rfilter", "box": "rfilter", "tent": "rfilter", "catmullrom": "rfilter", "mitchell": "rfilter", "lanczos": "rfilter",
-                 "direct": "integrator", "depth": "integrator", "moment": "integrator", "obj": "shape", "ply": "shape", "serialized": "shape", "rectangle": "shape", "diffuse": "bsdf", "area": "emitter", "constant": "emitter", "envmap": "emitter", "bitmap": "texture", "checkerboard": "texture", "scene": "scene"}
+                 "direct": "integrator", "depth": "integrator", "moment": "integrator", "obj": "shape", "ply": "shape", "serialized": "shape", "rectangle": "shape", "diffuse": "bsdf", "area": "emitter", "constant": "emitter", "envmap": "emitter", "point": "emitter", "spot": "emitter", "directional": "emitter", "bitmap": "texture", "checkerboard": "texture", "scene": "scene"}
 
 
 def _node_from_dict(d, ctx):

@@ -34,6 +34,11 @@ void mo_kat_bilinear_to_square(float v00, float v10, float v01, float v11, float
 void mo_kat_envmap(int w, int h, const float *rgb, float scale, const float *to_world9, uint64_t n, const float *sample2, float *out11);
 /* Re-orders the emitter list: new emitter i = old emitter order[i] (Scene::m_emitters follows the order of the scene's
  * children, scene.cpp:31-56). */
+/* delta emitters: type 3 `point` (src/emitters/point.cpp: position, intensity), 4 `spot` (spot.cpp: position, intensity,
+ * to_world9 = rotation part of to_world, cutoff_angle / beam_width in degrees), 5 `directional` (directional.cpp: unit direction
+ * the light travels in = to_world * (0, 0, 1), irradiance).  Returns the emitter index. */
+int mo_scene_add_delta_emitter(mo_scene *s, int type, const float *rgb, const float *position3, const float *direction3,
+                               const float *to_world9, float cutoff_angle_deg, float beam_width_deg);
 int mo_scene_set_emitter_order(mo_scene *s, uint32_t n, const uint32_t *order);
 /* Bitmap texture (src/textures/bitmap.cpp, linear RGB data, identity to_uv): returns its index.  A texture is
  * attached to the reflectance of a shape's diffuse BSDF with mo_scene_set_texture (-1 detaches). */

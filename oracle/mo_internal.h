@@ -14,7 +14,7 @@ typedef struct {
 } mo_si;
 
 /* DirectionSample (include/mitsuba/render/records.h:121-174) */
-typedef struct { mo_v3 p, n, d; float dist, pdf; uint32_t emitter; float pdf_single; mo_v2 uv; } mo_dsample;   /* pdf_single: before the emitter-selection probability; uv: envmap samples */
+typedef struct { mo_v3 p, n, d; float dist, pdf; uint32_t emitter; float pdf_single; mo_v2 uv; int delta; float falloff, scale; } mo_dsample;   /* delta emitters: spec = (L * falloff) * scale */   /* pdf_single: before the emitter-selection probability; uv: envmap samples */
 
 /* a BSDF instance: the descriptor plus the constants its constructor derives (plastic.cpp:162-176) */
 typedef struct {
@@ -55,7 +55,9 @@ float mo_envmap_pdf(const mo_envmap *e, mo_v3 d_world);
 
 /* type 0: `area` (src/emitters/area.cpp) attached to `shape`; type 1: `constant` environment (src/emitters/constant.cpp)
  * with the scene's bounding sphere (set_scene, constant.cpp:47-51); type 2: `envmap` (src/emitters/envmap.cpp) */
-typedef struct { uint32_t shape; float radiance[3]; float coeff[3], d65_scale; int type; mo_v3 center; float radius; mo_envmap *env; } mo_emitter;
+typedef struct { uint32_t shape; float radiance[3]; float coeff[3], d65_scale; int type; mo_v3 center; float radius; mo_envmap *env;
+                 /* type 3: `point` (point.cpp), 4: `spot` (spot.cpp), 5: `directional` (directional.cpp): delta emitters */
+                 mo_v3 pos, dir; float to_local[9], cutoff_angle, cos_cutoff, cos_beam, inv_transition; } mo_emitter;
 /* kind 0: bitmap (src/textures/bitmap.cpp), kind 1: checkerboard (src/textures/checkerboard.cpp); uvm = upper-left 2x3 of the
  * extracted to_uv transform: uv' = (uvm[0] u + uvm[1] v + uvm[2], uvm[3] u + uvm[4] v + uvm[5]) */
 typedef struct { int w, h; float *data; int kind; float uvm[6]; float color0[3], color1[3];

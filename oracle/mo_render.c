@@ -466,7 +466,7 @@ static void path_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, 
                 mo_v3 wo = mo_to_local(&si.sh, ds.d);
                 float bsdf_val[3], bsdf_pdf;
                 mo_bsdf_eval_pdf(bsdf, refl, si.wi, wo, bsdf_val, &bsdf_pdf);
-                float mis = mis_weight(ds.pdf, bsdf_pdf);      /* area lights are never delta (path.cpp:170) */
+                float mis = ds.delta ? 1.0f : mis_weight(ds.pdf, bsdf_pdf);      /* path.cpp:170 */
                 for (int k = 0; k < 3; ++k)
                     result[k] += ((mis * throughput[k]) * bsdf_val[k]) * emitter_val[k];
             }
@@ -547,7 +547,7 @@ static void direct_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray, i
             mo_v3 wo = mo_to_local(&si.sh, ds.d);
             float bsdf_val[3], bsdf_pdf;
             mo_bsdf_eval_pdf(bsdf, refl, si.wi, wo, bsdf_val, &bsdf_pdf);
-            float mis = mis_weight(ds.pdf * frac_lum, bsdf_pdf * frac_bsdf) * weight_lum;
+            float mis = ds.delta ? 1.0f : mis_weight(ds.pdf * frac_lum, bsdf_pdf * frac_bsdf) * weight_lum;      /* direct.cpp:155-156 */
             for (int k = 0; k < 3; ++k) result[k] += (mis * bsdf_val[k]) * emitter_val[k];
         }
     }
@@ -650,10 +650,10 @@ static void path_sample_spectral(const mo_scene *s, mo_pcg32 *rng, const mo_ray 
                 mo_v3 wo = mo_to_local(&si.sh, ds.d);
                 float bv[MO_WAV], bsdf_pdf, le[MO_WAV];
                 mo_bsdf_eval_pdf_n(bsdf, MO_WAV, &chan, si.wi, wo, bv, &bsdf_pdf);
-                float mis = mis_weight(ds.pdf, bsdf_pdf);
+                float mis = ds.delta ? 1.0f : mis_weight(ds.pdf, bsdf_pdf);
                 emitter_spectrum(e, wav, &ds.d, &ds.uv, le);
                 for (int k = 0; k < MO_WAV; ++k) {
-                    float spec = le[k] * r1;
+                    float spec = ds.delta ? (le[k] * ds.falloff) * ds.scale : le[k] * r1;
                     if (s->n_emitters > 1) spec *= r2;
                     if (occluded) spec = 0.0f;
                     result[k] += ((mis * throughput[k]) * bv[k]) * spec;
@@ -947,7 +947,7 @@ static int path_sample_rec(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_i
                 mo_v3 wo = mo_to_local(&si.sh, ds.d);
                 if (si.wi.z > 0.0f && wo.z > 0.0f) {
                     float bsdf_pdf = mo_square_to_cosine_hemisphere_pdf(wo);
-                    float k = mis_weight(ds.pdf, bsdf_pdf) * (MO_INV_PI * wo.z);
+                    float k = (ds.delta ? 1.0f : mis_weight(ds.pdf, bsdf_pdf)) * (MO_INV_PI * wo.z);
                     for (int c = 0; c < 3; ++c) r->Nc[c] = k * emitter_val[c];
                 }
             }

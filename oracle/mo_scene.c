@@ -108,6 +108,33 @@ int mo_scene_add_envmap_emitter(mo_scene *s, int w, int h, const float *rgb, flo
     s->environment = (int) s->n_emitters;
     return (int) s->n_emitters++;
 }
+int mo_scene_add_delta_emitter(mo_scene *s, int type, const float *rgb, const float *position3, const float *direction3,
+                               const float *to_world9, float cutoff_angle_deg, float beam_width_deg) {
+    if (!s || !rgb || type < 3 || type > 5) return -1;
+    s->emitters = (mo_emitter *) realloc(s->emitters, sizeof(mo_emitter) * (s->n_emitters + 1));
+    mo_emitter *e = &s->emitters[s->n_emitters];
+    memset(e, 0, sizeof(*e));
+    e->type = type; e->shape = 0xffffffffu; e->radius = 1.0f;
+    for (int k = 0; k < 3; ++k) e->radiance[k] = rgb[k];
+    if (position3) e->pos = mo_v3_make(position3[0], position3[1], position3[2]);
+    if (direction3) e->dir = mo_v3_make(direction3[0], direction3[1], direction3[2]);
+    if (type == 4) {
+        static const float ident[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+        const float *m = to_world9 ? to_world9 : ident;
+        double a = m[0], b = m[1], c = m[2], d = m[3], ee = m[4], f = m[5], g = m[6], hh = m[7], i = m[8];
+        double det = a * (ee * i - f * hh) - b * (d * i - f * g) + c * (d * hh - ee * g);
+        double inv[9] = { (ee * i - f * hh) / det, (c * hh - b * i) / det, (b * f - c * ee) / det,
+                          (f * g - d * i) / det, (a * i - c * g) / det, (c * d - a * f) / det,
+                          (d * hh - ee * g) / det, (b * g - a * hh) / det, (a * ee - b * d) / det };
+        for (int k = 0; k < 9; ++k) e->to_local[k] = (float) inv[k];
+        /* spot.cpp:81-90 */
+        float cutoff = cutoff_angle_deg * (MO_PI_F / 180.0f), beam = beam_width_deg * (MO_PI_F / 180.0f);
+        e->cutoff_angle = cutoff;
+        e->inv_transition = 1.0f / (cutoff - beam);
+        e->cos_cutoff = cosf(cutoff); e->cos_beam = cosf(beam);
+    }
+    return (int) s->n_emitters++;
+}
 int mo_scene_set_emitter_order(mo_scene *s, uint32_t n, const uint32_t *order) {
     if (!s || n != s->n_emitters) return -1;
     mo_emitter *ne = (mo_emitter *) malloc(sizeof(mo_emitter) * (n ? n : 1));
@@ -115,8 +142,8 @@ int mo_scene_set_emitter_order(mo_scene *s, uint32_t n, const uint32_t *order) {
     free(s->emitters); s->emitters = ne;
     s->environment = -1;
     for (uint32_t i = 0; i < n; ++i) {
-        if (ne[i].type != 0) s->environment = (int) i;
-        else s->meshes[ne[i].shape].emitter = (int) i;
+        if (ne[i].type == 1 || ne[i].type == 2) s->environment = (int) i;
+        else if (ne[i].type == 0) s->meshes[ne[i].shape].emitter = (int) i;
     }
     return 0;
 }
@@ -427,7 +454,7 @@ int mo_scene_finalize(mo_scene *s) {
      * (bbox.h:329-332), radius * (1 + RayEpsilon) */
     for (uint32_t i = 0; i < s->n_emitters; ++i) {
         mo_emitter *e = &s->emitters[i];
-        if (e->type == 0) continue;
+        if (e->type == 0 || e->type == 3 || e->type == 4) continue;      /* directional.cpp:65-70 does the same as the environment emitters */
         mo_v3 mn = mo_v3_make((float) lo[0], (float) lo[1], (float) lo[2]), mx = mo_v3_make((float) hi[0], (float) hi[1], (float) hi[2]);
         e->center = mo_scale(mo_add(mx, mn), 0.5f);
         float r = mo_norm(mo_sub(e->center, mx));
@@ -620,6 +647,42 @@ void mo_sample_emitter_direction(const mo_scene *s, mo_v3 ref_p, mo_v2 sample, m
         ds->p = mo_add(ref_p, mo_scale(d, ds->dist));
         ds->n = mo_neg(d); ds->d = d; ds->pdf = pdf; ds->emitter = index; ds->pdf_single = pdf;
         for (int k = 0; k < 3; ++k) spec[k] = val[k];
+        if (s->n_emitters > 1) {
+            ds->pdf *= emitter_pdf;
+            float r = mo_rcp(emitter_pdf);
+            for (int k = 0; k < 3; ++k) spec[k] *= r;
+        }
+        return;
+    }
+    if (e->type >= 3) {
+        /* PointLight / SpotLight / DirectionalEmitter::sample_direction (point.cpp:76-101, spot.cpp:129-151,
+         * directional.cpp:104-129): pdf = 1, delta */
+        ds->pdf = ds->pdf_single = 1.0f; ds->delta = 1; ds->emitter = index;
+        if (e->type == 5) {
+            ds->dist = 2.0f * e->radius;
+            ds->p = mo_sub(ref_p, mo_scale(e->dir, ds->dist));
+            ds->n = e->dir; ds->d = mo_neg(e->dir);
+            ds->falloff = 1.0f; ds->scale = 1.0f;
+            for (int k = 0; k < 3; ++k) spec[k] = e->radiance[k];
+        } else {
+            ds->p = e->pos;
+            ds->d = mo_sub(ds->p, ref_p);
+            ds->dist = mo_norm(ds->d);
+            float inv_dist = mo_rcp(ds->dist);
+            ds->d = mo_scale(ds->d, inv_dist);
+            float falloff = 1.0f;
+            if (e->type == 4) {                              /* falloff_curve (spot.cpp:95-113) */
+                const float *m = e->to_local;
+                mo_v3 nd = mo_neg(ds->d);
+                mo_v3 ld = mo_v3_make(fmaf(m[2], nd.z, fmaf(m[1], nd.y, m[0] * nd.x)), fmaf(m[5], nd.z, fmaf(m[4], nd.y, m[3] * nd.x)),
+                                      fmaf(m[8], nd.z, fmaf(m[7], nd.y, m[6] * nd.x)));
+                float cos_theta = mo_normalize(ld).z;
+                if (!(cos_theta >= e->cos_beam)) falloff = (e->cutoff_angle - acosf(cos_theta)) * e->inv_transition;
+                if (cos_theta <= e->cos_cutoff) falloff = 0.0f;
+            }
+            ds->falloff = falloff; ds->scale = inv_dist * inv_dist;
+            for (int k = 0; k < 3; ++k) spec[k] = (e->radiance[k] * falloff) * ds->scale;
+        }
         if (s->n_emitters > 1) {
             ds->pdf *= emitter_pdf;
             float r = mo_rcp(emitter_pdf);

@@ -106,6 +106,7 @@ def lib():
         L.mo_kat_diffuse.argtypes = [vp] * 9
         L.mo_kat_sample_emitter.argtypes = [vp] * 4
         L.mo_scene_set_spectral.argtypes = [vp, C.c_char_p]
+        L.mo_scene_add_delta_emitter.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_float, C.c_float]
         L.mo_scene_set_bsdf.argtypes = [vp, C.c_uint32, C.POINTER(BsdfDesc)]
         L.mo_scene_add_constant_emitter.argtypes = [vp, f32p]
         L.mo_scene_set_emitter_order.argtypes = [vp, C.c_uint32, vp]
@@ -193,6 +194,15 @@ class OracleScene:
                 img = _f(e["data"])
                 tw = _f(np.asarray(e["to_world"], np.float32).reshape(4, 4)[:3, :3]) if e.get("to_world") is not None else None
                 assert L.mo_scene_add_envmap_emitter(self.h, img.shape[1], img.shape[0], _p(img), float(e.get("scale", 1.0)), _p(tw)) == len(created)
+                created.append(ei)
+            elif e.get("type", "area") in ("point", "spot", "directional"):
+                from mitsuba2_amd import emitters as E
+                n = E.normalize(e)                                    # parameter defaults shared with the product
+                tw = n["to_world"]
+                pos, direction, rot = _f(tw[:3, 3]), _f(tw[:3, 2]), _f(tw[:3, :3])
+                rc = L.mo_scene_add_delta_emitter(self.h, n["type"], _p(_f(n["radiance"])), _p(pos), _p(direction), _p(rot),
+                                                  n["cutoff_angle"], n["beam_width"])
+                assert rc == len(created), rc
                 created.append(ei)
         if created != list(range(len(created))):
             order = np.array([created.index(i) for i in range(len(created))], dtype=np.uint32)

@@ -192,3 +192,53 @@ def test_uniform_envmap_equals_constant_emitter():
         imgs.append(sensor.film().bitmap().cpu().numpy()[..., :3])
     assert abs(imgs[0].mean() - imgs[1].mean()) < 0.01 * imgs[0].mean()
     assert np.mean((imgs[0] - imgs[1]) ** 2 / (imgs[0] ** 2 + 1e-2)) < 5e-3
+
+
+def _delta_lights():
+    from mitsuba2_amd import scenes
+    spot_tw = scenes.look_at([278, 500, 200], [300, 0, 320], [0, 0, 1])
+    return {
+        "point": [{"type": "point", "position": [278, 400, 279], "intensity": [4e5, 3e5, 2e5]}],
+        "spot": [{"type": "spot", "to_world": spot_tw, "intensity": [9e5, 9e5, 6e5], "cutoff_angle": 35.0, "beam_width": 20.0}],
+        "directional": [{"type": "directional", "direction": [0.3, -1.0, 0.4], "irradiance": [3.0, 2.5, 2.0]}],
+        "mixed": [{"type": "point", "position": [100, 300, 100], "intensity": [2e5, 2e5, 3e5]},
+                  {"type": "spot", "to_world": spot_tw, "intensity": [5e5, 3e5, 3e5]},
+                  {"type": "directional", "direction": [0.3, -1.0, 0.4], "irradiance": [1.0, 1.0, 1.0]}],
+    }
+
+
+@pytest.mark.parametrize("lights", ["point", "spot", "directional", "mixed", "mixed+area"])
+@pytest.mark.parametrize("integrator", ["path", "direct"])
+def test_delta_emitters_match_oracle(lights, integrator):
+    """src/emitters/point.cpp, spot.cpp, directional.cpp: pdf 1 / MIS weight 1 (path.cpp:170, direct.cpp:155-156), never hit by
+    BSDF sampling; alone, mixed and next to the area light; RGB and spectral variant; fused == split"""
+    from mitsuba2_amd import render as R, scenes
+    cb = _open_scene(lights.endswith("+area"))
+    area = [e for e in cb["emitters"] if e.get("type", "area") == "area"]
+    cb["emitters"] = _delta_lights()[lights.split("+")[0]] + area
+    for m in cb["meshes"]:
+        if m.get("emitter", -1) >= 0:
+            m["emitter"] = len(cb["emitters"]) - 1
+    sp = dict(scenes.cornell_box_sensor(64, 64, spp=4, seed=23), max_depth=5)
+    scene, sensor = R.Scene(cb), R.make_sensor(sp)
+    integ = R.PathIntegrator(max_depth=5) if integrator == "path" else R.DirectIntegrator(emitter_samples=2, bsdf_samples=1)
+    n = 64 * 64 * 4
+    rgb, mask, pos = integ.sample(scene, sensor, 0, n)
+    op = dict(sp, integrator=integrator, emitter_samples=2 if integrator == "direct" else 0, bsdf_samples=1 if integrator == "direct" else 0)
+    want, wpos = ob.OracleScene(cb).sample_radiance(ob.make_desc(op), 0, n)
+    assert np.array_equal(pos.cpu().numpy(), wpos) and np.array_equal(mask.cpu().numpy(), want[:, 3] > 0.5)
+    got = rgb.cpu().numpy()
+    assert want[:, :3].mean() > 1e-3
+    close = np.isclose(got, want[:, :3], rtol=5e-3, atol=1e-4 * max(1.0, want[:, :3].mean())).all(1)
+    assert close.mean() > 0.99, close.mean()
+    assert abs(got.mean() - want[:, :3].mean()) < 0.02 * want[:, :3].mean()
+    if integrator == "path":
+        a, _, _ = R.PathIntegrator(max_depth=5, pipeline=2).sample(scene, sensor, 0, n)
+        assert torch.equal(a, rgb)
+        sscene = R.Scene(cb, variant="spectral")
+        xyz, _, _ = R.PathIntegrator(max_depth=5, pipeline=1).sample(sscene, sensor, 0, n)
+        xyz2, _, _ = R.PathIntegrator(max_depth=5, pipeline=2).sample(sscene, sensor, 0, n)
+        assert torch.equal(xyz, xyz2)
+        swant, _ = ob.OracleScene(cb, spectral_path=R.srgb_coeff_path()).sample_radiance(ob.make_desc(sp), 0, n)
+        sclose = np.isclose(xyz.cpu().numpy(), swant[:, :3], rtol=5e-3, atol=1e-4 * max(1.0, swant[:, :3].mean())).all(1)
+        assert sclose.mean() > 0.99, sclose.mean()

@@ -340,3 +340,26 @@ def test_serialized_meshes(tmp_path, version):
     open(str(tmp_path / "bad.serialized"), "wb").write(b"\x00\x00\x04\x00abcdef")
     with pytest.raises(RuntimeError, match="invalid file format"):
         loaders.load_serialized(str(tmp_path / "bad.serialized"))
+
+
+def test_xml_delta_emitters():
+    """<emitter type="point|spot|directional"> at scene level (point.cpp:52-65, spot.cpp:68-91, directional.cpp:43-63)"""
+    from mitsuba2_amd import xml as mxml, emitters as E
+    x = """<scene version="2.0.0">
+        <emitter type="point"><point name="position" x="1" y="2" z="3"/><rgb name="intensity" value="5, 6, 7"/></emitter>
+        <emitter type="spot"><transform name="to_world"><lookat origin="0, 4, 0" target="0, 0, 0" up="0, 0, 1"/></transform>
+            <spectrum name="intensity" value="2"/><float name="cutoff_angle" value="30"/></emitter>
+        <emitter type="directional"><vector name="direction" x="0" y="-2" z="0"/></emitter>
+        <shape type="rectangle"/></scene>"""
+    desc = mxml.parse_string(x)
+    em = desc.scene_dict["emitters"]
+    assert [e["type"] for e in em] == ["point", "spot", "directional"]
+    n = [E.normalize(e) for e in em]
+    assert np.allclose(n[0]["to_world"][:3, 3], [1, 2, 3]) and n[0]["radiance"] == [5.0, 6.0, 7.0]
+    assert n[1]["cutoff_angle"] == 30.0 and n[1]["beam_width"] == 22.5 and np.allclose(n[1]["to_world"][:3, 2], [0, -1, 0], atol=1e-6)
+    assert n[1]["radiance"] == [2.0, 2.0, 2.0] and np.allclose(n[1]["to_world"][:3, 3], [0, 4, 0])
+    assert np.allclose(n[2]["to_world"][:3, 2], [0, -1, 0]) and n[2]["radiance"] == [1.0, 1.0, 1.0]
+    with pytest.raises(mxml.XMLError, match="Only one of the parameters"):
+        mxml.parse_string(x.replace('<point name="position" x="1" y="2" z="3"/>', '<point name="position" x="1" y="2" z="3"/><transform name="to_world"><translate x="1"/></transform>'))
+    with pytest.raises(mxml.XMLError, match="unreferenced"):
+        mxml.parse_string(x.replace('<float name="cutoff_angle" value="30"/>', '<float name="cutoff" value="30"/>'))
