@@ -288,6 +288,7 @@ static void gauss_legendre(int n, float *nodes, float *weights) {
 struct mtsamd_scene {
     int32_t environment = -1;        // index of the `constant` emitter
     bool general_bsdfs = false;      // any BSDF other than one-sided `diffuse`: the kernels with the BSDF switch are used
+    bool delta_emitters = false;     // point / spot / directional emitters: handled by the same general kernels
     int device = 0;
     int cu_count = 256;
     BvhOutput bvh;
@@ -474,6 +475,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         if (ed.type != MTSAMD_EMITTER_POINT && ed.type != MTSAMD_EMITTER_SPOT && ed.type != MTSAMD_EMITTER_DIRECTIONAL) continue;
         DevEmitter &e = s->emitters[ei];
         std::memset(&e, 0, sizeof(e));
+        s->delta_emitters = true;
         e.r = ed.radiance[0]; e.g = ed.radiance[1]; e.b = ed.radiance[2];
         e.shape = 0xffffffffu; e.pad0 = (uint32_t) ed.type;
         const float *m = ed.to_world;
@@ -771,7 +773,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     v.n_shapes = desc->mesh_count; v.n_bsdfs = desc->bsdf_count;
     v.textures = s->d_textures; v.n_textures = desc->texture_count;
     v.flat_recs = s->d_flat; v.flat = flat ? 1u : 0u;
-    v.general = s->general_bsdfs ? 1u : 0u;
+    v.general = (s->general_bsdfs || s->delta_emitters) ? 1u : 0u;       // the diffuse / area-light fast path (kernels.hip) handles neither
     v.flat_pairs = s->d_pairs; v.n_pairs = n_pairs;
     if (bounce_lds_bytes(v) > 150 * 1024) {
         mtsamd_scene_destroy(s);
@@ -992,6 +994,7 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
 
     RenderParams p{};
     p.sv = j.s->view; p.cam = j.cam;
+    if (p.cam.aperture_radius > 0.0f) p.sv.general = 1u;      // thin lens: aperture sampling lives in the general kernels
     p.cursor = w.cursor; p.cursor_end = w.cursor_end; p.wave_stats = w.wave_stats;
     p.out_rgba = w.out_rgba; p.out_pos = w.out_pos;
     p.cursor_pix = w.cursor_pix; p.cursor_rem = w.cursor_rem; p.count_shadow = w.count_shadow;
@@ -1208,7 +1211,7 @@ int mtsamd_render_adjoint(mtsamd_scene *s, const mtsamd_render_desc *d, const fl
     if (d->part_count > 1 || d->row_begin != 0 || d->row_end > 0) return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass renders the whole crop window");
     if (s->spectral) return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass is implemented for the RGB variant only");
     if (s->general_bsdfs) return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass is implemented for one-sided diffuse BSDFs only");
-    if (s->environment >= 0) return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass does not handle environment emitters");
+    if (s->environment >= 0 || s->delta_emitters) return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass handles area emitters only");
     if (s->bsdfs.size() > 32 && grad_bsdf) return fail(MTSAMD_ERR_UNSUPPORTED, "at most 32 BSDFs with constant-reflectance gradients");
     HIP_TRY(hipSetDevice(s->device));
     AdjointParams a{};

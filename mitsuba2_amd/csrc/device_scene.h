@@ -439,7 +439,8 @@ struct DirectionSample { f3 p, n, d; float dist, pdf; uint32_t emitter; f2 uv; b
 
 // Scene::sample_emitter_direction without the visibility test.  The emitted spectrum is returned in factored
 // form: spec = (radiance * r1) * r2 with r1 = 1/pdf (0 when the sample is masked) and r2 = emitter count.
-template <bool FLAT>
+// DELTA = false compiles the point / spot / directional branch out (the diffuse / area-light fast path).
+template <bool FLAT, bool DELTA = true>
 MTS_DEV void sample_emitter_direction(const Geo<FLAT> &g, f3 ref_p, f2 sample, DirectionSample &ds, float &r1, float &r2) {
     const SceneView &sv = g.sv;
     ds.pdf = 0.0f; ds.dist = 0.0f; ds.emitter = 0;
@@ -467,7 +468,7 @@ MTS_DEV void sample_emitter_direction(const Geo<FLAT> &g, f3 ref_p, f2 sample, D
         if (sv.n_emitters > 1) { ds.pdf *= emitter_pdf; r2 = rcp(emitter_pdf); }
         return;
     }
-    if (e.pad0 >= kEmitterPoint) {
+    if (DELTA && e.pad0 >= kEmitterPoint) {
         // PointLight / SpotLight / DirectionalEmitter::sample_direction (point.cpp:76-101, spot.cpp:129-151,
         // directional.cpp:104-129): pdf = 1, delta; spec = (L * falloff) * r1 with r1 = 1 / dist^2 (1 for `directional`)
         ds.pdf = 1.0f; ds.delta = true; ds.emitter = index;
@@ -554,16 +555,16 @@ MTS_DEV void sample_emitter_direction(const Geo<FLAT> &g, f3 ref_p, f2 sample, D
     }
 }
 // RGB form: spec = radiance / pdf (masked)
-template <bool FLAT>
+template <bool FLAT, bool DELTA = true>
 MTS_DEV void sample_emitter_direction(const Geo<FLAT> &g, f3 ref_p, f2 sample, DirectionSample &ds, f3 &spec) {
     float r1, r2;
-    sample_emitter_direction(g, ref_p, sample, ds, r1, r2);
+    sample_emitter_direction<FLAT, DELTA>(g, ref_p, sample, ds, r1, r2);
     spec = mk3(0, 0, 0);
     if (g.sv.n_emitters == 0) return;
     const DevEmitter e = g.emitter(ds.emitter);
     f3 rad = mk3(e.r, e.g, e.b);
     if (e.pad0 == kEmitterEnvmap) rad = envmap_lookup(*g.sv.envmap, ds.uv.x, ds.uv.y);      // eval_spectrum at the sampled (u, v)
-    if (ds.delta) rad = mk3(rad.x * ds.falloff, rad.y * ds.falloff, rad.z * ds.falloff);
+    if (DELTA && ds.delta) rad = mk3(rad.x * ds.falloff, rad.y * ds.falloff, rad.z * ds.falloff);
     spec = mk3(rad.x * r1, rad.y * r1, rad.z * r1);
     if (g.sv.n_emitters > 1) spec = spec * r2;
 }
@@ -649,6 +650,7 @@ struct CameraView {
     float near_clip, far_clip;
     float aperture_radius, focus_distance;
 };
+template <bool LENS = true>
 MTS_DEV void camera_ray(const CameraView &c, float sx, float sy, f2 aperture_sample, f3 &o, f3 &d, float &mint, float &maxt) {
     float r[4];
 #pragma unroll
@@ -662,7 +664,7 @@ MTS_DEV void camera_ray(const CameraView &c, float sx, float sy, f2 aperture_sam
     float iw = rcp(r[3]);
     const f3 near_p = mk3(r[0] * iw, r[1] * iw, r[2] * iw);
     f3 dl;
-    if (c.aperture_radius > 0.0f) {
+    if (LENS && c.aperture_radius > 0.0f) {
         const f2 t = square_to_uniform_disk_concentric(aperture_sample);
         const f3 aperture_p = mk3(c.aperture_radius * t.x, c.aperture_radius * t.y, 0.0f);
         const f3 focus_p = near_p * (c.focus_distance / near_p.z);

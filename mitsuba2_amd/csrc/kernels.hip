@@ -148,13 +148,13 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
     if (!GENERAL || bsdf_is_smooth(bsdf)) {                  // active_e: only BSDFs with a smooth component (path.cpp:154)
         f2 s2; s2.x = pcg_next_f32(s.rng); s2.y = pcg_next_f32(s.rng);
         DirectionSample ds; f3 spec;
-        sample_emitter_direction(geo, si.p, s2, ds, spec);
+        sample_emitter_direction<FLAT, GENERAL>(geo, si.p, s2, ds, spec);
         if (ds.pdf != 0.0f) {
             f3 wo = to_local(si.sh, ds.d);
             f3 bv; float bp;
             if (GENERAL) bsdf_eval_pdf(bsdf, refl, si.wi, wo, bv, bp);
             else diffuse_eval_pdf(refl, si.wi, wo, bv, bp);
-            float mis = ds.delta ? 1.0f : mis_weight(ds.pdf, bp);      // path.cpp:170
+            float mis = (GENERAL && ds.delta) ? 1.0f : mis_weight(ds.pdf, bp);      // path.cpp:170
             f3 contrib = mk3(((mis * s.thr.x) * bv.x) * spec.x, ((mis * s.thr.y) * bv.y) * spec.y,
                              ((mis * s.thr.z) * bv.z) * spec.z);
             // The visibility test only ever zeroes `spec` (scene.cpp:178-182): trace the shadow
@@ -213,6 +213,7 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
 // render_sample up to the camera ray (integrator.cpp:224-246).  `lp` = local pixel index (row-major over the rows
 // this render owns), `j` = sample number inside the pixel; the RNG stream is seeded with the GLOBAL sample index
 // pixel * spp + j, so the image does not depend on how the film is partitioned.
+template <bool GENERAL = true>
 MTS_DEV void generate_path(const RenderParams &P, uint64_t ordinal, uint32_t lp, uint32_t j, PathState &s, float2 *pos_out = nullptr) {
     const uint32_t w = (uint32_t) P.crop_w;
     const uint32_t lr = lp / w, px = lp - lr * w;
@@ -222,10 +223,10 @@ MTS_DEV void generate_path(const RenderParams &P, uint64_t ordinal, uint32_t lp,
     float jx = pcg_next_f32(s.rng), jy = pcg_next_f32(s.rng);
     float psx = ((float) px + (float) P.crop_x) + jx, psy = ((float) py + (float) P.crop_y) + jy;
     f2 ap; ap.x = ap.y = 0.5f;                               // needs_aperture_sample(): integrator.cpp:229-231
-    if (P.cam.aperture_radius > 0.0f) { ap.x = pcg_next_f32(s.rng); ap.y = pcg_next_f32(s.rng); }
+    if (GENERAL && P.cam.aperture_radius > 0.0f) { ap.x = pcg_next_f32(s.rng); ap.y = pcg_next_f32(s.rng); }
     (void) pcg_next_f32(s.rng);                              // wavelength sample (drawn even in RGB mode)
     float ax = (psx - (float) P.crop_x) / (float) P.crop_w, ay = (psy - (float) P.crop_y) / (float) P.crop_h;
-    camera_ray(P.cam, ax, ay, ap, s.o, s.d, s.mint, s.maxt);
+    camera_ray<GENERAL>(P.cam, ax, ay, ap, s.o, s.d, s.mint, s.maxt);
     s.thr = mk3(1.0f, 1.0f, 1.0f); s.bs_pdf = 0.0f;
     s.res = mk3(0.0f, 0.0f, 0.0f); s.eta = 1.0f;
     s.ordinal = P.plane_pixels ? j * P.plane_pixels + (lp - P.plane_pix0) : (uint32_t) (ordinal - P.first_ordinal);
@@ -292,7 +293,7 @@ void k_bounce(const RenderParams P) {
         if (lane < n_new) {
             PathState s;
             uint32_t r = crem + lane, q = r / spp;
-            generate_path(P, cursor + lane, cpix + q, r - q * spp, s);
+            generate_path<GENERAL>(P, cursor + lane, cpix + q, r - q * spp, s);
             store_state(P.out, base + n_out + lane, s);
         }
         n_out += n_new; cursor += n_new;
@@ -511,7 +512,7 @@ MTS_DEV bool bounce_step_spectral(const RenderParams &P, const LdsView &lds, Pat
     if (!GENERAL || bsdf_is_smooth(bsdf)) {
         f2 s2; s2.x = pcg_next_f32(s.rng); s2.y = pcg_next_f32(s.rng);
         DirectionSample ds; float r1, r2;
-        sample_emitter_direction(geo, si.p, s2, ds, r1, r2);
+        sample_emitter_direction<FLAT, GENERAL>(geo, si.p, s2, ds, r1, r2);
         if (ds.pdf != 0.0f) {
             const DevEmitter e = geo.emitter(ds.emitter);
             f3 wo = to_local(si.sh, ds.d);
@@ -519,12 +520,12 @@ MTS_DEV bool bounce_step_spectral(const RenderParams &P, const LdsView &lds, Pat
             float bp = front ? kInvPi * wo.z : 0.0f;
             float bvs[kWav];
             if (GENERAL) bsdf_eval_pdf_n<kWav>(bsdf, chan, si.wi, wo, bvs, bp);
-            float mis = ds.delta ? 1.0f : mis_weight(ds.pdf, bp);
+            float mis = (GENERAL && ds.delta) ? 1.0f : mis_weight(ds.pdf, bp);
             Spec4 contrib; bool nz = false;
             const Spec4 le4 = emitter_spectrum(sv, e, s.wav, ds.uv);
 #pragma unroll
             for (int k = 0; k < kWav; ++k) {
-                float le = ds.delta ? le4.v[k] * ds.falloff : le4.v[k];
+                float le = (GENERAL && ds.delta) ? le4.v[k] * ds.falloff : le4.v[k];
                 float spec = le * r1;
                 if (sv.n_emitters > 1) spec *= r2;
                 float bv = GENERAL ? bvs[k] : (front ? (refl.v[k] * kInvPi) * wo.z : 0.0f);
@@ -716,13 +717,13 @@ __global__ __launch_bounds__(kBlock) void k_direct(const RenderParams P, uint64_
                 for (int32_t i = 0; i < ne; ++i) {
                     f2 s2; s2.x = pcg_next_f32(s.rng); s2.y = pcg_next_f32(s.rng);
                     DirectionSample ds; f3 spec;
-                    sample_emitter_direction(geo, si.p, s2, ds, spec);
+                    sample_emitter_direction<FLAT, GENERAL>(geo, si.p, s2, ds, spec);
                     if (ds.pdf == 0.0f) continue;
                     const f3 wo = to_local(si.sh, ds.d);
                     f3 bv; float bp;
                     if (GENERAL) bsdf_eval_pdf(bsdf, refl, si.wi, wo, bv, bp);
                     else diffuse_eval_pdf(refl, si.wi, wo, bv, bp);
-                    const float mis = ds.delta ? 1.0f : mis_weight(ds.pdf * frac_lum, bp * frac_bsdf) * weight_lum;      // direct.cpp:155-156
+                    const float mis = (GENERAL && ds.delta) ? 1.0f : mis_weight(ds.pdf * frac_lum, bp * frac_bsdf) * weight_lum;      // direct.cpp:155-156
                     const f3 contrib = mk3((mis * bv.x) * spec.x, (mis * bv.y) * spec.y, (mis * bv.z) * spec.z);
                     if (contrib.x != 0.0f || contrib.y != 0.0f || contrib.z != 0.0f) {
                         Hit sh;
