@@ -212,10 +212,12 @@ typedef struct {
     int32_t part_index, part_count, part_tile_rows;
     /* scheduler knobs (0 = library default) */
     int32_t paths_per_wave;    /* in-flight path slots per scheduling wave */
-    int32_t pipeline;          /* 0 = automatic: fused bounce kernel for LDS-resident scenes (<= 64 primitives), split
-                                  trace / shade / trace kernels for hierarchy scenes; 1 = force fused; 2 = force split;
+    int32_t pipeline;          /* 0 = automatic: schedule 4 for LDS-resident scenes (<= 64 primitives), split trace / shade /
+                                  trace kernels for hierarchy scenes; 1 = force the fused bounce kernel; 2 = force split;
                                   3 = LDS-resident scenes only: closest hit fused with shading, shadow rays queued and
-                                  resolved in dense batches by a second kernel.  All produce identical samples. */
+                                  resolved in dense batches by a second kernel; 4 = LDS-resident scenes only: one kernel,
+                                  shadow rays collected in a per-wave LDS ring and resolved 64 at a time (full waves in
+                                  the any-hit loop).  All produce identical samples. */
     int32_t film_rgb;          /* 0: film channels X,Y,Z,A,W (integrator.cpp:72-74, 254-268);
                                   1: R,G,B,A,W -- linear RGB as mitsuba.python.autodiff._render_helper accumulates (autodiff.py:53-72) */
     int32_t integrator;        /* 0 = path (src/integrators/path.cpp), 1 = direct (direct.cpp), 2 = depth (depth.cpp) */

@@ -914,7 +914,7 @@ static int check_desc(const mtsamd_render_desc *d) {
     if (d->sample_count <= 0) return fail(MTSAMD_ERR_INVALID, "sample_count must be positive");
     if (d->integrator < 0 || d->integrator > 2) return fail(MTSAMD_ERR_UNSUPPORTED, "integrator %d is not implemented (0 path, 1 direct, 2 depth)", d->integrator);
     if (d->emitter_samples < 0 || d->bsdf_samples < 0) return fail(MTSAMD_ERR_INVALID, "Must have at least 1 BSDF or emitter sample!");
-    if (d->pipeline < 0 || d->pipeline > 3) return fail(MTSAMD_ERR_UNSUPPORTED, "pipeline %d is not available in this build", d->pipeline);
+    if (d->pipeline < 0 || d->pipeline > 4) return fail(MTSAMD_ERR_UNSUPPORTED, "pipeline %d is not available in this build", d->pipeline);
     return 0;
 }
 
@@ -970,7 +970,7 @@ struct Job {
     RowMap rows{};
     int store_xyz = 1;
     uint32_t plane_pix0 = 0, plane_pixels = 0;
-    bool split = false, shadow_queue = false;
+    bool split = false, shadow_queue = false, shadow_ring = false;
 };
 
 // Traces the local sample ordinals [first, first+n) of this render's rows to completion; results land in
@@ -1005,7 +1005,7 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     p.spp = j.d->sample_count; p.crop_x = j.d->crop_x; p.crop_y = j.d->crop_y; p.crop_w = j.d->crop_width; p.crop_h = j.d->crop_height;
     p.max_depth = j.d->max_depth; p.rr_depth = j.d->rr_depth;
     p.spectral = j.s->spectral ? 1 : 0;
-    p.split = j.shadow_queue ? 2 : (j.split ? 1 : 0);
+    p.split = j.shadow_ring ? 3 : (j.shadow_queue ? 2 : (j.split ? 1 : 0));
     p.integrator = j.d->integrator; p.emitter_samples = j.d->emitter_samples; p.bsdf_samples = j.d->bsdf_samples;
     p.hide_emitters = j.d->hide_emitters;
     if (j.d->integrator != 0) {          // direct / depth: one launch finishes the whole pass
@@ -1068,22 +1068,25 @@ int setup_job(Job &j, mtsamd_scene *s, const mtsamd_render_desc *d, hipStream_t 
     // pool empties, so fewer, larger passes waste less (cbox 1024^2 @ 256 spp: 4 passes of 2^26 -> 1 pass: +7 %).
     uint64_t pass_limit = 1ull << 28;
     if (const char *e = getenv("MTSAMD_PASS_LOG2")) pass_limit = 1ull << std::min(31, std::max(10, atoi(e)));      // experiment switch
-    // pipeline 0: fused kernel for LDS-resident (flat) scenes, split kernels for hierarchy scenes; 1 / 2 force one of them
+    // pipeline 0: one kernel with the in-kernel shadow ring (4) for LDS-resident (flat) scenes, split kernels (2) for hierarchy
+    // scenes; 1 / 2 / 3 / 4 force one schedule
     if (s->spectral && d->integrator != 0) return fail(MTSAMD_ERR_UNSUPPORTED, "the direct and depth integrators are implemented for the RGB variant only");
     j.split = d->integrator == 0 && (d->pipeline == 2 || (d->pipeline == 0 && !s->view.flat));
     j.shadow_queue = d->integrator == 0 && s->view.flat && d->pipeline == 3;
-    if (d->pipeline == 3 && !s->view.flat) return fail(MTSAMD_ERR_INVALID, "pipeline 3 (queued shadow rays) applies to LDS-resident scenes only");
+    j.shadow_ring = d->integrator == 0 && s->view.flat && (d->pipeline == 4 || d->pipeline == 0);
+    if ((d->pipeline == 3 || d->pipeline == 4) && !s->view.flat) return fail(MTSAMD_ERR_INVALID, "pipelines 3 and 4 (queued shadow rays) apply to LDS-resident scenes only");
     // Paths in flight.  A launch advances every in-flight path by one segment and ends with a tail in which the CUs run
     // dry one by one; the tails (and, for the split pipeline, the gaps between its three launches) only amortise over large
     // launches.  Measured on MI355X -- fused kernel, cbox 1024^2 @ 256 spp, scheduling waves per CU x slots per wave:
     // 16 x 256 -> 1753, 48 x 256 -> 1953, 72 x 512 -> 2366, 104 x 512 -> 2459, 208 x 1024 -> 2507 Msample/s (power-of-two
     // wave counts alias in the memory channels: 64 x 256 is slower than 72 x 256); split pipeline, 261 k-triangle mesh:
-    // 16 / 64 / 128 / 208 waves per CU x 256 slots -> 705 / 1162 / 1339 / 1407 Msample/s.
+    // 16 / 64 / 128 / 208 waves per CU x 256 slots -> 705 / 1162 / 1339 / 1407 Msample/s; shadow-ring kernel (schedule 4), cbox:
+    // 72 x 512 -> 2453, 104 x 512 -> 2554, 144 x 512 -> 2576, 208 x 512 -> 2629, 104 x 1024 -> 2598 Msample/s.
     j.target = d->paths_per_wave > 0 ? (uint32_t) d->paths_per_wave : (j.split ? 256u : 512u);
     j.target = std::min<uint32_t>(std::max<uint32_t>(j.target, 64u), 4096u);
     {   // no more scheduling waves than the pass can fill
         const uint64_t want = (std::min<uint64_t>(max_pass, pass_limit) + j.target - 1) / j.target;
-        const uint64_t lo = (uint64_t) s->cu_count * 16u, hi = (uint64_t) s->cu_count * (j.split ? 208u : 104u);
+        const uint64_t lo = (uint64_t) s->cu_count * 16u, hi = (uint64_t) s->cu_count * ((j.split || j.shadow_ring) ? 208u : 104u);
         j.n_waves = (uint32_t) std::min<uint64_t>(std::max<uint64_t>(want, lo), hi);
     }
     if (const char *e = getenv("MTSAMD_WAVES_PER_CU")) j.n_waves = (uint32_t) s->cu_count * (uint32_t) std::max(1, atoi(e));    // experiment switch

@@ -69,7 +69,9 @@ struct RenderParams {
     int32_t max_depth, rr_depth;
     int32_t spectral;           // 0: RGB variant, 1: spectral variant (4 wavelengths per sample)
     int32_t integrator, emitter_samples, bsdf_samples, hide_emitters;   // 0 path; 1 direct (direct.cpp); 2 depth (depth.cpp)
-    int32_t split;              // 0: fused k_bounce, 1: k_trace<closest> + k_shade + k_trace<any> per iteration
+    int32_t split;              // 0: fused k_bounce, 1: k_trace<closest> + k_shade + k_trace<any> per iteration, 2: k_shade (flat) + k_trace<any>,
+                                // 3: k_shade (flat) with the in-kernel shadow ring
+    uint32_t lds_queue_offset;  // split == 3: start of the per-wave shadow rings in LDS, in float4 units
 };
 
 struct FilmParams {

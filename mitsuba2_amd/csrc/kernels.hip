@@ -819,13 +819,46 @@ MTS_DEV void start_path(const RenderParams &P, uint64_t ordinal, uint32_t lp, ui
 
 // FLAT = false: hierarchy scene, closest hits precomputed by k_trace<false>; FLAT = true: LDS-resident scene, closest hit
 // inline (wave-uniform primitive loop), only the shadow rays are queued
-template <typename State, bool GENERAL, bool FLAT>
+// INLINE (flat scenes only): the shadow rays of consecutive 64-path chunks are collected in a per-wave LDS ring and resolved
+// 64 at a time inside this kernel -- the any-hit loop then always runs on full waves (only about two thirds of the paths cast
+// a shadow ray) -- and `nee` is added to the radiance the wave has already stored in its output segment.
+constexpr uint32_t kShadowRing = 128u;                       // >= 63 queued + 64 pushed
+template <typename State> struct ShadowRing { float4 *o, *d, *nee; uint32_t *slot; };
+
+template <typename State, bool GENERAL>
+MTS_DEV void drain_shadow_ring(const RenderParams &P, const LdsView &lds, const ShadowRing<State> &q, uint32_t head, uint32_t count,
+                               size_t base, Counters &c) {
+    // the wave's earlier stores to its output segment must have reached L2 before other lanes read-modify-write them
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    const uint32_t lane = lane_id();
+    if (lane < count) {
+        const uint32_t k = (head + lane) & (kShadowRing - 1u);
+        const float4 o = q.o[k], d = q.d[k];
+        Hit h;
+        if (!traverse<true, true>(P.sv, lds, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), o.w, d.w, h, c.tri_tests)) {
+            const size_t slot = base + q.slot[k];
+            float4 r = P.out.res[slot];
+            const float4 e = q.nee[k];
+            r.x += e.x; r.y += e.y; r.z += e.z; r.w += e.w;      // RGB: w = eta + 0
+            P.out.res[slot] = r;
+        }
+    }
+}
+
+template <typename State, bool GENERAL, bool FLAT, bool INLINE = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FLAT ? MTS_BOUNCE_WAVES : 1, FLAT ? MTS_BOUNCE_WAVES : 8)))
 void k_shade(const RenderParams P) {
+    static_assert(FLAT || !INLINE, "the in-kernel shadow queue is for LDS-resident scenes");
     extern __shared__ float4 smem[];
     LdsView lds = {};                      // Geo<false> reads the scene tables from global memory
     if (FLAT) lds = lds_stage<true>(P.sv, smem);
     const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    ShadowRing<State> ring = {};
+    if (INLINE) {
+        float4 *qb = smem + P.lds_queue_offset + (size_t) (threadIdx.x >> 6) * (kShadowRing * 13u / 4u);
+        ring.o = qb; ring.d = qb + kShadowRing; ring.nee = qb + 2u * kShadowRing;
+        ring.slot = reinterpret_cast<uint32_t *>(qb + 3u * kShadowRing);
+    }
     if (wave >= P.n_waves) return;
     const uint32_t lane = lane_id();
     const uint32_t n_in = __builtin_amdgcn_readfirstlane(P.count_in[wave]);
@@ -833,6 +866,7 @@ void k_shade(const RenderParams P) {
     uint32_t n_out = 0;
     Counters c = { 0u, 0u, 0u, 0u };
     uint32_t n_sh = 0;
+    uint32_t q_head = 0, q_count = 0;
 
     for (uint32_t i0 = 0; i0 < n_in; i0 += 64u) {
         State s;
@@ -863,16 +897,32 @@ void k_shade(const RenderParams P) {
             const uint32_t slot = n_out + mask_rank(m);
             store_state(P.out, base + slot, s);
             if (df.pending) {
-                const size_t q = base + n_sh + mask_rank(ms);
-                P.out.sh_o[q] = make_float4(df.so.x, df.so.y, df.so.z, df.smint);
-                P.out.sh_d[q] = make_float4(df.sd.x, df.sd.y, df.sd.z, df.smaxt);
-                P.out.nee[q] = make_float4(df.nee[0], df.nee[1], df.nee[2], df.nee[3]);
-                P.out.sh_slot[q] = slot;
+                if (INLINE) {
+                    const uint32_t k = (q_head + q_count + mask_rank(ms)) & (kShadowRing - 1u);
+                    ring.o[k] = make_float4(df.so.x, df.so.y, df.so.z, df.smint);
+                    ring.d[k] = make_float4(df.sd.x, df.sd.y, df.sd.z, df.smaxt);
+                    ring.nee[k] = make_float4(df.nee[0], df.nee[1], df.nee[2], df.nee[3]);
+                    ring.slot[k] = slot;
+                } else {
+                    const size_t q = base + n_sh + mask_rank(ms);
+                    P.out.sh_o[q] = make_float4(df.so.x, df.so.y, df.so.z, df.smint);
+                    P.out.sh_d[q] = make_float4(df.sd.x, df.sd.y, df.sd.z, df.smaxt);
+                    P.out.nee[q] = make_float4(df.nee[0], df.nee[1], df.nee[2], df.nee[3]);
+                    P.out.sh_slot[q] = slot;
+                }
             }
         }
         n_out += (uint32_t) __popcll(m);
         n_sh += (uint32_t) __popcll(ms);
+        if (INLINE) {
+            q_count += (uint32_t) __popcll(ms);
+            if (q_count >= 64u) {
+                drain_shadow_ring<State, GENERAL>(P, lds, ring, q_head, 64u, base, c);
+                q_head = (q_head + 64u) & (kShadowRing - 1u); q_count -= 64u;
+            }
+        }
     }
+    if (INLINE && q_count > 0u) drain_shadow_ring<State, GENERAL>(P, lds, ring, q_head, q_count, base, c);
 
     uint64_t cursor = P.cursor[wave];
     const uint64_t end = P.cursor_end[wave];
@@ -899,7 +949,7 @@ void k_shade(const RenderParams P) {
         for (int off = 32; off > 0; off >>= 1) tot[k] += __shfl_xor(tot[k], off);
     if (lane == 0) {
         P.count_out[wave] = n_out;
-        P.count_shadow[wave] = n_sh;
+        if (!INLINE) P.count_shadow[wave] = n_sh;
         P.cursor[wave] = cursor; P.cursor_pix[wave] = cpix; P.cursor_rem[wave] = crem;
         uint64_t *ws = P.wave_stats + 4u * (size_t) wave;
         ws[0] += tot[0]; ws[1] += tot[1]; ws[2] += tot[2];
@@ -967,7 +1017,19 @@ __global__ __launch_bounds__(kBlock) void k_trace(const RenderParams P) {
 
 size_t trace_lds_bytes(const SceneView &sv) { return (size_t) 4 * sv.stack_depth * kBlock; }
 
-hipError_t launch_bounce(const RenderParams &p, hipStream_t s) {
+hipError_t launch_bounce(const RenderParams &p_, hipStream_t s) {
+    RenderParams p = p_;
+    if (p.split == 3) {       // LDS-resident scene, one kernel: shadow rays collected in a per-wave LDS ring and resolved 64 at a time
+        const uint32_t shade_blocks = (p.n_waves * 64u + kBlock - 1) / kBlock;
+        const size_t scene_bytes = (bounce_lds_bytes(p.sv) + 15u) & ~(size_t) 15u;
+        p.lds_queue_offset = (uint32_t) (scene_bytes / 16u);
+        const size_t lds = scene_bytes + (size_t) (kBlock / 64u) * kShadowRing * 52u;
+        if (p.spectral && p.sv.general) hipLaunchKernelGGL((k_shade<PathStateS, true, true, true>), dim3(shade_blocks), dim3(kBlock), lds, s, p);
+        else if (p.spectral) hipLaunchKernelGGL((k_shade<PathStateS, false, true, true>), dim3(shade_blocks), dim3(kBlock), lds, s, p);
+        else if (p.sv.general) hipLaunchKernelGGL((k_shade<PathState, true, true, true>), dim3(shade_blocks), dim3(kBlock), lds, s, p);
+        else hipLaunchKernelGGL((k_shade<PathState, false, true, true>), dim3(shade_blocks), dim3(kBlock), lds, s, p);
+        return hipGetLastError();
+    }
     if (p.split == 2) {       // LDS-resident scene: closest hit + shading fused, shadow rays queued and resolved in dense batches
         const uint32_t shade_blocks = (p.n_waves * 64u + kBlock - 1) / kBlock;
         const size_t lds = bounce_lds_bytes(p.sv);

@@ -25,6 +25,10 @@ def test_cbox_fused_equals_split(variant):
     b, sb = _render(cb, sp, 2, variant)
     q, sq = _render(cb, sp, 3, variant)          # closest hit fused, shadow rays queued
     assert np.array_equal(a, b) and np.array_equal(a, q) and sq["any_hit_rays"] == sa["any_hit_rays"] and sq["tri_tests"] == sa["tri_tests"]
+    r, sr = _render(cb, sp, 4, variant)          # one kernel, shadow rays resolved 64 at a time from a per-wave LDS ring
+    assert np.array_equal(a, r) and sr["any_hit_rays"] == sa["any_hit_rays"] and sr["tri_tests"] == sa["tri_tests"]
+    r2, _ = _render(cb, sp, 4, variant, paths_per_wave=100)      # segments that are not a multiple of the wave size
+    assert np.array_equal(a, r2)
     for k in ("closest_hit_rays", "any_hit_rays", "samples", "segments"):
         assert sa[k] == sb[k]
     assert a[..., 4].min() > 0 and np.isfinite(a).all() and a[..., :3].max() > 0
@@ -51,3 +55,4 @@ def test_split_max_depth_and_textures():
         a, _ = _render(cb, sp, 1, max_depth=depth)
         b, _ = _render(cb, sp, 2, max_depth=depth)
         assert np.array_equal(a, b)
+        assert np.array_equal(a, _render(cb, sp, 4, max_depth=depth)[0])
