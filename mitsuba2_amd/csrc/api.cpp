@@ -773,7 +773,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     v.n_shapes = desc->mesh_count; v.n_bsdfs = desc->bsdf_count;
     v.textures = s->d_textures; v.n_textures = desc->texture_count;
     v.flat_recs = s->d_flat; v.flat = flat ? 1u : 0u;
-    v.general = (s->general_bsdfs || s->delta_emitters) ? 1u : 0u;       // the diffuse / area-light fast path (kernels.hip) handles neither
+    v.general = (s->general_bsdfs || s->delta_emitters || s->environment >= 0) ? 1u : 0u;       // the diffuse / area-light fast path (kernels.hip) handles none of these
     v.flat_pairs = s->d_pairs; v.n_pairs = n_pairs;
     if (bounce_lds_bytes(v) > 150 * 1024) {
         mtsamd_scene_destroy(s);

@@ -439,7 +439,7 @@ struct DirectionSample { f3 p, n, d; float dist, pdf; uint32_t emitter; f2 uv; b
 
 // Scene::sample_emitter_direction without the visibility test.  The emitted spectrum is returned in factored
 // form: spec = (radiance * r1) * r2 with r1 = 1/pdf (0 when the sample is masked) and r2 = emitter count.
-// DELTA = false compiles the point / spot / directional branch out (the diffuse / area-light fast path).
+// DELTA = false compiles everything but area lights out (the diffuse / area-light fast path): environment and delta emitters.
 template <bool FLAT, bool DELTA = true>
 MTS_DEV void sample_emitter_direction(const Geo<FLAT> &g, f3 ref_p, f2 sample, DirectionSample &ds, float &r1, float &r2) {
     const SceneView &sv = g.sv;
@@ -457,7 +457,7 @@ MTS_DEV void sample_emitter_direction(const Geo<FLAT> &g, f3 ref_p, f2 sample, D
         sample.x = (sample.x - (float) index * emitter_pdf) * nf;
     }
     const DevEmitter e = g.emitter(index);
-    if (e.pad0 == kEmitterEnvmap) {
+    if (DELTA && e.pad0 == kEmitterEnvmap) {
         // EnvironmentMapEmitter::sample_direction (envmap.cpp:154-190); r1 = 1 / pdf, the radiance is looked up by the caller
         f3 d; f2 uv; float pdf;
         envmap_sample(*sv.envmap, sample, d, pdf, uv);
@@ -494,7 +494,7 @@ MTS_DEV void sample_emitter_direction(const Geo<FLAT> &g, f3 ref_p, f2 sample, D
         if (sv.n_emitters > 1) { ds.pdf *= emitter_pdf; r2 = rcp(emitter_pdf); }
         return;
     }
-    if (e.pad0 == kEmitterConstant) {
+    if (DELTA && e.pad0 == kEmitterConstant) {
         // ConstantBackgroundEmitter::sample_direction (constant.cpp:82-107), square_to_uniform_sphere (warp.h:262-267)
         const float z = fmaf(-2.0f, sample.y, 1.0f), r = safe_sqrt(fmaf(-z, z, 1.0f));
         const float ang = 2.0f * kPi * sample.x;
@@ -563,7 +563,7 @@ MTS_DEV void sample_emitter_direction(const Geo<FLAT> &g, f3 ref_p, f2 sample, D
     if (g.sv.n_emitters == 0) return;
     const DevEmitter e = g.emitter(ds.emitter);
     f3 rad = mk3(e.r, e.g, e.b);
-    if (e.pad0 == kEmitterEnvmap) rad = envmap_lookup(*g.sv.envmap, ds.uv.x, ds.uv.y);      // eval_spectrum at the sampled (u, v)
+    if (DELTA && e.pad0 == kEmitterEnvmap) rad = envmap_lookup(*g.sv.envmap, ds.uv.x, ds.uv.y);      // eval_spectrum at the sampled (u, v)
     if (DELTA && ds.delta) rad = mk3(rad.x * ds.falloff, rad.y * ds.falloff, rad.z * ds.falloff);
     spec = mk3(rad.x * r1, rad.y * r1, rad.z * r1);
     if (g.sv.n_emitters > 1) spec = spec * r2;

@@ -116,7 +116,7 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
             }
         }
     }
-    if (!REC && !found && sv.env_emitter >= 0) {             // si.emitter(scene) of an escaped ray: the environment
+    if (GENERAL && !REC && !found && sv.env_emitter >= 0) {  // si.emitter(scene) of an escaped ray: the environment
         const DevEmitter e = geo.emitter((uint32_t) sv.env_emitter);
         float ew = 1.0f;
         if (s.depth > 1u) ew = mis_weight(s.bs_pdf, (GENERAL && (s.flags & kFlagDelta)) ? 0.0f : pdf_environment(sv, e, s.d));
@@ -474,7 +474,7 @@ MTS_DEV bool bounce_step_spectral(const RenderParams &P, const LdsView &lds, Pat
             }
         }
     }
-    if (!found && sv.env_emitter >= 0) {                     // si.emitter(scene) of an escaped ray: the environment
+    if (GENERAL && !found && sv.env_emitter >= 0) {          // si.emitter(scene) of an escaped ray: the environment
         const DevEmitter e = geo.emitter((uint32_t) sv.env_emitter);
         float ew = 1.0f;
         if (s.depth > 1u) ew = mis_weight(s.bs_pdf, (GENERAL && (s.flags & kFlagDelta)) ? 0.0f : pdf_environment(sv, e, s.d));
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(kBlock) void k_direct(const RenderParams P, uint64_
             const float t = found ? hit.t : 0.0f;
             s.res = mk3(t, t, t);
         } else if (!found) {
-            if (!P.hide_emitters && sv.env_emitter >= 0) {
+            if (GENERAL && !P.hide_emitters && sv.env_emitter >= 0) {
                 const DevEmitter e = geo.emitter((uint32_t) sv.env_emitter);
                 const f3 le = environment_radiance(sv, e, s.d);
                 s.res = mk3(s.res.x + le.x, s.res.y + le.y, s.res.z + le.z);
@@ -751,7 +751,7 @@ __global__ __launch_bounds__(kBlock) void k_direct(const RenderParams P, uint64_
                 const f3 d2 = to_world(si.sh, wo);
                 f3 le; float pe;
                 if (!traverse<FLAT, false>(sv, lds, si.p, d2, (1.0f + hmax_abs(si.p)) * kRayEpsilon, __builtin_inff(), h2, c.tri_tests)) {
-                    if (sv.env_emitter < 0) continue;
+                    if (!GENERAL || sv.env_emitter < 0) continue;
                     const DevEmitter e = geo.emitter((uint32_t) sv.env_emitter);
                     le = environment_radiance(sv, e, d2);
                     pe = delta ? 0.0f : pdf_environment(sv, e, d2);
