@@ -136,7 +136,9 @@ def main():
         tot_closest, tot_any, tot_samples = float(acc["closest_hit_rays"]), float(acc["any_hit_rays"]), float(acc["samples"])
 
     if rank == 0:
-        # roofline of the dominant kernel (k_bounce) on rank 0: algorithmic bytes per launch / average launch time.
+        # roofline of the dominant kernel on rank 0 -- the one that advances every in-flight path by one segment: k_shade<PathState,
+        # false, true, true> (closest hit + shading + in-kernel shadow ring, the default schedule for LDS-resident scenes) or k_bounce
+        # with --pipeline 1: algorithmic bytes per launch / average launch time.
         # Per segment the kernel reads one 88-B path record and writes one (a survivor or a regenerated camera path:
         # survivors + generated == segments over a whole render); per finished sample it writes 16 B radiance + 8 B
         # film position.  Launch durations come from HIP events recorded on the render stream inside mtsamd_render.
@@ -149,7 +151,10 @@ def main():
         # counted to algorithmic bytes; scaled here to this run's bytes per launch (launch sizes differ with the sample count).
         traffic, traffic_src = None, None
         import glob
-        pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_k_bounce.json")))
+        kernel = {0: "k_shade<mtsamd::PathState, false, true, true>", 4: "k_shade<mtsamd::PathState, false, true, true>",
+                  1: "k_bounce<true, false>", 2: "k_trace<false, false> + k_shade<mtsamd::PathState, false, false, false> + k_trace<true, false>",
+                  3: "k_shade<mtsamd::PathState, false, true, false> + k_trace<true, true>"}[args.pipeline]
+        pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bounce_kernel.json")))
         if pmc:
             try:
                 traffic = json.load(open(pmc[-1]))["traffic_over_algorithmic"] * (alg_bytes / launches)
@@ -172,9 +177,9 @@ def main():
                        "partition": "interleaved 32-row film tiles + RCCL reduce" if n > 1 else "single GPU"},
             "mray_per_s": (tot_closest + tot_any) / dt / 1e6,
             "segments_per_sample": acc["segments"] / max(acc["samples"], 1),
-            "kernel_ms": {"k_bounce_per_step": acc["bounce_ns"] / args.steps * 1e-6, "k_film_tiles_per_step": acc["film_ns"] / args.steps * 1e-6,
-                          "k_bounce_launches_per_step": launches / args.steps, "k_bounce_avg_launch_us": bounce_s / launches * 1e6},
-            "roofline": {"bound": "hbm", "kernel": "k_bounce", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "kernel_ms": {"bounce_kernel_per_step": acc["bounce_ns"] / args.steps * 1e-6, "k_film_tiles_per_step": acc["film_ns"] / args.steps * 1e-6,
+                          "bounce_kernel_launches_per_step": launches / args.steps, "bounce_kernel_avg_launch_us": bounce_s / launches * 1e6},
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "alg_bytes_per_launch": alg_bytes / launches},
         }

@@ -2,7 +2,8 @@
 """Turns gpurun_out/prof_<tag>/ (scripts/collect_profiles.sh) into the summaries committed under profiles/:
   profiles/<tag>_kernel_stats.csv      rocprofv3 --kernel-trace --stats of `bench.py --steps 3 --warmup 1`
   profiles/<tag>_bench.json            the bench line printed by that same run
-  profiles/<tag>_pmc_k_bounce.json     per-launch HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) and SQ counters
+  profiles/<tag>_pmc_bounce_kernel.json     per-launch HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) and SQ counters of the
+                                            kernel that advances the paths by one segment (bench line: roofline.kernel)
 """
 import collections
 import csv
@@ -32,12 +33,16 @@ def bench_line(log):
 json.dump(bench_line(os.path.join(src, "trace.log")), open(os.path.join(dst, tag + "_bench.json"), "w"), indent=1)
 
 
+KERNEL = bench_line(os.path.join(src, "trace.log"))["roofline"]["kernel"]
+KEY = KERNEL.split("<")[0]                      # k_shade / k_bounce: the only instantiation the bench command launches
+
+
 def counters(sub):
     f = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))[0]
     agg = collections.defaultdict(float)
     launches = set()
     for r in csv.DictReader(open(f)):
-        if "k_bounce" in r["Kernel_Name"]:
+        if KEY + "<" in r["Kernel_Name"] or KEY + "(" in r["Kernel_Name"]:
             agg[r["Counter_Name"]] += float(r["Counter_Value"])
             launches.add(r["Dispatch_Id"])
     return dict(agg), len(launches), bench_line(os.path.join(src, sub + ".log"))
@@ -50,8 +55,8 @@ sq, n_s, b_s = counters("sq")
 # (MI355X_MICROARCH.md, HBM section) -> corrected read bytes = 2 x FETCH_SIZE; WRITE_SIZE is exact for 16-B stores.
 alg_per_launch = b_f["roofline"]["alg_bytes_per_launch"]
 out = {
-    "command": "rocprofv3 --pmc <counter> -- python3 bench.py --steps 1 --warmup 0 --spp 32 --no-cpu-baseline (one pass per TCC counter)",
-    "kernel": "k_bounce<true, false>",
+    "command": "rocprofv3 --pmc <counter> -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline (one pass per TCC counter)",
+    "kernel": KERNEL,
     "launches": n_f,
     "fetch_size_kib_raw": fetch.get("FETCH_SIZE", 0.0),
     "write_size_kib_raw": write.get("WRITE_SIZE", 0.0),
@@ -65,7 +70,7 @@ out["hbm_bytes_per_launch"] = out["hbm_read_bytes_per_launch_corrected"] + out["
 out["traffic_over_algorithmic"] = out["hbm_bytes_per_launch"] / alg_per_launch
 if sq.get("SQ_ACTIVE_INST_VALU"):
     out["valu_lane_utilisation"] = sq["SQ_THREAD_CYCLES_VALU"] / (sq["SQ_ACTIVE_INST_VALU"] * 64.0)
-    seg = b_s["segments_per_sample"] * 1024 * 1024 * 32
+    seg = b_s["segments_per_sample"] * b_s["value"] * 1e6 * b_s["ms_per_step"] * 1e-3 * b_s["steps"]      # segments of the profiled run
     out["valu_instructions_per_wave_segment"] = sq["SQ_INSTS_VALU"] / (seg / 64.0)
-json.dump(out, open(os.path.join(dst, tag + "_pmc_k_bounce.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(dst, tag + "_pmc_bounce_kernel.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
