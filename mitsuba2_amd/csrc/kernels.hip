@@ -1276,7 +1276,11 @@ __global__ __launch_bounds__(kBlock) void k_film_gather(const FilmParams F) {
 // the first footprint pixel (lo) and the <= 4 filter taps per axis, exactly as imageblock.cpp:117-147 computes
 // them -- and then every thread gathers its pixel's taps from those records, branch-free.  Each film pixel is
 // accumulated by one thread in a fixed order: bitwise reproducible, no atomics.
-constexpr int kFilmTile = 16, kFilmChunk = 2, kFilmTaps = 5;      // taps per axis seen from the source pixel: 2R+1 <= 5
+// samples staged per barrier pair; cbox 1024^2 @ 256 spp: 1 -> 14.2 ms, 2 -> 8.8 ms, 3 -> 14.9 ms, 4 -> 29.1 ms (LDS occupancy)
+#ifndef MTS_FILM_CHUNK
+#define MTS_FILM_CHUNK 2
+#endif
+constexpr int kFilmTile = 16, kFilmChunk = MTS_FILM_CHUNK, kFilmTaps = 5;      // taps per axis seen from the source pixel: 2R+1 <= 5
 
 // Filter weights of one sample along one axis for the 2R+1 film pixels q-R .. q+R around its source pixel q
 // (block coordinates t = q + border + k - R), exactly as imageblock.cpp:117-147 evaluates them: 0 outside [lo, hi]
@@ -1321,7 +1325,7 @@ __global__ __launch_bounds__(kBlock) void k_film_tiles(const FilmParams F) {
     float acc[5] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
     // Every thread stages up to kStage records per chunk.  Their stream slots for sample plane s are slot0 + s * step;
     // the loads of the NEXT chunk are issued before the gather of the current one so that their latency is hidden.
-    constexpr int kStage = 4;
+    constexpr int kStage = (kFilmChunk * (kFilmTile + 4) * (kFilmTile + 4) + kBlock - 1) / kBlock;
     int64_t slot0[kStage]; int64_t step[kStage]; int ent_c[kStage]; int tap_x0[kStage], tap_y0[kStage];
 #pragma unroll
     for (int k = 0; k < kStage; ++k) {
