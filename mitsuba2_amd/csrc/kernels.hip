@@ -257,8 +257,15 @@ template <bool FLAT, bool GENERAL>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MTS_BOUNCE_WAVES, MTS_BOUNCE_WAVES)))
 void k_bounce(const RenderParams P) {
     extern __shared__ float4 smem[];
-    const LdsView lds = lds_stage<FLAT>(P.sv, smem);
     const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    {   // a workgroup whose scheduling waves are all idle (pool drain at the end of a pass) leaves before staging the scene
+        const bool work = wave < P.n_waves && (P.count_in[wave] > 0u || P.cursor[wave] < P.cursor_end[wave]);
+        if (!__syncthreads_or(work ? 1 : 0)) {
+            if (wave < P.n_waves && lane_id() == 0u) P.count_out[wave] = 0u;
+            return;
+        }
+    }
+    const LdsView lds = lds_stage<FLAT>(P.sv, smem);
     if (wave >= P.n_waves) return;
     const uint32_t lane = lane_id();
     const uint32_t n_in = __builtin_amdgcn_readfirstlane(P.count_in[wave]);
@@ -851,8 +858,20 @@ void k_shade(const RenderParams P) {
     static_assert(FLAT || !INLINE, "the in-kernel shadow queue is for LDS-resident scenes");
     extern __shared__ float4 smem[];
     LdsView lds = {};                      // Geo<false> reads the scene tables from global memory
-    if (FLAT) lds = lds_stage<true>(P.sv, smem);
     const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    if (FLAT) {
+        // While the pool drains at the end of a pass most scheduling waves have nothing left to do: a workgroup whose four
+        // waves are all idle leaves before staging the scene into LDS (its output counts still have to be reset).
+        const bool work = wave < P.n_waves && (P.count_in[wave] > 0u || P.cursor[wave] < P.cursor_end[wave]);
+        if (!__syncthreads_or(work ? 1 : 0)) {
+            if (wave < P.n_waves && lane_id() == 0u) {
+                P.count_out[wave] = 0u;
+                if (!INLINE) P.count_shadow[wave] = 0u;
+            }
+            return;
+        }
+        lds = lds_stage<true>(P.sv, smem);
+    }
     ShadowRing<State> ring = {};
     if (INLINE) {
         float4 *qb = smem + P.lds_queue_offset + (size_t) (threadIdx.x >> 6) * (kShadowRing * 13u / 4u);
