@@ -622,7 +622,9 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     }
 
     // ---- accelerator -------------------------------------------------------------------------
-    if (s->n_prims > 0) build_bvh(tri_pos.data(), s->n_prims, 4, s->bvh);
+    uint32_t max_leaf = 4;
+    if (const char *e = std::getenv("MTSAMD_BVH_LEAF")) max_leaf = (uint32_t) std::min(15, std::max(1, atoi(e)));      // experiment switch
+    if (s->n_prims > 0) build_bvh(tri_pos.data(), s->n_prims, max_leaf, s->bvh);
     else { s->bvh = BvhOutput{}; s->bvh.root = 0x80000000u; }       // a leaf with no triangles
     if (s->environment >= 0) {       // ConstantBackgroundEmitter::set_scene (constant.cpp:47-51): bounding sphere of Scene::bbox()
         DevEmitter &e = s->emitters[s->environment];

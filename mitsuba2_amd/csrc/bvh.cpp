@@ -5,6 +5,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <queue>
 
 namespace mtsamd {
@@ -171,7 +172,18 @@ void build_bvh(const float *tri_pos, uint32_t n_prims, uint32_t max_leaf, BvhOut
     // array is what gets staged in LDS), triangle slots in the order their leaves are reached.
     std::vector<int32_t> inner_index(b.nodes.size(), -1);
     std::vector<int32_t> bfs;
-    {
+    const char *order_env = std::getenv("MTSAMD_BVH_ORDER");      // experiment switch: "dfs" = pre-order layout
+    if (order_env && order_env[0] == 'd') {
+        std::vector<int32_t> st;
+        if (b.nodes[root].left >= 0) st.push_back(root);
+        while (!st.empty()) {
+            int32_t t = st.back(); st.pop_back();
+            inner_index[t] = (int32_t) bfs.size(); bfs.push_back(t);
+            const TmpNode &n = b.nodes[t];
+            if (b.nodes[n.right].left >= 0) st.push_back(n.right);
+            if (b.nodes[n.left].left >= 0) st.push_back(n.left);
+        }
+    } else {
         std::queue<int32_t> q;
         if (b.nodes[root].left >= 0) q.push(root);
         while (!q.empty()) {
