@@ -182,77 +182,90 @@ MTS_DEV float clamp_inv(float d) {
 // rejects a triangle the fp32 Moeller-Trumbore test would accept.
 constexpr uint32_t kNoNode = 0x7fffffffu;       // "nothing left": not a leaf, never a valid inner index
 
+// State of one BVH walk.  `cur` == kNoNode: finished (or never started).
+struct BvhWalk {
+    f3 o, d, inv; float mint, maxt, best;
+    uint32_t sp, cur, best_prim; bool found;
+    Hit hit;
+};
+MTS_DEV void walk_begin(BvhWalk &w, const SceneView &sv, f3 o, f3 d, float mint, float maxt) {
+    w.o = o; w.d = d; w.inv = mk3(clamp_inv(d.x), clamp_inv(d.y), clamp_inv(d.z));
+    w.mint = mint; w.maxt = maxt; w.best = maxt;
+    w.sp = 0; w.cur = sv.root; w.best_prim = kNoPrim; w.found = false;
+}
+// One round of the "while-while" traversal: the lane descends until it holds a leaf (or nothing), then the wave tests leaves
+// together -- the two phases are not interleaved lane by lane, which keeps more lanes busy in each of them.  ANY: the walk
+// ends (cur = kNoNode, found = true) at the first hit.
+template <bool ANY>
+MTS_DEV void walk_round(BvhWalk &w, const SceneView &sv, uint32_t *stack, uint32_t stride, uint32_t &tri_tests) {
+    uint32_t cur = w.cur, sp = w.sp;
+    const f3 o = w.o, inv = w.inv;
+    while ((int32_t) cur >= 0 && cur != kNoNode) {
+        const float4 *p = sv.nodes + 4u * cur;
+        const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+        float ax = (q0.x - o.x) * inv.x, bx = (q0.w - o.x) * inv.x;
+        float ay = (q0.y - o.y) * inv.y, by = (q1.x - o.y) * inv.y;
+        float az = (q0.z - o.z) * inv.z, bz = (q1.y - o.z) * inv.z;
+        float nearL = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), w.mint));
+        float farL = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), w.best));
+        ax = (q1.z - o.x) * inv.x; bx = (q2.y - o.x) * inv.x;
+        ay = (q1.w - o.y) * inv.y; by = (q2.z - o.y) * inv.y;
+        az = (q2.x - o.z) * inv.z; bz = (q2.w - o.z) * inv.z;
+        float nearR = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), w.mint));
+        float farR = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), w.best));
+        const bool hl = nearL <= farL, hr = nearR <= farR;
+        const uint32_t cl = __float_as_uint(q3.x), cr = __float_as_uint(q3.y);
+        if (hl && hr) {
+            const bool lf = nearL <= nearR;
+            stack[sp * stride] = lf ? cr : cl;
+            ++sp;
+            cur = lf ? cl : cr;
+        } else if (hl) {
+            cur = cl;
+        } else if (hr) {
+            cur = cr;
+        } else if (sp) {
+            --sp;
+            cur = stack[sp * stride];
+        } else {
+            cur = kNoNode;
+        }
+    }
+    if (cur & kLeafFlag) {
+        const uint32_t start = cur & kLeafStartMask, count = (cur >> kLeafCountShift) & 0xfu;
+        for (uint32_t i = 0; i < count; ++i) {
+            const float4 *p = sv.tris + 3u * (start + i);
+            const float4 t0 = p[0], t1 = p[1], t2 = p[2];
+            float u, v, t;
+            ++tri_tests;
+            if (tri_test(mk3(t0.x, t0.y, t0.z), mk3(t0.w, t1.x, t1.y), mk3(t1.z, t1.w, t2.x), o, w.d, w.mint, w.maxt, u, v, t)) {
+                if (ANY) { w.found = true; w.cur = kNoNode; w.sp = 0; return; }
+                const uint32_t prim = __float_as_uint(t2.y);
+                if (!w.found || t < w.best || (t == w.best && prim > w.best_prim)) {
+                    w.found = true; w.best = t; w.best_prim = prim;
+                    w.hit.t = t; w.hit.prim = prim; w.hit.u = u; w.hit.v = v;
+                }
+            }
+        }
+        if (sp) {
+            --sp;
+            cur = stack[sp * stride];
+        } else {
+            cur = kNoNode;
+        }
+    }
+    w.cur = cur; w.sp = sp;
+}
+
 template <bool ANY>
 MTS_DEV bool traverse_bvh(const SceneView &sv, const LdsView &lds, f3 o, f3 d, float mint, float maxt,
                           Hit &hit, uint32_t &tri_tests) {
-    const f3 inv = mk3(clamp_inv(d.x), clamp_inv(d.y), clamp_inv(d.z));
+    BvhWalk w;
+    walk_begin(w, sv, o, d, mint, maxt);
     uint32_t *stack = lds.stack + threadIdx.x;
-    const uint32_t stride = lds.stride;
-    uint32_t sp = 0;
-    uint32_t cur = sv.root;
-    float best = maxt;
-    uint32_t best_prim = kNoPrim;
-    bool found = false;
-
-    // "while-while" traversal: every lane descends until it holds a leaf (or nothing), then the wave tests leaves
-    // together -- the two phases are not interleaved lane by lane, which keeps more lanes busy in each of them.
-    while (cur != kNoNode) {
-        while ((int32_t) cur >= 0 && cur != kNoNode) {
-            const float4 *p = sv.nodes + 4u * cur;
-            const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-            float ax = (q0.x - o.x) * inv.x, bx = (q0.w - o.x) * inv.x;
-            float ay = (q0.y - o.y) * inv.y, by = (q1.x - o.y) * inv.y;
-            float az = (q0.z - o.z) * inv.z, bz = (q1.y - o.z) * inv.z;
-            float nearL = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), mint));
-            float farL = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best));
-            ax = (q1.z - o.x) * inv.x; bx = (q2.y - o.x) * inv.x;
-            ay = (q1.w - o.y) * inv.y; by = (q2.z - o.y) * inv.y;
-            az = (q2.x - o.z) * inv.z; bz = (q2.w - o.z) * inv.z;
-            float nearR = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), mint));
-            float farR = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best));
-            const bool hl = nearL <= farL, hr = nearR <= farR;
-            const uint32_t cl = __float_as_uint(q3.x), cr = __float_as_uint(q3.y);
-            if (hl && hr) {
-                const bool lf = nearL <= nearR;
-                stack[sp * stride] = lf ? cr : cl;
-                ++sp;
-                cur = lf ? cl : cr;
-            } else if (hl) {
-                cur = cl;
-            } else if (hr) {
-                cur = cr;
-            } else if (sp) {
-                --sp;
-                cur = stack[sp * stride];
-            } else {
-                cur = kNoNode;
-            }
-        }
-        if (cur & kLeafFlag) {
-            const uint32_t start = cur & kLeafStartMask, count = (cur >> kLeafCountShift) & 0xfu;
-            for (uint32_t i = 0; i < count; ++i) {
-                const float4 *p = sv.tris + 3u * (start + i);
-                const float4 t0 = p[0], t1 = p[1], t2 = p[2];
-                float u, v, t;
-                ++tri_tests;
-                if (tri_test(mk3(t0.x, t0.y, t0.z), mk3(t0.w, t1.x, t1.y), mk3(t1.z, t1.w, t2.x), o, d, mint, maxt, u, v, t)) {
-                    if (ANY) return true;
-                    const uint32_t prim = __float_as_uint(t2.y);
-                    if (!found || t < best || (t == best && prim > best_prim)) {
-                        found = true; best = t; best_prim = prim;
-                        hit.t = t; hit.prim = prim; hit.u = u; hit.v = v;
-                    }
-                }
-            }
-            if (sp) {
-                --sp;
-                cur = stack[sp * stride];
-            } else {
-                cur = kNoNode;
-            }
-        }
-    }
-    return found;
+    while (w.cur != kNoNode) walk_round<ANY>(w, sv, stack, lds.stride, tri_tests);
+    if (!ANY && w.found) hit = w.hit;
+    return w.found;
 }
 
 // Flat scenes: a wave-uniform loop over every primitive record in LDS (broadcast reads, no stack,

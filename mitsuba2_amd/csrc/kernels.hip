@@ -993,44 +993,89 @@ __global__ __launch_bounds__(kBlock) void k_trace(const RenderParams P) {
         lds.stack = reinterpret_cast<uint32_t *>(smem);
     }
     uint32_t tri_tests = 0;
-    Hit h;
-    if (ANY) {
-        const PoolView &pool = P.out;
-        const uint32_t w0 = blockIdx.x * kShadowGroup;
-        uint32_t cnt[kShadowGroup], total = 0;
+    // work list of this workgroup: the shadow queues (ANY) or the path slots (closest hit) of kShadowGroup scheduling waves
+    const PoolView &pool = ANY ? P.out : P.in;
+    const uint32_t w0 = blockIdx.x * kShadowGroup;
+    uint32_t cnt[kShadowGroup], total = 0;
+    const uint32_t *counts = ANY ? P.count_shadow : P.count_in;
 #pragma unroll
-        for (uint32_t g = 0; g < kShadowGroup; ++g) { cnt[g] = (w0 + g < P.n_waves) ? P.count_shadow[w0 + g] : 0u; total += cnt[g]; }
+    for (uint32_t g = 0; g < kShadowGroup; ++g) { cnt[g] = (w0 + g < P.n_waves) ? counts[w0 + g] : 0u; total += cnt[g]; }
+    auto locate = [&](uint32_t idx) -> size_t {              // work item -> pool index
+        uint32_t wave = w0, i = idx;
+#pragma unroll
+        for (uint32_t g = 0; g + 1 < kShadowGroup; ++g)
+            if (wave == w0 + g && i >= cnt[g]) { i -= cnt[g]; ++wave; }
+        return (size_t) wave * P.seg_cap + i;
+    };
+    auto retire_any = [&](size_t k) {                        // unoccluded shadow ray: radiance[slot] += nee
+        const size_t slot = (k / P.seg_cap) * P.seg_cap + pool.sh_slot[k];
+        float4 r = pool.res[slot];
+        const float4 e = pool.nee[k];
+        r.x += e.x; r.y += e.y; r.z += e.z; r.w += e.w;      // RGB: w = eta + 0
+        pool.res[slot] = r;
+    };
+    if (FLAT) {
+        Hit h;
         for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
-            uint32_t wave = w0, i = idx;
-#pragma unroll
-            for (uint32_t g = 0; g + 1 < kShadowGroup; ++g)
-                if (wave == w0 + g && i >= cnt[g]) { i -= cnt[g]; ++wave; }
-            const size_t base = (size_t) wave * P.seg_cap, k = base + i;
+            const size_t k = locate(idx);
             const float4 o = pool.sh_o[k], d = pool.sh_d[k];
-            if (!traverse<FLAT, true>(P.sv, lds, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), o.w, d.w, h, tri_tests)) {
-                const size_t slot = base + pool.sh_slot[k];
-                float4 r = pool.res[slot];
-                const float4 e = pool.nee[k];
-                r.x += e.x; r.y += e.y; r.z += e.z; r.w += e.w;      // RGB: w = eta + 0
-                pool.res[slot] = r;
-            }
+            if (!traverse<true, true>(P.sv, lds, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), o.w, d.w, h, tri_tests)) retire_any(k);
         }
     } else {
-        const PoolView &pool = P.in;
-        const uint32_t wave = blockIdx.x, n = P.count_in[wave];
-        const size_t base = (size_t) wave * P.seg_cap;
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-            const size_t k = base + i;
-            if ((pool.misc[k].y >> 16) & kFlagZombie) continue;
-            const float4 o = pool.ray_o[k], d = pool.ray_d[k];
-            const bool found = traverse_bvh<false>(P.sv, lds, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), o.w, d.w, h, tri_tests);
-            pool.hit[k] = found ? make_float4(h.t, __uint_as_float(h.prim), h.u, h.v)
-                                : make_float4(__builtin_inff(), __uint_as_float(kNoPrim), 0.0f, 0.0f);
+        // Dynamic ray fetch: a lane that has finished its walk takes the next item of the workgroup's list at once instead of
+        // idling until the slowest lane of its wave is done (the walks of incoherent rays differ several-fold in length: with
+        // one ray per lane and loop trip only 22-29 % of the VALU lane-cycles were useful).
+        __shared__ uint32_t s_next;
+        if (threadIdx.x == 0) s_next = 0u;
+        __syncthreads();
+        const uint32_t lane = lane_id();
+        uint32_t *stack = lds.stack + threadIdx.x;
+        BvhWalk w;
+        w.cur = kNoNode; w.sp = 0u; w.found = false;
+        bool busy = false;                                   // the lane holds a work item
+        size_t k = 0;
+        bool exhausted = false;
+        while (true) {
+            const bool need = w.cur == kNoNode;
+            if (need && busy) {                              // retire the finished item
+                if (ANY) { if (!w.found) retire_any(k); }
+                else pool.hit[k] = w.found ? make_float4(w.hit.t, __uint_as_float(w.hit.prim), w.hit.u, w.hit.v)
+                                           : make_float4(__builtin_inff(), __uint_as_float(kNoPrim), 0.0f, 0.0f);
+                busy = false;
+            }
+            const uint64_t m = __ballot(need);
+            if (m && !exhausted) {
+                const uint32_t first = (uint32_t) __ffsll((long long) m) - 1u, want = (uint32_t) __popcll(m);
+                uint32_t base = 0u;
+                if (lane == first) base = atomicAdd(&s_next, want);
+                base = __shfl(base, (int) first);
+                exhausted = base + want >= total;
+                if (need) {
+                    const uint32_t idx = base + mask_rank(m);
+                    if (idx < total) {
+                        k = locate(idx);
+                        if (ANY) {
+                            const float4 o = pool.sh_o[k], d = pool.sh_d[k];
+                            walk_begin(w, P.sv, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), o.w, d.w);
+                            busy = true;
+                        } else if (!((pool.misc[k].y >> 16) & kFlagZombie)) {      // zombies only wait for their shadow ray
+                            const float4 o = pool.ray_o[k], d = pool.ray_d[k];
+                            walk_begin(w, P.sv, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), o.w, d.w);
+                            busy = true;
+                        }
+                    }
+                }
+            }
+            if (__ballot(w.cur != kNoNode) == 0ull) {
+                if (exhausted) break;
+                continue;                                    // only zombies were fetched: try again
+            }
+            if (w.cur != kNoNode) walk_round<ANY>(w, P.sv, stack, lds.stride, tri_tests);
         }
     }
     for (int off = 32; off > 0; off >>= 1) tri_tests += __shfl_xor(tri_tests, off);
     if (lane_id() == 0 && tri_tests)
-        atomicAdd(reinterpret_cast<unsigned long long *>(P.wave_stats + 4u * (size_t) (ANY ? blockIdx.x * kShadowGroup : blockIdx.x) + 3u),
+        atomicAdd(reinterpret_cast<unsigned long long *>(P.wave_stats + 4u * (size_t) (blockIdx.x * kShadowGroup) + 3u),
                   (unsigned long long) tri_tests);
 }
 
@@ -1061,7 +1106,7 @@ hipError_t launch_bounce(const RenderParams &p_, hipStream_t s) {
     }
     if (p.split) {
         const uint32_t shade_blocks = (p.n_waves * 64u + kBlock - 1) / kBlock;
-        hipLaunchKernelGGL((k_trace<false, false>), dim3(p.n_waves), dim3(kBlock), trace_lds_bytes(p.sv), s, p);
+        hipLaunchKernelGGL((k_trace<false, false>), dim3((p.n_waves + kShadowGroup - 1) / kShadowGroup), dim3(kBlock), trace_lds_bytes(p.sv), s, p);
         if (p.spectral && p.sv.general) hipLaunchKernelGGL((k_shade<PathStateS, true, false>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
         else if (p.spectral) hipLaunchKernelGGL((k_shade<PathStateS, false, false>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
         else if (p.sv.general) hipLaunchKernelGGL((k_shade<PathState, true, false>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
