@@ -296,6 +296,7 @@ struct mtsamd_scene {
     std::vector<DevBsdf> bsdfs;
     std::vector<DevEmitter> emitters;
     float4 *d_nodes = nullptr, *d_tris = nullptr;
+    uint4 *d_qnodes = nullptr;
     float *d_tri_pos = nullptr, *d_tri_nrm = nullptr, *d_tri_uv = nullptr;
     uint32_t *d_prim_shape = nullptr;
     DevShape *d_shapes = nullptr; DevBsdf *d_bsdfs = nullptr; DevEmitter *d_emitters = nullptr;
@@ -328,7 +329,7 @@ void mtsamd_scene_destroy(mtsamd_scene *s) {
     if (!s) return;
     (void) hipSetDevice(s->device);
     s->ws.release();
-    (void) hipFree(s->d_nodes); (void) hipFree(s->d_tris); (void) hipFree(s->d_tri_pos); (void) hipFree(s->d_tri_nrm); (void) hipFree(s->d_tri_uv);
+    (void) hipFree(s->d_nodes); (void) hipFree(s->d_qnodes); (void) hipFree(s->d_tris); (void) hipFree(s->d_tri_pos); (void) hipFree(s->d_tri_nrm); (void) hipFree(s->d_tri_uv);
     (void) hipFree(s->d_prim_shape); (void) hipFree(s->d_shapes); (void) hipFree(s->d_bsdfs); (void) hipFree(s->d_emitters);
     (void) hipFree(s->d_area_pmf); (void) hipFree(s->d_area_cdf); (void) hipFree(s->d_rough_tables);
     (void) hipFree(s->d_env_texels); (void) hipFree(s->d_env_warp); (void) hipFree(s->d_envmap); (void) hipFree(s->d_flat); (void) hipFree(s->d_pairs);
@@ -652,6 +653,8 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
 
     std::vector<float4> nodes(4 * (size_t) s->bvh.n_nodes), tris(3 * (size_t) s->bvh.n_slots);
     std::memcpy(nodes.data(), s->bvh.nodes.data(), s->bvh.nodes.size() * sizeof(float));
+    std::vector<uint4> qnodes(2 * (size_t) s->bvh.n_nodes);
+    std::memcpy(qnodes.data(), s->bvh.qnodes.data(), s->bvh.qnodes.size() * sizeof(uint32_t));
     std::memcpy(tris.data(), s->bvh.tris.data(), s->bvh.tris.size() * sizeof(float));
     // flat scenes: 64-byte records in primitive order (device_scene.h)
     uint32_t flat_max = kFlatMaxPrims;
@@ -686,7 +689,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         pair_recs[5 * k + 4] = make_float4(a[8], b[8], 0.0f, 0.0f);
     }
     int rc = 0;
-    if ((rc = upload(&s->d_textures, s->textures)) || (rc = upload(&s->d_flat, flat_recs)) || (rc = upload(&s->d_pairs, pair_recs)) || (rc = upload(&s->d_nodes, nodes)) || (rc = upload(&s->d_tris, tris)) || (rc = upload(&s->d_tri_pos, tri_pos)) ||
+    if ((rc = upload(&s->d_textures, s->textures)) || (rc = upload(&s->d_flat, flat_recs)) || (rc = upload(&s->d_pairs, pair_recs)) || (rc = upload(&s->d_nodes, nodes)) || (rc = upload(&s->d_qnodes, qnodes)) || (rc = upload(&s->d_tris, tris)) || (rc = upload(&s->d_tri_pos, tri_pos)) ||
         (rc = upload(&s->d_tri_nrm, tri_nrm)) || (rc = upload(&s->d_tri_uv, tri_uv)) || (rc = upload(&s->d_prim_shape, prim_shape)) ||
         (rc = upload(&s->d_shapes, shapes)) || (rc = upload(&s->d_bsdfs, s->bsdfs)) || (rc = upload(&s->d_emitters, s->emitters)) ||
         (rc = upload(&s->d_area_pmf, area_pmf)) || (rc = upload(&s->d_area_cdf, area_cdf))) {
@@ -759,7 +762,8 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         }
     }
     SceneView &v = s->view;
-    v.nodes = s->d_nodes; v.tris = s->d_tris; v.root = s->bvh.root;
+    v.nodes = s->d_nodes; v.qnodes = s->d_qnodes; v.tris = s->d_tris; v.root = s->bvh.root;
+    for (int k = 0; k < 3; ++k) { v.q_lo[k] = s->bvh.q_lo[k]; v.q_step[k] = s->bvh.q_step[k]; }
     v.n_nodes = s->bvh.n_nodes; v.n_slots = s->bvh.n_slots; v.n_prims = s->n_prims;
     // LDS residency: flat scenes keep everything in LDS (see flat_recs below).  For hierarchy scenes staging the
     // top of the tree (nodes are stored in BFS order) was measured to LOSE: 384 staged nodes 2.5-3.2 Gray/s vs none

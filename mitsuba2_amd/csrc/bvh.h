@@ -13,6 +13,8 @@ namespace mtsamd {
 
 struct BvhOutput {
     std::vector<float> nodes;      // 16 floats per node (see device_scene.h for the layout)
+    std::vector<uint32_t> qnodes;  // 8 words per node: the same child boxes on a 16-bit grid over the scene box, rounded outward
+    float q_lo[3] = { 0, 0, 0 }, q_step[3] = { 1, 1, 1 };      // grid origin and cell size per axis
     std::vector<float> tris;       // 12 floats per triangle slot
     uint32_t root = 0;             // child reference of the root
     uint32_t n_nodes = 0, n_slots = 0, depth = 0;

@@ -55,6 +55,8 @@ constexpr float kInvFourPi = 0.07957747154594766788f;
 
 struct SceneView {
     const float4 *nodes;       // 4 per node
+    const uint4 *qnodes;       // 2 per node: child boxes on a 16-bit grid (origin q_lo, cell q_step), child references
+    float q_lo[3], q_step[3];
     const float4 *tris;        // 3 per slot (leaf order)
     uint32_t root;             // child ref of the root
     uint32_t n_nodes, n_slots, n_prims;
@@ -170,6 +172,7 @@ MTS_DEV bool tri_test(f3 p0, f3 e1, f3 e2, f3 o, f3 d, float mint, float maxt, f
     return ok && (t >= mint) && (t <= maxt);
 }
 
+MTS_DEV float clamp_mag(float r) { return fabsf(r) <= 3.0e38f ? r : copysignf(3.0e38f, r); }
 MTS_DEV float clamp_inv(float d) {
     float r = 1.0f / d;
     // zero / denormal components: keep the slab test NaN-free (0 * huge = 0, never inf * 0)
@@ -183,13 +186,24 @@ MTS_DEV float clamp_inv(float d) {
 constexpr uint32_t kNoNode = 0x7fffffffu;       // "nothing left": not a leaf, never a valid inner index
 
 // State of one BVH walk.  `cur` == kNoNode: finished (or never started).
+#ifndef MTS_QNODES
+#define MTS_QNODES 1
+#endif
 struct BvhWalk {
-    f3 o, d, inv; float mint, maxt, best;
+    f3 o, d, inv; float mint, maxt, best;      // MTS_QNODES: o / inv of the slab test are in grid units (o_q, inv_q)
+    f3 o_q;
     uint32_t sp, cur, best_prim; bool found;
     Hit hit;
 };
 MTS_DEV void walk_begin(BvhWalk &w, const SceneView &sv, f3 o, f3 d, float mint, float maxt) {
     w.o = o; w.d = d; w.inv = mk3(clamp_inv(d.x), clamp_inv(d.y), clamp_inv(d.z));
+#if MTS_QNODES
+    // box coordinate x = q_lo + q * q_step  =>  t = (q - o_q) * inv_q with o_q = (o - q_lo) / q_step, inv_q = q_step / d
+    w.o_q = mk3((o.x - sv.q_lo[0]) / sv.q_step[0], (o.y - sv.q_lo[1]) / sv.q_step[1], (o.z - sv.q_lo[2]) / sv.q_step[2]);
+    w.inv = mk3(clamp_mag(w.inv.x * sv.q_step[0]), clamp_mag(w.inv.y * sv.q_step[1]), clamp_mag(w.inv.z * sv.q_step[2]));
+#else
+    w.o_q = o;
+#endif
     w.mint = mint; w.maxt = maxt; w.best = maxt;
     w.sp = 0; w.cur = sv.root; w.best_prim = kNoPrim; w.found = false;
 }
@@ -201,6 +215,22 @@ MTS_DEV void walk_round(BvhWalk &w, const SceneView &sv, uint32_t *stack, uint32
     uint32_t cur = w.cur, sp = w.sp;
     const f3 o = w.o, inv = w.inv;
     while ((int32_t) cur >= 0 && cur != kNoNode) {
+#if MTS_QNODES
+        const f3 oq = w.o_q;
+        const uint4 a = sv.qnodes[2u * cur], bq = sv.qnodes[2u * cur + 1u];
+        float ax = ((float) (a.x & 0xffffu) - oq.x) * inv.x, bx = ((float) (a.y >> 16) - oq.x) * inv.x;
+        float ay = ((float) (a.x >> 16) - oq.y) * inv.y, by = ((float) (a.z & 0xffffu) - oq.y) * inv.y;
+        float az = ((float) (a.y & 0xffffu) - oq.z) * inv.z, bz = ((float) (a.z >> 16) - oq.z) * inv.z;
+        float nearL = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), w.mint));
+        float farL = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), w.best));
+        ax = ((float) (a.w & 0xffffu) - oq.x) * inv.x; bx = ((float) (bq.x >> 16) - oq.x) * inv.x;
+        ay = ((float) (a.w >> 16) - oq.y) * inv.y; by = ((float) (bq.y & 0xffffu) - oq.y) * inv.y;
+        az = ((float) (bq.x & 0xffffu) - oq.z) * inv.z; bz = ((float) (bq.y >> 16) - oq.z) * inv.z;
+        float nearR = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), w.mint));
+        float farR = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), w.best));
+        const bool hl = nearL <= farL, hr = nearR <= farR;
+        const uint32_t cl = bq.z, cr = bq.w;
+#else
         const float4 *p = sv.nodes + 4u * cur;
         const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
         float ax = (q0.x - o.x) * inv.x, bx = (q0.w - o.x) * inv.x;
@@ -215,6 +245,7 @@ MTS_DEV void walk_round(BvhWalk &w, const SceneView &sv, uint32_t *stack, uint32
         float farR = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), w.best));
         const bool hl = nearL <= farL, hr = nearR <= farR;
         const uint32_t cl = __float_as_uint(q3.x), cr = __float_as_uint(q3.y);
+#endif
         if (hl && hr) {
             const bool lf = nearL <= nearR;
             stack[sp * stride] = lf ? cr : cl;
