@@ -183,6 +183,7 @@ struct Workspace {
     uint32_t *cursor_pix = nullptr, *cursor_rem = nullptr, *count_shadow = nullptr;
     float4 *out_rgba = nullptr; float2 *out_pos = nullptr;
     float *moment_film = nullptr; uint64_t moment_pixels = 0;     // moment integrator: two scratch 5-channel films
+    uint32_t *trace_spill = nullptr; size_t trace_spill_words = 0;      // k_trace: deep stack entries
     uint32_t *h_counts = nullptr;        // pinned, 4 * n_waves
     uint64_t *h_cursor = nullptr;        // pinned, 2 * n_waves
     hipEvent_t ev[4] = {};
@@ -199,6 +200,7 @@ struct Workspace {
         }
         (void) hipFree(cursor); (void) hipFree(cursor_end); (void) hipFree(wave_stats); (void) hipFree(cursor_pix); (void) hipFree(cursor_rem);
         (void) hipFree(count_shadow); count_shadow = nullptr;
+        (void) hipFree(trace_spill); trace_spill = nullptr; trace_spill_words = 0;
         (void) hipFree(moment_film); moment_film = nullptr; moment_pixels = 0;
         cursor_pix = cursor_rem = nullptr; (void) hipFree(out_rgba); (void) hipFree(out_pos);
         cursor = cursor_end = wave_stats = nullptr; out_rgba = nullptr; out_pos = nullptr;
@@ -1012,6 +1014,15 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     p.max_depth = j.d->max_depth; p.rr_depth = j.d->rr_depth;
     p.spectral = j.s->spectral ? 1 : 0;
     p.split = j.shadow_ring ? 3 : (j.shadow_queue ? 2 : (j.split ? 1 : 0));
+    if (p.split == 1) {       // k_trace: short per-lane stack in LDS, deep entries in a global spill area
+        const size_t words = trace_spill_words(p.sv, nw);
+        if (words > w.trace_spill_words) {
+            (void) hipFree(w.trace_spill); w.trace_spill = nullptr; w.trace_spill_words = 0;
+            HIP_TRY(hipMalloc((void **) &w.trace_spill, words * sizeof(uint32_t)));
+            w.trace_spill_words = words;
+        }
+        p.trace_lds_depth = trace_lds_depth(p.sv); p.trace_spill = w.trace_spill;
+    }
     p.integrator = j.d->integrator; p.emitter_samples = j.d->emitter_samples; p.bsdf_samples = j.d->bsdf_samples;
     p.hide_emitters = j.d->hide_emitters;
     if (j.d->integrator != 0) {          // direct / depth: one launch finishes the whole pass

@@ -228,7 +228,8 @@ void build_bvh(const float *tri_pos, uint32_t n_prims, uint32_t max_leaf, BvhOut
         q[8] = rlo[2]; q[9] = rhi[0]; q[10] = rhi[1]; q[11] = rhi[2];
         q[12] = bits(cl); q[13] = bits(cr); q[14] = 0.0f; q[15] = 0.0f;
     }
-    // 32-byte nodes: child boxes snapped outward to a 65536^3 grid over the (padded) scene box.  One traversal step then costs two
+    // 32-byte nodes: child boxes snapped outward (by at least 1/8 cell: the device decodes them with an error below 0.07 cells)
+    // to a 65536^3 grid over the (padded) scene box.  One traversal step then costs two
     // 16-byte loads per lane instead of four; the walk only culls with the boxes, so hits are unchanged.
     {
         double glo[3], gstep[3];
@@ -241,11 +242,11 @@ void build_bvh(const float *tri_pos, uint32_t n_prims, uint32_t max_leaf, BvhOut
             glo[k] = (double) out.q_lo[k]; gstep[k] = (double) out.q_step[k];
         }
         auto qlo = [&](float v, int k) -> uint32_t {
-            double q = std::floor(((double) v - glo[k]) / gstep[k]) - 1.0;
+            double q = std::floor(((double) v - glo[k]) / gstep[k] - 0.125);
             return (uint32_t) std::min(65535.0, std::max(0.0, q));
         };
         auto qhi = [&](float v, int k) -> uint32_t {
-            double q = std::ceil(((double) v - glo[k]) / gstep[k]) + 1.0;
+            double q = std::ceil(((double) v - glo[k]) / gstep[k] + 0.125);
             return (uint32_t) std::min(65535.0, std::max(0.0, q));
         };
         out.qnodes.assign(8 * bfs.size(), 0u);
@@ -253,9 +254,12 @@ void build_bvh(const float *tri_pos, uint32_t n_prims, uint32_t max_leaf, BvhOut
             const float *q = out.nodes.data() + 16 * i;
             const float llo[3] = { q[0], q[1], q[2] }, lhi[3] = { q[3], q[4], q[5] }, rlo[3] = { q[6], q[7], q[8] }, rhi[3] = { q[9], q[10], q[11] };
             uint32_t *w = out.qnodes.data() + 8 * i;
-            w[0] = qlo(llo[0], 0) | (qlo(llo[1], 1) << 16); w[1] = qlo(llo[2], 2) | (qhi(lhi[0], 0) << 16);
-            w[2] = qhi(lhi[1], 1) | (qhi(lhi[2], 2) << 16); w[3] = qlo(rlo[0], 0) | (qlo(rlo[1], 1) << 16);
-            w[4] = qlo(rlo[2], 2) | (qhi(rhi[0], 0) << 16); w[5] = qhi(rhi[1], 1) | (qhi(rhi[2], 2) << 16);
+            // one word per child and axis: lo | hi << 16 (the walk swaps the halves with one v_perm_b32 according to the sign
+            // of the ray direction and so gets (near plane, far plane) without min / max)
+            for (int k = 0; k < 3; ++k) {
+                w[k] = qlo(llo[k], k) | (qhi(lhi[k], k) << 16);
+                w[3 + k] = qlo(rlo[k], k) | (qhi(rhi[k], k) << 16);
+            }
             std::memcpy(&w[6], &q[12], 4); std::memcpy(&w[7], &q[13], 4);
         }
     }

@@ -173,6 +173,7 @@ MTS_DEV bool tri_test(f3 p0, f3 e1, f3 e2, f3 o, f3 d, float mint, float maxt, f
 }
 
 MTS_DEV float clamp_mag(float r) { return fabsf(r) <= 3.0e38f ? r : copysignf(3.0e38f, r); }
+MTS_DEV float clamp_mag33(float r) { return fabsf(r) <= 1.0e33f ? r : copysignf(1.0e33f, r); }
 MTS_DEV float clamp_inv(float d) {
     float r = 1.0f / d;
     // zero / denormal components: keep the slab test NaN-free (0 * huge = 0, never inf * 0)
@@ -191,7 +192,9 @@ constexpr uint32_t kNoNode = 0x7fffffffu;       // "nothing left": not a leaf, n
 #endif
 struct BvhWalk {
     f3 o, d, inv; float mint, maxt, best;      // MTS_QNODES: o / inv of the slab test are in grid units (o_q, inv_q)
-    f3 o_q;
+    f3 o_q, noi;                               // noi = -(o_q * inv): t = fma(q, inv, noi)
+    bool far;                                  // origin too far from the scene box for the fma form (cancellation)
+    uint32_t sel[3];                           // v_perm_b32 selectors: (lo | hi << 16) -> (near | far << 16) per axis
     uint32_t sp, cur, best_prim; bool found;
     Hit hit;
 };
@@ -199,10 +202,18 @@ MTS_DEV void walk_begin(BvhWalk &w, const SceneView &sv, f3 o, f3 d, float mint,
     w.o = o; w.d = d; w.inv = mk3(clamp_inv(d.x), clamp_inv(d.y), clamp_inv(d.z));
 #if MTS_QNODES
     // box coordinate x = q_lo + q * q_step  =>  t = (q - o_q) * inv_q with o_q = (o - q_lo) / q_step, inv_q = q_step / d
+    // |inv| <= 1e33 keeps q * inv finite for q <= 65535 (a direction component that small is parallel to the slab either way)
     w.o_q = mk3((o.x - sv.q_lo[0]) / sv.q_step[0], (o.y - sv.q_lo[1]) / sv.q_step[1], (o.z - sv.q_lo[2]) / sv.q_step[2]);
-    w.inv = mk3(clamp_mag(w.inv.x * sv.q_step[0]), clamp_mag(w.inv.y * sv.q_step[1]), clamp_mag(w.inv.z * sv.q_step[2]));
+    w.inv = mk3(clamp_mag33(w.inv.x * sv.q_step[0]), clamp_mag33(w.inv.y * sv.q_step[1]), clamp_mag33(w.inv.z * sv.q_step[2]));
+    w.noi = mk3(-(w.o_q.x * w.inv.x), -(w.o_q.y * w.inv.y), -(w.o_q.z * w.inv.z));
+    // fma(q, inv, noi) is off by at most eps * |o_q| grid cells (0.06 cells at |o_q| = 1e6, i.e. an origin ~15 scene extents away);
+    // the boxes are padded by 1/8 cell or more.  Farther origins use (q - o_q) * inv, which is exact in q and consistent in o_q.
+    w.far = !(hmax_abs(w.o_q) <= 1.0e6f);
+    w.sel[0] = w.inv.x >= 0.0f ? 0x03020100u : 0x01000302u;
+    w.sel[1] = w.inv.y >= 0.0f ? 0x03020100u : 0x01000302u;
+    w.sel[2] = w.inv.z >= 0.0f ? 0x03020100u : 0x01000302u;
 #else
-    w.o_q = o;
+    w.o_q = o; w.noi = o; w.far = true; w.sel[0] = w.sel[1] = w.sel[2] = 0u;
 #endif
     w.mint = mint; w.maxt = maxt; w.best = maxt;
     w.sp = 0; w.cur = sv.root; w.best_prim = kNoPrim; w.found = false;
@@ -210,24 +221,40 @@ MTS_DEV void walk_begin(BvhWalk &w, const SceneView &sv, f3 o, f3 d, float mint,
 // One round of the "while-while" traversal: the lane descends until it holds a leaf (or nothing), then the wave tests leaves
 // together -- the two phases are not interleaved lane by lane, which keeps more lanes busy in each of them.  ANY: the walk
 // ends (cur = kNoNode, found = true) at the first hit.
-template <bool ANY>
-MTS_DEV void walk_round(BvhWalk &w, const SceneView &sv, uint32_t *stack, uint32_t stride, uint32_t &tri_tests) {
+// Traversal stack of one lane: the first `lds_depth` entries live in LDS ([depth][lane], conflict-free), deeper ones -- rare:
+// a walk seldom defers more than a dozen subtrees -- in a global spill area, so that the LDS footprint does not cap occupancy.
+struct WalkStack { uint32_t *lds; uint32_t stride, lds_depth; uint32_t *spill; uint32_t spill_stride; };
+MTS_DEV void stack_push(const WalkStack &st, uint32_t sp, uint32_t v) {
+    if (sp < st.lds_depth) st.lds[sp * st.stride] = v;
+    else st.spill[(size_t) (sp - st.lds_depth) * st.spill_stride] = v;
+}
+MTS_DEV uint32_t stack_pop(const WalkStack &st, uint32_t sp) {
+    return sp < st.lds_depth ? st.lds[sp * st.stride] : st.spill[(size_t) (sp - st.lds_depth) * st.spill_stride];
+}
+
+template <bool ANY, bool FAR = true>
+MTS_DEV void walk_round(BvhWalk &w, const SceneView &sv, const WalkStack &st, uint32_t &tri_tests) {
     uint32_t cur = w.cur, sp = w.sp;
     const f3 o = w.o, inv = w.inv;
     while ((int32_t) cur >= 0 && cur != kNoNode) {
 #if MTS_QNODES
-        const f3 oq = w.o_q;
+        const f3 oq = w.o_q, noi = w.noi;
         const uint4 a = sv.qnodes[2u * cur], bq = sv.qnodes[2u * cur + 1u];
-        float ax = ((float) (a.x & 0xffffu) - oq.x) * inv.x, bx = ((float) (a.y >> 16) - oq.x) * inv.x;
-        float ay = ((float) (a.x >> 16) - oq.y) * inv.y, by = ((float) (a.z & 0xffffu) - oq.y) * inv.y;
-        float az = ((float) (a.y & 0xffffu) - oq.z) * inv.z, bz = ((float) (a.z >> 16) - oq.z) * inv.z;
-        float nearL = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), w.mint));
-        float farL = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), w.best));
-        ax = ((float) (a.w & 0xffffu) - oq.x) * inv.x; bx = ((float) (bq.x >> 16) - oq.x) * inv.x;
-        ay = ((float) (a.w >> 16) - oq.y) * inv.y; by = ((float) (bq.y & 0xffffu) - oq.y) * inv.y;
-        az = ((float) (bq.x & 0xffffu) - oq.z) * inv.z; bz = ((float) (bq.y >> 16) - oq.z) * inv.z;
-        float nearR = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), w.mint));
-        float farR = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), w.best));
+        auto slab = [&](uint32_t q, float o1, float i1, float n1) -> float {
+            return FAR ? ((float) q - o1) * i1 : fmaf((float) q, i1, n1);
+        };
+        // per axis: one v_perm_b32 orders the two planes by the sign of the direction, so near = t(low half), far = t(high half)
+        const uint32_t lx = __builtin_amdgcn_perm(a.x, a.x, w.sel[0]), ly = __builtin_amdgcn_perm(a.y, a.y, w.sel[1]),
+                       lz = __builtin_amdgcn_perm(a.z, a.z, w.sel[2]), rx = __builtin_amdgcn_perm(a.w, a.w, w.sel[0]),
+                       ry = __builtin_amdgcn_perm(bq.x, bq.x, w.sel[1]), rz = __builtin_amdgcn_perm(bq.y, bq.y, w.sel[2]);
+        const float nearL = fmaxf(fmaxf(slab(lx & 0xffffu, oq.x, inv.x, noi.x), slab(ly & 0xffffu, oq.y, inv.y, noi.y)),
+                                  fmaxf(slab(lz & 0xffffu, oq.z, inv.z, noi.z), w.mint));
+        const float farL = fminf(fminf(slab(lx >> 16, oq.x, inv.x, noi.x), slab(ly >> 16, oq.y, inv.y, noi.y)),
+                                 fminf(slab(lz >> 16, oq.z, inv.z, noi.z), w.best));
+        const float nearR = fmaxf(fmaxf(slab(rx & 0xffffu, oq.x, inv.x, noi.x), slab(ry & 0xffffu, oq.y, inv.y, noi.y)),
+                                  fmaxf(slab(rz & 0xffffu, oq.z, inv.z, noi.z), w.mint));
+        const float farR = fminf(fminf(slab(rx >> 16, oq.x, inv.x, noi.x), slab(ry >> 16, oq.y, inv.y, noi.y)),
+                                 fminf(slab(rz >> 16, oq.z, inv.z, noi.z), w.best));
         const bool hl = nearL <= farL, hr = nearR <= farR;
         const uint32_t cl = bq.z, cr = bq.w;
 #else
@@ -248,7 +275,7 @@ MTS_DEV void walk_round(BvhWalk &w, const SceneView &sv, uint32_t *stack, uint32
 #endif
         if (hl && hr) {
             const bool lf = nearL <= nearR;
-            stack[sp * stride] = lf ? cr : cl;
+            stack_push(st, sp, lf ? cr : cl);
             ++sp;
             cur = lf ? cl : cr;
         } else if (hl) {
@@ -257,7 +284,7 @@ MTS_DEV void walk_round(BvhWalk &w, const SceneView &sv, uint32_t *stack, uint32
             cur = cr;
         } else if (sp) {
             --sp;
-            cur = stack[sp * stride];
+            cur = stack_pop(st, sp);
         } else {
             cur = kNoNode;
         }
@@ -280,7 +307,7 @@ MTS_DEV void walk_round(BvhWalk &w, const SceneView &sv, uint32_t *stack, uint32
         }
         if (sp) {
             --sp;
-            cur = stack[sp * stride];
+            cur = stack_pop(st, sp);
         } else {
             cur = kNoNode;
         }
@@ -293,8 +320,11 @@ MTS_DEV bool traverse_bvh(const SceneView &sv, const LdsView &lds, f3 o, f3 d, f
                           Hit &hit, uint32_t &tri_tests) {
     BvhWalk w;
     walk_begin(w, sv, o, d, mint, maxt);
-    uint32_t *stack = lds.stack + threadIdx.x;
-    while (w.cur != kNoNode) walk_round<ANY>(w, sv, stack, lds.stride, tri_tests);
+    const WalkStack st = { lds.stack + threadIdx.x, lds.stride, 0xffffffffu, nullptr, 0u };      // whole stack in LDS
+    while (w.cur != kNoNode) {
+        if (w.far) walk_round<ANY, true>(w, sv, st, tri_tests);
+        else walk_round<ANY, false>(w, sv, st, tri_tests);
+    }
     if (!ANY && w.found) hit = w.hit;
     return w.found;
 }

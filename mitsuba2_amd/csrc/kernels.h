@@ -72,6 +72,8 @@ struct RenderParams {
     int32_t split;              // 0: fused k_bounce, 1: k_trace<closest> + k_shade + k_trace<any> per iteration, 2: k_shade (flat) + k_trace<any>,
                                 // 3: k_shade (flat) with the in-kernel shadow ring
     uint32_t lds_queue_offset;  // split == 3: start of the per-wave shadow rings in LDS, in float4 units
+    uint32_t trace_lds_depth;   // k_trace: stack entries per lane kept in LDS; deeper ones go to trace_spill
+    uint32_t *trace_spill;      // k_trace: [workgroup][entry][thread]
 };
 
 struct FilmParams {
@@ -103,6 +105,8 @@ struct RayStreams {
 
 size_t bounce_lds_bytes(const SceneView &sv);
 hipError_t launch_bounce(const RenderParams &p, hipStream_t s);
+uint32_t trace_lds_depth(const SceneView &sv);
+size_t trace_spill_words(const SceneView &sv, uint32_t n_waves);
 // `direct` / `depth` integrators: every sample of [first_ordinal, first_ordinal + n) is finished by one thread
 hipError_t launch_direct(const RenderParams &p, uint64_t n, hipStream_t s);
 hipError_t launch_adjoint(const AdjointParams &a, hipStream_t s);

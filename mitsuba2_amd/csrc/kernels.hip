@@ -981,6 +981,12 @@ void k_shade(const RenderParams P) {
 // Only about a third of the paths queue a shadow ray, so one workgroup drains the queues of kShadowGroup scheduling
 // waves back to back to keep its lanes filled.  (64-thread workgroups sized to the queues were measured slower.)
 constexpr uint32_t kShadowGroup = 8;
+// LDS part of k_trace's per-lane stack: 16 entries = 16 KB per workgroup, 8 workgroups (32 waves) per CU; a full 25-entry stack
+// (261 k-triangle mesh) caps the CU at 6 workgroups
+#ifndef MTS_TRACE_LDS_DEPTH
+#define MTS_TRACE_LDS_DEPTH 16
+#endif
+constexpr uint32_t kTraceLdsDepth = MTS_TRACE_LDS_DEPTH;
 
 template <bool ANY, bool FLAT = false>
 __global__ __launch_bounds__(kBlock) void k_trace(const RenderParams P) {
@@ -1029,7 +1035,11 @@ __global__ __launch_bounds__(kBlock) void k_trace(const RenderParams P) {
         if (threadIdx.x == 0) s_next = 0u;
         __syncthreads();
         const uint32_t lane = lane_id();
-        uint32_t *stack = lds.stack + threadIdx.x;
+        // LDS holds the first P.trace_lds_depth stack entries of every lane; deeper entries spill to this workgroup's slice of
+        // P.trace_spill ([entry][thread])
+        const uint32_t spill_depth = P.sv.stack_depth > P.trace_lds_depth ? P.sv.stack_depth - P.trace_lds_depth : 0u;
+        const WalkStack st = { lds.stack + threadIdx.x, lds.stride, P.trace_lds_depth,
+                               P.trace_spill + (size_t) blockIdx.x * spill_depth * kBlock + threadIdx.x, kBlock };
         BvhWalk w;
         w.cur = kNoNode; w.sp = 0u; w.found = false;
         bool busy = false;                                   // the lane holds a work item
@@ -1070,7 +1080,11 @@ __global__ __launch_bounds__(kBlock) void k_trace(const RenderParams P) {
                 if (exhausted) break;
                 continue;                                    // only zombies were fetched: try again
             }
-            if (w.cur != kNoNode) walk_round<ANY>(w, P.sv, stack, lds.stride, tri_tests);
+            if (__ballot(w.cur != kNoNode && w.far) != 0ull) {      // wave-uniform choice of the slab-test form
+                if (w.cur != kNoNode) walk_round<ANY, true>(w, P.sv, st, tri_tests);
+            } else {
+                if (w.cur != kNoNode) walk_round<ANY, false>(w, P.sv, st, tri_tests);
+            }
         }
     }
     for (int off = 32; off > 0; off >>= 1) tri_tests += __shfl_xor(tri_tests, off);
@@ -1079,7 +1093,12 @@ __global__ __launch_bounds__(kBlock) void k_trace(const RenderParams P) {
                   (unsigned long long) tri_tests);
 }
 
-size_t trace_lds_bytes(const SceneView &sv) { return (size_t) 4 * sv.stack_depth * kBlock; }
+size_t trace_lds_bytes(const SceneView &sv) { return (size_t) 4 * std::min(sv.stack_depth, kTraceLdsDepth) * kBlock; }
+uint32_t trace_lds_depth(const SceneView &sv) { return std::min(sv.stack_depth, kTraceLdsDepth); }
+size_t trace_spill_words(const SceneView &sv, uint32_t n_waves) {
+    const uint32_t spill = sv.stack_depth > kTraceLdsDepth ? sv.stack_depth - kTraceLdsDepth : 0u;
+    return (size_t) ((n_waves + kShadowGroup - 1) / kShadowGroup) * spill * kBlock;
+}
 
 hipError_t launch_bounce(const RenderParams &p_, hipStream_t s) {
     RenderParams p = p_;
