@@ -190,6 +190,9 @@ constexpr uint32_t kNoNode = 0x7fffffffu;       // "nothing left": not a leaf, n
 #ifndef MTS_QNODES
 #define MTS_QNODES 1
 #endif
+#ifndef MTS_WALK_T
+#define MTS_WALK_T 24
+#endif
 struct BvhWalk {
     f3 o, d, inv; float mint, maxt, best;      // MTS_QNODES: o / inv of the slab test are in grid units (o_q, inv_q)
     f3 o_q, noi;                               // noi = -(o_q * inv): t = fma(q, inv, noi)
@@ -236,7 +239,14 @@ template <bool ANY, bool FAR = true>
 MTS_DEV void walk_round(BvhWalk &w, const SceneView &sv, const WalkStack &st, uint32_t &tri_tests) {
     uint32_t cur = w.cur, sp = w.sp;
     const f3 o = w.o, inv = w.inv;
-    while ((int32_t) cur >= 0 && cur != kNoNode) {
+    // The descent loop ends for the whole wave as soon as fewer than MTS_WALK_T lanes are still inside the tree while others
+    // wait at a leaf: a few long walks no longer hold the wave in a sparsely populated loop (0 = every lane reaches its leaf).
+    while (true) {
+        const bool inner = (int32_t) cur >= 0 && cur != kNoNode;
+        const uint64_t mi = __ballot(inner);
+        if (mi == 0ull) break;
+        if (MTS_WALK_T > 0 && __popcll(mi) < MTS_WALK_T && __ballot((int32_t) cur < 0) != 0ull) break;
+        if (!inner) continue;
 #if MTS_QNODES
         const f3 oq = w.o_q, noi = w.noi;
         const uint4 a = sv.qnodes[2u * cur], bq = sv.qnodes[2u * cur + 1u];
