@@ -1108,7 +1108,8 @@ int setup_job(Job &j, mtsamd_scene *s, const mtsamd_render_desc *d, hipStream_t 
     }
     if (const char *e = getenv("MTSAMD_WAVES_PER_CU")) j.n_waves = (uint32_t) s->cu_count * (uint32_t) std::max(1, atoi(e));    // experiment switch
     j.pass_cap = std::max<uint64_t>(std::min<uint64_t>(max_pass, pass_limit), 1);
-    if (int rc = ensure_workspace(s, j.n_waves, j.target, j.pass_cap, j.split || j.shadow_queue)) return rc;
+    // segments hold a multiple of 64 slots: k_shade deals whole 64-path chunks of a workgroup's list to its waves
+    if (int rc = ensure_workspace(s, j.n_waves, (j.target + 63u) & ~63u, j.pass_cap, j.split || j.shadow_queue)) return rc;
     j.pass_cap = s->ws.pass_cap;
     HIP_TRY(hipMemsetAsync(s->ws.wave_stats, 0, 4 * (size_t) j.n_waves * sizeof(uint64_t), stream));
     s->cancel.store(0);

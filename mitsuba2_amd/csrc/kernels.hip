@@ -859,10 +859,13 @@ void k_shade(const RenderParams P) {
     extern __shared__ float4 smem[];
     LdsView lds = {};                      // Geo<false> reads the scene tables from global memory
     const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    __shared__ uint32_t s_cnt[kBlock / 64u];
     if (FLAT) {
         // While the pool drains at the end of a pass most scheduling waves have nothing left to do: a workgroup whose four
         // waves are all idle leaves before staging the scene into LDS (its output counts still have to be reset).
-        const bool work = wave < P.n_waves && (P.count_in[wave] > 0u || P.cursor[wave] < P.cursor_end[wave]);
+        const uint32_t n_own = wave < P.n_waves ? P.count_in[wave] : 0u;
+        if (lane_id() == 0u) s_cnt[threadIdx.x >> 6] = n_own;
+        const bool work = wave < P.n_waves && (n_own > 0u || P.cursor[wave] < P.cursor_end[wave]);
         if (!__syncthreads_or(work ? 1 : 0)) {
             if (wave < P.n_waves && lane_id() == 0u) {
                 P.count_out[wave] = 0u;
@@ -880,20 +883,38 @@ void k_shade(const RenderParams P) {
     }
     if (wave >= P.n_waves) return;
     const uint32_t lane = lane_id();
-    const uint32_t n_in = __builtin_amdgcn_readfirstlane(P.count_in[wave]);
     const size_t base = (size_t) wave * P.seg_cap;
     uint32_t n_out = 0;
     Counters c = { 0u, 0u, 0u, 0u };
     uint32_t n_sh = 0;
     uint32_t q_head = 0, q_count = 0;
+    // FLAT: the input segments of the workgroup's scheduling waves form one list whose 64-path chunks are dealt round-robin to
+    // the waves -- at most one partial chunk per workgroup instead of one per wave while the pool drains.  Survivors go to the
+    // output segment of the wave that processed them (seg_cap is a multiple of 64, so a wave never gets more than it can hold).
+    const uint32_t wg_wave0 = wave - (threadIdx.x >> 6);
+    const uint32_t n_valid = FLAT ? min((uint32_t) (kBlock / 64u), P.n_waves - wg_wave0) : 1u;
+    uint32_t cnt4[kBlock / 64u], n_in = 0;
+    if (FLAT) {
+#pragma unroll
+        for (uint32_t g = 0; g < kBlock / 64u; ++g) { cnt4[g] = g < n_valid ? s_cnt[g] : 0u; n_in += cnt4[g]; }
+    } else {
+        n_in = __builtin_amdgcn_readfirstlane(P.count_in[wave]);
+    }
 
-    for (uint32_t i0 = 0; i0 < n_in; i0 += 64u) {
+    for (uint32_t i0 = FLAT ? 64u * (threadIdx.x >> 6) : 0u; i0 < n_in; i0 += 64u * n_valid) {
         State s;
         Deferred df;
         df.pending = false;
         bool alive = false;
         if (i0 + lane < n_in) {
-            const size_t i = base + i0 + lane;
+            size_t i = base + i0 + lane;
+            if (FLAT) {
+                uint32_t src = wg_wave0, j = i0 + lane;
+#pragma unroll
+                for (uint32_t g = 0; g + 1 < kBlock / 64u; ++g)
+                    if (src == wg_wave0 + g && j >= cnt4[g]) { j -= cnt4[g]; ++src; }
+                i = (size_t) src * P.seg_cap + j;
+            }
             load_state(P.in, i, s);
             if (s.flags & kFlagZombie) {
                 finish_path(P, s);
