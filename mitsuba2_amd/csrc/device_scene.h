@@ -193,6 +193,9 @@ constexpr uint32_t kNoNode = 0x7fffffffu;       // "nothing left": not a leaf, n
 #ifndef MTS_WALK_T
 #define MTS_WALK_T 24
 #endif
+#ifndef MTS_WALK_T_ANY
+#define MTS_WALK_T_ANY MTS_WALK_T
+#endif
 struct BvhWalk {
     f3 o, d, inv; float mint, maxt, best;      // MTS_QNODES: o / inv of the slab test are in grid units (o_q, inv_q)
     f3 o_q, noi;                               // noi = -(o_q * inv): t = fma(q, inv, noi)
@@ -245,7 +248,8 @@ MTS_DEV void walk_round(BvhWalk &w, const SceneView &sv, const WalkStack &st, ui
         const bool inner = (int32_t) cur >= 0 && cur != kNoNode;
         const uint64_t mi = __ballot(inner);
         if (mi == 0ull) break;
-        if (MTS_WALK_T > 0 && __popcll(mi) < MTS_WALK_T && __ballot((int32_t) cur < 0) != 0ull) break;
+        constexpr int kT = ANY ? MTS_WALK_T_ANY : MTS_WALK_T;
+        if (kT > 0 && __popcll(mi) < kT && __ballot((int32_t) cur < 0) != 0ull) break;
         if (!inner) continue;
 #if MTS_QNODES
         const f3 oq = w.o_q, noi = w.noi;

@@ -1001,7 +1001,10 @@ void k_shade(const RenderParams P) {
 // k_trace<true>: visibility of the queued shadow rays (output pool of k_shade), radiance[slot] += nee if unoccluded.
 // Only about a third of the paths queue a shadow ray, so one workgroup drains the queues of kShadowGroup scheduling
 // waves back to back to keep its lanes filled.  (64-thread workgroups sized to the queues were measured slower.)
-constexpr uint32_t kShadowGroup = 8;
+#ifndef MTS_TRACE_GROUP
+#define MTS_TRACE_GROUP 8
+#endif
+constexpr uint32_t kShadowGroup = MTS_TRACE_GROUP;
 // LDS part of k_trace's per-lane stack: 16 entries = 16 KB per workgroup, 8 workgroups (32 waves) per CU; a full 25-entry stack
 // (261 k-triangle mesh) caps the CU at 6 workgroups
 #ifndef MTS_TRACE_LDS_DEPTH
