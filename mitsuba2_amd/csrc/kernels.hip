@@ -1596,10 +1596,78 @@ static uint32_t stream_grid(uint64_t n) {
     return (uint32_t) (blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks));
 }
 
+// Hierarchy scenes, plain hit records (no full SurfaceInteraction): every workgroup owns a contiguous chunk of the stream and its
+// lanes fetch the next ray of the chunk as soon as their walk ends (dynamic ray fetch, as k_trace does for the path pool).
+constexpr uint32_t kRayChunk = 16u * kBlock;
+template <bool ANY>
+__global__ __launch_bounds__(kBlock) void k_ray_walk(const SceneView sv, uint64_t n, const RayStreams r, float *t, uint32_t *prim,
+                                                     uint32_t *shape, float *u, float *v, uint8_t *hit) {
+    extern __shared__ float4 smem[];
+    __shared__ uint32_t s_next;
+    if (threadIdx.x == 0) s_next = 0u;
+    __syncthreads();
+    const uint64_t base = (uint64_t) blockIdx.x * kRayChunk;
+    const uint32_t total = (uint32_t) min((uint64_t) kRayChunk, n - base), lane = lane_id();
+    const WalkStack st = { reinterpret_cast<uint32_t *>(smem) + threadIdx.x, kBlock, 0xffffffffu, nullptr, 0u };
+    const LdsView lds = {};
+    const Geo<false> geo{ sv, lds };
+    BvhWalk w;
+    w.cur = kNoNode; w.sp = 0u; w.found = false;
+    bool busy = false, exhausted = false;
+    uint64_t i = 0;
+    uint32_t tri_tests = 0;
+    auto retire = [&](uint64_t k, bool found) {
+        if (ANY) { hit[k] = found ? 1 : 0; return; }
+        t[k] = found ? w.hit.t : __builtin_inff();
+        prim[k] = found ? w.hit.prim : kNoPrim;
+        if (shape) shape[k] = found ? geo.prim_shape(w.hit.prim) : kNoPrim;
+        if (u) u[k] = found ? w.hit.u : 0.0f;
+        if (v) v[k] = found ? w.hit.v : 0.0f;
+    };
+    while (true) {
+        const bool need = w.cur == kNoNode;
+        if (need && busy) { retire(i, w.found); busy = false; }
+        const uint64_t m = __ballot(need);
+        if (m && !exhausted) {
+            const uint32_t first = (uint32_t) __ffsll((long long) m) - 1u, want = (uint32_t) __popcll(m);
+            uint32_t b0 = 0u;
+            if (lane == first) b0 = atomicAdd(&s_next, want);
+            b0 = __shfl(b0, (int) first);
+            exhausted = b0 + want >= total;
+            if (need) {
+                const uint32_t idx = b0 + mask_rank(m);
+                if (idx < total) {
+                    i = base + idx;
+                    if (r.active && r.active[i] == 0) {
+                        w.found = false; retire(i, false);            // inactive lanes: t = inf, no shape (optix_rt.cu:35-37)
+                    } else {
+                        walk_begin(w, sv, mk3(r.ox[i], r.oy[i], r.oz[i]), mk3(r.dx[i], r.dy[i], r.dz[i]), r.mint[i], r.maxt[i]);
+                        busy = true;
+                    }
+                }
+            }
+        }
+        if (__ballot(w.cur != kNoNode) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        if (__ballot(w.cur != kNoNode && w.far) != 0ull) {
+            if (w.cur != kNoNode) walk_round<ANY, true>(w, sv, st, tri_tests);
+        } else {
+            if (w.cur != kNoNode) walk_round<ANY, false>(w, sv, st, tri_tests);
+        }
+    }
+}
+
 hipError_t launch_ray_intersect(const SceneView &sv, uint64_t n, const RayStreams &r, int mode, float *t,
                                 uint32_t *prim, uint32_t *shape, float *u, float *v, float *si26, hipStream_t s) {
     if (n == 0) return hipSuccess;
     size_t lds = bounce_lds_bytes(sv);
+    if (mode == 0 && !sv.flat && !si26) {
+        hipLaunchKernelGGL((k_ray_walk<false>), dim3((uint32_t) ((n + kRayChunk - 1) / kRayChunk)), dim3(kBlock), (size_t) 4 * sv.stack_depth * kBlock, s,
+                           sv, n, r, t, prim, shape, u, v, (uint8_t *) nullptr);
+        return hipGetLastError();
+    }
     if (mode == 0 && sv.flat)
         hipLaunchKernelGGL((k_ray_intersect<0, true>), dim3(stream_grid(n)), dim3(kBlock), lds, s, sv, n, r, t, prim, shape, u, v, si26);
     else if (mode == 0)
@@ -1614,7 +1682,8 @@ hipError_t launch_ray_intersect(const SceneView &sv, uint64_t n, const RayStream
 hipError_t launch_ray_test(const SceneView &sv, uint64_t n, const RayStreams &r, uint8_t *hit, hipStream_t s) {
     if (n == 0) return hipSuccess;
     if (sv.flat) hipLaunchKernelGGL(k_ray_test<true>, dim3(stream_grid(n)), dim3(kBlock), bounce_lds_bytes(sv), s, sv, n, r, hit);
-    else hipLaunchKernelGGL(k_ray_test<false>, dim3(stream_grid(n)), dim3(kBlock), bounce_lds_bytes(sv), s, sv, n, r, hit);
+    else hipLaunchKernelGGL((k_ray_walk<true>), dim3((uint32_t) ((n + kRayChunk - 1) / kRayChunk)), dim3(kBlock), (size_t) 4 * sv.stack_depth * kBlock, s,
+                            sv, n, r, (float *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, (float *) nullptr, (float *) nullptr, hit);
     return hipGetLastError();
 }
 
