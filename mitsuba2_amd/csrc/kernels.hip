@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(const RenderParams P) {
         // P.trace_spill ([entry][thread])
         const uint32_t spill_depth = P.sv.stack_depth > P.trace_lds_depth ? P.sv.stack_depth - P.trace_lds_depth : 0u;
         const WalkStack st = { lds.stack + threadIdx.x, lds.stride, P.trace_lds_depth,
-                               P.trace_spill + (size_t) blockIdx.x * spill_depth * kBlock + threadIdx.x, kBlock };
+                               P.trace_spill + (size_t) blockIdx.x * spill_depth * kBlock + threadIdx.x, blockDim.x };
         BvhWalk w;
         w.cur = kNoNode; w.sp = 0u; w.found = false;
         bool busy = false;                                   // the lane holds a work item
@@ -1117,7 +1117,11 @@ __global__ __launch_bounds__(kBlock) void k_trace(const RenderParams P) {
                   (unsigned long long) tri_tests);
 }
 
-size_t trace_lds_bytes(const SceneView &sv) { return (size_t) 4 * std::min(sv.stack_depth, kTraceLdsDepth) * kBlock; }
+#ifndef MTS_TRACE_BLOCK
+#define MTS_TRACE_BLOCK 256
+#endif
+constexpr uint32_t kTraceBlock = MTS_TRACE_BLOCK;      // threads per k_trace workgroup (hierarchy scenes)
+size_t trace_lds_bytes(const SceneView &sv) { return (size_t) 4 * std::min(sv.stack_depth, kTraceLdsDepth) * kTraceBlock; }
 uint32_t trace_lds_depth(const SceneView &sv) { return std::min(sv.stack_depth, kTraceLdsDepth); }
 size_t trace_spill_words(const SceneView &sv, uint32_t n_waves) {
     const uint32_t spill = sv.stack_depth > kTraceLdsDepth ? sv.stack_depth - kTraceLdsDepth : 0u;
@@ -1149,12 +1153,12 @@ hipError_t launch_bounce(const RenderParams &p_, hipStream_t s) {
     }
     if (p.split) {
         const uint32_t shade_blocks = (p.n_waves * 64u + kBlock - 1) / kBlock;
-        hipLaunchKernelGGL((k_trace<false, false>), dim3((p.n_waves + kShadowGroup - 1) / kShadowGroup), dim3(kBlock), trace_lds_bytes(p.sv), s, p);
+        hipLaunchKernelGGL((k_trace<false, false>), dim3((p.n_waves + kShadowGroup - 1) / kShadowGroup), dim3(kTraceBlock), trace_lds_bytes(p.sv), s, p);
         if (p.spectral && p.sv.general) hipLaunchKernelGGL((k_shade<PathStateS, true, false>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
         else if (p.spectral) hipLaunchKernelGGL((k_shade<PathStateS, false, false>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
         else if (p.sv.general) hipLaunchKernelGGL((k_shade<PathState, true, false>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
         else hipLaunchKernelGGL((k_shade<PathState, false, false>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
-        hipLaunchKernelGGL((k_trace<true, false>), dim3((p.n_waves + kShadowGroup - 1) / kShadowGroup), dim3(kBlock), trace_lds_bytes(p.sv), s, p);
+        hipLaunchKernelGGL((k_trace<true, false>), dim3((p.n_waves + kShadowGroup - 1) / kShadowGroup), dim3(kTraceBlock), trace_lds_bytes(p.sv), s, p);
         return hipGetLastError();
     }
     uint32_t blocks = (p.n_waves * 64u + kBlock - 1) / kBlock;
