@@ -826,6 +826,9 @@ MTS_DEV void start_path(const RenderParams &P, uint64_t ordinal, uint32_t lp, ui
 
 // FLAT = false: hierarchy scene, closest hits precomputed by k_trace<false>; FLAT = true: LDS-resident scene, closest hit
 // inline (wave-uniform primitive loop), only the shadow rays are queued
+#ifndef MTS_SHADE_WAVES_MIN
+#define MTS_SHADE_WAVES_MIN 1
+#endif
 // INLINE (flat scenes only): the shadow rays of consecutive 64-path chunks are collected in a per-wave LDS ring and resolved
 // 64 at a time inside this kernel -- the any-hit loop then always runs on full waves (only about two thirds of the paths cast
 // a shadow ray) -- and `nee` is added to the radiance the wave has already stored in its output segment.
@@ -853,7 +856,7 @@ MTS_DEV void drain_shadow_ring(const RenderParams &P, const LdsView &lds, const 
 }
 
 template <typename State, bool GENERAL, bool FLAT, bool INLINE = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FLAT ? MTS_BOUNCE_WAVES : 1, FLAT ? MTS_BOUNCE_WAVES : 8)))
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FLAT ? MTS_BOUNCE_WAVES : MTS_SHADE_WAVES_MIN, FLAT ? MTS_BOUNCE_WAVES : 8)))
 void k_shade(const RenderParams P) {
     static_assert(FLAT || !INLINE, "the in-kernel shadow queue is for LDS-resident scenes");
     extern __shared__ float4 smem[];
