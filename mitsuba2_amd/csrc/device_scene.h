@@ -252,23 +252,32 @@ MTS_DEV void walk_round(BvhWalk &w, const SceneView &sv, const WalkStack &st, ui
         if (kT > 0 && __popcll(mi) < kT && __ballot((int32_t) cur < 0) != 0ull) break;
         if (!inner) continue;
 #if MTS_QNODES
-        const f3 oq = w.o_q, noi = w.noi;
+        // FAR: (q - o_q) is only good to eps * |o_q| cells out there, so that form widens every slab interval by that much (in t)
+        // instead -- an axis the ray is parallel to then stops culling, nothing is ever culled wrongly.  The pad is recomputed
+        // per step (a wave walks in one form, chosen by its farthest origin, so every lane needs it and a register is dearer).
+        const f3 oq = w.o_q;
+        const f3 noi = FAR ? mk3(fminf(2.4e-7f * fabsf(oq.x * inv.x), 1.0e30f), fminf(2.4e-7f * fabsf(oq.y * inv.y), 1.0e30f),
+                                 fminf(2.4e-7f * fabsf(oq.z * inv.z), 1.0e30f)) : w.noi;
         const uint4 a = sv.qnodes[2u * cur], bq = sv.qnodes[2u * cur + 1u];
-        auto slab = [&](uint32_t q, float o1, float i1, float n1) -> float {
-            return FAR ? ((float) q - o1) * i1 : fmaf((float) q, i1, n1);
+        // near plane (low half after the permute) / far plane (high half).  FAR: noi holds the error pad e >= 0 of the axis
+        auto slab_n = [&](uint32_t q, float o1, float i1, float n1) -> float {
+            return FAR ? fmaf((float) q - o1, i1, -n1) : fmaf((float) q, i1, n1);
+        };
+        auto slab_f = [&](uint32_t q, float o1, float i1, float n1) -> float {
+            return FAR ? fmaf((float) q - o1, i1, n1) : fmaf((float) q, i1, n1);
         };
         // per axis: one v_perm_b32 orders the two planes by the sign of the direction, so near = t(low half), far = t(high half)
         const uint32_t lx = __builtin_amdgcn_perm(a.x, a.x, w.sel[0]), ly = __builtin_amdgcn_perm(a.y, a.y, w.sel[1]),
                        lz = __builtin_amdgcn_perm(a.z, a.z, w.sel[2]), rx = __builtin_amdgcn_perm(a.w, a.w, w.sel[0]),
                        ry = __builtin_amdgcn_perm(bq.x, bq.x, w.sel[1]), rz = __builtin_amdgcn_perm(bq.y, bq.y, w.sel[2]);
-        const float nearL = fmaxf(fmaxf(slab(lx & 0xffffu, oq.x, inv.x, noi.x), slab(ly & 0xffffu, oq.y, inv.y, noi.y)),
-                                  fmaxf(slab(lz & 0xffffu, oq.z, inv.z, noi.z), w.mint));
-        const float farL = fminf(fminf(slab(lx >> 16, oq.x, inv.x, noi.x), slab(ly >> 16, oq.y, inv.y, noi.y)),
-                                 fminf(slab(lz >> 16, oq.z, inv.z, noi.z), w.best));
-        const float nearR = fmaxf(fmaxf(slab(rx & 0xffffu, oq.x, inv.x, noi.x), slab(ry & 0xffffu, oq.y, inv.y, noi.y)),
-                                  fmaxf(slab(rz & 0xffffu, oq.z, inv.z, noi.z), w.mint));
-        const float farR = fminf(fminf(slab(rx >> 16, oq.x, inv.x, noi.x), slab(ry >> 16, oq.y, inv.y, noi.y)),
-                                 fminf(slab(rz >> 16, oq.z, inv.z, noi.z), w.best));
+        const float nearL = fmaxf(fmaxf(slab_n(lx & 0xffffu, oq.x, inv.x, noi.x), slab_n(ly & 0xffffu, oq.y, inv.y, noi.y)),
+                                  fmaxf(slab_n(lz & 0xffffu, oq.z, inv.z, noi.z), w.mint));
+        const float farL = fminf(fminf(slab_f(lx >> 16, oq.x, inv.x, noi.x), slab_f(ly >> 16, oq.y, inv.y, noi.y)),
+                                 fminf(slab_f(lz >> 16, oq.z, inv.z, noi.z), w.best));
+        const float nearR = fmaxf(fmaxf(slab_n(rx & 0xffffu, oq.x, inv.x, noi.x), slab_n(ry & 0xffffu, oq.y, inv.y, noi.y)),
+                                  fmaxf(slab_n(rz & 0xffffu, oq.z, inv.z, noi.z), w.mint));
+        const float farR = fminf(fminf(slab_f(rx >> 16, oq.x, inv.x, noi.x), slab_f(ry >> 16, oq.y, inv.y, noi.y)),
+                                 fminf(slab_f(rz >> 16, oq.z, inv.z, noi.z), w.best));
         const bool hl = nearL <= farL, hr = nearR <= farR;
         const uint32_t cl = bq.z, cr = bq.w;
 #else

@@ -403,3 +403,39 @@ def test_film_develop_on_gpu(gpu, oracle):
     film.prepare()
     film._storage.data().copy_(torch.from_numpy(px))
     assert (film.bitmap().cpu().numpy() == oracle.film_develop(px)).all()
+
+
+def test_bvh_walk_corner_cases(gpu):
+    """The hierarchy walk against the brute-force kernel on rays that stress its arithmetic: origins far outside the scene box
+    (the slab test switches from fma(q, inv, -o*inv) to (q - o)*inv beyond 1e6 grid cells), axis-parallel directions (zero
+    components: clamped reciprocals), origins exactly on box planes, tiny and huge ray segments, and a scene far from the
+    world origin.  Hits must be identical (t, primitive, u, v), any-hit must agree with closest-hit."""
+    rng = np.random.RandomState(5)
+    for offset in (np.zeros(3, np.float32), np.float32([4000.0, -2500.0, 800.0])):
+        sd = scenes.bumpy_sphere(24, 48)
+        sd["meshes"] = [dict(m, positions=(np.asarray(m["positions"], np.float32) + offset)) for m in sd["meshes"]]
+        scene = gpu.Scene(sd)
+        pos = np.concatenate([np.asarray(m["positions"], np.float32).reshape(-1, 3) for m in sd["meshes"]])
+        lo, hi = pos.min(0), pos.max(0)
+        c, ext = 0.5 * (lo + hi), float((hi - lo).max())
+        n = 40000
+        target = (c + (rng.rand(n, 3) - 0.5) * 0.6 * ext).astype(np.float32)
+        kinds = np.arange(n) % 5
+        dirs = rng.randn(n, 3).astype(np.float32)
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        axis = np.eye(3, dtype=np.float32)[rng.randint(0, 3, n)] * np.where(rng.rand(n, 1) < 0.5, -1, 1).astype(np.float32)
+        dirs[kinds == 1] = axis[kinds == 1]                                  # axis-parallel: two zero components
+        dist = np.where(kinds == 0, 30.0 * ext, np.where(kinds == 2, 5000.0 * ext, 1.5 * ext)).astype(np.float32)[:, None]
+        o = (target - dirs * dist).astype(np.float32)                        # kinds 0 / 2: far and very far origins
+        on_plane = kinds == 3                                                # origins exactly on a scene-box plane
+        o[on_plane, 0] = lo[0]
+        mint = np.zeros(n, np.float32)
+        maxt = np.full(n, np.inf, np.float32)
+        maxt[kinds == 4] = (rng.rand((kinds == 4).sum()) * 2.0 * ext).astype(np.float32)      # finite segments
+        ray = _gpu_ray(gpu, o, dirs, mint, maxt)
+        fast, slow = scene.ray_intersect(ray, full=False), scene.ray_intersect_naive(ray)
+        assert torch.equal(fast.t, slow.t) and torch.equal(fast.prim_index, slow.prim_index)
+        assert torch.equal(fast.prim_uv, slow.prim_uv) and torch.equal(fast.shape_index, slow.shape_index)
+        assert torch.equal(scene.ray_test(ray), torch.isfinite(slow.t))
+        for k in range(5):
+            assert torch.isfinite(slow.t[torch.from_numpy(kinds == k).cuda()]).float().mean().item() > 0.02, k
