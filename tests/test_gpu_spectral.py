@@ -87,6 +87,8 @@ def test_spectral_materials_match_oracle(gpu, oracle, material):
     xyz, mask, pos = gpu.PathIntegrator(max_depth=6, pipeline=1).sample(scene, sensor, 0, n)
     xyz2, _, _ = gpu.PathIntegrator(max_depth=6, pipeline=2).sample(scene, sensor, 0, n)
     assert (xyz == xyz2).all()
+    xyz0, _, _ = gpu.PathIntegrator(max_depth=6).sample(scene, sensor, 0, n)          # default schedule: in-kernel shadow ring
+    assert (xyz == xyz0).all()
     ref, ref_pos = oracle.OracleScene(cb, spectral_path=path).sample_radiance(oracle.make_desc(p), 0, n)
     assert (pos.cpu().numpy() == ref_pos).all() and ((ref[:, 3] > 0.5) == mask.cpu().numpy()).all()
     close = np.isclose(xyz.cpu().numpy(), ref[:, :3], rtol=5e-3, atol=2e-4).all(axis=1)
