@@ -186,7 +186,8 @@ struct Workspace {
     uint32_t *trace_spill = nullptr; size_t trace_spill_words = 0;      // k_trace: deep stack entries
     uint32_t *h_counts = nullptr;        // pinned, 4 * n_waves
     uint64_t *h_cursor = nullptr;        // pinned, 2 * n_waves
-    hipEvent_t ev[4] = {};
+    hipEvent_t ev[4] = {};               // 0 / 1: count read-back checkpoints, 2: k_shade done, 3: k_trace<any> done
+    hipStream_t stream2 = nullptr;       // split pipeline: k_trace<any> of one iteration overlaps k_trace<closest> of the next
     hipEvent_t tev[3] = {};              // timing: bounce loop begin / end, film end
     bool have_events = false;
 
@@ -207,6 +208,8 @@ struct Workspace {
         if (h_counts) (void) hipHostFree(h_counts);
         if (h_cursor) (void) hipHostFree(h_cursor);
         h_counts = nullptr; h_cursor = nullptr;
+        if (stream2) (void) hipStreamDestroy(stream2);
+        stream2 = nullptr;
         if (have_events) for (auto &e : ev) (void) hipEventDestroy(e);
         have_events = false;
         n_waves = seg_cap = 0; pass_cap = 0;
@@ -962,6 +965,7 @@ static int ensure_workspace(mtsamd_scene *s, uint32_t n_waves, uint32_t seg_cap,
     HIP_TRY(hipHostMalloc((void **) &w.h_counts, 4 * (size_t) n_waves * sizeof(uint32_t), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **) &w.h_cursor, 3 * (size_t) n_waves * sizeof(uint64_t), hipHostMallocDefault));
     for (auto &e : w.ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (!w.stream2) HIP_TRY(hipStreamCreateWithFlags(&w.stream2, hipStreamNonBlocking));
     for (auto &e : w.tev) HIP_TRY(hipEventCreate(&e));
     w.have_events = true;
     w.n_waves = n_waves; w.seg_cap = seg_cap; w.pass_cap = pass_cap; w.spectral = s->spectral; w.split = split;
@@ -1048,11 +1052,24 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     while (true) {
         if (j.s->cancel.load(std::memory_order_relaxed)) {
             (void) hipStreamSynchronize(j.stream);
+            if (w.stream2) (void) hipStreamSynchronize(w.stream2);
             return fail(MTSAMD_ERR_CANCELLED, "render cancelled");
         }
         p.in = w.pool[cur]; p.out = w.pool[cur ^ 1];
         p.count_in = w.count[cur]; p.count_out = w.count[cur ^ 1];
-        HIP_TRY(launch_bounce(p, j.stream));
+        if (p.split == 1) {
+            // k_trace<any> of iteration i only adds to the radiance of the pool that iteration i + 1 reads its rays from: it runs on
+            // a second stream beside k_trace<closest> of iteration i + 1 (the two fill each other's launch tails); k_shade waits for it
+            HIP_TRY(launch_split_stage(p, 0, j.stream));
+            if (it > 0) HIP_TRY(hipStreamWaitEvent(j.stream, w.ev[3], 0));
+            HIP_TRY(launch_split_stage(p, 1, j.stream));
+            HIP_TRY(hipEventRecord(w.ev[2], j.stream));
+            HIP_TRY(hipStreamWaitEvent(w.stream2, w.ev[2], 0));
+            HIP_TRY(launch_split_stage(p, 2, w.stream2));
+            HIP_TRY(hipEventRecord(w.ev[3], w.stream2));
+        } else {
+            HIP_TRY(launch_bounce(p, j.stream));
+        }
         cur ^= 1; ++it;
         if (it >= min_iters && (it - min_iters) % stride == 0) {
             if (pending >= 0) {
@@ -1068,6 +1085,7 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
         }
         if (it > (1ull << 24)) return fail(MTSAMD_ERR_DEVICE, "wavefront scheduler did not converge");
     }
+    if (p.split == 1 && it > 0) HIP_TRY(hipStreamWaitEvent(j.stream, w.ev[3], 0));
     HIP_TRY(hipEventRecord(w.tev[1], j.stream));
     HIP_TRY(hipEventSynchronize(w.tev[1]));
     float ms = 0.0f;

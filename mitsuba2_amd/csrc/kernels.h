@@ -105,6 +105,7 @@ struct RayStreams {
 
 size_t bounce_lds_bytes(const SceneView &sv);
 hipError_t launch_bounce(const RenderParams &p, hipStream_t s);
+hipError_t launch_split_stage(const RenderParams &p, int stage, hipStream_t s);
 uint32_t trace_lds_depth(const SceneView &sv);
 size_t trace_spill_words(const SceneView &sv, uint32_t n_waves);
 // `direct` / `depth` integrators: every sample of [first_ordinal, first_ordinal + n) is finished by one thread

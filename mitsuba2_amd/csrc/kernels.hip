@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(const RenderParams P) {
         // P.trace_spill ([entry][thread])
         const uint32_t spill_depth = P.sv.stack_depth > P.trace_lds_depth ? P.sv.stack_depth - P.trace_lds_depth : 0u;
         const WalkStack st = { lds.stack + threadIdx.x, lds.stride, P.trace_lds_depth,
-                               P.trace_spill + (size_t) blockIdx.x * spill_depth * kBlock + threadIdx.x, blockDim.x };
+                               P.trace_spill + ((size_t) (ANY ? gridDim.x : 0u) + blockIdx.x) * spill_depth * kBlock + threadIdx.x, blockDim.x };
         BvhWalk w;
         w.cur = kNoNode; w.sp = 0u; w.found = false;
         bool busy = false;                                   // the lane holds a work item
@@ -1128,7 +1128,24 @@ size_t trace_lds_bytes(const SceneView &sv) { return (size_t) 4 * std::min(sv.st
 uint32_t trace_lds_depth(const SceneView &sv) { return std::min(sv.stack_depth, kTraceLdsDepth); }
 size_t trace_spill_words(const SceneView &sv, uint32_t n_waves) {
     const uint32_t spill = sv.stack_depth > kTraceLdsDepth ? sv.stack_depth - kTraceLdsDepth : 0u;
-    return (size_t) ((n_waves + kShadowGroup - 1) / kShadowGroup) * spill * kBlock;
+    return (size_t) 2 * ((n_waves + kShadowGroup - 1) / kShadowGroup) * spill * kBlock;      // closest-hit and any-hit launches may overlap
+}
+
+// split pipeline of hierarchy scenes, one stage at a time: 0 = k_trace<closest>, 1 = k_shade, 2 = k_trace<any>.  Stage 2 of one
+// iteration and stage 0 of the next touch disjoint arrays, so the host runs them on two streams (api.cpp).
+hipError_t launch_split_stage(const RenderParams &p, int stage, hipStream_t s) {
+    const uint32_t shade_blocks = (p.n_waves * 64u + kBlock - 1) / kBlock, trace_blocks = (p.n_waves + kShadowGroup - 1) / kShadowGroup;
+    if (stage == 0) {
+        hipLaunchKernelGGL((k_trace<false, false>), dim3(trace_blocks), dim3(kTraceBlock), trace_lds_bytes(p.sv), s, p);
+    } else if (stage == 1) {
+        if (p.spectral && p.sv.general) hipLaunchKernelGGL((k_shade<PathStateS, true, false>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
+        else if (p.spectral) hipLaunchKernelGGL((k_shade<PathStateS, false, false>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
+        else if (p.sv.general) hipLaunchKernelGGL((k_shade<PathState, true, false>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
+        else hipLaunchKernelGGL((k_shade<PathState, false, false>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
+    } else {
+        hipLaunchKernelGGL((k_trace<true, false>), dim3(trace_blocks), dim3(kTraceBlock), trace_lds_bytes(p.sv), s, p);
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_bounce(const RenderParams &p_, hipStream_t s) {
@@ -1155,14 +1172,10 @@ hipError_t launch_bounce(const RenderParams &p_, hipStream_t s) {
         return hipGetLastError();
     }
     if (p.split) {
-        const uint32_t shade_blocks = (p.n_waves * 64u + kBlock - 1) / kBlock;
-        hipLaunchKernelGGL((k_trace<false, false>), dim3((p.n_waves + kShadowGroup - 1) / kShadowGroup), dim3(kTraceBlock), trace_lds_bytes(p.sv), s, p);
-        if (p.spectral && p.sv.general) hipLaunchKernelGGL((k_shade<PathStateS, true, false>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
-        else if (p.spectral) hipLaunchKernelGGL((k_shade<PathStateS, false, false>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
-        else if (p.sv.general) hipLaunchKernelGGL((k_shade<PathState, true, false>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
-        else hipLaunchKernelGGL((k_shade<PathState, false, false>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
-        hipLaunchKernelGGL((k_trace<true, false>), dim3((p.n_waves + kShadowGroup - 1) / kShadowGroup), dim3(kTraceBlock), trace_lds_bytes(p.sv), s, p);
-        return hipGetLastError();
+        hipError_t e = launch_split_stage(p, 0, s);
+        if (e == hipSuccess) e = launch_split_stage(p, 1, s);
+        if (e == hipSuccess) e = launch_split_stage(p, 2, s);
+        return e;
     }
     uint32_t blocks = (p.n_waves * 64u + kBlock - 1) / kBlock;
     if (p.spectral) {
