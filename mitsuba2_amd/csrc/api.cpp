@@ -1116,12 +1116,14 @@ int setup_job(Job &j, mtsamd_scene *s, const mtsamd_render_desc *d, hipStream_t 
     // 16 x 256 -> 1753, 48 x 256 -> 1953, 72 x 512 -> 2366, 104 x 512 -> 2459, 208 x 1024 -> 2507 Msample/s (power-of-two
     // wave counts alias in the memory channels: 64 x 256 is slower than 72 x 256); split pipeline, 261 k-triangle mesh:
     // 16 / 64 / 128 / 208 waves per CU x 256 slots -> 705 / 1162 / 1339 / 1407 Msample/s; shadow-ring kernel (schedule 4), cbox:
-    // 72 x 512 -> 2453, 104 x 512 -> 2554, 144 x 512 -> 2576, 208 x 512 -> 2629, 104 x 1024 -> 2598 Msample/s.
+    // 72 x 512 -> 2453, 104 x 512 -> 2554, 144 x 512 -> 2576, 208 x 512 -> 2629, 104 x 1024 -> 2598 Msample/s.  Split pipeline
+    // after this round's traversal work (two-stream overlap included): 104 / 156 / 208 / 312 / 416 / 624 waves per CU x 256 slots
+    // -> 1747 / 1890 / 1946 / 2075 / 2118 / 2142 Msample/s.
     j.target = d->paths_per_wave > 0 ? (uint32_t) d->paths_per_wave : (j.split ? 256u : 512u);
     j.target = std::min<uint32_t>(std::max<uint32_t>(j.target, 64u), 4096u);
     {   // no more scheduling waves than the pass can fill
         const uint64_t want = (std::min<uint64_t>(max_pass, pass_limit) + j.target - 1) / j.target;
-        const uint64_t lo = (uint64_t) s->cu_count * 16u, hi = (uint64_t) s->cu_count * ((j.split || j.shadow_ring) ? 208u : 104u);
+        const uint64_t lo = (uint64_t) s->cu_count * 16u, hi = (uint64_t) s->cu_count * (j.split ? 416u : (j.shadow_ring ? 208u : 104u));
         j.n_waves = (uint32_t) std::min<uint64_t>(std::max<uint64_t>(want, lo), hi);
     }
     if (const char *e = getenv("MTSAMD_WAVES_PER_CU")) j.n_waves = (uint32_t) s->cu_count * (uint32_t) std::max(1, atoi(e));    // experiment switch
