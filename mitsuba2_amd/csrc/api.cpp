@@ -188,6 +188,7 @@ struct Workspace {
     uint64_t *h_cursor = nullptr;        // pinned, 2 * n_waves
     hipEvent_t ev[4] = {};               // 0 / 1: count read-back checkpoints, 2: k_shade done, 3: k_trace<any> done
     hipStream_t stream2 = nullptr;       // split pipeline: k_trace<any> of one iteration overlaps k_trace<closest> of the next
+    hipStream_t part_stream[3] = {}; hipEvent_t part_ev[3] = {};      // flat scenes: further parts of the scheduling waves
     hipEvent_t tev[3] = {};              // timing: bounce loop begin / end, film end
     bool have_events = false;
 
@@ -210,6 +211,8 @@ struct Workspace {
         h_counts = nullptr; h_cursor = nullptr;
         if (stream2) (void) hipStreamDestroy(stream2);
         stream2 = nullptr;
+        for (auto &ps : part_stream) { if (ps) (void) hipStreamDestroy(ps); ps = nullptr; }
+        for (auto &pe : part_ev) { if (pe) (void) hipEventDestroy(pe); pe = nullptr; }
         if (have_events) for (auto &e : ev) (void) hipEventDestroy(e);
         have_events = false;
         n_waves = seg_cap = 0; pass_cap = 0;
@@ -966,6 +969,8 @@ static int ensure_workspace(mtsamd_scene *s, uint32_t n_waves, uint32_t seg_cap,
     HIP_TRY(hipHostMalloc((void **) &w.h_cursor, 3 * (size_t) n_waves * sizeof(uint64_t), hipHostMallocDefault));
     for (auto &e : w.ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (!w.stream2) HIP_TRY(hipStreamCreateWithFlags(&w.stream2, hipStreamNonBlocking));
+    for (auto &ps : w.part_stream) if (!ps) HIP_TRY(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+    for (auto &pe : w.part_ev) if (!pe) HIP_TRY(hipEventCreateWithFlags(&pe, hipEventDisableTiming));
     for (auto &e : w.tev) HIP_TRY(hipEventCreate(&e));
     w.have_events = true;
     w.n_waves = n_waves; w.seg_cap = seg_cap; w.pass_cap = pass_cap; w.spectral = s->spectral; w.split = split;
@@ -1049,10 +1054,28 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     const uint64_t stride = 4;
     int pending = -1, slot = 0;
     HIP_TRY(hipEventRecord(w.tev[0], j.stream));
+    uint32_t n_parts = 2;
+    if (const char *e = getenv("MTSAMD_STREAMS")) n_parts = (uint32_t) std::min(4, std::max(1, atoi(e)));      // experiment switch
+    if (p.split != 3 || nw < 256u) n_parts = 1;
+    uint32_t part_lo[5] = { 0, nw, nw, nw, nw };
+    for (uint32_t k = 1; k < n_parts; ++k) part_lo[k] = (uint32_t) (((uint64_t) nw * k / n_parts + 3u) & ~3ull);
+    part_lo[n_parts] = nw;
+    auto join_parts = [&]() -> int {         // j.stream waits for the other parts' streams
+        for (uint32_t k = 1; k < n_parts; ++k) {
+            HIP_TRY(hipEventRecord(w.part_ev[k - 1], w.part_stream[k - 1]));
+            HIP_TRY(hipStreamWaitEvent(j.stream, w.part_ev[k - 1], 0));
+        }
+        return 0;
+    };
+    if (n_parts > 1) {          // the other streams start after the cursors and counts are in place
+        HIP_TRY(hipEventRecord(w.ev[2], j.stream));
+        for (uint32_t k = 1; k < n_parts; ++k) HIP_TRY(hipStreamWaitEvent(w.part_stream[k - 1], w.ev[2], 0));
+    }
     while (true) {
         if (j.s->cancel.load(std::memory_order_relaxed)) {
             (void) hipStreamSynchronize(j.stream);
             if (w.stream2) (void) hipStreamSynchronize(w.stream2);
+            for (auto &ps : w.part_stream) if (ps) (void) hipStreamSynchronize(ps);
             return fail(MTSAMD_ERR_CANCELLED, "render cancelled");
         }
         p.in = w.pool[cur]; p.out = w.pool[cur ^ 1];
@@ -1067,6 +1090,14 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
             HIP_TRY(hipStreamWaitEvent(w.stream2, w.ev[2], 0));
             HIP_TRY(launch_split_stage(p, 2, w.stream2));
             HIP_TRY(hipEventRecord(w.ev[3], w.stream2));
+        } else if (p.split == 3 && n_parts > 1) {
+            // the scheduling waves are independent of each other: part-size launches on their own streams advance in their own
+            // rhythm and fill each other's launch tails
+            RenderParams h = p;
+            for (uint32_t k = 0; k < n_parts; ++k) {
+                h.wave_first = part_lo[k]; h.wave_last = part_lo[k + 1];
+                HIP_TRY(launch_bounce(h, k == 0 ? j.stream : w.part_stream[k - 1]));
+            }
         } else {
             HIP_TRY(launch_bounce(p, j.stream));
         }
@@ -1079,6 +1110,7 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
                 for (uint32_t k = 0; k < nw; ++k) alive += hc[k];
                 if (alive == 0) break;
             }
+            if (n_parts > 1) { if (int rc = join_parts()) return rc; }
             HIP_TRY(hipMemcpyAsync(w.h_counts + (size_t) slot * nw, w.count[cur], nw * sizeof(uint32_t), hipMemcpyDeviceToHost, j.stream));
             HIP_TRY(hipEventRecord(w.ev[slot], j.stream));
             pending = slot; slot ^= 1;
@@ -1086,6 +1118,7 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
         if (it > (1ull << 24)) return fail(MTSAMD_ERR_DEVICE, "wavefront scheduler did not converge");
     }
     if (p.split == 1 && it > 0) HIP_TRY(hipStreamWaitEvent(j.stream, w.ev[3], 0));
+    if (n_parts > 1) { if (int rc = join_parts()) return rc; }
     HIP_TRY(hipEventRecord(w.tev[1], j.stream));
     HIP_TRY(hipEventSynchronize(w.tev[1]));
     float ms = 0.0f;

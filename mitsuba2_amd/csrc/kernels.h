@@ -72,6 +72,7 @@ struct RenderParams {
     int32_t split;              // 0: fused k_bounce, 1: k_trace<closest> + k_shade + k_trace<any> per iteration, 2: k_shade (flat) + k_trace<any>,
                                 // 3: k_shade (flat) with the in-kernel shadow ring
     uint32_t lds_queue_offset;  // split == 3: start of the per-wave shadow rings in LDS, in float4 units
+    uint32_t wave_first, wave_last;   // k_shade: scheduling waves covered by this launch (wave_last == 0: all)
     uint32_t trace_lds_depth;   // k_trace: stack entries per lane kept in LDS; deeper ones go to trace_spill
     uint32_t *trace_spill;      // k_trace: [workgroup][entry][thread]
 };

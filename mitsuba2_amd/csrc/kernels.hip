@@ -861,16 +861,18 @@ void k_shade(const RenderParams P) {
     static_assert(FLAT || !INLINE, "the in-kernel shadow queue is for LDS-resident scenes");
     extern __shared__ float4 smem[];
     LdsView lds = {};                      // Geo<false> reads the scene tables from global memory
-    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    // a launch covers the scheduling waves [wave_first, wave_last) (all of them, or one half when two launches share the GPU)
+    const uint32_t wave = P.wave_first + ((blockIdx.x * kBlock + threadIdx.x) >> 6);
+    const uint32_t wave_last = P.wave_last ? P.wave_last : P.n_waves;
     __shared__ uint32_t s_cnt[kBlock / 64u];
     if (FLAT) {
         // While the pool drains at the end of a pass most scheduling waves have nothing left to do: a workgroup whose four
         // waves are all idle leaves before staging the scene into LDS (its output counts still have to be reset).
-        const uint32_t n_own = wave < P.n_waves ? P.count_in[wave] : 0u;
+        const uint32_t n_own = wave < wave_last ? P.count_in[wave] : 0u;
         if (lane_id() == 0u) s_cnt[threadIdx.x >> 6] = n_own;
-        const bool work = wave < P.n_waves && (n_own > 0u || P.cursor[wave] < P.cursor_end[wave]);
+        const bool work = wave < wave_last && (n_own > 0u || P.cursor[wave] < P.cursor_end[wave]);
         if (!__syncthreads_or(work ? 1 : 0)) {
-            if (wave < P.n_waves && lane_id() == 0u) {
+            if (wave < wave_last && lane_id() == 0u) {
                 P.count_out[wave] = 0u;
                 if (!INLINE) P.count_shadow[wave] = 0u;
             }
@@ -884,7 +886,7 @@ void k_shade(const RenderParams P) {
         ring.o = qb; ring.d = qb + kShadowRing; ring.nee = qb + 2u * kShadowRing;
         ring.slot = reinterpret_cast<uint32_t *>(qb + 3u * kShadowRing);
     }
-    if (wave >= P.n_waves) return;
+    if (wave >= wave_last) return;
     const uint32_t lane = lane_id();
     const size_t base = (size_t) wave * P.seg_cap;
     uint32_t n_out = 0;
@@ -895,7 +897,7 @@ void k_shade(const RenderParams P) {
     // the waves -- at most one partial chunk per workgroup instead of one per wave while the pool drains.  Survivors go to the
     // output segment of the wave that processed them (seg_cap is a multiple of 64, so a wave never gets more than it can hold).
     const uint32_t wg_wave0 = wave - (threadIdx.x >> 6);
-    const uint32_t n_valid = FLAT ? min((uint32_t) (kBlock / 64u), P.n_waves - wg_wave0) : 1u;
+    const uint32_t n_valid = FLAT ? min((uint32_t) (kBlock / 64u), wave_last - wg_wave0) : 1u;
     uint32_t cnt4[kBlock / 64u], n_in = 0;
     if (FLAT) {
 #pragma unroll
@@ -1151,7 +1153,8 @@ hipError_t launch_split_stage(const RenderParams &p, int stage, hipStream_t s) {
 hipError_t launch_bounce(const RenderParams &p_, hipStream_t s) {
     RenderParams p = p_;
     if (p.split == 3) {       // LDS-resident scene, one kernel: shadow rays collected in a per-wave LDS ring and resolved 64 at a time
-        const uint32_t shade_blocks = (p.n_waves * 64u + kBlock - 1) / kBlock;
+        const uint32_t n_launch = (p.wave_last ? p.wave_last : p.n_waves) - p.wave_first;
+        const uint32_t shade_blocks = (n_launch * 64u + kBlock - 1) / kBlock;
         const size_t scene_bytes = (bounce_lds_bytes(p.sv) + 15u) & ~(size_t) 15u;
         p.lds_queue_offset = (uint32_t) (scene_bytes / 16u);
         const size_t lds = scene_bytes + (size_t) (kBlock / 64u) * kShadowRing * 52u;
