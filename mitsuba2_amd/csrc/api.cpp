@@ -1060,6 +1060,14 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     uint32_t part_lo[5] = { 0, nw, nw, nw, nw };
     for (uint32_t k = 1; k < n_parts; ++k) part_lo[k] = (uint32_t) (((uint64_t) nw * k / n_parts + 3u) & ~3ull);
     part_lo[n_parts] = nw;
+    uint32_t split_parts = p.split == 1 && nw >= 256u ? 2u : 1u;
+    if (getenv("MTSAMD_ONE_CHAIN")) split_parts = 1;      // experiment switch
+    uint32_t split_lo[3] = { 0, nw, nw };
+    if (split_parts == 2) split_lo[1] = (nw / 2u + 7u) & ~7u;      // multiple of the k_trace group size
+    if (split_parts == 2) {      // the second chain starts after the cursors and counts are in place
+        HIP_TRY(hipEventRecord(w.part_ev[2], j.stream));
+        HIP_TRY(hipStreamWaitEvent(w.part_stream[0], w.part_ev[2], 0));
+    }
     auto join_parts = [&]() -> int {         // j.stream waits for the other parts' streams
         for (uint32_t k = 1; k < n_parts; ++k) {
             HIP_TRY(hipEventRecord(w.part_ev[k - 1], w.part_stream[k - 1]));
@@ -1082,14 +1090,21 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
         p.count_in = w.count[cur]; p.count_out = w.count[cur ^ 1];
         if (p.split == 1) {
             // k_trace<any> of iteration i only adds to the radiance of the pool that iteration i + 1 reads its rays from: it runs on
-            // a second stream beside k_trace<closest> of iteration i + 1 (the two fill each other's launch tails); k_shade waits for it
-            HIP_TRY(launch_split_stage(p, 0, j.stream));
-            if (it > 0) HIP_TRY(hipStreamWaitEvent(j.stream, w.ev[3], 0));
-            HIP_TRY(launch_split_stage(p, 1, j.stream));
-            HIP_TRY(hipEventRecord(w.ev[2], j.stream));
-            HIP_TRY(hipStreamWaitEvent(w.stream2, w.ev[2], 0));
-            HIP_TRY(launch_split_stage(p, 2, w.stream2));
-            HIP_TRY(hipEventRecord(w.ev[3], w.stream2));
+            // a second stream beside k_trace<closest> of iteration i + 1 (the two fill each other's launch tails); k_shade waits for
+            // it.  The scheduling waves are independent, so two such chains (halves of the waves) run side by side.
+            for (uint32_t k = 0; k < split_parts; ++k) {
+                RenderParams h = p;
+                h.wave_first = split_lo[k]; h.wave_last = split_lo[k + 1];
+                hipStream_t s_main = k == 0 ? j.stream : w.part_stream[0], s_any = k == 0 ? w.stream2 : w.part_stream[1];
+                hipEvent_t e_shade = k == 0 ? w.ev[2] : w.part_ev[0], e_any = k == 0 ? w.ev[3] : w.part_ev[1];
+                HIP_TRY(launch_split_stage(h, 0, s_main));
+                if (it > 0) HIP_TRY(hipStreamWaitEvent(s_main, e_any, 0));
+                HIP_TRY(launch_split_stage(h, 1, s_main));
+                HIP_TRY(hipEventRecord(e_shade, s_main));
+                HIP_TRY(hipStreamWaitEvent(s_any, e_shade, 0));
+                HIP_TRY(launch_split_stage(h, 2, s_any));
+                HIP_TRY(hipEventRecord(e_any, s_any));
+            }
         } else if (p.split == 3 && n_parts > 1) {
             // the scheduling waves are independent of each other: part-size launches on their own streams advance in their own
             // rhythm and fill each other's launch tails
@@ -1111,13 +1126,24 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
                 if (alive == 0) break;
             }
             if (n_parts > 1) { if (int rc = join_parts()) return rc; }
+            if (split_parts == 2) {       // the counts of the second chain are written by its k_shade
+                HIP_TRY(hipEventRecord(w.part_ev[2], w.part_stream[0]));
+                HIP_TRY(hipStreamWaitEvent(j.stream, w.part_ev[2], 0));
+            }
             HIP_TRY(hipMemcpyAsync(w.h_counts + (size_t) slot * nw, w.count[cur], nw * sizeof(uint32_t), hipMemcpyDeviceToHost, j.stream));
             HIP_TRY(hipEventRecord(w.ev[slot], j.stream));
             pending = slot; slot ^= 1;
         }
         if (it > (1ull << 24)) return fail(MTSAMD_ERR_DEVICE, "wavefront scheduler did not converge");
     }
-    if (p.split == 1 && it > 0) HIP_TRY(hipStreamWaitEvent(j.stream, w.ev[3], 0));
+    if (p.split == 1 && it > 0) {
+        HIP_TRY(hipStreamWaitEvent(j.stream, w.ev[3], 0));
+        if (split_parts == 2) {
+            HIP_TRY(hipStreamWaitEvent(j.stream, w.part_ev[1], 0));
+            HIP_TRY(hipEventRecord(w.part_ev[2], w.part_stream[0]));
+            HIP_TRY(hipStreamWaitEvent(j.stream, w.part_ev[2], 0));
+        }
+    }
     if (n_parts > 1) { if (int rc = join_parts()) return rc; }
     HIP_TRY(hipEventRecord(w.tev[1], j.stream));
     HIP_TRY(hipEventSynchronize(w.tev[1]));

@@ -1030,11 +1030,14 @@ __global__ __launch_bounds__(kBlock) void k_trace(const RenderParams P) {
     uint32_t tri_tests = 0;
     // work list of this workgroup: the shadow queues (ANY) or the path slots (closest hit) of kShadowGroup scheduling waves
     const PoolView &pool = ANY ? P.out : P.in;
-    const uint32_t w0 = blockIdx.x * kShadowGroup;
+    // a launch covers the scheduling waves [wave_first, wave_last) (wave_first is a multiple of kShadowGroup)
+    const uint32_t wave_last = P.wave_last ? P.wave_last : P.n_waves;
+    const uint32_t group = P.wave_first / kShadowGroup + blockIdx.x;      // global group index
+    const uint32_t w0 = group * kShadowGroup;
     uint32_t cnt[kShadowGroup], total = 0;
     const uint32_t *counts = ANY ? P.count_shadow : P.count_in;
 #pragma unroll
-    for (uint32_t g = 0; g < kShadowGroup; ++g) { cnt[g] = (w0 + g < P.n_waves) ? counts[w0 + g] : 0u; total += cnt[g]; }
+    for (uint32_t g = 0; g < kShadowGroup; ++g) { cnt[g] = (w0 + g < wave_last) ? counts[w0 + g] : 0u; total += cnt[g]; }
     auto locate = [&](uint32_t idx) -> size_t {              // work item -> pool index
         uint32_t wave = w0, i = idx;
 #pragma unroll
@@ -1068,7 +1071,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(const RenderParams P) {
         // P.trace_spill ([entry][thread])
         const uint32_t spill_depth = P.sv.stack_depth > P.trace_lds_depth ? P.sv.stack_depth - P.trace_lds_depth : 0u;
         const WalkStack st = { lds.stack + threadIdx.x, lds.stride, P.trace_lds_depth,
-                               P.trace_spill + ((size_t) (ANY ? gridDim.x : 0u) + blockIdx.x) * spill_depth * kBlock + threadIdx.x, blockDim.x };
+                               P.trace_spill + ((size_t) (ANY ? (P.n_waves + kShadowGroup - 1u) / kShadowGroup : 0u) + group) * spill_depth * kBlock + threadIdx.x, blockDim.x };
         BvhWalk w;
         w.cur = kNoNode; w.sp = 0u; w.found = false;
         bool busy = false;                                   // the lane holds a work item
@@ -1118,7 +1121,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(const RenderParams P) {
     }
     for (int off = 32; off > 0; off >>= 1) tri_tests += __shfl_xor(tri_tests, off);
     if (lane_id() == 0 && tri_tests)
-        atomicAdd(reinterpret_cast<unsigned long long *>(P.wave_stats + 4u * (size_t) (blockIdx.x * kShadowGroup) + 3u),
+        atomicAdd(reinterpret_cast<unsigned long long *>(P.wave_stats + 4u * (size_t) w0 + 3u),
                   (unsigned long long) tri_tests);
 }
 
@@ -1136,7 +1139,8 @@ size_t trace_spill_words(const SceneView &sv, uint32_t n_waves) {
 // split pipeline of hierarchy scenes, one stage at a time: 0 = k_trace<closest>, 1 = k_shade, 2 = k_trace<any>.  Stage 2 of one
 // iteration and stage 0 of the next touch disjoint arrays, so the host runs them on two streams (api.cpp).
 hipError_t launch_split_stage(const RenderParams &p, int stage, hipStream_t s) {
-    const uint32_t shade_blocks = (p.n_waves * 64u + kBlock - 1) / kBlock, trace_blocks = (p.n_waves + kShadowGroup - 1) / kShadowGroup;
+    const uint32_t n_launch = (p.wave_last ? p.wave_last : p.n_waves) - p.wave_first;
+    const uint32_t shade_blocks = (n_launch * 64u + kBlock - 1) / kBlock, trace_blocks = (n_launch + kShadowGroup - 1) / kShadowGroup;
     if (stage == 0) {
         hipLaunchKernelGGL((k_trace<false, false>), dim3(trace_blocks), dim3(kTraceBlock), trace_lds_bytes(p.sv), s, p);
     } else if (stage == 1) {
