@@ -154,6 +154,7 @@ def main():
         kernel = {0: "k_shade<mtsamd::PathState, false, true, true>", 4: "k_shade<mtsamd::PathState, false, true, true>",
                   1: "k_bounce<true, false>", 2: "k_trace<false, false> + k_shade<mtsamd::PathState, false, false, false> + k_trace<true, false>",
                   3: "k_shade<mtsamd::PathState, false, true, false> + k_trace<true, true>"}[args.pipeline]
+        concurrent = min(4, max(1, int(os.environ.get("MTSAMD_STREAMS", "2")))) if args.pipeline in (0, 4) else 1
         pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bounce_kernel.json")))
         if pmc:
             try:
@@ -177,8 +178,11 @@ def main():
                        "partition": "interleaved 32-row film tiles + RCCL reduce" if n > 1 else "single GPU"},
             "mray_per_s": (tot_closest + tot_any) / dt / 1e6,
             "segments_per_sample": acc["segments"] / max(acc["samples"], 1),
+            # a "launch" is one iteration of the scheduler: with the default schedule it is issued as `concurrent` part-size kernels on
+            # their own streams, which run side by side (rocprofv3 lists them separately; each lasts about one iteration)
             "kernel_ms": {"bounce_kernel_per_step": acc["bounce_ns"] / args.steps * 1e-6, "k_film_tiles_per_step": acc["film_ns"] / args.steps * 1e-6,
-                          "bounce_kernel_launches_per_step": launches / args.steps, "bounce_kernel_avg_launch_us": bounce_s / launches * 1e6},
+                          "bounce_kernel_launches_per_step": launches / args.steps, "bounce_kernel_avg_launch_us": bounce_s / launches * 1e6,
+                          "bounce_kernel_concurrent": concurrent},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "alg_bytes_per_launch": alg_bytes / launches},
