@@ -43,3 +43,37 @@ def test_full_size_cbox_properties():
     down = got_rgb.reshape(64, 16, 64, 16, 3).mean((1, 3))
     assert np.allclose(down.mean((0, 1)), ref_rgb.mean((0, 1)), rtol=2e-2)
     assert np.mean((down - ref_rgb) ** 2 / (ref_rgb ** 2 + 1e-2)) < 1e-2          # different pixel footprints + the oracle's noise
+
+
+@pytest.mark.parametrize("variant", ["rgb", "spectral"])
+def test_full_size_mesh_properties(variant):
+    """BASELINE config 3 geometry (261 k triangles with vertex normals, 1920 x 1080) through the schedules: the default split
+    pipeline (two launch chains, any-hit overlapped with the next closest-hit, dynamic ray fetch, quantised nodes, spill stack)
+    must return the very film of the fused kernel, whatever the scheduler geometry; ray queries on the same scene agree
+    between the walk kernel, the full-SurfaceInteraction kernel and brute force on a sample of rays."""
+    from mitsuba2_amd import render as R, scenes
+    sd = scenes.bumpy_sphere(256, 512)
+    sp = scenes.bumpy_sphere_sensor(1920, 1080, 4)
+    scene = R.Scene(sd, variant=variant)
+    assert scene.info()["primitives"] > 250000
+    films = []
+    for kw in (dict(pipeline=0), dict(pipeline=1), dict(pipeline=2, paths_per_wave=100)):
+        sensor = R.make_sensor(sp)
+        integ = R.PathIntegrator(**kw)
+        assert integ.render(scene, sensor)
+        films.append(sensor.film().bitmap(raw=True))
+        assert integ.stats["samples"] == 1920 * 1080 * 4
+    assert torch.equal(films[0], films[1]) and torch.equal(films[0], films[2])
+    f = films[0].cpu().numpy()
+    assert np.isfinite(f).all() and f[..., 4].min() > 0 and f[..., :3].max() > 0
+    if variant == "rgb":
+        rng = np.random.RandomState(2)
+        n = 1 << 18
+        s = rng.rand(n, 2).astype(np.float32)
+        ray = R.make_sensor(sp).sample_ray(torch.from_numpy(s).cuda())
+        fast, full = scene.ray_intersect(ray, full=False), scene.ray_intersect(ray, full=True)
+        assert torch.equal(fast.t, full.t) and torch.equal(fast.prim_index, full.prim_index)
+        sub = R.Ray3f(o=ray.o[:4096].contiguous(), d=ray.d[:4096].contiguous(), mint=ray.mint[:4096].contiguous(), maxt=ray.maxt[:4096].contiguous())
+        slow = scene.ray_intersect_naive(sub)
+        assert torch.equal(fast.t[:4096], slow.t) and torch.equal(fast.prim_index[:4096], slow.prim_index)
+        assert torch.equal(scene.ray_test(ray), torch.isfinite(fast.t))
