@@ -1282,6 +1282,9 @@ int mtsamd_render(mtsamd_scene *s, const mtsamd_render_desc *d, float *film, uin
             g1 = (t1 * rows.count + rows.part) * rows.tile_rows + (l1 - t1 * rows.tile_rows);
         }
         f.row0 = std::max<int32_t>(0, g0 - R); f.row1 = std::min<int32_t>(d->crop_height, g1 + R + 1);
+        // partitioned film: the 16-row film tiles start R rows above the first local row also when that is above the film, so
+        // that every 32-row partition tile (+- R) is covered by three tile rows, not four
+        if (tiled && rows.count > 1) f.row0 = g0 - R;
         if (tiled) HIP_TRY(launch_film_tiles(f, stream));
         else HIP_TRY(launch_film_gather(f, stream));
         if (film_sq) {

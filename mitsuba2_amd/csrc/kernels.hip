@@ -1482,6 +1482,19 @@ __global__ __launch_bounds__(kBlock) void k_film_tiles(const FilmParams F) {
             }
         }
     }
+    // A rank's film partition is a set of interleaved row tiles: the launch spans all of them, and most workgroups in between
+    // see none of this pass's samples -- they leave at once.  Within a tile at the edge of a row tile, the waves whose film rows
+    // no local source row can reach skip the gather (their taps are all zero).
+    bool any_slot = false;
+#pragma unroll
+    for (int k = 0; k < kStage; ++k) any_slot |= slot0[k] >= 0;
+    if (!__syncthreads_or(any_slot)) return;
+    bool reach = false;
+    for (int dy = -R; dy <= R; ++dy) {
+        const int qy = y + dy;
+        reach |= qy >= 0 && qy < F.crop_h && row_to_local(F.rows, qy) >= 0;
+    }
+    const bool wave_gathers = __ballot(reach) != 0ull;
     float4 pv[kStage]; float2 pq[kStage];
     auto prefetch = [&](int s0) {
 #pragma unroll
@@ -1494,13 +1507,22 @@ __global__ __launch_bounds__(kBlock) void k_film_tiles(const FilmParams F) {
         }
     };
     prefetch(0);
+    // records of source pixels outside this pass stay zero for the whole launch
+#pragma unroll
+    for (int k = 0; k < kStage; ++k) {
+        const int e = (int) threadIdx.x + k * kBlock;
+        if (e < kFilmChunk * NS && slot0[k] < 0) {
+            V[e] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            for (int t = 0; t < kFilmTaps; ++t) { WX[kFilmTaps * e + t] = 0.0f; WY[kFilmTaps * e + t] = 0.0f; }
+        }
+    }
     __syncthreads();
     for (int s0 = 0; s0 < F.spp; s0 += kFilmChunk) {
         // ---- stage: one record per (sample plane, source pixel): value + 2R+1 taps per axis
 #pragma unroll
         for (int k = 0; k < kStage; ++k) {
             const int e = (int) threadIdx.x + k * kBlock;
-            if (e >= kFilmChunk * NS) continue;
+            if (e >= kFilmChunk * NS || slot0[k] < 0) continue;
             float4 val = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             float wxs[kFilmTaps], wys[kFilmTaps];
 #pragma unroll
@@ -1518,7 +1540,7 @@ __global__ __launch_bounds__(kBlock) void k_film_tiles(const FilmParams F) {
         __syncthreads();
         // ---- gather: film pixel (x, y) <- samples of the (2R+1)^2 neighbouring pixels, fixed order.  The source
         // pixel at offset (dx, dy) of the tile origin sees this film pixel as its tap (2R - dx, 2R - dy).
-        for (int c = 0; c < kFilmChunk; ++c)
+        for (int c = 0; wave_gathers && c < kFilmChunk; ++c)
             for (int dy = 0; dy <= 2 * R; ++dy)
                 for (int dx = 0; dx <= 2 * R; ++dx) {
                     const int e = c * NS + (ly + dy) * SW + (lx + dx);
@@ -1529,7 +1551,7 @@ __global__ __launch_bounds__(kBlock) void k_film_tiles(const FilmParams F) {
                 }
         __syncthreads();
     }
-    if (x < F.crop_w && y < F.row1) {
+    if (x < F.crop_w && y >= 0 && y < F.row1) {
         float *dst = F.film + 5u * ((size_t) y * (size_t) F.crop_w + (size_t) x);
 #pragma unroll
         for (int k = 0; k < 5; ++k) dst[k] += acc[k];

@@ -279,6 +279,23 @@ def test_render_is_deterministic_and_row_partition_adds_up(gpu, oracle):
     assert torch.allclose(tiles[0] + tiles[1] + tiles[2], films[0], rtol=1e-5, atol=1e-6)
     with pytest.raises(RuntimeError):
         integ.render(scene, gpu.make_sensor(p), partition=(3, 3, 8))
+    # the default 32-row tiles on a taller film: film tiles between a rank's row tiles leave early, the tile grid starts above
+    # the film for rank 0 -- the parts still add up to the unpartitioned film
+    p2 = scenes.cornell_box_sensor(48, 150, 6, seed=3)
+    whole = gpu.make_sensor(p2)
+    assert integ.render(scene, whole)
+    total = None
+    for part in range(2):
+        sensor = gpu.make_sensor(p2)
+        assert integ.render(scene, sensor, partition=(part, 2, 32))
+        f = sensor.film().bitmap(raw=True)
+        own = np.zeros(150, bool)
+        for r0 in range(32 * part, 150, 64):
+            own[r0:r0 + 32] = True
+        far = ~np.convolve(own, np.ones(5, bool), "same").astype(bool)             # rows no local sample can reach (radius 2)
+        assert float(f[torch.from_numpy(far).to(f.device)].abs().max()) == 0.0
+        total = f.clone() if total is None else total + f
+    assert torch.allclose(total, whole.film().bitmap(raw=True), rtol=1e-5, atol=1e-6)
     # a different scheduler geometry does not change the image (each sample owns its RNG stream)
     sensor = gpu.make_sensor(p)
     assert gpu.PathIntegrator(paths_per_wave=64).render(scene, sensor)
