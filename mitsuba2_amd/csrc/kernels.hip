@@ -1441,7 +1441,8 @@ MTS_DEV void axis_taps(const FilterView &f, const float *table, float pos, int s
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_film_tiles(const FilmParams F) {
+// PART: the film is partitioned into interleaved row tiles (rows.count > 1)
+template <bool PART> __device__ __forceinline__ void film_tiles_body(const FilmParams &F) {
     extern __shared__ float4 smem[];
     const FilterView &f = F.filter;
     const int b = f.border, R = (int) ceilf(f.radius), SW = kFilmTile + 2 * R, NS = SW * SW;
@@ -1485,16 +1486,19 @@ __global__ __launch_bounds__(kBlock) void k_film_tiles(const FilmParams F) {
     // A rank's film partition is a set of interleaved row tiles: the launch spans all of them, and most workgroups in between
     // see none of this pass's samples -- they leave at once.  Within a tile at the edge of a row tile, the waves whose film rows
     // no local source row can reach skip the gather (their taps are all zero).
-    bool any_slot = false;
+    bool wave_gathers = true;
+    if constexpr (PART) {
+        bool any_slot = false;
 #pragma unroll
-    for (int k = 0; k < kStage; ++k) any_slot |= slot0[k] >= 0;
-    if (!__syncthreads_or(any_slot)) return;
-    bool reach = false;
-    for (int dy = -R; dy <= R; ++dy) {
-        const int qy = y + dy;
-        reach |= qy >= 0 && qy < F.crop_h && row_to_local(F.rows, qy) >= 0;
+        for (int k = 0; k < kStage; ++k) any_slot |= slot0[k] >= 0;
+        if (!__syncthreads_or(any_slot)) return;
+        bool reach = false;
+        for (int dy = -R; dy <= R; ++dy) {
+            const int qy = y + dy;
+            reach |= qy >= 0 && qy < F.crop_h && row_to_local(F.rows, qy) >= 0;
+        }
+        wave_gathers = __ballot(reach) != 0ull;
     }
-    const bool wave_gathers = __ballot(reach) != 0ull;
     float4 pv[kStage]; float2 pq[kStage];
     auto prefetch = [&](int s0) {
 #pragma unroll
@@ -1509,7 +1513,7 @@ __global__ __launch_bounds__(kBlock) void k_film_tiles(const FilmParams F) {
     prefetch(0);
     // records of source pixels outside this pass stay zero for the whole launch
 #pragma unroll
-    for (int k = 0; k < kStage; ++k) {
+    for (int k = 0; PART && k < kStage; ++k) {
         const int e = (int) threadIdx.x + k * kBlock;
         if (e < kFilmChunk * NS && slot0[k] < 0) {
             V[e] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1522,7 +1526,7 @@ __global__ __launch_bounds__(kBlock) void k_film_tiles(const FilmParams F) {
 #pragma unroll
         for (int k = 0; k < kStage; ++k) {
             const int e = (int) threadIdx.x + k * kBlock;
-            if (e >= kFilmChunk * NS || slot0[k] < 0) continue;
+            if (e >= kFilmChunk * NS || (PART && slot0[k] < 0)) continue;
             float4 val = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             float wxs[kFilmTaps], wys[kFilmTaps];
 #pragma unroll
@@ -1540,7 +1544,7 @@ __global__ __launch_bounds__(kBlock) void k_film_tiles(const FilmParams F) {
         __syncthreads();
         // ---- gather: film pixel (x, y) <- samples of the (2R+1)^2 neighbouring pixels, fixed order.  The source
         // pixel at offset (dx, dy) of the tile origin sees this film pixel as its tap (2R - dx, 2R - dy).
-        for (int c = 0; wave_gathers && c < kFilmChunk; ++c)
+        for (int c = 0; (!PART || wave_gathers) && c < kFilmChunk; ++c)
             for (int dy = 0; dy <= 2 * R; ++dy)
                 for (int dx = 0; dx <= 2 * R; ++dx) {
                     const int e = c * NS + (ly + dy) * SW + (lx + dx);
@@ -1558,6 +1562,9 @@ __global__ __launch_bounds__(kBlock) void k_film_tiles(const FilmParams F) {
     }
 }
 
+__global__ __launch_bounds__(kBlock) void k_film_tiles(const FilmParams F) { film_tiles_body<false>(F); }
+__global__ __launch_bounds__(kBlock) void k_film_tiles_part(const FilmParams F) { film_tiles_body<true>(F); }
+
 bool film_tiles_supported(const FilterView &f) { return f.taps <= 4 && (int) ceilf(f.radius) <= 2; }
 
 hipError_t launch_film_tiles(const FilmParams &p, hipStream_t s) {
@@ -1565,7 +1572,8 @@ hipError_t launch_film_tiles(const FilmParams &p, hipStream_t s) {
     const int R = (int) std::ceil(p.filter.radius), SW = kFilmTile + 2 * R;
     const int tiles_x = (p.crop_w + kFilmTile - 1) / kFilmTile, tiles_y = (p.row1 - p.row0 + kFilmTile - 1) / kFilmTile;
     const size_t lds = (size_t) kFilmChunk * SW * SW * (sizeof(float4) + 2 * kFilmTaps * sizeof(float)) + 32 * sizeof(float);
-    hipLaunchKernelGGL(k_film_tiles, dim3((uint32_t) (tiles_x * tiles_y)), dim3(kBlock), lds, s, p);
+    if (p.rows.count > 1) hipLaunchKernelGGL(k_film_tiles_part, dim3((uint32_t) (tiles_x * tiles_y)), dim3(kBlock), lds, s, p);
+    else hipLaunchKernelGGL(k_film_tiles, dim3((uint32_t) (tiles_x * tiles_y)), dim3(kBlock), lds, s, p);
     return hipGetLastError();
 }
 
