@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MTSAMD_ABI_VERSION 3
+#define MTSAMD_ABI_VERSION 4
 
 typedef enum {
     MTSAMD_OK = 0,
@@ -42,6 +42,11 @@ int mtsamd_abi_version(void);
 const char *mtsamd_last_error(void);
 /* Number of HIP devices visible to this process (<0 on error). */
 int mtsamd_device_count(void);
+/* Plugin ABI of the reference (include/mitsuba/core/class.h:205-211, MTS_EXPORT_PLUGIN): PluginManager dlopen()s a
+ * plugin .so and reads these two symbols (src/libcore/plugin.cpp:19-31).  The library answers for the `path_amd`
+ * integrator shim shown in INTEGRATION.md, so that the shim can be this very shared object. */
+const char *plugin_name(void);
+const char *plugin_descr(void);
 
 /* ---- scene description ----------------------------------------------------
  * Mesh buffers exactly as Mesh exposes them (include/mitsuba/render/mesh.h:80-90,
@@ -229,6 +234,14 @@ typedef struct {
     /* ThinLensCamera (src/sensors/thinlens.cpp:110-118): aperture_radius > 0 selects the thin lens model -- two more sampler
      * dimensions per camera sample (integrator.cpp:229-231) -- focused at focus_distance (sensor.cpp:104); 0: pinhole */
     float aperture_radius, focus_distance;
+    /* SamplingIntegrator properties (integrator.cpp:27-39) */
+    float timeout;             /* seconds; <= 0: none.  Once exceeded no further pass is started and the running one is abandoned
+                                  (should_stop(), integrator.h:143-146); the call still returns MTSAMD_OK: only cancel() makes
+                                  render() return false (integrator.cpp:175) */
+    int32_t samples_per_pass;  /* <= 0: all of sample_count.  sample_count must be a multiple of it (integrator.cpp:59-66); the
+                                  image does not depend on it: the RNG streams are seeded per global sample index */
+    int32_t profile;           /* != 0: every trace / shade launch of the split pipeline is bracketed by HIP timing events on
+                                  the stream it is launched on (stats_host[8..13]) */
 } mtsamd_render_desc;
 
 /* SamplingIntegrator::render for the `path` integrator (src/librender/integrator.cpp:52-176,
@@ -238,9 +251,11 @@ typedef struct {
  * Seeding follows the reference's wavefront branch (one PCG32 stream per sample index,
  * integrator.cpp:144-169, independent.cpp:69-72) with samples_per_pass = sample_count.
  * Synchronous on `stream` (returns when the film is complete).
- * stats_host (may be NULL, 8 entries): [0] closest-hit queries, [1] any-hit queries, [2] camera samples,
- * [3] k_bounce launches, [4] path segments shaded, [5] device time of the k_bounce launches in ns
- * (HIP events on `stream`), [6] device time of the film gather in ns, [7] triangle tests. */
+ * stats_host (may be NULL, 16 entries): [0] closest-hit queries, [1] any-hit queries, [2] camera samples,
+ * [3] scheduler iterations (k_bounce launches), [4] path segments shaded, [5] device time of the bounce loop in ns
+ * (HIP events on `stream`), [6] device time of the film gather in ns, [7] triangle tests; with desc->profile and the
+ * split pipeline: [8] summed duration of the k_trace<closest> launches in ns, [9] their number, [10] / [11] the same for
+ * k_trace<any>, [12] / [13] for k_shade; [14] passes; [15] 1 if the render stopped at its timeout. */
 int mtsamd_render(mtsamd_scene *scene, const mtsamd_render_desc *desc, float *film_xyzaw_dev,
                   uint64_t *stats_host, void *stream);
 /* Integrator::cancel (integrator.h:51): thread-safe, makes a running mtsamd_render return

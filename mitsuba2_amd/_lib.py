@@ -60,7 +60,8 @@ class RenderDesc(C.Structure):
                 ("part_count", C.c_int32), ("part_tile_rows", C.c_int32), ("paths_per_wave", C.c_int32),
                 ("pipeline", C.c_int32), ("film_rgb", C.c_int32), ("integrator", C.c_int32), ("emitter_samples", C.c_int32),
                 ("bsdf_samples", C.c_int32), ("hide_emitters", C.c_int32), ("moment", C.c_int32),
-                ("aperture_radius", C.c_float), ("focus_distance", C.c_float)]
+                ("aperture_radius", C.c_float), ("focus_distance", C.c_float),
+                ("timeout", C.c_float), ("samples_per_pass", C.c_int32), ("profile", C.c_int32)]
 
 
 # every symbol include/mtsamd.h declares: name -> (restype, argtypes)
@@ -68,6 +69,8 @@ SYMBOLS = {
     "mtsamd_abi_version": (C.c_int, []),
     "mtsamd_last_error": (C.c_char_p, []),
     "mtsamd_device_count": (C.c_int, []),
+    "plugin_name": (C.c_char_p, []),
+    "plugin_descr": (C.c_char_p, []),
     "mtsamd_scene_create": (C.c_int, [C.POINTER(SceneDesc), C.c_int, C.POINTER(vp)]),
     "mtsamd_scene_destroy": (None, [vp]),
     "mtsamd_scene_bbox": (C.c_int, [vp, f32p]),
@@ -110,7 +113,7 @@ def lib():
             fn = getattr(handle, name)      # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if handle.mtsamd_abi_version() != 3:
+        if handle.mtsamd_abi_version() != 4:
             raise RuntimeError("libmtsamd.so ABI version mismatch")
         _lib = handle
     return _lib

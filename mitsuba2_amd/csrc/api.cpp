@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -191,6 +192,7 @@ struct Workspace {
     hipStream_t part_stream[3] = {}; hipEvent_t part_ev[3] = {};      // flat scenes: further parts of the scheduling waves
     hipEvent_t tev[3] = {};              // timing: bounce loop begin / end, film end
     bool have_events = false;
+    std::vector<hipEvent_t> prof_ev;     // desc->profile: begin / end events of the split pipeline's launches, reused pass after pass
 
     void release() {
         for (int k = 0; k < 2; ++k) {
@@ -215,6 +217,8 @@ struct Workspace {
         for (auto &pe : part_ev) { if (pe) (void) hipEventDestroy(pe); pe = nullptr; }
         if (have_events) for (auto &e : ev) (void) hipEventDestroy(e);
         have_events = false;
+        for (auto &e : prof_ev) (void) hipEventDestroy(e);
+        prof_ev.clear();
         n_waves = seg_cap = 0; pass_cap = 0;
     }
 };
@@ -324,6 +328,9 @@ struct mtsamd_scene {
 extern "C" {
 
 int mtsamd_abi_version(void) { return MTSAMD_ABI_VERSION; }
+// MTS_EXPORT_PLUGIN (include/mitsuba/core/class.h:205-211): what PluginManager reads after dlopen (src/libcore/plugin.cpp:19-31)
+const char *plugin_name(void) { return "path_amd"; }
+const char *plugin_descr(void) { return "Wavefront path tracer for AMD MI355X (gfx950)"; }
 const char *mtsamd_last_error(void) { return g_last_error.c_str(); }
 
 int mtsamd_device_count(void) {
@@ -926,6 +933,9 @@ static int check_desc(const mtsamd_render_desc *d) {
         d->crop_x + d->crop_width > d->film_width || d->crop_y + d->crop_height > d->film_height)
         return fail(MTSAMD_ERR_INVALID, "Invalid crop window specification!");      // film.cpp:24-32
     if (d->sample_count <= 0) return fail(MTSAMD_ERR_INVALID, "sample_count must be positive");
+    if (d->samples_per_pass > 0 && d->sample_count % std::min(d->samples_per_pass, d->sample_count) != 0)      // integrator.cpp:59-66
+        return fail(MTSAMD_ERR_INVALID, "sample_count (%d) must be a multiple of samples_per_pass (%d).", d->sample_count,
+                    std::min(d->samples_per_pass, d->sample_count));
     if (d->integrator < 0 || d->integrator > 2) return fail(MTSAMD_ERR_UNSUPPORTED, "integrator %d is not implemented (0 path, 1 direct, 2 depth)", d->integrator);
     if (d->emitter_samples < 0 || d->bsdf_samples < 0) return fail(MTSAMD_ERR_INVALID, "Must have at least 1 BSDF or emitter sample!");
     if (d->pipeline < 0 || d->pipeline > 4) return fail(MTSAMD_ERR_UNSUPPORTED, "pipeline %d is not available in this build", d->pipeline);
@@ -988,6 +998,13 @@ struct Job {
     int store_xyz = 1;
     uint32_t plane_pix0 = 0, plane_pixels = 0;
     bool split = false, shadow_queue = false, shadow_ring = false;
+    double stage_ms[3] = { 0.0, 0.0, 0.0 }; uint64_t stage_launches[3] = { 0, 0, 0 };      // desc->profile: k_trace<closest>, k_shade, k_trace<any>
+    uint64_t passes = 0;
+    std::chrono::steady_clock::time_point t_start;       // m_render_timer (integrator.cpp:107)
+    bool timed_out = false;
+    bool expired() const {                               // should_stop() without m_stop (integrator.h:143-146)
+        return d->timeout > 0.0f && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > (double) d->timeout;
+    }
 };
 
 // Traces the local sample ordinals [first, first+n) of this render's rows to completion; results land in
@@ -1068,6 +1085,28 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
         HIP_TRY(hipEventRecord(w.part_ev[2], j.stream));
         HIP_TRY(hipStreamWaitEvent(w.part_stream[0], w.part_ev[2], 0));
     }
+    // desc->profile: begin / end timing events around the launches of the split pipeline, each on the stream of its launch
+    const bool prof = j.d->profile != 0 && p.split == 1;
+    struct ProfRec { int stage; size_t e0; };
+    std::vector<ProfRec> prof_recs;
+    size_t prof_used = 0;
+    hipError_t prof_err = hipSuccess;
+    auto prof_mark = [&](hipStream_t st) -> size_t {
+        if (prof_used == w.prof_ev.size()) {
+            hipEvent_t e = nullptr;
+            const hipError_t rc = hipEventCreate(&e);
+            if (rc != hipSuccess) { prof_err = rc; return 0; }
+            w.prof_ev.push_back(e);
+        }
+        const hipError_t rc = hipEventRecord(w.prof_ev[prof_used], st);
+        if (rc != hipSuccess) prof_err = rc;
+        return prof_used++;
+    };
+    auto sync_all = [&]() {
+        (void) hipStreamSynchronize(j.stream);
+        if (w.stream2) (void) hipStreamSynchronize(w.stream2);
+        for (auto &ps : w.part_stream) if (ps) (void) hipStreamSynchronize(ps);
+    };
     auto join_parts = [&]() -> int {         // j.stream waits for the other parts' streams
         for (uint32_t k = 1; k < n_parts; ++k) {
             HIP_TRY(hipEventRecord(w.part_ev[k - 1], w.part_stream[k - 1]));
@@ -1081,10 +1120,13 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     }
     while (true) {
         if (j.s->cancel.load(std::memory_order_relaxed)) {
-            (void) hipStreamSynchronize(j.stream);
-            if (w.stream2) (void) hipStreamSynchronize(w.stream2);
-            for (auto &ps : w.part_stream) if (ps) (void) hipStreamSynchronize(ps);
+            sync_all();
             return fail(MTSAMD_ERR_CANCELLED, "render cancelled");
+        }
+        if (j.expired()) {                   // timeout: this pass is abandoned (a block that was not finished is never put)
+            sync_all();
+            j.timed_out = true;
+            return 1;
         }
         p.in = w.pool[cur]; p.out = w.pool[cur ^ 1];
         p.count_in = w.count[cur]; p.count_out = w.count[cur ^ 1];
@@ -1097,13 +1139,21 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
                 h.wave_first = split_lo[k]; h.wave_last = split_lo[k + 1];
                 hipStream_t s_main = k == 0 ? j.stream : w.part_stream[0], s_any = k == 0 ? w.stream2 : w.part_stream[1];
                 hipEvent_t e_shade = k == 0 ? w.ev[2] : w.part_ev[0], e_any = k == 0 ? w.ev[3] : w.part_ev[1];
+                size_t pe = 0;
+                if (prof) pe = prof_mark(s_main);
                 HIP_TRY(launch_split_stage(h, 0, s_main));
+                if (prof) { prof_mark(s_main); prof_recs.push_back({ 0, pe }); }
                 if (it > 0) HIP_TRY(hipStreamWaitEvent(s_main, e_any, 0));
+                if (prof) pe = prof_mark(s_main);
                 HIP_TRY(launch_split_stage(h, 1, s_main));
+                if (prof) { prof_mark(s_main); prof_recs.push_back({ 1, pe }); }
                 HIP_TRY(hipEventRecord(e_shade, s_main));
                 HIP_TRY(hipStreamWaitEvent(s_any, e_shade, 0));
+                if (prof) pe = prof_mark(s_any);
                 HIP_TRY(launch_split_stage(h, 2, s_any));
+                if (prof) { prof_mark(s_any); prof_recs.push_back({ 2, pe }); }
                 HIP_TRY(hipEventRecord(e_any, s_any));
+                HIP_TRY(prof_err);
             }
         } else if (p.split == 3 && n_parts > 1) {
             // the scheduling waves are independent of each other: part-size launches on their own streams advance in their own
@@ -1151,6 +1201,11 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     HIP_TRY(hipEventElapsedTime(&ms, w.tev[0], w.tev[1]));
     j.bounce_ms += ms;
     j.iterations += it;
+    for (const ProfRec &r : prof_recs) {        // every stream has been joined into j.stream: all events are complete
+        float sm = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&sm, w.prof_ev[r.e0], w.prof_ev[r.e0 + 1]));
+        j.stage_ms[r.stage] += sm; j.stage_launches[r.stage] += 1;
+    }
     return 0;
 }
 
@@ -1189,9 +1244,9 @@ int setup_job(Job &j, mtsamd_scene *s, const mtsamd_render_desc *d, hipStream_t 
     j.pass_cap = std::max<uint64_t>(std::min<uint64_t>(max_pass, pass_limit), 1);
     // segments hold a multiple of 64 slots: k_shade deals whole 64-path chunks of a workgroup's list to its waves
     if (int rc = ensure_workspace(s, j.n_waves, (j.target + 63u) & ~63u, j.pass_cap, j.split || j.shadow_queue)) return rc;
-    j.pass_cap = s->ws.pass_cap;
     HIP_TRY(hipMemsetAsync(s->ws.wave_stats, 0, 4 * (size_t) j.n_waves * sizeof(uint64_t), stream));
     s->cancel.store(0);
+    j.t_start = std::chrono::steady_clock::now();
     return 0;
 }
 
@@ -1204,6 +1259,10 @@ int collect_stats(Job &j, uint64_t samples, uint64_t *stats_host) {
     for (uint32_t k = 0; k < j.n_waves; ++k) for (int q = 0; q < 4; ++q) tot[q] += ws[4 * (size_t) k + q];
     stats_host[0] = tot[0]; stats_host[1] = tot[1]; stats_host[2] = samples; stats_host[3] = j.iterations; stats_host[4] = tot[2];
     stats_host[5] = (uint64_t) (j.bounce_ms * 1e6); stats_host[6] = (uint64_t) (j.film_ms * 1e6); stats_host[7] = tot[3];
+    stats_host[8] = (uint64_t) (j.stage_ms[0] * 1e6); stats_host[9] = j.stage_launches[0];
+    stats_host[10] = (uint64_t) (j.stage_ms[2] * 1e6); stats_host[11] = j.stage_launches[2];
+    stats_host[12] = (uint64_t) (j.stage_ms[1] * 1e6); stats_host[13] = j.stage_launches[1];
+    stats_host[14] = j.passes; stats_host[15] = j.timed_out ? 1u : 0u;
     return 0;
 }
 } // namespace
@@ -1266,7 +1325,12 @@ int mtsamd_render(mtsamd_scene *s, const mtsamd_render_desc *d, float *film, uin
         // (k_bounce's scattered 16-B result writes cost more than the film tiles' strided reads gain)
         constexpr bool kPlaneLayout = false;
         j.plane_pixels = (tiled && kPlaneLayout) ? (uint32_t) (nrows * (uint64_t) d->crop_width) : 0u;
-        if (int rc = trace_pass(j, a, n)) return rc;
+        if (j.expired()) { j.timed_out = true; break; }
+        if (int rc = trace_pass(j, a, n)) {
+            if (rc > 0) break;               // timeout inside the pass: its samples are dropped
+            return rc;
+        }
+        j.passes += 1;
         // Film::put: splat this pass into the film rows its samples can reach
         FilmParams f{};
         f.out_rgba = s->ws.out_rgba; f.out_pos = s->ws.out_pos; f.film = film_target; f.filter = j.filter;
@@ -1382,7 +1446,7 @@ int mtsamd_sample_radiance(mtsamd_scene *s, const mtsamd_render_desc *d, uint64_
     j.store_xyz = 0;
     for (uint64_t a = 0; a < count; a += j.pass_cap) {
         uint64_t n = std::min<uint64_t>(j.pass_cap, count - a);
-        if (int rc = trace_pass(j, first + a, n)) return rc;
+        if (int rc = trace_pass(j, first + a, n)) return rc > 0 ? fail(MTSAMD_ERR_INVALID, "timeout reached before every requested sample was traced") : rc;
         HIP_TRY(hipMemcpyAsync(rgba + 4 * a, s->ws.out_rgba, n * sizeof(float4), hipMemcpyDeviceToDevice, stream));
         if (pos) HIP_TRY(hipMemcpyAsync(pos + 2 * a, s->ws.out_pos, n * sizeof(float2), hipMemcpyDeviceToDevice, stream));
     }

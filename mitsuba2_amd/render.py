@@ -651,7 +651,7 @@ class Scene:
 class PathIntegrator:
     """src/integrators/path.cpp + MonteCarloIntegrator (src/librender/integrator.cpp:283-296)."""
 
-    def __init__(self, max_depth=-1, rr_depth=5, paths_per_wave=0, pipeline=0):
+    def __init__(self, max_depth=-1, rr_depth=5, paths_per_wave=0, pipeline=0, samples_per_pass=-1, timeout=-1.0, profile=False):
         if max_depth < 0 and max_depth != -1:
             raise RuntimeError("\"max_depth\" must be set to -1 (infinite) or a value >= 0")
         if rr_depth <= 0:
@@ -659,6 +659,9 @@ class PathIntegrator:
         self.max_depth, self.rr_depth = int(max_depth), int(rr_depth)
         self.paths_per_wave = int(paths_per_wave)
         self.pipeline = int(pipeline)          # 0 automatic, 1 fused kernel, 2 split trace/shade kernels (same samples)
+        # SamplingIntegrator properties (integrator.cpp:27-39): samples_per_pass (-1: all), timeout in seconds (-1: none)
+        self.samples_per_pass, self.timeout = int(samples_per_pass), float(timeout)
+        self.profile = bool(profile)           # per-launch HIP event timing of the split pipeline (stats: trace_*_ns)
         self._scene = None
         self.stats = None
 
@@ -671,6 +674,7 @@ class PathIntegrator:
             d.part_index, d.part_count, d.part_tile_rows = (int(x) for x in partition)
         d.paths_per_wave = self.paths_per_wave
         d.pipeline = self.pipeline
+        d.samples_per_pass, d.timeout, d.profile = self.samples_per_pass, self.timeout, int(self.profile)
         self._fill_integrator(d)
         return d
 
@@ -693,15 +697,16 @@ class PathIntegrator:
         film = sensor.film()
         film.prepare(self.aov_channels(), device="cuda:%d" % scene._device_index)
         d = self._desc(sensor, rows, partition)
-        stats = (C.c_uint64 * 8)()
+        stats = (C.c_uint64 * 16)()
         self._scene = scene
         rc = L.lib().mtsamd_render(scene._handle, C.byref(d), _ptr(film._storage.data()), stats, _stream())
         self._scene = None
         if rc == -4:                     # MTSAMD_ERR_CANCELLED: render() returns false (integrator.cpp:175)
             return False
         L.check(rc)
-        self.stats = dict(zip(("closest_hit_rays", "any_hit_rays", "samples", "iterations", "segments", "bounce_ns", "film_ns", "tri_tests"),
-                              [int(x) for x in stats]))
+        self.stats = dict(zip(("closest_hit_rays", "any_hit_rays", "samples", "iterations", "segments", "bounce_ns", "film_ns", "tri_tests",
+                               "trace_closest_ns", "trace_closest_launches", "trace_any_ns", "trace_any_launches", "shade_ns", "shade_launches",
+                               "passes", "timed_out"), [int(x) for x in stats]))
         return True
 
     def cancel(self):

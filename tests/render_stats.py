@@ -1,4 +1,4 @@
-"""Statistical regression protocol of the reference (src/librender/tests/test_renders.py:60-134): per-pixel Z-test of a render
+"""Test helper (not product code): statistical regression protocol of the reference (src/librender/tests/test_renders.py:60-134): per-pixel Z-test of a render
 against a reference mean / variance image, with the Sidak correction for the number of pixels tested."""
 import math
 

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "mtsamd.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(mtsamd_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b((?:mtsamd|plugin)_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_symbols_are_exported():
@@ -26,7 +26,20 @@ def test_header_symbols_are_exported():
     handle = C.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(handle, name), "libmtsamd.so does not export %s" % name
-    assert _lib.lib().mtsamd_abi_version() == 3
+    assert _lib.lib().mtsamd_abi_version() == 4
+    # the two symbols PluginManager reads from a plugin .so (class.h:205-211, plugin.cpp:19-31)
+    assert _lib.lib().plugin_name() == b"path_amd" and len(_lib.lib().plugin_descr()) > 0
+
+
+def test_integrator_properties_follow_the_reference():
+    # SamplingIntegrator (integrator.cpp:27-39): samples_per_pass default (size_t) -1, timeout default -1
+    from mitsuba2_amd import render
+    integ = render.PathIntegrator()
+    assert integ.samples_per_pass == -1 and integ.timeout == -1.0
+    sensor = render.make_sensor(dict(width=8, height=8, crop=(0, 0, 8, 8), rfilter="gaussian", rfilter_param=None, sample_count=12, seed=0,
+                                     to_world=np.eye(4, dtype=np.float32), fov=40.0, near_clip=0.1, far_clip=100.0))
+    d = render.PathIntegrator(samples_per_pass=4, timeout=2.5)._desc(sensor)
+    assert d.samples_per_pass == 4 and d.timeout == 2.5 and d.profile == 0 and d.sample_count == 12
 
 
 def test_every_entry_point_cites_the_reference():

@@ -81,3 +81,31 @@ def test_owned_rows_edge_cases():
         assert allr == list(range(h))
     # balance on the headline config: 1024 rows over 8 ranks in 32-row tiles -> 128 rows each
     assert {len(mdist.owned_rows(1024, k, 8)) for k in range(8)} == {128}
+
+
+def _bench(*argv, env=None):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(argv), env=e, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` (the driver's form) must start N ranks itself or refuse -- never report one rank as N GPUs.
+    The launcher and the rank-side collectives (max / sum / gather over gloo) run here without a GPU."""
+    import json
+    r = _bench("--gpus", "2", "--backend", "gloo", "--config", "launcher-selftest")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks"] == [0.0, 1.0] and line["sum"] == 3.0 and line["max"] == 1.0
+    if torch.cuda.device_count() < 2:
+        # fewer GPUs than ranks on the real backend: refused with a non-zero exit code, nothing printed on stdout
+        r = _bench("--gpus", "2")
+        assert r.returncode != 0 and "refusing" in r.stderr and r.stdout.strip() == ""
+    # a torchrun environment whose world size disagrees with --gpus is refused too
+    r = _bench("--gpus", "2", "--backend", "gloo", "--config", "launcher-selftest", env={"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in r.stderr

@@ -67,7 +67,8 @@ def test_depth_matches_ray_intersect():
 def test_moment_integrator_and_z_test():
     """src/integrators/moment.cpp:56-99 + the protocol of test_renders.py:60-134: the GPU render (wavefront seeding) must
     be statistically indistinguishable from the oracle's scalar_rgb block-mode samples, pixel by pixel."""
-    from mitsuba2_amd import render as R, scenes, testing
+    from mitsuba2_amd import render as R, scenes
+    import render_stats as testing
     cb = scenes.cornell_box()
     sp = dict(scenes.cornell_box_sensor(32, 32, spp=256, seed=3), rfilter="box", rfilter_param=0.5)
     scene, sensor = R.Scene(cb), R.make_sensor(sp)

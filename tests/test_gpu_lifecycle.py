@@ -1,0 +1,166 @@
+"""Life cycle of a render call on the GPU: several passes (the path every film above 2^28 samples takes), cancel() from another
+thread, the `timeout` and `samples_per_pass` properties of SamplingIntegrator (src/librender/integrator.cpp:27-66,122,175;
+include/mitsuba/render/integrator.h:44-51,143-146) and the per-rank shape of BASELINE config 5 (4096 x 4096 film cut into
+interleaved 32-row tiles over 8 ranks)."""
+import os
+import threading
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from mitsuba2_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+class _env:
+    """scoped environment switch read by the library at the start of a render (experiment switches of api.cpp)"""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            os.environ[k] = str(v)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _film(gpu, integ, scene, p, **kw):
+    sensor = gpu.make_sensor(p)
+    assert integ.render(scene, sensor, **kw)
+    return sensor.film().bitmap(raw=True).clone(), dict(integ.stats)
+
+
+@pytest.mark.parametrize("what", ["path", "path_mesh_spectral", "direct", "moment", "partition"])
+def test_multi_pass_film_equals_one_pass_film(gpu, what):
+    """A render above the pass capacity is cut into passes of whole film rows (api.cpp, mtsamd_render); each pass re-seeds the
+    per-wave cursors and splats filter aprons that overlap its neighbours'.  MTSAMD_PASS_LOG2 forces the cut on a small film:
+    same samples, same per-pixel accumulation order inside a pass, only the order of the row-border additions differs."""
+    variant = "rgb"
+    if what == "path_mesh_spectral":
+        sd, p, variant = scenes.bumpy_sphere(48, 96), scenes.bumpy_sphere_sensor(96, 64, 8), "spectral"
+    else:
+        sd, p = scenes.cornell_box(), scenes.cornell_box_sensor(96, 64, 16, seed=4)
+    scene = gpu.Scene(sd, variant=variant)
+    integ = {"direct": gpu.DirectIntegrator(), "moment": gpu.MomentIntegrator(gpu.PathIntegrator())}.get(what, gpu.PathIntegrator())
+    kw = dict(partition=(1, 3, 8)) if what == "partition" else {}
+    one, st1 = _film(gpu, integ, scene, p, **kw)
+    assert st1["passes"] == 1
+    with _env(MTSAMD_PASS_LOG2=13):              # 8192 samples per pass: 5 film rows of 96 px x 16 spp
+        many, stn = _film(gpu, integ, scene, p, **kw)
+    assert stn["passes"] >= 4 and stn["samples"] == st1["samples"]
+    assert stn["closest_hit_rays"] == st1["closest_hit_rays"] and stn["any_hit_rays"] == st1["any_hit_rays"]
+    assert torch.allclose(many, one, rtol=2e-5, atol=2e-5)
+    assert float((many - one).abs().max()) < 1e-3 * float(one.abs().max())
+
+
+def test_samples_per_pass_semantics(gpu):
+    # integrator.cpp:59-66: sample_count must be a multiple of samples_per_pass; values above sample_count mean one pass
+    sd, p = scenes.cornell_box(), scenes.cornell_box_sensor(32, 32, 12)
+    scene = gpu.Scene(sd)
+    ref, _ = _film(gpu, gpu.PathIntegrator(), scene, p)
+    with pytest.raises(RuntimeError, match=r"sample_count \(12\) must be a multiple of samples_per_pass \(5\)"):
+        gpu.PathIntegrator(samples_per_pass=5).render(scene, gpu.make_sensor(p))
+    for spp_pass in (4, 12, 64):
+        got, _ = _film(gpu, gpu.PathIntegrator(samples_per_pass=spp_pass), scene, p)
+        assert torch.equal(got, ref)             # the RNG streams are seeded per global sample index: the image cannot change
+
+
+def test_cancel_from_another_thread(gpu):
+    """Integrator::cancel may be called asynchronously (integrator.h:44-51); render() then returns false (integrator.cpp:175)
+    and the handle stays usable: the next render is bit-identical to one on a fresh scene."""
+    sd = scenes.cornell_box()
+    scene = gpu.Scene(sd)
+    big = scenes.cornell_box_sensor(1024, 1024, 1024)        # ~0.4 s of GPU work in 4 passes
+    small = scenes.cornell_box_sensor(64, 64, 8, seed=3)
+    integ = gpu.PathIntegrator()
+    fresh, _ = _film(gpu, gpu.PathIntegrator(), gpu.Scene(sd), small)
+    result = {}
+
+    def worker():
+        sensor = gpu.make_sensor(big)
+        t0 = time.perf_counter()
+        result["ok"] = integ.render(scene, sensor)
+        result["dt"] = time.perf_counter() - t0
+
+    _film(gpu, integ, scene, scenes.cornell_box_sensor(1024, 1024, 256))      # same scheduler geometry: the workspace exists
+    th = threading.Thread(target=worker)
+    th.start()
+    deadline = time.perf_counter() + 20.0
+    while integ._scene is None and time.perf_counter() < deadline:      # wait until render() is inside the library
+        time.sleep(0.001)
+    time.sleep(0.05)
+    while th.is_alive():                         # render() clears the flag when it starts (m_stop = false, integrator.cpp:54)
+        integ.cancel()
+        time.sleep(0.002)
+    th.join(60.0)
+    assert not th.is_alive()
+    assert result["ok"] is False, result
+    again, st = _film(gpu, integ, scene, small)
+    assert torch.equal(again, fresh)
+    assert st["samples"] == 64 * 64 * 8
+    # cancel() without a render in flight is a no-op
+    integ.cancel()
+    again2, _ = _film(gpu, integ, scene, small)
+    assert torch.equal(again2, fresh)
+
+
+def test_timeout_stops_between_passes(gpu):
+    """`timeout` (integrator.cpp:38, should_stop integrator.h:143-146): work stops being scheduled once the timer runs out;
+    render() still returns true (only cancel() sets m_stop) and the film holds what was put before."""
+    sd = scenes.cornell_box()
+    scene = gpu.Scene(sd)
+    p = scenes.cornell_box_sensor(512, 512, 256)
+    with _env(MTSAMD_PASS_LOG2=22):              # 16 passes of 32 rows
+        full, st_full = _film(gpu, gpu.PathIntegrator(), scene, p)
+        t0 = time.perf_counter()
+        full, st_full = _film(gpu, gpu.PathIntegrator(), scene, p)
+        dt = time.perf_counter() - t0
+        assert st_full["passes"] == 16 and st_full["timed_out"] == 0
+        integ = gpu.PathIntegrator(timeout=dt / 3.0)
+        part, st = _film(gpu, integ, scene, p)
+    assert st["timed_out"] == 1 and st["passes"] < 16, (st, dt)
+    done_rows = 32 * st["passes"]
+    w = part[..., 4].cpu().numpy()
+    assert (w[done_rows + 2:] == 0).all()                    # nothing was put for the rows of the abandoned passes
+    if done_rows > 4:
+        assert torch.equal(part[:done_rows - 2], full[:done_rows - 2])
+    # a generous timeout changes nothing
+    ok, st_ok = _film(gpu, gpu.PathIntegrator(timeout=600.0), scene, p)
+    assert st_ok["timed_out"] == 0
+
+
+def test_config5_per_rank_shape_adds_up(gpu):
+    """BASELINE config 5 on one GPU: 4096 x 4096 film, every one of the 8 ranks' partitions (interleaved 32-row tiles), at
+    least two passes per rank, reduced sample count.  The eight partial films add up to the unpartitioned film."""
+    sd = scenes.cornell_box()
+    scene = gpu.Scene(sd)
+    p = scenes.cornell_box_sensor(4096, 4096, 2, seed=1)
+    integ = gpu.PathIntegrator()
+    with _env(MTSAMD_PASS_LOG2=23):              # one film row = 2^13 samples: 4 passes of 1024 rows for the whole film
+        whole, st = _film(gpu, integ, scene, p)
+        assert st["passes"] == 4 and st["samples"] == 4096 * 4096 * 2
+    total = torch.zeros_like(whole)
+    with _env(MTSAMD_PASS_LOG2=21):              # a rank owns 512 rows = 2^22 samples: 2 passes of 256 rows (8 tiles)
+        for r in range(8):
+            part, st_r = _film(gpu, integ, scene, p, partition=(r, 8, 32))
+            assert st_r["samples"] == 4096 * 4096 * 2 // 8 and st_r["passes"] == 2
+            rows = torch.zeros(4096, dtype=torch.bool)
+            for t in range(r, 128, 8):
+                rows[32 * t: 32 * t + 32] = True
+            # a rank's splats stay within its tiles plus the 2-pixel filter apron
+            far = torch.ones(4096, dtype=torch.bool)
+            for t in range(r, 128, 8):
+                far[max(0, 32 * t - 2): 32 * t + 34] = False
+            assert float(part[far.cuda()].abs().max()) == 0.0
+            total += part
+    assert torch.allclose(total, whole, rtol=2e-5, atol=1e-4)

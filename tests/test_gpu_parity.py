@@ -74,21 +74,23 @@ def test_ray_queries_bit_exact(gpu, oracle, name):
         o[:, :2] = np.random.RandomState(3).rand(n, 2) * 1.2 - 0.1
         maxt[:] = np.inf
     ray = _gpu_ray(gpu, o, d, mint, maxt)
-    naive = sd["meshes"][0]["faces"].shape[0] < 2000 and name != "sphere_large"
-    t_o, prim_o, shape_o, u_o, v_o = S.ray_intersect(o, d, mint, maxt, naive=naive)
-    hit_o = S.ray_test(o, d, mint, maxt, naive=naive)
+    # the oracle's brute force (ray_intersect_naive, kdtree.h:2303-2328) is the reference for every scene: 36 k triangles x 60 k rays
+    # take it a few seconds
+    naive = True
+    t_o, prim_o, shape_o, u_o, v_o = S.ray_intersect(o, d, mint, maxt, naive=True)
+    hit_o = S.ray_test(o, d, mint, maxt, naive=True)
     res = scene.ray_intersect(ray, full=False)
     t_g, prim_g = res.t.cpu().numpy(), res.prim_index.cpu().numpy().astype(np.uint32)
     assert np.isfinite(t_o).sum() > n // 20
     mism = (t_g != t_o) | (prim_g != prim_o)
-    # bit-exact; a handful of grazing rays may be classified differently by the conservative box tests
-    assert mism.sum() <= max(2, n // 100000), "mismatches: %d of %d" % (mism.sum(), n)
-    ok = ~mism
-    assert (res.prim_uv.cpu().numpy()[ok] == np.stack([u_o, v_o], 1)[ok]).all()
-    assert (res.shape_index.cpu().numpy().astype(np.uint32)[ok] == shape_o[ok]).all()
+    # bit-exact, every ray: the padded boxes of the hierarchy only cull, they never reject a triangle Moeller-Trumbore accepts
+    assert mism.sum() == 0, "mismatches: %d of %d: %s" % (mism.sum(), n, [(int(i), o[i].tolist(), d[i].tolist(), float(mint[i]), float(maxt[i]), float(t_g[i]), int(prim_g[i]), float(t_o[i]), int(prim_o[i])) for i in np.nonzero(mism)[0][:8]])
+    assert (res.prim_uv.cpu().numpy() == np.stack([u_o, v_o], 1)).all()
+    assert (res.shape_index.cpu().numpy().astype(np.uint32) == shape_o).all()
     hit_g = scene.ray_test(ray).cpu().numpy()
-    assert (hit_g != hit_o).sum() <= max(2, n // 100000)
-    assert (hit_g[ok] == np.isfinite(t_o)[ok]).all()
+    bad = np.nonzero(hit_g != hit_o)[0]
+    assert bad.size == 0, "ray_test mismatches: %s" % [(int(i), o[i].tolist(), d[i].tolist(), float(mint[i]), float(maxt[i]), bool(hit_g[i]), bool(hit_o[i])) for i in bad[:8]]
+    assert (hit_g == np.isfinite(t_o)).all()
     if naive:
         rn = scene.ray_intersect_naive(ray)
         assert (rn.t.cpu().numpy() == t_o).all() and (rn.prim_index.cpu().numpy().astype(np.uint32) == prim_o).all()
@@ -235,16 +237,60 @@ def test_film_with_other_reconstruction_filters(gpu, oracle, rfilter):
 
 
 def test_film_statistically_matches_scalar_block_mode(gpu, oracle):
-    # scalar_rgb seeding (one PCG32 stream per spiral block) cannot be reproduced sample by sample on a
-    # parallel machine; the estimates must agree statistically (z-test style, test_renders.py:60-78)
+    """scalar_rgb seeding (one PCG32 stream per spiral block, integrator.cpp:129) cannot be reproduced sample by sample on a
+    parallel machine, so against that mode the estimates must agree statistically.  Checks, at north_star's 256 spp:
+      1. the bar itself: relMSE < 1e-3 between the GPU image and the scalar block-mode image, default gaussian filter;
+      2. the reference's own protocol (src/librender/tests/test_renders.py:60-134): per-pixel z-test of the 256-spp GPU image
+         against a 4096-spp scalar block-mode reference with the `moment` integrator's variance image, Sidak-corrected, >= 99.75 %
+         of the pixels must pass;
+      3. with a box filter (every pixel estimate is the plain mean of its own 256 samples) the relMSE between the two 256-spp
+         estimates must BE the noise floor of two independent estimates, 2 var / N: measured / predicted within [0.85, 1.15]
+         -- a bias of a few percent anywhere in the image pushes it out;
+      4. at 4096 spp the two estimates agree to relMSE < 1e-4 and 0.3 % in the mean."""
+    import render_stats as testing
     sd = scenes.cornell_box()
-    p = scenes.cornell_box_sensor(48, 48, 128)
-    scene, sensor = gpu.Scene(sd), gpu.make_sensor(p)
-    assert gpu.PathIntegrator().render(scene, sensor)
-    got = sensor.film().bitmap().cpu().numpy()[..., :3]
-    ref = oracle.film_develop(oracle.OracleScene(sd).render(oracle.make_desc(p), mode=0)[0])[..., :3]
-    assert abs(got.mean() - ref.mean()) / ref.mean() < 0.02
-    assert _relmse(got, ref) < 0.05
+    S = oracle.OracleScene(sd)
+    scene = gpu.Scene(sd)
+
+    def sensor_params(spp, rfilter):
+        return scenes.cornell_box_sensor(64, 64, spp, rfilter=rfilter) if rfilter != "gaussian" else scenes.cornell_box_sensor(64, 64, spp)
+
+    def gpu_xyz(spp, rfilter, moment=False):
+        sensor = gpu.make_sensor(sensor_params(spp, rfilter))
+        integ = gpu.MomentIntegrator(gpu.PathIntegrator()) if moment else gpu.PathIntegrator()
+        assert integ.render(scene, sensor)
+        if moment:
+            mean, var = gpu.MomentIntegrator.mean_and_variance(sensor.film())
+            return mean.cpu().numpy(), var.cpu().numpy()
+        raw = sensor.film().bitmap(raw=True).cpu().numpy()
+        return raw[..., :3] / raw[..., 4:5]
+
+    def block_xyz(spp, rfilter):
+        raw = S.render(oracle.make_desc(sensor_params(spp, rfilter)), mode=0)[0]
+        return raw[..., :3] / raw[..., 4:5]
+
+    # 1. north_star's bar at 256 spp, default filter
+    got, ref = gpu_xyz(256, "gaussian"), block_xyz(256, "gaussian")
+    bar = _relmse(got, ref)
+    # 2. z-test against a converged scalar block-mode reference
+    ref4096 = block_xyz(4096, "gaussian")
+    _, var_g = gpu_xyz(4096, "gaussian", moment=True)
+    ok, p_min, alpha = testing.accept(got, 256, ref4096, var_g)
+    assert ok, (p_min, alpha)
+    # 3. box filter: measured relMSE against the predicted noise floor
+    got_b, ref_b, ref_b4096 = gpu_xyz(256, "box"), block_xyz(256, "box"), block_xyz(4096, "box")
+    _, var_b = gpu_xyz(4096, "box", moment=True)          # per-sample variance of every pixel
+    floor = float(np.mean(2.0 * var_b / 256.0 / (ref_b4096 ** 2 + 1e-2)))
+    measured = _relmse(got_b, ref_b)
+    # 4. converged estimates
+    got4096 = gpu_xyz(4096, "gaussian")
+    conv = _relmse(got4096, ref4096)
+    print("relMSE vs scalar block mode, cbox 64x64: 256 spp gaussian %.3e (bar 1e-3); 256 spp box %.3e, predicted noise floor %.3e; 4096 spp gaussian %.3e"
+          % (bar, measured, floor, conv))
+    assert bar < 1e-3, bar
+    assert 0.85 < measured / floor < 1.15, (measured, floor)
+    assert conv < 1e-4, conv
+    assert abs(got4096.mean() - ref4096.mean()) / ref4096.mean() < 3e-3
 
 
 def test_render_is_deterministic_and_row_partition_adds_up(gpu, oracle):
