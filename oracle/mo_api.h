@@ -105,6 +105,11 @@ void mo_ray_intersect(const mo_scene *s, uint64_t n, const float *ox, const floa
 void mo_ray_test(const mo_scene *s, uint64_t n, const float *ox, const float *oy,
                  const float *oz, const float *dx, const float *dy, const float *dz,
                  const float *mint, const float *maxt, int naive, uint8_t *hit);
+/* The same two queries answered 8 rays at a time by the packet traversal of the packet_rgb-equivalent baseline (mo_packet.c):
+ * closest hit (t, prim, u, v) and any hit.  Results equal mo_ray_intersect / mo_ray_test with naive == 0. */
+void mo_packet_ray_intersect(const mo_scene *s, uint64_t n, const float *ox, const float *oy, const float *oz, const float *dx,
+                             const float *dy, const float *dz, const float *mint, const float *maxt, float *t, uint32_t *prim,
+                             float *u, float *v, uint8_t *any_hit);
 /* Full SurfaceInteraction for given hits (kdtree.h:2334-2367 + mesh.cpp:399-462).
  * out: 24 floats per ray: p(3) n(3) uv(2) sh_s(3) sh_t(3) sh_n(3) dp_du(3) dp_dv(3) wi(3) -> 26 */
 void mo_fill_si(const mo_scene *s, uint64_t n, const float *dx, const float *dy,
@@ -134,7 +139,10 @@ typedef struct {
 } mo_render_desc;
 
 /* mode 0: scalar_rgb block mode (spiral blocks, Morton order, one PCG32 stream per block);
- * mode 1: wavefront mode (one PCG32 stream per sample, TEA-seeded), single pass.
+ * mode 1: wavefront mode (one PCG32 stream per sample, TEA-seeded), single pass;
+ * mode 2: packet_rgb block mode (integrator.cpp:204-212: 8 sample indices per packet, 8 PCG32 streams per block, ray queries 8 wide
+ *         on AVX2 with lane voting, mo_packet.c) -- RGB `path` with a pinhole camera only, -2 otherwise;
+ * mode 3: the schedule and streams of mode 2 traced by the scalar code (the checker of mode 2: identical film).
  * film_xyzaw: crop_h*crop_w*5 floats, overwritten.  n_threads<=0: all cores.
  * block_size 0: reference rule (32 halved until #blocks >= n_threads).
  * stats (may be NULL): [0]=closest-hit queries, [1]=any-hit queries, [2]=samples. */

@@ -93,6 +93,12 @@ void mo_scene_set_naive(mo_scene *s, int naive);
 void mo_reflectance(const mo_scene *s, const mo_mesh *m, mo_v2 uv, float out[3], uint32_t *texel, float w1[2]);
 
 
+/* 8-wide ray queries of the packet_rgb-equivalent CPU baseline (mo_packet.c) */
+typedef struct mo_packet_accel mo_packet_accel;
+mo_packet_accel *mo_packet_accel_build(const mo_scene *s);
+void mo_packet_accel_free(mo_packet_accel *a);
+uint32_t mo_packet_intersect(const mo_scene *s, const mo_packet_accel *a, const mo_ray *rays, uint32_t lanes, int shadow, mo_hit *hits);
+
 /* BSDF models (mo_bsdf.c) */
 void mo_fresnel(float cos_theta_i, float eta, float out[4]);
 float mo_fresnel_conductor(float cos_theta_i, float eta_r, float eta_i);

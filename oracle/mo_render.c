@@ -503,6 +503,125 @@ static void path_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, 
     }
 }
 
+/* PathIntegrator::sample for a packet of 8 camera rays (the packet_rgb instantiation of path.cpp:100-211: the loop runs while any
+ * lane is active).  The two ray queries of an iteration are traced 8 wide (mo_packet.c: one stack, lane masks, lane voting); the
+ * stages between them run lane by lane through the scalar functions above, so every lane computes exactly what path_sample computes
+ * for its ray and RNG stream -- tests/test_oracle_packet.py checks that bit for bit. */
+static void packet_scene_intersect(const mo_scene *s, const mo_packet_accel *acc, const mo_ray *rays, uint32_t lanes, mo_si *si,
+                                   int *valid, ray_stats *st) {
+    mo_hit h[8];
+    st->closest += (uint64_t) __builtin_popcount(lanes);
+    const uint32_t found = mo_packet_intersect(s, acc, rays, lanes, 0, h);
+    for (int l = 0; l < 8; ++l) {
+        if (!((lanes >> l) & 1u)) continue;
+        if ((found >> l) & 1u) { mo_make_si(s, &rays[l], &h[l], &si[l]); valid[l] = 1; }
+        else { memset(&si[l], 0, sizeof(si[l])); si[l].t = INFINITY; si[l].wi = mo_neg(rays[l].d); valid[l] = 0; }
+    }
+}
+
+static void path_sample_packet(const mo_scene *s, const mo_packet_accel *acc, mo_pcg32 *rng, const mo_ray *rays_in, uint32_t lanes,
+                               int max_depth, int rr_depth, float (*result)[3], int *valid_ray, ray_stats *st) {
+    mo_ray ray[8]; mo_si si[8], si_bsdf[8]; int si_valid[8], v2[8], emitter[8], active[8];
+    float eta[8], emission_weight[8], throughput[8][3];
+    /* per-lane values that live from the emitter-sampling stage to the BSDF stage of one iteration */
+    float refl[8][3], emitter_val[8][3]; mo_dsample ds[8]; int active_e[8], smooth[8]; mo_bsample bs[8];
+    for (int l = 0; l < 8; ++l) {
+        ray[l] = rays_in[l]; eta[l] = 1.0f; emission_weight[l] = 1.0f; active[l] = 1; active_e[l] = 0; smooth[l] = 0;
+        for (int k = 0; k < 3; ++k) { throughput[l][k] = 1.0f; result[l][k] = 0.0f; }
+    }
+    packet_scene_intersect(s, acc, ray, lanes, si, si_valid, st);
+    for (int l = 0; l < 8; ++l) {
+        if (!((lanes >> l) & 1u)) continue;
+        valid_ray[l] = si_valid[l];
+        emitter[l] = si_valid[l] ? s->meshes[si[l].shape].emitter : s->environment;
+    }
+    uint32_t alive = lanes;                 /* lanes still inside the loop */
+    for (int depth = 1; alive; ++depth) {
+        mo_ray shadow[8]; uint32_t shadow_lanes = 0;
+        for (int l = 0; l < 8; ++l) {
+            if (!((alive >> l) & 1u)) continue;
+            if (emitter[l] >= 0 && active[l]) {
+                const mo_emitter *e = &s->emitters[emitter[l]];
+                if (e->type != 0 || si[l].wi.z > 0.0f) {
+                    float le_env[3];
+                    const float *le = e->radiance;
+                    if (e->type == 2) { mo_envmap_eval(e->env, mo_neg(si[l].wi), le_env); le = le_env; }
+                    for (int k = 0; k < 3; ++k) result[l][k] += (emission_weight[l] * throughput[l][k]) * le[k];
+                }
+            }
+            active[l] = active[l] && si_valid[l];
+            if (depth > rr_depth) {
+                float q = fminf(fmaxf(fmaxf(throughput[l][0], throughput[l][1]), throughput[l][2]) * (eta[l] * eta[l]), 0.95f);
+                if (active[l]) active[l] = mo_pcg32_next_f32(&rng[l]) < q;
+                float rq = mo_rcp(q);
+                for (int k = 0; k < 3; ++k) throughput[l][k] *= rq;
+            }
+            if ((uint32_t) depth >= (uint32_t) max_depth || !active[l]) { alive &= ~(1u << l); continue; }
+            const mo_mesh *mesh = &s->meshes[si[l].shape];
+            mo_reflectance(s, mesh, si[l].uv, refl[l], NULL, NULL);
+            smooth[l] = mo_bsdf_is_smooth(&mesh->bsdf);
+            active_e[l] = 0;
+            if (smooth[l]) {
+                mo_v2 s2; s2.x = mo_pcg32_next_f32(&rng[l]); s2.y = mo_pcg32_next_f32(&rng[l]);
+                mo_sample_emitter_direction(s, si[l].p, s2, &ds[l], emitter_val[l]);
+                active_e[l] = ds[l].pdf != 0.0f;
+                if (active_e[l] && s->n_emitters > 0) {
+                    shadow[l].o = si[l].p; shadow[l].d = ds[l].d;
+                    shadow[l].mint = MO_RAY_EPSILON * (1.0f + mo_hmax_abs(si[l].p));
+                    shadow[l].maxt = ds[l].dist * (1.0f - MO_SHADOW_EPSILON);
+                    shadow_lanes |= 1u << l;
+                }
+            }
+        }
+        if (!alive) break;
+        if (shadow_lanes) {
+            st->any += (uint64_t) __builtin_popcount(shadow_lanes);
+            const uint32_t occluded = mo_packet_intersect(s, acc, shadow, shadow_lanes, 1, NULL);
+            for (int l = 0; l < 8; ++l)
+                if ((occluded >> l) & 1u) emitter_val[l][0] = emitter_val[l][1] = emitter_val[l][2] = 0.0f;
+        }
+        uint32_t next_lanes = 0;
+        for (int l = 0; l < 8; ++l) {
+            if (!((alive >> l) & 1u)) continue;
+            const mo_bsdf *bsdf = &s->meshes[si[l].shape].bsdf;
+            if (smooth[l] && active_e[l]) {
+                mo_v3 wo = mo_to_local(&si[l].sh, ds[l].d);
+                float bsdf_val[3], bsdf_pdf;
+                mo_bsdf_eval_pdf(bsdf, refl[l], si[l].wi, wo, bsdf_val, &bsdf_pdf);
+                float mis = ds[l].delta ? 1.0f : mis_weight(ds[l].pdf, bsdf_pdf);
+                for (int k = 0; k < 3; ++k) result[l][k] += ((mis * throughput[l][k]) * bsdf_val[k]) * emitter_val[l][k];
+            }
+            float s1 = mo_pcg32_next_f32(&rng[l]);
+            mo_v2 s2; s2.x = mo_pcg32_next_f32(&rng[l]); s2.y = mo_pcg32_next_f32(&rng[l]);
+            float bsdf_w[3];
+            mo_bsdf_sample(bsdf, refl[l], si[l].wi, s1, s2, &bs[l], bsdf_w);
+            for (int k = 0; k < 3; ++k) throughput[l][k] = throughput[l][k] * bsdf_w[k];
+            active[l] = active[l] && (throughput[l][0] != 0.0f || throughput[l][1] != 0.0f || throughput[l][2] != 0.0f);
+            if (!active[l]) { alive &= ~(1u << l); continue; }
+            eta[l] *= bs[l].eta;
+            ray[l].o = si[l].p; ray[l].d = mo_to_world(&si[l].sh, bs[l].wo);
+            ray[l].mint = (1.0f + mo_hmax_abs(si[l].p)) * MO_RAY_EPSILON;
+            ray[l].maxt = INFINITY;
+            next_lanes |= 1u << l;
+        }
+        if (!next_lanes) break;
+        packet_scene_intersect(s, acc, ray, next_lanes, si_bsdf, v2, st);
+        for (int l = 0; l < 8; ++l) {
+            if (!((next_lanes >> l) & 1u)) continue;
+            emitter[l] = v2[l] ? s->meshes[si_bsdf[l].shape].emitter : s->environment;
+            if (emitter[l] >= 0) {
+                mo_v3 d = mo_sub(si_bsdf[l].p, si[l].p);
+                float dist = mo_norm(d);
+                d = mo_div_s(d, dist);
+                if (!v2[l]) { d = mo_neg(si_bsdf[l].wi); dist = 0.0f; si_bsdf[l].sh.n = d; }
+                float emitter_pdf = bs[l].delta ? 0.0f : mo_pdf_emitter_direction(s, (uint32_t) emitter[l], d, si_bsdf[l].sh.n, dist);
+                emission_weight[l] = mis_weight(bs[l].pdf, emitter_pdf);
+            }
+            si[l] = si_bsdf[l]; si_valid[l] = v2[l];
+        }
+    }
+}
+
 /* DirectIntegrator::sample (direct.cpp:105-196) */
 static void direct_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray, int emitter_samples, int bsdf_samples,
                           int hide_emitters, float result[3], int *valid_ray, ray_stats *st) {
@@ -808,8 +927,15 @@ int mo_render_rows(const mo_scene *s, const mo_render_desc *d, int row0, int row
 }
 
 /* scalar_rgb branch of SamplingIntegrator::render (integrator.cpp:76-143) + render_block (:178-203) */
+/* flavour 0: scalar_rgb (one PCG32 stream per block, pixels in Morton order, spp consecutive samples per pixel);
+ * flavour 2: packet_rgb (integrator.cpp:204-212): the block's pixel_count * spp sample indices are processed 8 at a time, lane l of
+ *            a packet takes index base + l (pixel = morton_decode(index / spp)), and the sampler holds 8 PCG32 streams seeded like
+ *            the wavefront flavour with idx = lane (independent.cpp:62-72); ray queries 8 wide (path_sample_packet);
+ * flavour 3: the same schedule and streams as 2, every lane traced by the scalar code -- the checker of flavour 2. */
 static int render_blocks(const mo_scene *s, const mo_render_desc *d, int n_threads, int block_size,
-                         float *film, uint64_t *stats) {
+                         float *film, uint64_t *stats, int flavour) {
+    if (flavour == 2 && (s->spectral || d->integrator != 0 || d->aperture_radius > 0.0f)) return -2;      /* RGB `path`, pinhole camera */
+    mo_packet_accel *acc = flavour == 2 ? mo_packet_accel_build(s) : NULL;
     camera cam; camera_init(d, &cam);
     rfilter f; rfilter_init(&f, d->rfilter, d->rfilter_param, d->rfilter_param2);
     if (block_size == 0) {
@@ -847,6 +973,53 @@ static int render_blocks(const mo_scene *s, const mo_render_desc *d, int n_threa
             mo_pcg32_seed(&rng, (uint64_t) ids[b] + d->base_seed, MO_PCG32_DEFAULT_STREAM);
             ray_stats st = { 0, 0 };
             uint32_t pixel_count = (uint32_t) (block_size * block_size);
+            if (flavour != 0) {
+                mo_pcg32 lane_rng[8];
+                for (uint64_t l = 0; l < 8; ++l) {       /* seed(block_id), array flavour: seed_value + idx streams (independent.cpp:66-72) */
+                    const uint64_t seed_value = (uint64_t) ids[b] + d->base_seed;
+                    mo_pcg32_seed(&lane_rng[l], mo_tea64_u64(seed_value, l, 4), mo_tea64_u64(l, seed_value, 4));
+                }
+                const uint64_t total = (uint64_t) pixel_count * (uint64_t) d->spp;
+                for (uint64_t base = 0; base < total; base += 8) {
+                    uint32_t lanes = 0; float px[8], py[8];
+                    for (uint32_t l = 0; l < 8; ++l) {
+                        const uint64_t index = base + l;
+                        if (index >= total) continue;
+                        uint32_t mx, my; mo_morton_decode2((uint32_t) (index / (uint64_t) d->spp), &mx, &my);
+                        if (mx >= (uint32_t) blk.w || my >= (uint32_t) blk.h) continue;
+                        px[l] = (float) (mx + (uint32_t) blk.ox); py[l] = (float) (my + (uint32_t) blk.oy);
+                        lanes |= 1u << l;
+                    }
+                    if (!lanes) continue;
+                    float aovs[8][5], ps[8][2];
+                    if (flavour == 3) {
+                        for (uint32_t l = 0; l < 8; ++l)
+                            if ((lanes >> l) & 1u) render_sample(s, d, &cam, &lane_rng[l], px[l], py[l], aovs[l], ps[l], NULL, NULL, &st);
+                    } else {
+                        /* render_sample (integrator.cpp:224-271) around the 8-wide PathIntegrator::sample */
+                        mo_ray rays[8]; float L[8][3]; int valid[8];
+                        for (uint32_t l = 0; l < 8; ++l) {
+                            if (!((lanes >> l) & 1u)) continue;
+                            float jx = mo_pcg32_next_f32(&lane_rng[l]), jy = mo_pcg32_next_f32(&lane_rng[l]);
+                            ps[l][0] = px[l] + jx; ps[l][1] = py[l] + jy;
+                            (void) mo_pcg32_next_f32(&lane_rng[l]);                  /* wavelength sample */
+                            float ax = (ps[l][0] - (float) d->crop_x) / (float) d->crop_w, ay = (ps[l][1] - (float) d->crop_y) / (float) d->crop_h;
+                            camera_sample_ray(&cam, ax, ay, 0.5f, 0.5f, &rays[l]);
+                        }
+                        path_sample_packet(s, acc, lane_rng, rays, lanes, d->max_depth, d->rr_depth, L, valid, &st);
+                        for (uint32_t l = 0; l < 8; ++l) {
+                            if (!((lanes >> l) & 1u)) continue;
+                            float xyz[3];
+                            srgb_to_xyz(L[l], xyz);
+                            if (d->film_rgb) { xyz[0] = L[l][0]; xyz[1] = L[l][1]; xyz[2] = L[l][2]; }
+                            aovs[l][0] = xyz[0]; aovs[l][1] = xyz[1]; aovs[l][2] = xyz[2]; aovs[l][3] = valid[l] ? 1.0f : 0.0f; aovs[l][4] = 1.0f;
+                        }
+                    }
+                    for (uint32_t l = 0; l < 8; ++l)
+                        if ((lanes >> l) & 1u) iblock_put(&blk, ps[l][0], ps[l][1], aovs[l]);
+                }
+                pixel_count = 0;            /* the scalar loop below is skipped */
+            }
             for (uint32_t i = 0; i < pixel_count; ++i) {
                 uint32_t mx, my; mo_morton_decode2(i, &mx, &my);
                 if (mx >= (uint32_t) blk.w || my >= (uint32_t) blk.h) continue;
@@ -867,6 +1040,7 @@ static int render_blocks(const mo_scene *s, const mo_render_desc *d, int n_threa
         }
     }
     free(bufs); free(bo); free(ids);
+    mo_packet_accel_free(acc);
     if (stats) { stats[0] = cl; stats[1] = an; stats[2] = (uint64_t) d->crop_w * d->crop_h * d->spp; }
     return 0;
 }
@@ -881,8 +1055,8 @@ int mo_render(const mo_scene *s, const mo_render_desc *d, int mode, int n_thread
 #else
     n_threads = 1;
 #endif
-    int rc = mode == 0 ? render_blocks(s, d, n_threads, block_size, film, stats)
-                       : render_wavefront_rows(s, d, 0, d->crop_h, film, stats);
+    int rc = mode == 1 ? render_wavefront_rows(s, d, 0, d->crop_h, film, stats)
+                       : render_blocks(s, d, n_threads, block_size, film, stats, mode);
 #ifdef _OPENMP
     omp_set_num_threads(prev);
 #endif

@@ -78,6 +78,7 @@ def lib():
         L.mo_ray_intersect.argtypes = [vp, C.c_uint64] + [vp] * 8 + [C.c_int] + [vp] * 5
         L.mo_ray_test.argtypes = [vp, C.c_uint64] + [vp] * 8 + [C.c_int, vp]
         L.mo_fill_si.argtypes = [vp, C.c_uint64] + [vp] * 7
+        L.mo_packet_ray_intersect.argtypes = [vp, C.c_uint64] + [vp] * 13
         L.mo_render.argtypes = [vp, C.POINTER(RenderDesc), C.c_int, C.c_int, C.c_int, vp, vp]
         L.mo_sample_radiance.argtypes = [vp, C.POINTER(RenderDesc), C.c_uint64, C.c_uint64, vp, vp]
         L.mo_render_rows.argtypes = [vp, C.POINTER(RenderDesc), C.c_int, C.c_int, vp]
@@ -248,6 +249,16 @@ class OracleScene:
         lib().mo_ray_test(self.h, n, *[_p(c) for c in cols], _p(mint), _p(maxt), 1 if naive else 0, _p(hit))
         return hit.astype(bool)
 
+    def packet_intersect(self, o, d, mint, maxt):
+        """closest hit + any hit through the 8-wide packet traversal (oracle/mo_packet.c): t, prim, u, v, hit"""
+        o, d, mint, maxt = _f(o), _f(d), _f(mint), _f(maxt)
+        n = o.shape[0]
+        cols = [np.ascontiguousarray(o[:, k]) for k in range(3)] + [np.ascontiguousarray(d[:, k]) for k in range(3)]
+        t = np.empty(n, np.float32); prim = np.empty(n, np.uint32); u = np.empty(n, np.float32); v = np.empty(n, np.float32)
+        hit = np.empty(n, np.uint8)
+        lib().mo_packet_ray_intersect(self.h, n, *[_p(c) for c in cols], _p(mint), _p(maxt), _p(t), _p(prim), _p(u), _p(v), _p(hit))
+        return t, prim, u, v, hit.astype(bool)
+
     def fill_si(self, d, prim, u, v):
         d = _f(d); n = d.shape[0]
         cols = [np.ascontiguousarray(d[:, k]) for k in range(3)]
@@ -338,6 +349,9 @@ def camera_rays(desc, sx, sy, aperture=None):
     lib().mo_camera_rays(C.byref(desc), n, _p(sx), _p(sy), _p(ap) if ap is not None else None, _p(o), _p(d), _p(mint), _p(maxt))
     return o, d, mint, maxt
 
+
+# mo_render modes (oracle/mo_api.h): scalar blocks, wavefront, packet blocks (8-wide ray queries), scalar emulation of the packet schedule
+SCALAR_MODE, WAVEFRONT_MODE, PACKET_MODE, PACKET_CHECK_MODE = 0, 1, 2, 3
 
 RFILTERS = {"gaussian": 0, "box": 1, "tent": 2, "catmullrom": 3, "mitchell": 4, "lanczos": 5}
 RFILTER_DEFAULTS = {"gaussian": [0.5, 0.0], "box": [0.5, 0.0], "tent": [0.0, 0.0], "catmullrom": [0.0, 0.0], "mitchell": [1.0 / 3.0, 1.0 / 3.0],
