@@ -184,6 +184,7 @@ struct Workspace {
     uint32_t *cursor_pix = nullptr, *cursor_rem = nullptr, *count_shadow = nullptr;
     float4 *out_rgba = nullptr; float2 *out_pos = nullptr;
     float *moment_film = nullptr; uint64_t moment_pixels = 0;     // moment integrator: two scratch 5-channel films
+    float *film_partials = nullptr; size_t film_partial_floats = 0;      // tiled film splat: one scratch tile per 16x16 source tile of a pass
     uint32_t *trace_spill = nullptr; size_t trace_spill_words = 0;      // k_trace: deep stack entries
     uint32_t *h_counts = nullptr;        // pinned, 4 * n_waves
     uint64_t *h_cursor = nullptr;        // pinned, 2 * n_waves
@@ -206,6 +207,7 @@ struct Workspace {
         (void) hipFree(count_shadow); count_shadow = nullptr;
         (void) hipFree(trace_spill); trace_spill = nullptr; trace_spill_words = 0;
         (void) hipFree(moment_film); moment_film = nullptr; moment_pixels = 0;
+        (void) hipFree(film_partials); film_partials = nullptr; film_partial_floats = 0;
         cursor_pix = cursor_rem = nullptr; (void) hipFree(out_rgba); (void) hipFree(out_pos);
         cursor = cursor_end = wave_stats = nullptr; out_rgba = nullptr; out_pos = nullptr;
         if (h_counts) (void) hipHostFree(h_counts);
@@ -1301,7 +1303,16 @@ int mtsamd_render(mtsamd_scene *s, const mtsamd_render_desc *d, float *film, uin
     const int R = (int) std::ceil(j.filter.radius);
     // passes hold whole local rows so that the sample stream can be stored as one plane per sample number
     if (per_row > j.pass_cap) return fail(MTSAMD_ERR_UNSUPPORTED, "one film row (%llu samples) exceeds the pass capacity", (unsigned long long) per_row);
-    const uint64_t rows_per_pass = std::max<uint64_t>(1, j.pass_cap / per_row);
+    // Passes hold whole local rows.  The film kernel cuts a pass into source tiles of tile_h <= 16 local rows that must be contiguous
+    // on the film: with a partitioned film (interleaved row tiles) tile_h divides the partition's tile height and passes start on
+    // multiples of tile_h.
+    uint64_t rows_per_pass = std::max<uint64_t>(1, j.pass_cap / per_row);
+    int32_t film_tile_h = 16;
+    if (rows.count > 1) {
+        while (rows.tile_rows % film_tile_h) film_tile_h >>= 1;
+        if (rows_per_pass >= (uint64_t) film_tile_h) rows_per_pass -= rows_per_pass % (uint64_t) film_tile_h;
+        else { while (rows_per_pass & (rows_per_pass - 1)) rows_per_pass &= rows_per_pass - 1; film_tile_h = (int32_t) rows_per_pass; }
+    }
     const bool tiled = film_tiles_supported(j.filter);
     // moment integrator: the sample stream is splatted twice (values, then squared values) into two scratch films
     float *film_target = film, *film_sq = nullptr;
@@ -1346,9 +1357,18 @@ int mtsamd_render(mtsamd_scene *s, const mtsamd_render_desc *d, float *film, uin
             g1 = (t1 * rows.count + rows.part) * rows.tile_rows + (l1 - t1 * rows.tile_rows);
         }
         f.row0 = std::max<int32_t>(0, g0 - R); f.row1 = std::min<int32_t>(d->crop_height, g1 + R + 1);
-        // partitioned film: the 16-row film tiles start R rows above the first local row also when that is above the film, so
-        // that every 32-row partition tile (+- R) is covered by three tile rows, not four
-        if (tiled && rows.count > 1) f.row0 = g0 - R;
+        if (tiled) {
+            f.pass_lr0 = (int32_t) lr0; f.pass_rows = (int32_t) nrows; f.tile_h = film_tile_h;
+            film_tile_grid(f);
+            Workspace &w = s->ws;
+            const size_t need = film_partial_floats(f);
+            if (need > w.film_partial_floats) {
+                (void) hipFree(w.film_partials); w.film_partials = nullptr; w.film_partial_floats = 0;
+                HIP_TRY(hipMalloc((void **) &w.film_partials, need * sizeof(float)));
+                w.film_partial_floats = need;
+            }
+            f.partials = w.film_partials;
+        }
         if (tiled) HIP_TRY(launch_film_tiles(f, stream));
         else HIP_TRY(launch_film_gather(f, stream));
         if (film_sq) {

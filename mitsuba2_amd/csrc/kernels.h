@@ -87,6 +87,11 @@ struct FilmParams {
     RowMap rows;
     int32_t spp, crop_x, crop_y, crop_w, crop_h;
     int32_t row0, row1;         // target (global) rows [row0,row1)
+    // tiled splat: the pass holds the local rows [pass_lr0, pass_lr0 + pass_rows), cut into 16x16 source tiles; every tile
+    // accumulates the film pixels it reaches into its scratch tile of `partials`
+    int32_t pass_lr0, pass_rows, tiles_x, tiles_y;
+    int32_t tile_h;             // local rows per source tile (<= 16; 16 unless a partitioned film forces less)
+    float *partials;
 };
 
 struct AdjointParams {
@@ -115,9 +120,11 @@ hipError_t launch_adjoint(const AdjointParams &a, hipStream_t s);
 // CIE x, y, z and D65 tables (95 floats each) -> device; call once before the first spectral launch
 hipError_t upload_spectral_tables(const float *x, const float *y, const float *z, const float *d65);
 hipError_t launch_film_gather(const FilmParams &p, hipStream_t s);
-// tiled variant for the plane layout and filters with <= 4 taps (gaussian stddev 0.5, box)
+// tiled variant for filters with <= 4 taps (gaussian stddev 0.5, box, tent): k_film_accum + k_film_merge
 hipError_t launch_film_tiles(const FilmParams &p, hipStream_t s);
 bool film_tiles_supported(const FilterView &f);
+void film_tile_grid(FilmParams &p);                 // tiles_x / tiles_y from crop_w / pass_rows
+size_t film_partial_floats(const FilmParams &p);    // size of `partials`
 // mode 0: closest (BVH), 1: closest (brute force)
 hipError_t launch_ray_intersect(const SceneView &sv, uint64_t n, const RayStreams &r, int mode, float *t,
                                 uint32_t *prim, uint32_t *shape, float *u, float *v, float *si26,

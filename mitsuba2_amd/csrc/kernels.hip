@@ -1405,16 +1405,16 @@ __global__ __launch_bounds__(kBlock) void k_film_gather(const FilmParams F) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// ImageBlock::put, tiled: a workgroup owns a 16x16 tile of film pixels.  For a chunk of kFilmChunk sample
-// planes it first turns every sample of the (16+2R)^2 source pixels into a record in LDS -- value (X,Y,Z,A),
-// the first footprint pixel (lo) and the <= 4 filter taps per axis, exactly as imageblock.cpp:117-147 computes
-// them -- and then every thread gathers its pixel's taps from those records, branch-free.  Each film pixel is
-// accumulated by one thread in a fixed order: bitwise reproducible, no atomics.
-// samples staged per barrier pair; cbox 1024^2 @ 256 spp: 1 -> 14.2 ms, 2 -> 8.8 ms, 3 -> 14.9 ms, 4 -> 29.1 ms (LDS occupancy)
-#ifndef MTS_FILM_CHUNK
-#define MTS_FILM_CHUNK 2
-#endif
-constexpr int kFilmTile = 16, kFilmChunk = MTS_FILM_CHUNK, kFilmTaps = 5;      // taps per axis seen from the source pixel: 2R+1 <= 5
+// ImageBlock::put, tiled by SOURCE pixels.  A workgroup owns a 16x16 block of source pixels (one thread each) of the pass and
+// reads every one of their samples exactly once: 8 samples per pixel at a time, i.e. 128 contiguous bytes of radiance and 64 of
+// film position -- whole sectors.  Two samples at a time it turns each sample into a record in LDS -- value (X,Y,Z,A) and the
+// <= 4 filter taps per axis, exactly as imageblock.cpp:117-147 computes them, stored source-aligned (tap k <-> film pixel
+// q - R + k) -- and the threads gather, branch-free and in a fixed order, the (16 + 2R)^2 film pixels the block's samples reach
+// (imageblock.cpp:148-161 as a gather).  The (16 + 2R)^2 x 5 sums go to a scratch tile; k_film_merge adds the <= 4 overlapping
+// tiles of every film pixel in a fixed order.  No atomics: the film is bitwise reproducible.  HBM traffic: 24 B per sample, once.
+constexpr int kFilmTile = 16, kFilmTaps = 5;      // taps per axis seen from the source pixel: 2R+1 <= 5
+constexpr int kFilmDest = kFilmTile + 4;          // scratch tiles are laid out for the widest supported apron (R = 2)
+constexpr int kFilmPartial = kFilmDest * kFilmDest * 5;      // floats per scratch tile
 
 // Filter weights of one sample along one axis for the 2R+1 film pixels q-R .. q+R around its source pixel q
 // (block coordinates t = q + border + k - R), exactly as imageblock.cpp:117-147 evaluates them: 0 outside [lo, hi]
@@ -1441,139 +1441,153 @@ MTS_DEV void axis_taps(const FilterView &f, const float *table, float pos, int s
     }
 }
 
-// PART: the film is partitioned into interleaved row tiles (rows.count > 1)
-template <bool PART> __device__ __forceinline__ void film_tiles_body(const FilmParams &F) {
-    extern __shared__ float4 smem[];
+// One thread per source pixel.  The 5 x 5 x 5 partial sums of its own samples -- for every tap (kx, ky) of the pixel's
+// neighbourhood the sum over the samples of w_y[ky] w_x[kx] (X, Y, Z, A, 1) -- stay in registers for the whole pass: the main loop
+// touches neither LDS (beyond the 32-entry filter table) nor a barrier.  At the end the block exchanges the sums through LDS, one tap
+// row at a time, and every film pixel of the (16 + 2R)^2 region adds up the <= 25 source pixels that reach it.
+#ifndef MTS_FILM_PREFETCH
+#define MTS_FILM_PREFETCH 4
+#endif
+constexpr int kFilmPrefetch = MTS_FILM_PREFETCH;     // samples in flight per thread (x 24 B)
+__global__ __launch_bounds__(kBlock) void k_film_accum(const FilmParams F) {
+    __shared__ float table[32];
+    __shared__ float E[kFilmTile * kFilmTile * (kFilmTaps * 5 + 1)];      // one tap row of every source pixel: [pixel][kx][channel], padded
     const FilterView &f = F.filter;
-    const int b = f.border, R = (int) ceilf(f.radius), SW = kFilmTile + 2 * R, NS = SW * SW;
-    float4 *V = smem;
-    float *WX = reinterpret_cast<float *>(V + kFilmChunk * NS), *WY = WX + kFilmTaps * kFilmChunk * NS;
-    float *table = WY + kFilmTaps * kFilmChunk * NS;
+    const int b = f.border, R = (int) ceilf(f.radius), DW = kFilmTile + 2 * R;
     if (threadIdx.x < 32) table[threadIdx.x] = f.table[threadIdx.x];
-    const int tiles_x = (F.crop_w + kFilmTile - 1) / kFilmTile;
-    const int tx0 = (int) (blockIdx.x % (uint32_t) tiles_x) * kFilmTile, ty0 = F.row0 + (int) (blockIdx.x / (uint32_t) tiles_x) * kFilmTile;
-    const int lx = (int) threadIdx.x % kFilmTile, ly = (int) threadIdx.x / kFilmTile;
-    const int x = tx0 + lx, y = ty0 + ly;
+    const int tcx = (int) (blockIdx.x % (uint32_t) F.tiles_x), tcy = (int) (blockIdx.x / (uint32_t) F.tiles_x);
+    const int sp = (int) threadIdx.x, lx = sp % kFilmTile, ly = sp / kFilmTile;
+    // this thread's source pixel: column qx, local row lr (the pass holds whole local rows; a tile's rows are contiguous on the film)
+    const int qx = tcx * kFilmTile + lx, lr = F.pass_lr0 + tcy * F.tile_h + ly;
+    const bool have = qx < F.crop_w && ly < F.tile_h && lr < F.pass_lr0 + F.pass_rows;
+    const int qy = have ? row_to_global(F.rows, lr) : 0;
     const int sx = F.crop_w + 2 * b, sy = F.crop_h + 2 * b;
     const float offx = (float) (F.crop_x - b) + 0.5f, offy = (float) (F.crop_y - b) + 0.5f;
-    const uint32_t pix0 = F.plane_pix0, npix = F.plane_pixels;
-    float acc[5] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
-    // Every thread stages up to kStage records per chunk.  Their stream slots for sample plane s are slot0 + s * step;
-    // the loads of the NEXT chunk are issued before the gather of the current one so that their latency is hidden.
-    constexpr int kStage = (kFilmChunk * (kFilmTile + 4) * (kFilmTile + 4) + kBlock - 1) / kBlock;
-    int64_t slot0[kStage]; int64_t step[kStage]; int ent_c[kStage]; int tap_x0[kStage], tap_y0[kStage];
+    const int tap_x0 = qx + b - R, tap_y0 = qy + b - R;
+    const size_t slot0 = have ? (size_t) (((uint64_t) lr * (uint64_t) F.crop_w + (uint64_t) qx) * (uint64_t) F.spp - F.first_ordinal) : 0;
+    __syncthreads();
+    float acc[kFilmTaps][kFilmTaps][5];
 #pragma unroll
-    for (int k = 0; k < kStage; ++k) {
-        const int e = (int) threadIdx.x + k * kBlock;
-        slot0[k] = -1; step[k] = 0; ent_c[k] = 0; tap_x0[k] = tap_y0[k] = 0;
-        if (e < kFilmChunk * NS) {
-            const int c = e / NS, sp = e - c * NS;
-            const int qx = tx0 - R + sp % SW, qy = ty0 - R + sp / SW;
-            ent_c[k] = c; tap_x0[k] = qx + b - R; tap_y0[k] = qy + b - R;
-            const int lr = (qx >= 0 && qx < F.crop_w && qy >= 0 && qy < F.crop_h) ? row_to_local(F.rows, qy) : -1;
-            if (lr >= 0) {
-                const uint32_t lp = (uint32_t) lr * (uint32_t) F.crop_w + (uint32_t) qx;
-                if (npix) {
-                    if (lp >= pix0 && lp - pix0 < npix) { slot0[k] = (int64_t) c * npix + (lp - pix0); step[k] = (int64_t) npix; }
-                } else {
-                    const uint64_t ord = (uint64_t) lp * (uint64_t) F.spp + (uint64_t) c;
-                    // passes hold whole film rows: a pixel is either completely inside the stream or not at all
-                    if (ord >= F.first_ordinal && ord - F.first_ordinal < F.n_samples) { slot0[k] = (int64_t) (ord - F.first_ordinal); step[k] = 1; }
+    for (int ky = 0; ky < kFilmTaps; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < kFilmTaps; ++kx)
+#pragma unroll
+            for (int c = 0; c < 5; ++c) acc[ky][kx][c] = 0.0f;
+    float4 pv[kFilmPrefetch]; float2 pq[kFilmPrefetch];
+    const int n_spp = have ? F.spp : 0;
+#pragma unroll
+    for (int k = 0; k < kFilmPrefetch; ++k) {
+        pv[k] = make_float4(0.0f, 0.0f, 0.0f, -1.0f); pq[k] = make_float2(0.0f, 0.0f);
+        if (k < n_spp) { pv[k] = F.out_rgba[slot0 + (size_t) k]; pq[k] = F.out_pos[slot0 + (size_t) k]; }
+    }
+    for (int s0 = 0; s0 < n_spp; s0 += kFilmPrefetch) {
+#pragma unroll
+        for (int k = 0; k < kFilmPrefetch; ++k) {
+            const float4 rec = pv[k]; const float2 rp = pq[k];
+            {   // the register is free: fetch the sample that will be processed kFilmPrefetch samples from now
+                const int j = s0 + kFilmPrefetch + k;
+                pv[k] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+                if (j < n_spp) { pv[k] = F.out_rgba[slot0 + (size_t) j]; pq[k] = F.out_pos[slot0 + (size_t) j]; }
+            }
+            if (!(rec.w >= 0.0f)) continue;                  // (X, Y, Z, alpha); alpha < 0: invalid or absent sample
+            float wxs[kFilmTaps], wys[kFilmTaps];
+            axis_taps(f, table, rp.x - offx, sx, tap_x0, R, wxs);
+            axis_taps(f, table, rp.y - offy, sy, tap_y0, R, wys);
+            // a zero weight adds (signed) zeros, which leaves the sums as they are: the film equals the one of a loop over the non-zero
+            // taps only (imageblock.cpp:148-161)
+#pragma unroll
+            for (int ky = 0; ky < kFilmTaps; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < kFilmTaps; ++kx) {
+                    const float w = wys[ky] * wxs[kx];
+                    acc[ky][kx][0] += rec.x * w; acc[ky][kx][1] += rec.y * w; acc[ky][kx][2] += rec.z * w; acc[ky][kx][3] += rec.w * w;
+                    acc[ky][kx][4] += 1.0f * w;
                 }
-            }
         }
     }
-    // A rank's film partition is a set of interleaved row tiles: the launch spans all of them, and most workgroups in between
-    // see none of this pass's samples -- they leave at once.  Within a tile at the edge of a row tile, the waves whose film rows
-    // no local source row can reach skip the gather (their taps are all zero).
-    bool wave_gathers = true;
-    if constexpr (PART) {
-        bool any_slot = false;
+    // ---- exchange: film pixel (dx, dy) of the region <- tap (dx - sxl, dy - syl) of the source pixel at block position (sxl, syl),
+    // in ascending (ky, kx) order
+    constexpr int kStride = kFilmTaps * 5 + 1;
+    const int n_dest = DW * DW;
+    float out0[5] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f }, out1[5] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+    const int d0 = (int) threadIdx.x, d1 = (int) threadIdx.x + kBlock;
+    auto collect = [&](int d, int ky, float (&out)[5]) {
+        const int dy = d / DW, dx = d - dy * DW, syl = dy - ky;
+        if (syl < 0 || syl >= kFilmTile) return;
 #pragma unroll
-        for (int k = 0; k < kStage; ++k) any_slot |= slot0[k] >= 0;
-        if (!__syncthreads_or(any_slot)) return;
-        bool reach = false;
-        for (int dy = -R; dy <= R; ++dy) {
-            const int qy = y + dy;
-            reach |= qy >= 0 && qy < F.crop_h && row_to_local(F.rows, qy) >= 0;
-        }
-        wave_gathers = __ballot(reach) != 0ull;
-    }
-    float4 pv[kStage]; float2 pq[kStage];
-    auto prefetch = [&](int s0) {
+        for (int kx = 0; kx < kFilmTaps; ++kx) {
+            const int sxl = dx - kx;
+            if (kx > 2 * R || sxl < 0 || sxl >= kFilmTile) continue;
+            const float *e = E + (syl * kFilmTile + sxl) * kStride + kx * 5;
 #pragma unroll
-        for (int k = 0; k < kStage; ++k) {
-            pv[k] = make_float4(0.0f, 0.0f, 0.0f, -1.0f); pq[k] = make_float2(0.0f, 0.0f);
-            if (slot0[k] >= 0 && s0 + ent_c[k] < F.spp) {
-                const size_t slot = (size_t) (slot0[k] + (int64_t) s0 * step[k]);
-                pv[k] = F.out_rgba[slot]; pq[k] = F.out_pos[slot];
-            }
+            for (int c = 0; c < 5; ++c) out[c] += e[c];
         }
     };
-    prefetch(0);
-    // records of source pixels outside this pass stay zero for the whole launch
 #pragma unroll
-    for (int k = 0; PART && k < kStage; ++k) {
-        const int e = (int) threadIdx.x + k * kBlock;
-        if (e < kFilmChunk * NS && slot0[k] < 0) {
-            V[e] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            for (int t = 0; t < kFilmTaps; ++t) { WX[kFilmTaps * e + t] = 0.0f; WY[kFilmTaps * e + t] = 0.0f; }
-        }
-    }
-    __syncthreads();
-    for (int s0 = 0; s0 < F.spp; s0 += kFilmChunk) {
-        // ---- stage: one record per (sample plane, source pixel): value + 2R+1 taps per axis
-#pragma unroll
-        for (int k = 0; k < kStage; ++k) {
-            const int e = (int) threadIdx.x + k * kBlock;
-            if (e >= kFilmChunk * NS || (PART && slot0[k] < 0)) continue;
-            float4 val = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            float wxs[kFilmTaps], wys[kFilmTaps];
-#pragma unroll
-            for (int t = 0; t < kFilmTaps; ++t) wxs[t] = wys[t] = 0.0f;
-            if (pv[k].w >= 0.0f) {                          // (X, Y, Z, alpha); alpha < 0: invalid or absent sample
-                val = pv[k];
-                axis_taps(f, table, pq[k].x - offx, sx, tap_x0[k], R, wxs);
-                axis_taps(f, table, pq[k].y - offy, sy, tap_y0[k], R, wys);
-            }
-            V[e] = val;
-#pragma unroll
-            for (int t = 0; t < kFilmTaps; ++t) { WX[kFilmTaps * e + t] = wxs[t]; WY[kFilmTaps * e + t] = wys[t]; }
-        }
-        if (s0 + kFilmChunk < F.spp) prefetch(s0 + kFilmChunk);
+    for (int ky = 0; ky < kFilmTaps; ++ky) {
+        if (ky > 2 * R) break;
         __syncthreads();
-        // ---- gather: film pixel (x, y) <- samples of the (2R+1)^2 neighbouring pixels, fixed order.  The source
-        // pixel at offset (dx, dy) of the tile origin sees this film pixel as its tap (2R - dx, 2R - dy).
-        for (int c = 0; (!PART || wave_gathers) && c < kFilmChunk; ++c)
-            for (int dy = 0; dy <= 2 * R; ++dy)
-                for (int dx = 0; dx <= 2 * R; ++dx) {
-                    const int e = c * NS + (ly + dy) * SW + (lx + dx);
-                    const float w = WY[kFilmTaps * e + (2 * R - dy)] * WX[kFilmTaps * e + (2 * R - dx)];
-                    if (w == 0.0f) continue;               // a skipped tap adds nothing (imageblock.cpp:148-161)
-                    const float4 v = V[e];
-                    acc[0] += v.x * w; acc[1] += v.y * w; acc[2] += v.z * w; acc[3] += v.w * w; acc[4] += 1.0f * w;
-                }
-        __syncthreads();
-    }
-    if (x < F.crop_w && y >= 0 && y < F.row1) {
-        float *dst = F.film + 5u * ((size_t) y * (size_t) F.crop_w + (size_t) x);
 #pragma unroll
-        for (int k = 0; k < 5; ++k) dst[k] += acc[k];
+        for (int kx = 0; kx < kFilmTaps; ++kx)
+#pragma unroll
+            for (int c = 0; c < 5; ++c) E[sp * kStride + kx * 5 + c] = acc[ky][kx][c];
+        __syncthreads();
+        collect(d0, ky, out0);
+        if (d1 < n_dest) collect(d1, ky, out1);
     }
+    float *dst = F.partials + (size_t) blockIdx.x * kFilmPartial;
+    if (d0 < n_dest)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) dst[5 * d0 + k] = out0[k];
+    if (d1 < n_dest)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) dst[5 * d1 + k] = out1[k];
 }
 
-__global__ __launch_bounds__(kBlock) void k_film_tiles(const FilmParams F) { film_tiles_body<false>(F); }
-__global__ __launch_bounds__(kBlock) void k_film_tiles_part(const FilmParams F) { film_tiles_body<true>(F); }
+// film[y][x] += the scratch tiles that reach (x, y), in ascending (tile row, tile column) order
+__global__ __launch_bounds__(kBlock) void k_film_merge(const FilmParams F) {
+    const int R = (int) ceilf(F.filter.radius), DW = kFilmTile + 2 * R;
+    const uint32_t n_rows = (uint32_t) (F.row1 - F.row0);
+    const uint64_t i = (uint64_t) blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (uint64_t) n_rows * (uint64_t) F.crop_w) return;
+    const int x = (int) (i % (uint64_t) F.crop_w), y = F.row0 + (int) (i / (uint64_t) F.crop_w);
+    const int tc0 = max(x - R, 0) / kFilmTile, tc1 = min(x + R, F.crop_w - 1) / kFilmTile;
+    float acc[5] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+    int prev = -1;
+    for (int gy = max(y - R, 0); gy <= min(y + R, F.crop_h - 1); ++gy) {
+        const int lr = row_to_local(F.rows, gy);
+        if (lr < F.pass_lr0 || lr >= F.pass_lr0 + F.pass_rows) continue;
+        const int tr = (lr - F.pass_lr0) / F.tile_h;
+        if (tr == prev) continue;
+        prev = tr;
+        const int g0 = row_to_global(F.rows, F.pass_lr0 + tr * F.tile_h);       // film row of the tile's first source row
+        const int dy = y - (g0 - R);
+        for (int tc = tc0; tc <= tc1; ++tc) {
+            const int dx = x - (tc * kFilmTile - R);
+            if (dx < 0 || dx >= DW || dy < 0 || dy >= DW) continue;
+            const float *p = F.partials + (size_t) (tr * F.tiles_x + tc) * kFilmPartial + 5 * (dy * DW + dx);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) acc[k] += p[k];
+        }
+    }
+    if (prev < 0) return;                  // a film row between two of this rank's row tiles: nothing of this pass reaches it
+    float *dst = F.film + 5u * ((size_t) y * (size_t) F.crop_w + (size_t) x);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) dst[k] += acc[k];
+}
 
 bool film_tiles_supported(const FilterView &f) { return f.taps <= 4 && (int) ceilf(f.radius) <= 2; }
+size_t film_partial_floats(const FilmParams &p) { return (size_t) p.tiles_x * (size_t) p.tiles_y * kFilmPartial; }
+void film_tile_grid(FilmParams &p) {
+    p.tiles_x = (p.crop_w + kFilmTile - 1) / kFilmTile;
+    p.tiles_y = (p.pass_rows + p.tile_h - 1) / p.tile_h;
+}
 
 hipError_t launch_film_tiles(const FilmParams &p, hipStream_t s) {
-    if (p.row1 <= p.row0) return hipSuccess;
-    const int R = (int) std::ceil(p.filter.radius), SW = kFilmTile + 2 * R;
-    const int tiles_x = (p.crop_w + kFilmTile - 1) / kFilmTile, tiles_y = (p.row1 - p.row0 + kFilmTile - 1) / kFilmTile;
-    const size_t lds = (size_t) kFilmChunk * SW * SW * (sizeof(float4) + 2 * kFilmTaps * sizeof(float)) + 32 * sizeof(float);
-    if (p.rows.count > 1) hipLaunchKernelGGL(k_film_tiles_part, dim3((uint32_t) (tiles_x * tiles_y)), dim3(kBlock), lds, s, p);
-    else hipLaunchKernelGGL(k_film_tiles, dim3((uint32_t) (tiles_x * tiles_y)), dim3(kBlock), lds, s, p);
+    if (p.row1 <= p.row0 || p.pass_rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_film_accum, dim3((uint32_t) (p.tiles_x * p.tiles_y)), dim3(kBlock), 0, s, p);
+    const uint64_t n = (uint64_t) (p.row1 - p.row0) * (uint64_t) p.crop_w;
+    hipLaunchKernelGGL(k_film_merge, dim3((uint32_t) ((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, p);
     return hipGetLastError();
 }
 
