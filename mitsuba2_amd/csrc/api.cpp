@@ -183,6 +183,8 @@ struct Workspace {
     uint64_t *cursor = nullptr, *cursor_end = nullptr, *wave_stats = nullptr;
     uint32_t *cursor_pix = nullptr, *cursor_rem = nullptr, *count_shadow = nullptr;
     float4 *out_rgba = nullptr; float2 *out_pos = nullptr;
+    float4 *out_rgba2 = nullptr; float2 *out_pos2 = nullptr; uint64_t pass_cap2 = 0;      // second sample stream: pass k + 1 is traced while pass k is splatted
+    hipStream_t film_stream = nullptr; hipEvent_t film_done[2] = {};
     float *moment_film = nullptr; uint64_t moment_pixels = 0;     // moment integrator: two scratch 5-channel films
     float *film_partials = nullptr; size_t film_partial_floats = 0;      // tiled film splat: one scratch tile per 16x16 source tile of a pass
     uint32_t *trace_spill = nullptr; size_t trace_spill_words = 0;      // k_trace: deep stack entries
@@ -194,6 +196,7 @@ struct Workspace {
     hipEvent_t tev[3] = {};              // timing: bounce loop begin / end, film end
     bool have_events = false;
     std::vector<hipEvent_t> prof_ev;     // desc->profile: begin / end events of the split pipeline's launches, reused pass after pass
+    std::vector<hipEvent_t> film_ev;     // begin / end events of the film splats of a render
 
     void release() {
         for (int k = 0; k < 2; ++k) {
@@ -209,6 +212,10 @@ struct Workspace {
         (void) hipFree(moment_film); moment_film = nullptr; moment_pixels = 0;
         (void) hipFree(film_partials); film_partials = nullptr; film_partial_floats = 0;
         cursor_pix = cursor_rem = nullptr; (void) hipFree(out_rgba); (void) hipFree(out_pos);
+        (void) hipFree(out_rgba2); (void) hipFree(out_pos2); out_rgba2 = nullptr; out_pos2 = nullptr; pass_cap2 = 0;
+        if (film_stream) (void) hipStreamDestroy(film_stream);
+        film_stream = nullptr;
+        for (auto &e : film_done) { if (e) (void) hipEventDestroy(e); e = nullptr; }
         cursor = cursor_end = wave_stats = nullptr; out_rgba = nullptr; out_pos = nullptr;
         if (h_counts) (void) hipHostFree(h_counts);
         if (h_cursor) (void) hipHostFree(h_cursor);
@@ -221,6 +228,8 @@ struct Workspace {
         have_events = false;
         for (auto &e : prof_ev) (void) hipEventDestroy(e);
         prof_ev.clear();
+        for (auto &e : film_ev) (void) hipEventDestroy(e);
+        film_ev.clear();
         n_waves = seg_cap = 0; pass_cap = 0;
     }
 };
@@ -310,7 +319,8 @@ struct mtsamd_scene {
     std::vector<DevBsdf> bsdfs;
     std::vector<DevEmitter> emitters;
     float4 *d_nodes = nullptr, *d_tris = nullptr;
-    uint4 *d_qnodes = nullptr;
+    uint4 *d_qnodes = nullptr, *d_wnodes = nullptr;
+    StackEntry *d_walk_spill = nullptr;
     float *d_tri_pos = nullptr, *d_tri_nrm = nullptr, *d_tri_uv = nullptr;
     uint32_t *d_prim_shape = nullptr;
     DevShape *d_shapes = nullptr; DevBsdf *d_bsdfs = nullptr; DevEmitter *d_emitters = nullptr;
@@ -346,7 +356,7 @@ void mtsamd_scene_destroy(mtsamd_scene *s) {
     if (!s) return;
     (void) hipSetDevice(s->device);
     s->ws.release();
-    (void) hipFree(s->d_nodes); (void) hipFree(s->d_qnodes); (void) hipFree(s->d_tris); (void) hipFree(s->d_tri_pos); (void) hipFree(s->d_tri_nrm); (void) hipFree(s->d_tri_uv);
+    (void) hipFree(s->d_nodes); (void) hipFree(s->d_qnodes); (void) hipFree(s->d_wnodes); (void) hipFree(s->d_walk_spill); (void) hipFree(s->d_tris); (void) hipFree(s->d_tri_pos); (void) hipFree(s->d_tri_nrm); (void) hipFree(s->d_tri_uv);
     (void) hipFree(s->d_prim_shape); (void) hipFree(s->d_shapes); (void) hipFree(s->d_bsdfs); (void) hipFree(s->d_emitters);
     (void) hipFree(s->d_area_pmf); (void) hipFree(s->d_area_cdf); (void) hipFree(s->d_rough_tables);
     (void) hipFree(s->d_env_texels); (void) hipFree(s->d_env_warp); (void) hipFree(s->d_envmap); (void) hipFree(s->d_flat); (void) hipFree(s->d_pairs);
@@ -672,6 +682,8 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     std::memcpy(nodes.data(), s->bvh.nodes.data(), s->bvh.nodes.size() * sizeof(float));
     std::vector<uint4> qnodes(2 * (size_t) s->bvh.n_nodes);
     std::memcpy(qnodes.data(), s->bvh.qnodes.data(), s->bvh.qnodes.size() * sizeof(uint32_t));
+    std::vector<uint4> wnodes(4 * (size_t) s->bvh.n_wnodes);
+    std::memcpy(wnodes.data(), s->bvh.wnodes.data(), s->bvh.wnodes.size() * sizeof(uint32_t));
     std::memcpy(tris.data(), s->bvh.tris.data(), s->bvh.tris.size() * sizeof(float));
     // flat scenes: 64-byte records in primitive order (device_scene.h)
     uint32_t flat_max = kFlatMaxPrims;
@@ -706,7 +718,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         pair_recs[5 * k + 4] = make_float4(a[8], b[8], 0.0f, 0.0f);
     }
     int rc = 0;
-    if ((rc = upload(&s->d_textures, s->textures)) || (rc = upload(&s->d_flat, flat_recs)) || (rc = upload(&s->d_pairs, pair_recs)) || (rc = upload(&s->d_nodes, nodes)) || (rc = upload(&s->d_qnodes, qnodes)) || (rc = upload(&s->d_tris, tris)) || (rc = upload(&s->d_tri_pos, tri_pos)) ||
+    if ((rc = upload(&s->d_textures, s->textures)) || (rc = upload(&s->d_flat, flat_recs)) || (rc = upload(&s->d_pairs, pair_recs)) || (rc = upload(&s->d_nodes, nodes)) || (rc = upload(&s->d_qnodes, qnodes)) || (rc = upload(&s->d_wnodes, wnodes)) || (rc = upload(&s->d_tris, tris)) || (rc = upload(&s->d_tri_pos, tri_pos)) ||
         (rc = upload(&s->d_tri_nrm, tri_nrm)) || (rc = upload(&s->d_tri_uv, tri_uv)) || (rc = upload(&s->d_prim_shape, prim_shape)) ||
         (rc = upload(&s->d_shapes, shapes)) || (rc = upload(&s->d_bsdfs, s->bsdfs)) || (rc = upload(&s->d_emitters, s->emitters)) ||
         (rc = upload(&s->d_area_pmf, area_pmf)) || (rc = upload(&s->d_area_cdf, area_cdf))) {
@@ -779,7 +791,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         }
     }
     SceneView &v = s->view;
-    v.nodes = s->d_nodes; v.qnodes = s->d_qnodes; v.tris = s->d_tris; v.root = s->bvh.root;
+    v.nodes = s->d_nodes; v.qnodes = s->d_qnodes; v.wnodes = s->d_wnodes; v.wroot = s->bvh.wroot; v.tris = s->d_tris; v.root = s->bvh.root;
     for (int k = 0; k < 3; ++k) { v.q_lo[k] = s->bvh.q_lo[k]; v.q_step[k] = s->bvh.q_step[k]; }
     v.n_nodes = s->bvh.n_nodes; v.n_slots = s->bvh.n_slots; v.n_prims = s->n_prims;
     // LDS residency: flat scenes keep everything in LDS (see flat_recs below).  For hierarchy scenes staging the
@@ -787,7 +799,16 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     // 3.8-4.8 Gray/s on a 261 k-triangle mesh -- the 24 KB cost occupancy and the LDS/global select compiles to
     // generic (flat) loads, while the top levels stay L1/L2-resident anyway.  Only the traversal stack lives in LDS.
     v.lds_nodes = 0; v.lds_slots = 0;      // nodes and triangle slots are always read through L1/L2
-    v.stack_depth = std::max<uint32_t>(s->bvh.depth, 2);
+    // BVH2: one deferred subtree per level; BVH4: up to three
+    v.stack_depth = MTS_BVH4 ? 3u * s->bvh.wdepth + 2u : std::max<uint32_t>(s->bvh.depth, 2);
+    // standalone ray streams: 8 persistent workgroups per CU, the first 12 (BVH2: 16) stack entries of a lane in LDS
+    v.walk_lds_depth = std::min<uint32_t>(v.stack_depth, MTS_BVH4 ? 12u : 16u);
+    v.walk_blocks = 8u * (uint32_t) s->cu_count;
+    if (!flat && v.stack_depth > v.walk_lds_depth) {
+        const size_t entries = (size_t) v.walk_blocks * (v.stack_depth - v.walk_lds_depth) * 256u;
+        if (hipMalloc((void **) &s->d_walk_spill, entries * sizeof(StackEntry)) != hipSuccess) { mtsamd_scene_destroy(s); return fail(MTSAMD_ERR_NOMEM, "traversal spill area"); }
+    }
+    v.walk_spill = s->d_walk_spill;
     v.tri_pos = s->d_tri_pos; v.tri_nrm = any_nrm ? s->d_tri_nrm : nullptr; v.tri_uv = any_uv ? s->d_tri_uv : nullptr;
     v.prim_shape = s->d_prim_shape; v.shapes = s->d_shapes; v.bsdfs = s->d_bsdfs;
     v.emitters = s->d_emitters; v.n_emitters = desc->emitter_count;
@@ -1002,6 +1023,7 @@ struct Job {
     bool split = false, shadow_queue = false, shadow_ring = false;
     double stage_ms[3] = { 0.0, 0.0, 0.0 }; uint64_t stage_launches[3] = { 0, 0, 0 };      // desc->profile: k_trace<closest>, k_shade, k_trace<any>
     uint64_t passes = 0;
+    int buf = 0;                 // sample stream buffer this pass writes
     std::chrono::steady_clock::time_point t_start;       // m_render_timer (integrator.cpp:107)
     bool timed_out = false;
     bool expired() const {                               // should_stop() without m_stop (integrator.h:143-146)
@@ -1032,7 +1054,7 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     p.sv = j.s->view; p.cam = j.cam;
     if (p.cam.aperture_radius > 0.0f) p.sv.general = 1u;      // thin lens: aperture sampling lives in the general kernels
     p.cursor = w.cursor; p.cursor_end = w.cursor_end; p.wave_stats = w.wave_stats;
-    p.out_rgba = w.out_rgba; p.out_pos = w.out_pos;
+    p.out_rgba = j.buf ? w.out_rgba2 : w.out_rgba; p.out_pos = j.buf ? w.out_pos2 : w.out_pos;
     p.cursor_pix = w.cursor_pix; p.cursor_rem = w.cursor_rem; p.count_shadow = w.count_shadow;
     p.first_ordinal = first; p.base_seed = j.d->seed;
     p.rows = j.rows; p.store_xyz = j.store_xyz;
@@ -1046,7 +1068,7 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
         const size_t words = trace_spill_words(p.sv, nw);
         if (words > w.trace_spill_words) {
             (void) hipFree(w.trace_spill); w.trace_spill = nullptr; w.trace_spill_words = 0;
-            HIP_TRY(hipMalloc((void **) &w.trace_spill, words * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc((void **) &w.trace_spill, std::max<size_t>(words, 1) * sizeof(uint32_t)));
             w.trace_spill_words = words;
         }
         p.trace_lds_depth = trace_lds_depth(p.sv); p.trace_spill = w.trace_spill;
@@ -1106,6 +1128,7 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     };
     auto sync_all = [&]() {
         (void) hipStreamSynchronize(j.stream);
+        if (w.film_stream) (void) hipStreamSynchronize(w.film_stream);
         if (w.stream2) (void) hipStreamSynchronize(w.stream2);
         for (auto &ps : w.part_stream) if (ps) (void) hipStreamSynchronize(ps);
     };
@@ -1215,9 +1238,10 @@ int setup_job(Job &j, mtsamd_scene *s, const mtsamd_render_desc *d, hipStream_t 
     j.s = s; j.d = d; j.stream = stream;
     if (int rc = make_camera(*d, j.cam)) return rc;
     if (int rc = make_filter(d->rfilter, d->rfilter_param, d->rfilter_param2, d->rfilter_analytic, j.filter)) return rc;
-    // One pass holds up to 2^28 camera samples (6 GiB of sample stream): every pass ends with a drain phase in which the
-    // pool empties, so fewer, larger passes waste less (cbox 1024^2 @ 256 spp: 4 passes of 2^26 -> 1 pass: +7 %).
-    uint64_t pass_limit = 1ull << 28;
+    // One pass holds up to 2^30 camera samples (24 GiB of sample stream; a second buffer of that size lets the film splat of a pass run
+    // beside the tracing of the next): every pass ends with a drain phase in which the pool empties, so fewer, larger passes waste
+    // less (cbox 1024^2 @ 256 spp: 4 passes of 2^26 -> 1 pass: +7 %).
+    uint64_t pass_limit = 1ull << 30;
     if (const char *e = getenv("MTSAMD_PASS_LOG2")) pass_limit = 1ull << std::min(31, std::max(10, atoi(e)));      // experiment switch
     // pipeline 0: one kernel with the in-kernel shadow ring (4) for LDS-resident (flat) scenes, split kernels (2) for hierarchy
     // scenes; 1 / 2 / 3 / 4 force one schedule
@@ -1328,23 +1352,58 @@ int mtsamd_render(mtsamd_scene *s, const mtsamd_render_desc *d, float *film, uin
         HIP_TRY(hipMemsetAsync(w.moment_film, 0, 2 * 5 * n_pixels * sizeof(float), stream));
         film_target = w.moment_film; film_sq = w.moment_film + 5 * n_pixels;
     }
-    for (uint64_t lr0 = 0; lr0 < (uint64_t) rows.local_rows; lr0 += rows_per_pass) {
+    // Several passes: the film splat of pass k runs on its own stream while pass k + 1 is traced into the other sample stream buffer.
+    Workspace &ws = s->ws;
+    const uint64_t n_passes = ((uint64_t) rows.local_rows + rows_per_pass - 1) / rows_per_pass;
+    const bool overlap = n_passes > 1;
+    hipStream_t fstream = stream;
+    if (overlap) {
+        const uint64_t cap2 = std::min<uint64_t>(rows_per_pass * per_row, j.pass_cap);
+        if (ws.pass_cap2 < cap2) {
+            (void) hipFree(ws.out_rgba2); (void) hipFree(ws.out_pos2); ws.out_rgba2 = nullptr; ws.out_pos2 = nullptr; ws.pass_cap2 = 0;
+            HIP_TRY(hipMalloc((void **) &ws.out_rgba2, cap2 * sizeof(float4)));
+            HIP_TRY(hipMalloc((void **) &ws.out_pos2, cap2 * sizeof(float2)));
+            ws.pass_cap2 = cap2;
+        }
+        if (!ws.film_stream) HIP_TRY(hipStreamCreateWithFlags(&ws.film_stream, hipStreamNonBlocking));
+        for (auto &e : ws.film_done) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        fstream = ws.film_stream;
+        // the film (and the moment scratch films) may still be written by work queued on `stream` before this call
+        HIP_TRY(hipEventRecord(ws.film_done[0], stream));
+        HIP_TRY(hipStreamWaitEvent(fstream, ws.film_done[0], 0));
+    }
+    if (tiled) {          // scratch tiles of the largest pass
+        FilmParams f{};
+        f.crop_w = d->crop_width; f.pass_rows = (int32_t) std::min<uint64_t>(rows_per_pass, (uint64_t) rows.local_rows); f.tile_h = film_tile_h;
+        film_tile_grid(f);
+        const size_t need = film_partial_floats(f);
+        if (need > ws.film_partial_floats) {
+            (void) hipFree(ws.film_partials); ws.film_partials = nullptr; ws.film_partial_floats = 0;
+            HIP_TRY(hipMalloc((void **) &ws.film_partials, need * sizeof(float)));
+            ws.film_partial_floats = need;
+        }
+    }
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> film_ev;      // timing of the splats on their stream
+    int rc_loop = 0;
+    uint64_t pass_index = 0;
+    for (uint64_t lr0 = 0; lr0 < (uint64_t) rows.local_rows; lr0 += rows_per_pass, ++pass_index) {
         const uint64_t nrows = std::min<uint64_t>(rows_per_pass, (uint64_t) rows.local_rows - lr0);
         const uint64_t a = lr0 * per_row, n = nrows * per_row;
         j.plane_pix0 = (uint32_t) (lr0 * (uint64_t) d->crop_width);
-        // sample-stream layout: pixel-major measured faster overall than one plane per sample number
-        // (k_bounce's scattered 16-B result writes cost more than the film tiles' strided reads gain)
-        constexpr bool kPlaneLayout = false;
-        j.plane_pixels = (tiled && kPlaneLayout) ? (uint32_t) (nrows * (uint64_t) d->crop_width) : 0u;
+        j.plane_pixels = 0u;          // sample stream: pixel-major
+        j.buf = overlap ? (int) (pass_index & 1u) : 0;
         if (j.expired()) { j.timed_out = true; break; }
+        // the buffer this pass writes was read by the splat of pass k - 2
+        if (overlap && pass_index >= 2) HIP_TRY(hipStreamWaitEvent(stream, ws.film_done[j.buf], 0));
         if (int rc = trace_pass(j, a, n)) {
             if (rc > 0) break;               // timeout inside the pass: its samples are dropped
-            return rc;
+            rc_loop = rc;
+            break;
         }
         j.passes += 1;
-        // Film::put: splat this pass into the film rows its samples can reach
+        // Film::put: splat this pass into the film rows its samples can reach (trace_pass returns when its samples are complete)
         FilmParams f{};
-        f.out_rgba = s->ws.out_rgba; f.out_pos = s->ws.out_pos; f.film = film_target; f.filter = j.filter;
+        f.out_rgba = j.buf ? ws.out_rgba2 : ws.out_rgba; f.out_pos = j.buf ? ws.out_pos2 : ws.out_pos; f.film = film_target; f.filter = j.filter;
         f.first_ordinal = a; f.n_samples = n; f.spp = d->sample_count; f.rows = rows;
         f.plane_pix0 = j.plane_pix0; f.plane_pixels = j.plane_pixels;
         f.crop_x = d->crop_x; f.crop_y = d->crop_y; f.crop_w = d->crop_width; f.crop_h = d->crop_height;
@@ -1360,27 +1419,37 @@ int mtsamd_render(mtsamd_scene *s, const mtsamd_render_desc *d, float *film, uin
         if (tiled) {
             f.pass_lr0 = (int32_t) lr0; f.pass_rows = (int32_t) nrows; f.tile_h = film_tile_h;
             film_tile_grid(f);
-            Workspace &w = s->ws;
-            const size_t need = film_partial_floats(f);
-            if (need > w.film_partial_floats) {
-                (void) hipFree(w.film_partials); w.film_partials = nullptr; w.film_partial_floats = 0;
-                HIP_TRY(hipMalloc((void **) &w.film_partials, need * sizeof(float)));
-                w.film_partial_floats = need;
-            }
-            f.partials = w.film_partials;
+            f.partials = ws.film_partials;
         }
-        if (tiled) HIP_TRY(launch_film_tiles(f, stream));
-        else HIP_TRY(launch_film_gather(f, stream));
+        if (ws.film_ev.size() < 2 * (film_ev.size() + 1)) {
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            HIP_TRY(hipEventCreate(&e0)); ws.film_ev.push_back(e0);
+            HIP_TRY(hipEventCreate(&e1)); ws.film_ev.push_back(e1);
+        }
+        film_ev.push_back({ ws.film_ev[2 * film_ev.size()], ws.film_ev[2 * film_ev.size() + 1] });
+        HIP_TRY(hipEventRecord(film_ev.back().first, fstream));
+        if (tiled) HIP_TRY(launch_film_tiles(f, fstream));
+        else HIP_TRY(launch_film_gather(f, fstream));
         if (film_sq) {
-            HIP_TRY(launch_square_stream(s->ws.out_rgba, n, stream));
+            HIP_TRY(launch_square_stream(const_cast<float4 *>(f.out_rgba), n, fstream));
             f.film = film_sq;
-            if (tiled) HIP_TRY(launch_film_tiles(f, stream));
-            else HIP_TRY(launch_film_gather(f, stream));
+            if (tiled) HIP_TRY(launch_film_tiles(f, fstream));
+            else HIP_TRY(launch_film_gather(f, fstream));
         }
-        HIP_TRY(hipEventRecord(s->ws.tev[2], stream));
-        HIP_TRY(hipEventSynchronize(s->ws.tev[2]));
+        HIP_TRY(hipEventRecord(film_ev.back().second, fstream));
+        if (overlap) HIP_TRY(hipEventRecord(ws.film_done[j.buf], fstream));
+    }
+    if (overlap) {          // `stream` continues after the last splat
+        HIP_TRY(hipEventRecord(ws.film_done[0], fstream));
+        HIP_TRY(hipStreamWaitEvent(stream, ws.film_done[0], 0));
+        HIP_TRY(hipStreamSynchronize(fstream));
+    } else {
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    if (rc_loop) return rc_loop;
+    for (auto &e : film_ev) {
         float fms = 0.0f;
-        HIP_TRY(hipEventElapsedTime(&fms, s->ws.tev[1], s->ws.tev[2]));
+        HIP_TRY(hipEventElapsedTime(&fms, e.first, e.second));
         j.film_ms += fms;
     }
     if (film_sq) HIP_TRY(launch_moment_pack(film_target, film_sq, film, n_pixels, stream));

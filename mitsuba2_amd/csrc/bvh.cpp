@@ -211,10 +211,11 @@ void build_bvh(const float *tri_pos, uint32_t n_prims, uint32_t max_leaf, BvhOut
         }
         return kLeafFlag | (n.count << kLeafCountShift) | start;
     };
+    std::vector<uint32_t> leaf_ref(b.nodes.size(), 0u);
     auto child_ref = [&](int32_t t) -> uint32_t {
         const TmpNode &n = b.nodes[t];
         if (n.left >= 0) return (uint32_t) inner_index[t];
-        return emit_leaf(n);
+        return leaf_ref[t] = emit_leaf(n);
     };
     for (size_t i = 0; i < bfs.size(); ++i) {
         const TmpNode &n = b.nodes[bfs[i]];
@@ -265,6 +266,51 @@ void build_bvh(const float *tri_pos, uint32_t n_prims, uint32_t max_leaf, BvhOut
     }
     if (bfs.empty()) out.root = emit_leaf(b.nodes[root]);   // whole scene is one leaf
     else out.root = 0;
+    // ---- BVH4: collapse (open the child of largest surface area until four children), BFS order, same grid
+    out.wnodes.clear(); out.wroot = out.root; out.n_wnodes = 0; out.wdepth = 1;
+    if (!bfs.empty()) {
+        double glo[3], gstep[3];
+        for (int k = 0; k < 3; ++k) { glo[k] = (double) out.q_lo[k]; gstep[k] = (double) out.q_step[k]; }
+        auto qlo = [&](float v, int k) -> uint32_t { return (uint32_t) std::min(65535.0, std::max(0.0, std::floor(((double) v - glo[k]) / gstep[k] - 0.125))); };
+        auto qhi = [&](float v, int k) -> uint32_t { return (uint32_t) std::min(65535.0, std::max(0.0, std::ceil(((double) v - glo[k]) / gstep[k] + 0.125))); };
+        struct Wide { int32_t child[4]; int n; uint32_t depth; };
+        std::vector<Wide> wide;
+        std::vector<int32_t> wide_of(b.nodes.size(), -1);      // BVH2 inner node -> wide node that replaces it
+        std::queue<std::pair<int32_t, uint32_t>> q;
+        q.push({ root, 1u });
+        wide_of[root] = 0; wide.push_back(Wide{});
+        while (!q.empty()) {
+            const int32_t t = q.front().first; const uint32_t depth = q.front().second; q.pop();
+            Wide wn{}; wn.depth = depth;
+            wn.child[0] = b.nodes[t].left; wn.child[1] = b.nodes[t].right; wn.n = 2;
+            while (wn.n < 4) {
+                int best = -1; double best_area = -1.0;
+                for (int c = 0; c < wn.n; ++c)
+                    if (b.nodes[wn.child[c]].left >= 0 && b.nodes[wn.child[c]].box.area() > best_area) { best = c; best_area = b.nodes[wn.child[c]].box.area(); }
+                if (best < 0) break;
+                const int32_t open = wn.child[best];
+                wn.child[best] = b.nodes[open].left; wn.child[wn.n++] = b.nodes[open].right;
+            }
+            for (int c = 0; c < wn.n; ++c)
+                if (b.nodes[wn.child[c]].left >= 0) { wide_of[wn.child[c]] = (int32_t) wide.size(); wide.push_back(Wide{}); q.push({ wn.child[c], depth + 1 }); }
+            wide[wide_of[t]] = wn;
+            out.wdepth = std::max(out.wdepth, depth);
+        }
+        out.n_wnodes = (uint32_t) wide.size();
+        out.wnodes.assign(16 * wide.size(), 0u);
+        for (size_t i = 0; i < wide.size(); ++i) {
+            uint32_t *w = out.wnodes.data() + 16 * i;
+            for (int c = 0; c < 4; ++c) {
+                if (c >= wide[i].n) { w[4 * c] = w[4 * c + 1] = w[4 * c + 2] = 65535u; w[4 * c + 3] = 0x7fffffffu; continue; }      // lo = 65535, hi = 0
+                const int32_t t = wide[i].child[c];
+                float lo[3], hi[3];
+                padded(b.nodes[t].box, extent, lo, hi);
+                for (int k = 0; k < 3; ++k) w[4 * c + k] = qlo(lo[k], k) | (qhi(hi[k], k) << 16);
+                w[4 * c + 3] = b.nodes[t].left >= 0 ? (uint32_t) wide_of[t] : leaf_ref[t];
+            }
+        }
+        out.wroot = 0;
+    }
     out.n_nodes = (uint32_t) bfs.size();
     out.n_slots = slot;
     out.depth = b.max_depth + 1;

@@ -15,6 +15,10 @@ struct BvhOutput {
     std::vector<float> nodes;      // 16 floats per node (see device_scene.h for the layout)
     std::vector<uint32_t> qnodes;  // 8 words per node: the same child boxes on a 16-bit grid over the scene box, rounded outward
     float q_lo[3] = { 0, 0, 0 }, q_step[3] = { 1, 1, 1 };      // grid origin and cell size per axis
+    // BVH4 collapsed from the BVH2 (the child of largest surface area is opened until a node has four children): 16 words per node,
+    // per child (lo | hi << 16) x, y, z on the grid + child reference; an absent child has reference 0x7fffffff and an inverted box
+    std::vector<uint32_t> wnodes;
+    uint32_t wroot = 0, n_wnodes = 0, wdepth = 0;
     std::vector<float> tris;       // 12 floats per triangle slot
     uint32_t root = 0;             // child reference of the root
     uint32_t n_nodes = 0, n_slots = 0, depth = 0;

@@ -25,6 +25,17 @@ constexpr uint32_t kLeafCountShift = 27;
 constexpr uint32_t kLeafStartMask = (1u << kLeafCountShift) - 1u;
 constexpr uint32_t kNoPrim = 0xffffffffu;
 
+#ifndef MTS_BVH4
+#define MTS_BVH4 1
+#endif
+#if MTS_BVH4
+// BVH4 walk: an entry is (child reference, distance at which the ray enters the child's box): a popped subtree whose entry distance
+// lies beyond the closest hit found meanwhile is dropped without touching its node.
+typedef uint2 StackEntry;
+#else
+typedef uint32_t StackEntry;
+#endif
+
 // BVH2 node, 64 B: both child boxes + child references.
 //   q0 = (l.min.x, l.min.y, l.min.z, l.max.x)   q1 = (l.max.y, l.max.z, r.min.x, r.min.y)
 //   q2 = (r.min.z, r.max.x, r.max.y, r.max.z)   q3 = (left ref, right ref, -, -) as bits
@@ -56,6 +67,9 @@ constexpr float kInvFourPi = 0.07957747154594766788f;
 struct SceneView {
     const float4 *nodes;       // 4 per node
     const uint4 *qnodes;       // 2 per node: child boxes on a 16-bit grid (origin q_lo, cell q_step), child references
+    const uint4 *wnodes;       // BVH4 collapsed from the BVH2, 4 per node: per child (x, y, z) = lo | hi << 16 on the same grid, w = child
+                               // reference (kNoNode: no child, its box is inverted); wroot = reference of the root
+    uint32_t wroot;
     float q_lo[3], q_step[3];
     const float4 *tris;        // 3 per slot (leaf order)
     uint32_t root;             // child ref of the root
@@ -63,6 +77,10 @@ struct SceneView {
     uint32_t lds_nodes;        // nodes [0, lds_nodes) are staged in LDS
     uint32_t lds_slots;        // triangle slots [0, lds_slots) are staged in LDS
     uint32_t stack_depth;      // entries per lane
+    // standalone ray queries (k_ray_walk): LDS part of the per-lane stack, global spill area [workgroup][entry][thread] for the rest,
+    // number of (persistent) workgroups the spill area is sized for
+    uint32_t walk_lds_depth, walk_blocks;
+    StackEntry *walk_spill;
     const float *tri_pos;      // 9 per prim (p0,p1,p2)
     const float *tri_nrm;      // 9 per prim or nullptr
     const float *tri_uv;       // 6 per prim or nullptr
@@ -146,7 +164,7 @@ inline size_t lds_bytes(const SceneView &sv, uint32_t block) {
     if (sv.flat)
         return (size_t) 64 * sv.n_prims + (size_t) 80 * (sv.n_pairs + 1) + sizeof(DevShape) * sv.n_shapes + sizeof(DevBsdf) * sv.n_bsdfs +
                sizeof(DevEmitter) * sv.n_emitters + (size_t) 8 * sv.n_prims;
-    return (size_t) 64 * sv.lds_nodes + (size_t) 48 * sv.lds_slots + (size_t) 4 * sv.stack_depth * block;
+    return (size_t) 64 * sv.lds_nodes + (size_t) 48 * sv.lds_slots + sizeof(StackEntry) * sv.stack_depth * block;
 }
 
 #ifndef MTS_FLAT_UNROLL
@@ -222,22 +240,113 @@ MTS_DEV void walk_begin(BvhWalk &w, const SceneView &sv, f3 o, f3 d, float mint,
     w.o_q = o; w.noi = o; w.far = true; w.sel[0] = w.sel[1] = w.sel[2] = 0u;
 #endif
     w.mint = mint; w.maxt = maxt; w.best = maxt;
-    w.sp = 0; w.cur = sv.root; w.best_prim = kNoPrim; w.found = false;
+    w.sp = 0; w.cur = MTS_BVH4 ? sv.wroot : sv.root; w.best_prim = kNoPrim; w.found = false;
 }
 // One round of the "while-while" traversal: the lane descends until it holds a leaf (or nothing), then the wave tests leaves
 // together -- the two phases are not interleaved lane by lane, which keeps more lanes busy in each of them.  ANY: the walk
 // ends (cur = kNoNode, found = true) at the first hit.
 // Traversal stack of one lane: the first `lds_depth` entries live in LDS ([depth][lane], conflict-free), deeper ones -- rare:
 // a walk seldom defers more than a dozen subtrees -- in a global spill area, so that the LDS footprint does not cap occupancy.
-struct WalkStack { uint32_t *lds; uint32_t stride, lds_depth; uint32_t *spill; uint32_t spill_stride; };
-MTS_DEV void stack_push(const WalkStack &st, uint32_t sp, uint32_t v) {
+struct WalkStack { StackEntry *lds; uint32_t stride, lds_depth; StackEntry *spill; uint32_t spill_stride; };
+MTS_DEV void stack_push(const WalkStack &st, uint32_t sp, StackEntry v) {
     if (sp < st.lds_depth) st.lds[sp * st.stride] = v;
     else st.spill[(size_t) (sp - st.lds_depth) * st.spill_stride] = v;
 }
-MTS_DEV uint32_t stack_pop(const WalkStack &st, uint32_t sp) {
+MTS_DEV StackEntry stack_pop(const WalkStack &st, uint32_t sp) {
     return sp < st.lds_depth ? st.lds[sp * st.stride] : st.spill[(size_t) (sp - st.lds_depth) * st.spill_stride];
 }
 
+#if MTS_BVH4
+// Triangle tests of the leaf a lane holds (all lanes of the wave together), then the next subtree from the stack.
+template <bool ANY>
+MTS_DEV void walk_leaf(BvhWalk &w, const SceneView &sv, uint32_t cur, uint32_t &tri_tests) {
+    const uint32_t start = cur & kLeafStartMask, count = (cur >> kLeafCountShift) & 0xfu;
+    for (uint32_t i = 0; i < count; ++i) {
+        const float4 *p = sv.tris + 3u * (start + i);
+        const float4 t0 = p[0], t1 = p[1], t2 = p[2];
+        float u, v, t;
+        ++tri_tests;
+        if (tri_test(mk3(t0.x, t0.y, t0.z), mk3(t0.w, t1.x, t1.y), mk3(t1.z, t1.w, t2.x), w.o, w.d, w.mint, w.maxt, u, v, t)) {
+            if (ANY) { w.found = true; return; }
+            const uint32_t prim = __float_as_uint(t2.y);
+            if (!w.found || t < w.best || (t == w.best && prim > w.best_prim)) {
+                w.found = true; w.best = t; w.best_prim = prim;
+                w.hit.t = t; w.hit.prim = prim; w.hit.u = u; w.hit.v = v;
+            }
+        }
+    }
+}
+
+// One round of the "while-while" traversal over the BVH4: the lane descends until it holds a leaf (or nothing), then the wave tests
+// leaves together.  A step loads one 64-byte node, tests the four child boxes (per child: 3 v_perm_b32, 6 cvt, 6 fma, min3 / max3),
+// sorts the hit children by entry distance (5 compare-exchanges), continues with the nearest and pushes the others, farthest first,
+// together with their entry distances.
+template <bool ANY, bool FAR = true>
+MTS_DEV void walk_round(BvhWalk &w, const SceneView &sv, const WalkStack &st, uint32_t &tri_tests) {
+    uint32_t cur = w.cur, sp = w.sp;
+    const f3 inv = w.inv;
+    constexpr float kInf = __builtin_inff();
+    // next subtree from the stack whose entry distance is not beyond the closest hit
+    auto pop_next = [&]() {
+        cur = kNoNode;
+        while (sp) {
+            --sp;
+            const StackEntry e = stack_pop(st, sp);
+            if (__uint_as_float(e.y) <= w.best) { cur = e.x; break; }
+        }
+    };
+    while (true) {
+        const bool inner = (int32_t) cur >= 0 && cur != kNoNode;
+        const uint64_t mi = __ballot(inner);
+        if (mi == 0ull) break;
+        constexpr int kT = ANY ? MTS_WALK_T_ANY : MTS_WALK_T;
+        if (kT > 0 && __popcll(mi) < kT && __ballot((int32_t) cur < 0) != 0ull) break;
+        if (!inner) continue;
+        const f3 oq = w.o_q;
+        const f3 noi = FAR ? mk3(fminf(2.4e-7f * fabsf(oq.x * inv.x), 1.0e30f), fminf(2.4e-7f * fabsf(oq.y * inv.y), 1.0e30f),
+                                 fminf(2.4e-7f * fabsf(oq.z * inv.z), 1.0e30f)) : w.noi;
+        const uint4 *node = sv.wnodes + 4u * cur;
+        const uint4 c0 = node[0], c1 = node[1], c2 = node[2], c3 = node[3];
+        auto slab_n = [&](uint32_t q, float o1, float i1, float n1) -> float {
+            return FAR ? fmaf((float) q - o1, i1, -n1) : fmaf((float) q, i1, n1);
+        };
+        auto slab_f = [&](uint32_t q, float o1, float i1, float n1) -> float {
+            return FAR ? fmaf((float) q - o1, i1, n1) : fmaf((float) q, i1, n1);
+        };
+        // entry distance of the ray into a child box, +inf if it misses (an absent child has an inverted box)
+        auto child = [&](const uint4 &c) -> float {
+            const uint32_t px = __builtin_amdgcn_perm(c.x, c.x, w.sel[0]), py = __builtin_amdgcn_perm(c.y, c.y, w.sel[1]),
+                           pz = __builtin_amdgcn_perm(c.z, c.z, w.sel[2]);
+            const float tn = fmaxf(fmaxf(slab_n(px & 0xffffu, oq.x, inv.x, noi.x), slab_n(py & 0xffffu, oq.y, inv.y, noi.y)),
+                                   fmaxf(slab_n(pz & 0xffffu, oq.z, inv.z, noi.z), w.mint));
+            const float tf = fminf(fminf(slab_f(px >> 16, oq.x, inv.x, noi.x), slab_f(py >> 16, oq.y, inv.y, noi.y)),
+                                   fminf(slab_f(pz >> 16, oq.z, inv.z, noi.z), w.best));
+            return tn <= tf ? tn : kInf;
+        };
+        float t0 = child(c0), t1 = child(c1), t2 = child(c2), t3 = child(c3);
+        uint32_t r0 = c0.w, r1 = c1.w, r2 = c2.w, r3 = c3.w;
+        // sorting network (0,1)(2,3)(0,2)(1,3)(1,2): ascending entry distance, misses (+inf) last
+        auto cswap = [](float &ta, uint32_t &ra, float &tb, uint32_t &rb) {
+            const bool s = tb < ta;
+            const float tlo = s ? tb : ta, thi = s ? ta : tb;
+            const uint32_t rlo = s ? rb : ra, rhi = s ? ra : rb;
+            ta = tlo; tb = thi; ra = rlo; rb = rhi;
+        };
+        cswap(t0, r0, t1, r1); cswap(t2, r2, t3, r3); cswap(t0, r0, t2, r2); cswap(t1, r1, t3, r3); cswap(t1, r1, t2, r2);
+        if (t3 < kInf) { stack_push(st, sp, make_uint2(r3, __float_as_uint(t3))); ++sp; }
+        if (t2 < kInf) { stack_push(st, sp, make_uint2(r2, __float_as_uint(t2))); ++sp; }
+        if (t1 < kInf) { stack_push(st, sp, make_uint2(r1, __float_as_uint(t1))); ++sp; }
+        if (t0 < kInf) cur = r0;
+        else pop_next();
+    }
+    if (cur & kLeafFlag) {
+        walk_leaf<ANY>(w, sv, cur, tri_tests);
+        if (ANY && w.found) { w.cur = kNoNode; w.sp = 0; return; }
+        pop_next();
+    }
+    w.cur = cur; w.sp = sp;
+}
+#else
 template <bool ANY, bool FAR = true>
 MTS_DEV void walk_round(BvhWalk &w, const SceneView &sv, const WalkStack &st, uint32_t &tri_tests) {
     uint32_t cur = w.cur, sp = w.sp;
@@ -338,12 +447,14 @@ MTS_DEV void walk_round(BvhWalk &w, const SceneView &sv, const WalkStack &st, ui
     w.cur = cur; w.sp = sp;
 }
 
+#endif
+
 template <bool ANY>
 MTS_DEV bool traverse_bvh(const SceneView &sv, const LdsView &lds, f3 o, f3 d, float mint, float maxt,
                           Hit &hit, uint32_t &tri_tests) {
     BvhWalk w;
     walk_begin(w, sv, o, d, mint, maxt);
-    const WalkStack st = { lds.stack + threadIdx.x, lds.stride, 0xffffffffu, nullptr, 0u };      // whole stack in LDS
+    const WalkStack st = { reinterpret_cast<StackEntry *>(lds.stack) + threadIdx.x, lds.stride, 0xffffffffu, nullptr, 0u };      // whole stack in LDS
     while (w.cur != kNoNode) {
         if (w.far) walk_round<ANY, true>(w, sv, st, tri_tests);
         else walk_round<ANY, false>(w, sv, st, tri_tests);

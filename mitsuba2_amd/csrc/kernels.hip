@@ -1013,7 +1013,7 @@ constexpr uint32_t kShadowGroup = MTS_TRACE_GROUP;
 // LDS part of k_trace's per-lane stack: 16 entries = 16 KB per workgroup, 8 workgroups (32 waves) per CU; a full 25-entry stack
 // (261 k-triangle mesh) caps the CU at 6 workgroups
 #ifndef MTS_TRACE_LDS_DEPTH
-#define MTS_TRACE_LDS_DEPTH 16
+#define MTS_TRACE_LDS_DEPTH (MTS_BVH4 ? 12 : 16)
 #endif
 constexpr uint32_t kTraceLdsDepth = MTS_TRACE_LDS_DEPTH;
 
@@ -1070,8 +1070,8 @@ __global__ __launch_bounds__(kBlock) void k_trace(const RenderParams P) {
         // LDS holds the first P.trace_lds_depth stack entries of every lane; deeper entries spill to this workgroup's slice of
         // P.trace_spill ([entry][thread])
         const uint32_t spill_depth = P.sv.stack_depth > P.trace_lds_depth ? P.sv.stack_depth - P.trace_lds_depth : 0u;
-        const WalkStack st = { lds.stack + threadIdx.x, lds.stride, P.trace_lds_depth,
-                               P.trace_spill + ((size_t) (ANY ? (P.n_waves + kShadowGroup - 1u) / kShadowGroup : 0u) + group) * spill_depth * kBlock + threadIdx.x, blockDim.x };
+        const WalkStack st = { reinterpret_cast<StackEntry *>(lds.stack) + threadIdx.x, lds.stride, P.trace_lds_depth,
+                               reinterpret_cast<StackEntry *>(P.trace_spill) + ((size_t) (ANY ? (P.n_waves + kShadowGroup - 1u) / kShadowGroup : 0u) + group) * spill_depth * kBlock + threadIdx.x, blockDim.x };
         BvhWalk w;
         w.cur = kNoNode; w.sp = 0u; w.found = false;
         bool busy = false;                                   // the lane holds a work item
@@ -1129,11 +1129,11 @@ __global__ __launch_bounds__(kBlock) void k_trace(const RenderParams P) {
 #define MTS_TRACE_BLOCK 256
 #endif
 constexpr uint32_t kTraceBlock = MTS_TRACE_BLOCK;      // threads per k_trace workgroup (hierarchy scenes)
-size_t trace_lds_bytes(const SceneView &sv) { return (size_t) 4 * std::min(sv.stack_depth, kTraceLdsDepth) * kTraceBlock; }
+size_t trace_lds_bytes(const SceneView &sv) { return sizeof(StackEntry) * std::min(sv.stack_depth, kTraceLdsDepth) * kTraceBlock; }
 uint32_t trace_lds_depth(const SceneView &sv) { return std::min(sv.stack_depth, kTraceLdsDepth); }
 size_t trace_spill_words(const SceneView &sv, uint32_t n_waves) {
     const uint32_t spill = sv.stack_depth > kTraceLdsDepth ? sv.stack_depth - kTraceLdsDepth : 0u;
-    return (size_t) 2 * ((n_waves + kShadowGroup - 1) / kShadowGroup) * spill * kBlock;      // closest-hit and any-hit launches may overlap
+    return (sizeof(StackEntry) / 4) * (size_t) 2 * ((n_waves + kShadowGroup - 1) / kShadowGroup) * spill * kBlock;      // closest-hit and any-hit launches may overlap
 }
 
 // split pipeline of hierarchy scenes, one stage at a time: 0 = k_trace<closest>, 1 = k_shade, 2 = k_trace<any>.  Stage 2 of one
@@ -1675,18 +1675,25 @@ __global__ __launch_bounds__(kBlock) void k_ray_walk(const SceneView sv, uint64_
                                                      uint32_t *shape, float *u, float *v, uint8_t *hit) {
     extern __shared__ float4 smem[];
     __shared__ uint32_t s_next;
-    if (threadIdx.x == 0) s_next = 0u;
-    __syncthreads();
-    const uint64_t base = (uint64_t) blockIdx.x * kRayChunk;
-    const uint32_t total = (uint32_t) min((uint64_t) kRayChunk, n - base), lane = lane_id();
-    const WalkStack st = { reinterpret_cast<uint32_t *>(smem) + threadIdx.x, kBlock, 0xffffffffu, nullptr, 0u };
+    const uint32_t lane = lane_id();
+    // the first sv.walk_lds_depth stack entries of a lane live in LDS, deeper ones in this workgroup's slice of sv.walk_spill
+    const uint32_t spill_depth = sv.stack_depth > sv.walk_lds_depth ? sv.stack_depth - sv.walk_lds_depth : 0u;
+    const WalkStack st = { reinterpret_cast<StackEntry *>(smem) + threadIdx.x, kBlock, sv.walk_lds_depth,
+                           sv.walk_spill + (size_t) blockIdx.x * spill_depth * kBlock + threadIdx.x, kBlock };
     const LdsView lds = {};
     const Geo<false> geo{ sv, lds };
+    uint32_t tri_tests = 0;
+    const uint64_t n_chunks = (n + kRayChunk - 1) / kRayChunk;
+    for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {      // persistent workgroups: a bounded spill area
+    __syncthreads();
+    if (threadIdx.x == 0) s_next = 0u;
+    __syncthreads();
+    const uint64_t base = chunk * kRayChunk;
+    const uint32_t total = (uint32_t) min((uint64_t) kRayChunk, n - base);
     BvhWalk w;
     w.cur = kNoNode; w.sp = 0u; w.found = false;
     bool busy = false, exhausted = false;
     uint64_t i = 0;
-    uint32_t tri_tests = 0;
     auto retire = [&](uint64_t k, bool found) {
         if (ANY) { hit[k] = found ? 1 : 0; return; }
         t[k] = found ? w.hit.t : __builtin_inff();
@@ -1728,14 +1735,19 @@ __global__ __launch_bounds__(kBlock) void k_ray_walk(const SceneView sv, uint64_
             if (w.cur != kNoNode) walk_round<ANY, false>(w, sv, st, tri_tests);
         }
     }
+    }
 }
+static uint32_t walk_grid(const SceneView &sv, uint64_t n) {
+    return (uint32_t) std::min<uint64_t>((n + kRayChunk - 1) / kRayChunk, sv.walk_blocks);
+}
+static size_t walk_lds(const SceneView &sv) { return sizeof(StackEntry) * std::min(sv.stack_depth, sv.walk_lds_depth) * kBlock; }
 
 hipError_t launch_ray_intersect(const SceneView &sv, uint64_t n, const RayStreams &r, int mode, float *t,
                                 uint32_t *prim, uint32_t *shape, float *u, float *v, float *si26, hipStream_t s) {
     if (n == 0) return hipSuccess;
     size_t lds = bounce_lds_bytes(sv);
     if (mode == 0 && !sv.flat && !si26) {
-        hipLaunchKernelGGL((k_ray_walk<false>), dim3((uint32_t) ((n + kRayChunk - 1) / kRayChunk)), dim3(kBlock), (size_t) 4 * sv.stack_depth * kBlock, s,
+        hipLaunchKernelGGL((k_ray_walk<false>), dim3(walk_grid(sv, n)), dim3(kBlock), walk_lds(sv), s,
                            sv, n, r, t, prim, shape, u, v, (uint8_t *) nullptr);
         return hipGetLastError();
     }
@@ -1753,7 +1765,7 @@ hipError_t launch_ray_intersect(const SceneView &sv, uint64_t n, const RayStream
 hipError_t launch_ray_test(const SceneView &sv, uint64_t n, const RayStreams &r, uint8_t *hit, hipStream_t s) {
     if (n == 0) return hipSuccess;
     if (sv.flat) hipLaunchKernelGGL(k_ray_test<true>, dim3(stream_grid(n)), dim3(kBlock), bounce_lds_bytes(sv), s, sv, n, r, hit);
-    else hipLaunchKernelGGL((k_ray_walk<true>), dim3((uint32_t) ((n + kRayChunk - 1) / kRayChunk)), dim3(kBlock), (size_t) 4 * sv.stack_depth * kBlock, s,
+    else hipLaunchKernelGGL((k_ray_walk<true>), dim3(walk_grid(sv, n)), dim3(kBlock), walk_lds(sv), s,
                             sv, n, r, (float *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, (float *) nullptr, (float *) nullptr, hit);
     return hipGetLastError();
 }

@@ -80,10 +80,11 @@ def test_full_size_mesh_properties(variant):
 
 
 def test_config3_full_size_against_oracle_rows():
-    """BASELINE config 3 as stated: ~250 k triangles, spectral variant, 1920 x 1080 @ 1024 spp = 2.1e9 camera samples in 8 passes
-    of 136 film rows.  The oracle cannot render that (hours); it renders, in wavefront mode with the very same per-sample seeds,
-    the seven film rows 541..547 around the border between passes 4 and 5 (13.8 M samples).  Film rows 543..545 receive splats
-    from exactly those source rows (gaussian radius 2), so there the full-size GPU film and the oracle's film hold the same sum."""
+    """BASELINE config 3 as stated: ~250 k triangles, spectral variant, 1920 x 1080 @ 1024 spp = 2.1e9 camera samples in 2 passes
+    (546 + 534 film rows: a pass holds up to 2^30 samples).  The oracle cannot render that (hours); it renders, in wavefront mode with
+    the very same per-sample seeds, the seven film rows 543..549 around the border between the passes (13.8 M samples).  Film rows
+    545..547 receive splats from exactly those source rows (gaussian radius 2), so there the full-size GPU film and the oracle's film
+    hold the same sum."""
     from mitsuba2_amd import render as R, scenes
     sd = scenes.bumpy_sphere(256, 512)
     sp = scenes.bumpy_sphere_sensor(1920, 1080, 1024)
@@ -93,12 +94,12 @@ def test_config3_full_size_against_oracle_rows():
     integ = R.PathIntegrator()
     assert integ.render(scene, sensor)
     st = integ.stats
-    assert st["samples"] == 1920 * 1080 * 1024 and st["passes"] == 8
+    assert st["samples"] == 1920 * 1080 * 1024 and st["passes"] == 2
     film = sensor.film().bitmap(raw=True)
     assert torch.isfinite(film).all()
-    got = film[543:546].cpu().numpy()
+    got = film[545:548].cpu().numpy()
     S = ob.OracleScene(sd, spectral_path=R.srgb_coeff_path())
-    ref = S.render_rows(ob.make_desc(sp), 541, 548)[543:546]
+    ref = S.render_rows(ob.make_desc(sp), 543, 550)[545:548]
     assert ref[..., 3].mean() > 0.1 * ref[..., 4].mean()                 # the rows cross the object
     assert np.allclose(got[..., 3:], ref[..., 3:], rtol=1e-4, atol=1e-3)    # alpha and weight: sums of 1024 x ~12 filter taps
     rgb_g, rgb_r = ob.film_develop(got)[..., :3], ob.film_develop(ref)[..., :3]
