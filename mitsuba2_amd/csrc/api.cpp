@@ -1192,6 +1192,19 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
             HIP_TRY(launch_bounce(p, j.stream));
         }
         cur ^= 1; ++it;
+        if (getenv("MTSAMD_TRACE_ITERS")) {      // diagnostic: alive paths and wall time of every scheduler iteration (serialises the loop)
+            sync_all();
+            static thread_local std::vector<uint32_t> hc;
+            hc.resize(nw);
+            HIP_TRY(hipMemcpy(hc.data(), w.count[cur], nw * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            uint64_t alive = 0, busy_waves = 0;
+            for (uint32_t k = 0; k < nw; ++k) { alive += hc[k]; busy_waves += hc[k] ? 1 : 0; }
+            static thread_local std::chrono::steady_clock::time_point t_prev;
+            const auto t_now = std::chrono::steady_clock::now();
+            fprintf(stderr, "iter %llu alive %llu waves_with_paths %llu dt_us %.0f\n", (unsigned long long) it, (unsigned long long) alive,
+                    (unsigned long long) busy_waves, it > 1 ? std::chrono::duration<double, std::micro>(t_now - t_prev).count() : 0.0);
+            t_prev = std::chrono::steady_clock::now();
+        }
         if (it >= min_iters && (it - min_iters) % stride == 0) {
             if (pending >= 0) {
                 HIP_TRY(hipEventSynchronize(w.ev[pending]));
