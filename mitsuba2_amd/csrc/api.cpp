@@ -181,7 +181,7 @@ struct Workspace {
     PoolView pool[2] = {};
     uint32_t *count[2] = { nullptr, nullptr };
     uint64_t *cursor = nullptr, *cursor_end = nullptr, *wave_stats = nullptr;
-    uint32_t *cursor_pix = nullptr, *cursor_rem = nullptr, *count_shadow = nullptr;
+    uint32_t *count_shadow = nullptr;
     float4 *out_rgba = nullptr; float2 *out_pos = nullptr;
     float4 *out_rgba2 = nullptr; float2 *out_pos2 = nullptr; uint64_t pass_cap2 = 0;      // second sample stream: pass k + 1 is traced while pass k is splatted
     hipStream_t film_stream = nullptr; hipEvent_t film_done[2] = {};
@@ -190,6 +190,7 @@ struct Workspace {
     uint32_t *trace_spill = nullptr; size_t trace_spill_words = 0;      // k_trace: deep stack entries
     uint32_t *h_counts = nullptr;        // pinned, 4 * n_waves
     uint64_t *h_cursor = nullptr;        // pinned, 2 * n_waves
+    uint64_t *h_cursor_rb = nullptr;     // pinned, 2 slots x n_waves: cursors read back with the counts (pool-drain gathering)
     hipEvent_t ev[4] = {};               // 0 / 1: count read-back checkpoints, 2: k_shade done, 3: k_trace<any> done
     hipStream_t stream2 = nullptr;       // split pipeline: k_trace<any> of one iteration overlaps k_trace<closest> of the next
     hipStream_t part_stream[3] = {}; hipEvent_t part_ev[3] = {};      // flat scenes: further parts of the scheduling waves
@@ -206,12 +207,12 @@ struct Workspace {
             (void) hipFree(pool[k].hit); (void) hipFree(pool[k].sh_o); (void) hipFree(pool[k].sh_d); (void) hipFree(pool[k].nee); (void) hipFree(pool[k].sh_slot);
             pool[k] = PoolView{}; count[k] = nullptr;
         }
-        (void) hipFree(cursor); (void) hipFree(cursor_end); (void) hipFree(wave_stats); (void) hipFree(cursor_pix); (void) hipFree(cursor_rem);
+        (void) hipFree(cursor); (void) hipFree(cursor_end); (void) hipFree(wave_stats);
         (void) hipFree(count_shadow); count_shadow = nullptr;
         (void) hipFree(trace_spill); trace_spill = nullptr; trace_spill_words = 0;
         (void) hipFree(moment_film); moment_film = nullptr; moment_pixels = 0;
         (void) hipFree(film_partials); film_partials = nullptr; film_partial_floats = 0;
-        cursor_pix = cursor_rem = nullptr; (void) hipFree(out_rgba); (void) hipFree(out_pos);
+        (void) hipFree(out_rgba); (void) hipFree(out_pos);
         (void) hipFree(out_rgba2); (void) hipFree(out_pos2); out_rgba2 = nullptr; out_pos2 = nullptr; pass_cap2 = 0;
         if (film_stream) (void) hipStreamDestroy(film_stream);
         film_stream = nullptr;
@@ -219,6 +220,8 @@ struct Workspace {
         cursor = cursor_end = wave_stats = nullptr; out_rgba = nullptr; out_pos = nullptr;
         if (h_counts) (void) hipHostFree(h_counts);
         if (h_cursor) (void) hipHostFree(h_cursor);
+        if (h_cursor_rb) (void) hipHostFree(h_cursor_rb);
+        h_cursor_rb = nullptr;
         h_counts = nullptr; h_cursor = nullptr;
         if (stream2) (void) hipStreamDestroy(stream2);
         stream2 = nullptr;
@@ -993,13 +996,12 @@ static int ensure_workspace(mtsamd_scene *s, uint32_t n_waves, uint32_t seg_cap,
     HIP_TRY(hipMalloc((void **) &w.cursor, n_waves * sizeof(uint64_t)));
     HIP_TRY(hipMalloc((void **) &w.cursor_end, n_waves * sizeof(uint64_t)));
     HIP_TRY(hipMalloc((void **) &w.wave_stats, 4 * (size_t) n_waves * sizeof(uint64_t)));
-    HIP_TRY(hipMalloc((void **) &w.cursor_pix, n_waves * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **) &w.cursor_rem, n_waves * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **) &w.count_shadow, n_waves * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **) &w.out_rgba, pass_cap * sizeof(float4)));
     HIP_TRY(hipMalloc((void **) &w.out_pos, pass_cap * sizeof(float2)));
     HIP_TRY(hipHostMalloc((void **) &w.h_counts, 4 * (size_t) n_waves * sizeof(uint32_t), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **) &w.h_cursor, 3 * (size_t) n_waves * sizeof(uint64_t), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **) &w.h_cursor_rb, 2 * (size_t) n_waves * sizeof(uint64_t), hipHostMallocDefault));
     for (auto &e : w.ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (!w.stream2) HIP_TRY(hipStreamCreateWithFlags(&w.stream2, hipStreamNonBlocking));
     for (auto &ps : w.part_stream) if (!ps) HIP_TRY(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
@@ -1037,16 +1039,20 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     Workspace &w = j.s->ws;
     const uint32_t nw = j.n_waves;
     const uint64_t spp = (uint64_t) j.d->sample_count;
-    uint32_t *h_pix = reinterpret_cast<uint32_t *>(w.h_cursor + 2 * (size_t) nw), *h_rem = h_pix + nw;
+    // the pass's samples are dealt to the scheduling waves in chunks, round-robin (kernels.hip, cursor_sample): wave k owns the
+    // chunks k, k + nw, ...; its cursor counts the samples of its own it has generated.  64-sample chunks for LDS-resident scenes,
+    // one chunk per wave (consecutive pixels) for hierarchy scenes
+    const uint64_t chunk = j.s->view.flat ? 64u : std::max<uint64_t>((n + nw - 1) / nw, 1u);
+    const uint64_t n_chunks = (n + chunk - 1u) / chunk, last_size = n - (n_chunks - 1u) * chunk;
     for (uint32_t k = 0; k < nw; ++k) {
-        uint64_t c0 = first + (uint64_t) (((unsigned __int128) n * k) / nw), c1 = first + (uint64_t) (((unsigned __int128) n * (k + 1)) / nw);
-        w.h_cursor[k] = c0; w.h_cursor[nw + k] = c1;
-        h_pix[k] = (uint32_t) (c0 / spp); h_rem[k] = (uint32_t) (c0 % spp);
+        const uint64_t mine = k < n_chunks ? (n_chunks - 1u - k) / nw + 1u : 0u;
+        uint64_t samples = mine * chunk;
+        if (mine && (n_chunks - 1u) % nw == k) samples -= chunk - last_size;       // the last, partial chunk of the pass
+        w.h_cursor[k] = 0; w.h_cursor[nw + k] = samples;
     }
+    if (n >= (1ull << 31)) return fail(MTSAMD_ERR_INVALID, "a pass holds fewer than 2^31 samples");
     HIP_TRY(hipMemcpyAsync(w.cursor, w.h_cursor, nw * sizeof(uint64_t), hipMemcpyHostToDevice, j.stream));
     HIP_TRY(hipMemcpyAsync(w.cursor_end, w.h_cursor + nw, nw * sizeof(uint64_t), hipMemcpyHostToDevice, j.stream));
-    HIP_TRY(hipMemcpyAsync(w.cursor_pix, h_pix, nw * sizeof(uint32_t), hipMemcpyHostToDevice, j.stream));
-    HIP_TRY(hipMemcpyAsync(w.cursor_rem, h_rem, nw * sizeof(uint32_t), hipMemcpyHostToDevice, j.stream));
     HIP_TRY(hipMemsetAsync(w.count[0], 0, nw * sizeof(uint32_t), j.stream));
     HIP_TRY(hipMemsetAsync(w.count[1], 0, nw * sizeof(uint32_t), j.stream));
 
@@ -1055,8 +1061,9 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     if (p.cam.aperture_radius > 0.0f) p.sv.general = 1u;      // thin lens: aperture sampling lives in the general kernels
     p.cursor = w.cursor; p.cursor_end = w.cursor_end; p.wave_stats = w.wave_stats;
     p.out_rgba = j.buf ? w.out_rgba2 : w.out_rgba; p.out_pos = j.buf ? w.out_pos2 : w.out_pos;
-    p.cursor_pix = w.cursor_pix; p.cursor_rem = w.cursor_rem; p.count_shadow = w.count_shadow;
-    p.first_ordinal = first; p.base_seed = j.d->seed;
+    p.count_shadow = w.count_shadow;
+    p.first_ordinal = first; p.first_pix = (uint32_t) (first / spp); p.first_rem = (uint32_t) (first % spp);
+    p.chunk = (uint32_t) (j.s->view.flat ? 64u : std::max<uint64_t>((n + nw - 1) / nw, 1u)); p.base_seed = j.d->seed;
     p.rows = j.rows; p.store_xyz = j.store_xyz;
     p.plane_pix0 = j.plane_pix0; p.plane_pixels = j.plane_pixels;
     p.n_waves = nw; p.seg_cap = w.seg_cap; p.target = j.target;
@@ -1101,6 +1108,14 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     uint32_t part_lo[5] = { 0, nw, nw, nw, nw };
     for (uint32_t k = 1; k < n_parts; ++k) part_lo[k] = (uint32_t) (((uint64_t) nw * k / n_parts + 3u) & ~3ull);
     part_lo[n_parts] = nw;
+    // Pool drain of LDS-resident scenes: once every cursor is dry, a workgroup gathers the paths of gather_w consecutive scheduling
+    // waves at the front of the group (k_shade).  gather_w grows by powers of four as the pool empties -- decided on the counts read
+    // back every `stride` launches; they are upper bounds, counts only shrink from then on -- and its groups lie inside one part.
+    uint32_t gather_max = 4u, gather_w = 4u;
+    if (p.split == 3 && !getenv("MTSAMD_NO_GATHER")) {
+        gather_max = 1024u;
+        for (uint32_t k = 0; k <= n_parts; ++k) while (gather_max > 4u && part_lo[k] % gather_max) gather_max >>= 2;
+    }
     uint32_t split_parts = p.split == 1 && nw >= 256u ? 2u : 1u;
     if (getenv("MTSAMD_ONE_CHAIN")) split_parts = 1;      // experiment switch
     uint32_t split_lo[3] = { 0, nw, nw };
@@ -1184,11 +1199,13 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
             // the scheduling waves are independent of each other: part-size launches on their own streams advance in their own
             // rhythm and fill each other's launch tails
             RenderParams h = p;
+            h.gather_w = gather_w;
             for (uint32_t k = 0; k < n_parts; ++k) {
                 h.wave_first = part_lo[k]; h.wave_last = part_lo[k + 1];
                 HIP_TRY(launch_bounce(h, k == 0 ? j.stream : w.part_stream[k - 1]));
             }
         } else {
+            p.gather_w = gather_w;
             HIP_TRY(launch_bounce(p, j.stream));
         }
         cur ^= 1; ++it;
@@ -1201,8 +1218,8 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
             for (uint32_t k = 0; k < nw; ++k) { alive += hc[k]; busy_waves += hc[k] ? 1 : 0; }
             static thread_local std::chrono::steady_clock::time_point t_prev;
             const auto t_now = std::chrono::steady_clock::now();
-            fprintf(stderr, "iter %llu alive %llu waves_with_paths %llu dt_us %.0f\n", (unsigned long long) it, (unsigned long long) alive,
-                    (unsigned long long) busy_waves, it > 1 ? std::chrono::duration<double, std::micro>(t_now - t_prev).count() : 0.0);
+            fprintf(stderr, "iter %llu alive %llu waves_with_paths %llu dt_us %.0f gather_w %u\n", (unsigned long long) it, (unsigned long long) alive,
+                    (unsigned long long) busy_waves, it > 1 ? std::chrono::duration<double, std::micro>(t_now - t_prev).count() : 0.0, gather_w);
             t_prev = std::chrono::steady_clock::now();
         }
         if (it >= min_iters && (it - min_iters) % stride == 0) {
@@ -1212,6 +1229,20 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
                 const uint32_t *hc = w.h_counts + (size_t) pending * nw;
                 for (uint32_t k = 0; k < nw; ++k) alive += hc[k];
                 if (alive == 0) break;
+                if (gather_w < gather_max) {
+                    const uint64_t *hcur = w.h_cursor_rb + (size_t) pending * nw;
+                    bool dry = true;
+                    for (uint32_t k = 0; k < nw && dry; ++k) dry = hcur[k] >= w.h_cursor[nw + k];
+                    if (getenv("MTSAMD_TRACE_ITERS")) {
+                        uint32_t wet = 0, first_wet = 0;
+                        for (uint32_t k = 0; k < nw; ++k) if (hcur[k] < w.h_cursor[nw + k]) { if (!wet) first_wet = k; ++wet; }
+                        fprintf(stderr, "check at it %llu: alive %llu wet %u first_wet %u cur %llu end %llu\n", (unsigned long long) it, (unsigned long long) alive, wet, first_wet,
+                                (unsigned long long) hcur[first_wet], (unsigned long long) w.h_cursor[nw + first_wet]);
+                    }
+                    // a workgroup may take up to eight segments' worth of paths on average (the counts are a few launches old: an
+                    // upper bound); a fuller group just takes longer, its survivors spill into the group's next waves
+                    while (dry && gather_w < gather_max && alive * (uint64_t) (4u * gather_w) <= 8ull * w.seg_cap * (uint64_t) nw) gather_w *= 4u;
+                }
             }
             if (n_parts > 1) { if (int rc = join_parts()) return rc; }
             if (split_parts == 2) {       // the counts of the second chain are written by its k_shade
@@ -1219,6 +1250,7 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
                 HIP_TRY(hipStreamWaitEvent(j.stream, w.part_ev[2], 0));
             }
             HIP_TRY(hipMemcpyAsync(w.h_counts + (size_t) slot * nw, w.count[cur], nw * sizeof(uint32_t), hipMemcpyDeviceToHost, j.stream));
+            if (gather_w < gather_max) HIP_TRY(hipMemcpyAsync(w.h_cursor_rb + (size_t) slot * nw, w.cursor, nw * sizeof(uint64_t), hipMemcpyDeviceToHost, j.stream));
             HIP_TRY(hipEventRecord(w.ev[slot], j.stream));
             pending = slot; slot ^= 1;
         }

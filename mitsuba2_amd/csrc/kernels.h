@@ -50,12 +50,13 @@ struct RenderParams {
     const uint32_t *count_in;   // per scheduling wave
     uint32_t *count_out;
     uint32_t *count_shadow;     // split pipeline: queued shadow rays per scheduling wave (output pool)
-    uint64_t *cursor;           // per wave: next sample ordinal to generate
+    uint64_t *cursor;           // per wave: how many of its samples it has generated (kernels.hip cursor_sample maps them to ordinals)
     const uint64_t *cursor_end;
     uint64_t *wave_stats;       // per wave: closest, any, segments, tri tests
     float4 *out_rgba;           // per sample ordinal: radiance rgb + valid_ray
     float2 *out_pos;            // per sample ordinal: film position sample
-    uint32_t *cursor_pix, *cursor_rem;   // per wave: local pixel of the cursor and its remainder (cursor == pix * spp + rem)
+    uint32_t chunk;             // samples per chunk dealt to a scheduling wave (kernels.hip, cursor_sample)
+    uint32_t first_pix, first_rem;       // first_ordinal = first_pix * spp + first_rem (film renders: passes start on a pixel, first_rem == 0)
     uint64_t first_ordinal;     // local sample ordinal of slot 0 of out_rgba / out_pos
     uint64_t base_seed;
     RowMap rows;                // which film rows this render owns (multi-GPU film partition)
@@ -73,6 +74,8 @@ struct RenderParams {
                                 // 3: k_shade (flat) with the in-kernel shadow ring
     uint32_t lds_queue_offset;  // split == 3: start of the per-wave shadow rings in LDS, in float4 units
     uint32_t wave_first, wave_last;   // k_shade: scheduling waves covered by this launch (wave_last == 0: all)
+    uint32_t gather_w;          // k_shade on LDS-resident scenes: a workgroup gathers the paths of gather_w (4, 16, ... 1024) consecutive scheduling
+                                // waves into the first four (pool drain: the sample cursors of the launch are dry); 0 / 4: no gathering
     uint32_t trace_lds_depth;   // k_trace: stack entries per lane kept in LDS; deeper ones go to trace_spill
     uint32_t *trace_spill;      // k_trace: [workgroup][entry][thread]
 };

@@ -250,6 +250,21 @@ MTS_DEV void store_result(const RenderParams &P, const PathState &s) {
     }
 }
 
+// Sample ordinals are dealt to the scheduling waves in chunks of P.chunk, round-robin: wave k traces the chunks k, k + n_waves, ... of
+// the pass.  LDS-resident scenes use chunks of 64, so that every wave sees the same mix of cheap and expensive pixels and the pool
+// stays full until all cursors run dry together (contiguous ranges per wave left waves over easy pixels idle from a third of the pass
+// on: 94 -> 82 launches per render); hierarchy scenes keep one chunk per wave -- consecutive pixels -- because the rays of a
+// workgroup's scheduling waves should walk the same part of the BVH (64-sample chunks cost them 5 %).  The cursor of a wave counts
+// its own samples; this maps the v-th of them to its place in the pass, (local pixel, sample number) included.  Which wave traces a
+// sample has no influence on the result: its RNG stream and its slot in the sample stream depend on the ordinal alone.
+MTS_DEV void cursor_sample(const RenderParams &P, uint32_t wave, uint64_t v, uint64_t &ordinal, uint32_t &lp, uint32_t &j) {
+    const uint32_t t = (uint32_t) v / P.chunk, within = (uint32_t) v - t * P.chunk;
+    const uint32_t in_pass = (t * P.n_waves + wave) * P.chunk + within;      // < 2^31
+    ordinal = P.first_ordinal + in_pass;
+    const uint32_t r = in_pass + P.first_rem, q = r / (uint32_t) P.spp;
+    lp = P.first_pix + q; j = r - q * (uint32_t) P.spp;
+}
+
 #ifndef MTS_BOUNCE_WAVES
 #define MTS_BOUNCE_WAVES 4
 #endif
@@ -291,21 +306,18 @@ void k_bounce(const RenderParams P) {
     // (local pixel, sample-in-pixel) so that no 64-bit division is needed per generated path.
     uint64_t cursor = P.cursor[wave];
     const uint64_t end = P.cursor_end[wave];
-    uint32_t cpix = P.cursor_pix[wave], crem = P.cursor_rem[wave];
-    const uint32_t spp = (uint32_t) P.spp;
     while (n_out < P.target && cursor < end) {
         uint64_t left = end - cursor;
         uint32_t n_new = min(64u, P.target - n_out);
         if ((uint64_t) n_new > left) n_new = (uint32_t) left;
         if (lane < n_new) {
             PathState s;
-            uint32_t r = crem + lane, q = r / spp;
-            generate_path<GENERAL>(P, cursor + lane, cpix + q, r - q * spp, s);
+            uint64_t ordinal; uint32_t lp, sj;
+            cursor_sample(P, wave, cursor + lane, ordinal, lp, sj);
+            generate_path<GENERAL>(P, ordinal, lp, sj, s);
             store_state(P.out, base + n_out + lane, s);
         }
         n_out += n_new; cursor += n_new;
-        uint32_t r = crem + n_new, q = r / spp;
-        cpix += q; crem = r - q * spp;
     }
 
     // per-wave bookkeeping (each wave owns its slots: no atomics)
@@ -315,7 +327,7 @@ void k_bounce(const RenderParams P) {
         for (int off = 32; off > 0; off >>= 1) tot[k] += __shfl_xor(tot[k], off);
     if (lane == 0) {
         P.count_out[wave] = n_out;
-        P.cursor[wave] = cursor; P.cursor_pix[wave] = cpix; P.cursor_rem[wave] = crem;
+        P.cursor[wave] = cursor;
         uint64_t *ws = P.wave_stats + 4u * (size_t) wave;
         ws[0] += tot[0]; ws[1] += tot[1]; ws[2] += tot[2]; ws[3] += tot[3];
     }
@@ -648,21 +660,18 @@ __global__ __launch_bounds__(kBlock) void k_bounce_spectral(const RenderParams P
     }
     uint64_t cursor = P.cursor[wave];
     const uint64_t end = P.cursor_end[wave];
-    uint32_t cpix = P.cursor_pix[wave], crem = P.cursor_rem[wave];
-    const uint32_t spp = (uint32_t) P.spp;
     while (n_out < P.target && cursor < end) {
         uint64_t left = end - cursor;
         uint32_t n_new = min(64u, P.target - n_out);
         if ((uint64_t) n_new > left) n_new = (uint32_t) left;
         if (lane < n_new) {
             PathStateS s;
-            uint32_t r = crem + lane, q = r / spp;
-            generate_path_spectral(P, cursor + lane, cpix + q, r - q * spp, s);
+            uint64_t ordinal; uint32_t lp, sj;
+            cursor_sample(P, wave, cursor + lane, ordinal, lp, sj);
+            generate_path_spectral(P, ordinal, lp, sj, s);
             store_state(P.out, base + n_out + lane, s);
         }
         n_out += n_new; cursor += n_new;
-        uint32_t r = crem + n_new, q = r / spp;
-        cpix += q; crem = r - q * spp;
     }
     uint32_t tot[4] = { c.closest, c.any, c.segments, c.tri_tests };
 #pragma unroll
@@ -670,7 +679,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce_spectral(const RenderParams P
         for (int off = 32; off > 0; off >>= 1) tot[k] += __shfl_xor(tot[k], off);
     if (lane == 0) {
         P.count_out[wave] = n_out;
-        P.cursor[wave] = cursor; P.cursor_pix[wave] = cpix; P.cursor_rem[wave] = crem;
+        P.cursor[wave] = cursor;
         uint64_t *ws = P.wave_stats + 4u * (size_t) wave;
         ws[0] += tot[0]; ws[1] += tot[1]; ws[2] += tot[2]; ws[3] += tot[3];
     }
@@ -861,11 +870,38 @@ void k_shade(const RenderParams P) {
     static_assert(FLAT || !INLINE, "the in-kernel shadow queue is for LDS-resident scenes");
     extern __shared__ float4 smem[];
     LdsView lds = {};                      // Geo<false> reads the scene tables from global memory
-    // a launch covers the scheduling waves [wave_first, wave_last) (all of them, or one half when two launches share the GPU)
-    const uint32_t wave = P.wave_first + ((blockIdx.x * kBlock + threadIdx.x) >> 6);
+    // a launch covers the scheduling waves [wave_first, wave_last) (all of them, or one half when two launches share the GPU).
+    // Pool drain (FLAT, gather_w > 4): once the sample cursors are dry the host lets one workgroup take the paths of gather_w
+    // consecutive scheduling waves and leave the survivors at the front of the group -- hardware wave h fills the segments of the
+    // waves h, h + 4, h + 8, ... of the group one after the other: the pool is compacted as it is advanced, and the number of
+    // workgroups that stage the scene for a handful of paths shrinks with it.
+    const uint32_t gw = (FLAT && P.gather_w > 4u) ? P.gather_w : 4u;
+    const uint32_t hw = threadIdx.x >> 6;
+    const uint32_t wave = gw > 4u ? P.wave_first + blockIdx.x * gw + hw : P.wave_first + ((blockIdx.x * kBlock + threadIdx.x) >> 6);
     const uint32_t wave_last = P.wave_last ? P.wave_last : P.n_waves;
     __shared__ uint32_t s_cnt[kBlock / 64u];
-    if (FLAT) {
+    __shared__ uint32_t s_pre[FLAT ? 1025 : 1];      // gather: s_pre[k] = paths in the group's waves before the k-th
+    if (FLAT && gw > 4u) {
+        const uint32_t g0 = wave - hw;
+        for (uint32_t k = threadIdx.x; k < gw; k += kBlock) s_pre[k + 1u] = (g0 + k < wave_last) ? P.count_in[g0 + k] : 0u;
+        if (threadIdx.x == 0u) s_pre[0] = 0u;
+        __syncthreads();
+        if (hw == 0u) {                      // inclusive prefix sums by one wave: a run of `per` entries per lane + a wave scan
+            const uint32_t per = (gw + 63u) / 64u, ln = lane_id();
+            uint32_t local = 0u;
+            for (uint32_t i = 0; i < per; ++i) { const uint32_t idx = ln * per + i; if (idx < gw) local += s_pre[idx + 1u]; }
+            uint32_t incl = local;
+            for (uint32_t off = 1u; off < 64u; off <<= 1) { const uint32_t v = __shfl_up(incl, off); if (ln >= off) incl += v; }
+            uint32_t run = incl - local;
+            for (uint32_t i = 0; i < per; ++i) { const uint32_t idx = ln * per + i; if (idx < gw) { run += s_pre[idx + 1u]; s_pre[idx + 1u] = run; } }
+        }
+        __syncthreads();
+        if (s_pre[gw] == 0u) {               // nothing left in the whole group
+            for (uint32_t k = threadIdx.x; k < gw; k += kBlock) if (g0 + k < wave_last) P.count_out[g0 + k] = 0u;
+            return;
+        }
+        lds = lds_stage<true>(P.sv, smem);
+    } else if (FLAT) {
         // While the pool drains at the end of a pass most scheduling waves have nothing left to do: a workgroup whose four
         // waves are all idle leaves before staging the scene into LDS (its output counts still have to be reset).
         const uint32_t n_own = wave < wave_last ? P.count_in[wave] : 0u;
@@ -899,7 +935,9 @@ void k_shade(const RenderParams P) {
     const uint32_t wg_wave0 = wave - (threadIdx.x >> 6);
     const uint32_t n_valid = FLAT ? min((uint32_t) (kBlock / 64u), wave_last - wg_wave0) : 1u;
     uint32_t cnt4[kBlock / 64u], n_in = 0;
-    if (FLAT) {
+    if (FLAT && gw > 4u) {
+        n_in = s_pre[gw];
+    } else if (FLAT) {
 #pragma unroll
         for (uint32_t g = 0; g < kBlock / 64u; ++g) { cnt4[g] = g < n_valid ? s_cnt[g] : 0u; n_in += cnt4[g]; }
     } else {
@@ -913,7 +951,12 @@ void k_shade(const RenderParams P) {
         bool alive = false;
         if (i0 + lane < n_in) {
             size_t i = base + i0 + lane;
-            if (FLAT) {
+            if (FLAT && gw > 4u) {          // s_pre[k] <= index < s_pre[k + 1]: the k-th wave of the group holds the path
+                const uint32_t idx = i0 + lane;
+                uint32_t k = 0u;
+                for (uint32_t step = gw >> 1; step; step >>= 1) if (s_pre[k + step] <= idx) k += step;
+                i = (size_t) (wg_wave0 + k) * P.seg_cap + (idx - s_pre[k]);
+            } else if (FLAT) {
                 uint32_t src = wg_wave0, j = i0 + lane;
 #pragma unroll
                 for (uint32_t g = 0; g + 1 < kBlock / 64u; ++g)
@@ -940,14 +983,16 @@ void k_shade(const RenderParams P) {
         const uint64_t m = __ballot(alive), ms = __ballot(alive && df.pending);
         if (alive) {
             const uint32_t slot = n_out + mask_rank(m);
-            store_state(P.out, base + slot, s);
+            // gathering: the segment of wave + 4 q takes the slots [q seg_cap, (q + 1) seg_cap) of this hardware wave
+            const size_t oidx = (FLAT && gw > 4u) ? ((size_t) wave + 4u * (slot / P.seg_cap)) * P.seg_cap + slot % P.seg_cap : base + slot;
+            store_state(P.out, oidx, s);
             if (df.pending) {
                 if (INLINE) {
                     const uint32_t k = (q_head + q_count + mask_rank(ms)) & (kShadowRing - 1u);
                     ring.o[k] = make_float4(df.so.x, df.so.y, df.so.z, df.smint);
                     ring.d[k] = make_float4(df.sd.x, df.sd.y, df.sd.z, df.smaxt);
                     ring.nee[k] = make_float4(df.nee[0], df.nee[1], df.nee[2], df.nee[3]);
-                    ring.slot[k] = slot;
+                    ring.slot[k] = (uint32_t) (oidx - base);      // may exceed the segment (gathering): an offset from `base` all the same
                 } else {
                     const size_t q = base + n_sh + mask_rank(ms);
                     P.out.sh_o[q] = make_float4(df.so.x, df.so.y, df.so.z, df.smint);
@@ -971,31 +1016,34 @@ void k_shade(const RenderParams P) {
 
     uint64_t cursor = P.cursor[wave];
     const uint64_t end = P.cursor_end[wave];
-    uint32_t cpix = P.cursor_pix[wave], crem = P.cursor_rem[wave];
-    const uint32_t spp = (uint32_t) P.spp;
     while (n_out < P.target && cursor < end) {
         uint64_t left = end - cursor;
         uint32_t n_new = min(64u, P.target - n_out);
         if ((uint64_t) n_new > left) n_new = (uint32_t) left;
         if (lane < n_new) {
             State s;
-            uint32_t r = crem + lane, q = r / spp;
-            start_path(P, cursor + lane, cpix + q, r - q * spp, s);
+            uint64_t ordinal; uint32_t lp, sj;
+            cursor_sample(P, wave, cursor + lane, ordinal, lp, sj);
+            start_path(P, ordinal, lp, sj, s);
             store_state(P.out, base + n_out + lane, s);
         }
         n_out += n_new; cursor += n_new;
-        uint32_t r = crem + n_new, q = r / spp;
-        cpix += q; crem = r - q * spp;
     }
 
     uint32_t tot[4] = { c.closest, c.any, c.segments, c.tri_tests };
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         for (int off = 32; off > 0; off >>= 1) tot[k] += __shfl_xor(tot[k], off);
+    if (FLAT && gw > 4u) {               // the segments this hardware wave filled: full ones, one partial, empty ones
+        for (uint32_t q = lane; q < gw / 4u; q += 64u) {
+            const uint32_t w2 = wave + 4u * q, lo = q * P.seg_cap;
+            if (w2 < wave_last) P.count_out[w2] = n_out > lo ? min(n_out - lo, P.seg_cap) : 0u;
+        }
+    }
     if (lane == 0) {
-        P.count_out[wave] = n_out;
+        if (!(FLAT && gw > 4u)) P.count_out[wave] = n_out;
         if (!INLINE) P.count_shadow[wave] = n_sh;
-        P.cursor[wave] = cursor; P.cursor_pix[wave] = cpix; P.cursor_rem[wave] = crem;
+        P.cursor[wave] = cursor;
         uint64_t *ws = P.wave_stats + 4u * (size_t) wave;
         ws[0] += tot[0]; ws[1] += tot[1]; ws[2] += tot[2];
         if (FLAT) ws[3] += tot[3];
@@ -1158,7 +1206,7 @@ hipError_t launch_bounce(const RenderParams &p_, hipStream_t s) {
     RenderParams p = p_;
     if (p.split == 3) {       // LDS-resident scene, one kernel: shadow rays collected in a per-wave LDS ring and resolved 64 at a time
         const uint32_t n_launch = (p.wave_last ? p.wave_last : p.n_waves) - p.wave_first;
-        const uint32_t shade_blocks = (n_launch * 64u + kBlock - 1) / kBlock;
+        const uint32_t shade_blocks = p.gather_w > 4u ? (n_launch + p.gather_w - 1u) / p.gather_w : (n_launch * 64u + kBlock - 1) / kBlock;
         const size_t scene_bytes = (bounce_lds_bytes(p.sv) + 15u) & ~(size_t) 15u;
         p.lds_queue_offset = (uint32_t) (scene_bytes / 16u);
         const size_t lds = scene_bytes + (size_t) (kBlock / 64u) * kShadowRing * 52u;

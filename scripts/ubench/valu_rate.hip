@@ -12,8 +12,10 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, unsigned long lo
     float2_t p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, p4 = {a1, a0}, p5 = {a3, a2}, p6 = {a5, a4}, p7 = {a7, a6};
     const float b = 1.0001f, c = 0.5f;
     const float2_t b2 = {b, b}, c2 = {c, c};
+    // PK == 2: v_fma_f32 with only the lower 32 lanes enabled -- does a SIMD-32 skip the pass of an all-inactive half?
+    if (PK == 2 && (threadIdx.x & 32)) { out[blockIdx.x * 256 + threadIdx.x] = 0.0f; return; }
     for (int i = 0; i < iters; ++i) {
-        if (PK == 0) {
+        if (PK == 0 || PK == 2) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
@@ -38,12 +40,13 @@ int main() {
     unsigned long long *stamps; hipMalloc(&stamps, 2 * 8192 * 8);
     static unsigned long long h[2 * 8192];
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int pk = 0; pk < 2; ++pk)
+    for (int pk = 0; pk < 3; ++pk)
         for (int blocks_per_cu = 1; blocks_per_cu <= 8; blocks_per_cu *= 2) {
             int blocks = 256 * blocks_per_cu, iters = 20000;
             for (int rep = 0; rep < 2; ++rep) {
                 hipEventRecord(e0);
-                if (pk) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, out, iters, stamps);
+                if (pk == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, out, iters, stamps);
+                else if (pk == 2) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), 0, 0, out, iters, stamps);
                 else hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), 0, 0, out, iters, stamps);
                 hipEventRecord(e1); hipEventSynchronize(e1);
             }
@@ -57,7 +60,7 @@ int main() {
             // a workgroup's 4 waves sit on 4 SIMDs: its waves issue 4 * iters * 64 instructions per SIMD ... per wave: iters * 64
             double real_cyc_per_instr = in_kernel / ((double) iters * 64.0) / blocks_per_cu;
             printf("pk=%d waves/SIMD=%d: %.3f ms, %.2f SIMD-cycles(@2.4GHz)/wave-instr, %.1f TFLOP/s, in-kernel clock %.2f GHz, %.2f real SIMD-cycles/wave-instr\n", pk, blocks_per_cu, ms, cyc_per_instr,
-                   instr * 64 * 2 * (pk ? 2 : 1) / (ms * 1e-3) / 1e12, clk * 1e-9, real_cyc_per_instr);
+                   instr * 64 * 2 * (pk == 1 ? 2 : 1) / (ms * 1e-3) / 1e12, clk * 1e-9, real_cyc_per_instr);
         }
     return 0;
 }
