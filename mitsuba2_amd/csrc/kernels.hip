@@ -1494,8 +1494,30 @@ MTS_DEV void axis_taps(const FilterView &f, const float *table, float pos, int s
 // touches neither LDS (beyond the 32-entry filter table) nor a barrier.  At the end the block exchanges the sums through LDS, one tap
 // row at a time, and every film pixel of the (16 + 2R)^2 region adds up the <= 25 source pixels that reach it.
 #ifndef MTS_FILM_PREFETCH
-#define MTS_FILM_PREFETCH 4
+#define MTS_FILM_PREFETCH 2
 #endif
+#ifndef MTS_FILM_NT
+#define MTS_FILM_NT 0
+#endif
+typedef float film_v4 __attribute__((ext_vector_type(4)));
+typedef float film_v2 __attribute__((ext_vector_type(2)));
+MTS_DEV float4 film_load(const float4 *p) {
+#if MTS_FILM_NT
+    const film_v4 v = __builtin_nontemporal_load(reinterpret_cast<const film_v4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+MTS_DEV float2 film_load(const float2 *p) {
+#if MTS_FILM_NT
+    const film_v2 v = __builtin_nontemporal_load(reinterpret_cast<const film_v2 *>(p));
+    return make_float2(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+#define MTS_FILM_LOAD(p) film_load(p)
 constexpr int kFilmPrefetch = MTS_FILM_PREFETCH;     // samples in flight per thread (x 24 B)
 __global__ __launch_bounds__(kBlock) void k_film_accum(const FilmParams F) {
     __shared__ float table[32];
@@ -1526,7 +1548,7 @@ __global__ __launch_bounds__(kBlock) void k_film_accum(const FilmParams F) {
 #pragma unroll
     for (int k = 0; k < kFilmPrefetch; ++k) {
         pv[k] = make_float4(0.0f, 0.0f, 0.0f, -1.0f); pq[k] = make_float2(0.0f, 0.0f);
-        if (k < n_spp) { pv[k] = F.out_rgba[slot0 + (size_t) k]; pq[k] = F.out_pos[slot0 + (size_t) k]; }
+        if (k < n_spp) { pv[k] = MTS_FILM_LOAD(F.out_rgba + slot0 + (size_t) k); pq[k] = MTS_FILM_LOAD(F.out_pos + slot0 + (size_t) k); }
     }
     for (int s0 = 0; s0 < n_spp; s0 += kFilmPrefetch) {
 #pragma unroll
@@ -1535,7 +1557,7 @@ __global__ __launch_bounds__(kBlock) void k_film_accum(const FilmParams F) {
             {   // the register is free: fetch the sample that will be processed kFilmPrefetch samples from now
                 const int j = s0 + kFilmPrefetch + k;
                 pv[k] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
-                if (j < n_spp) { pv[k] = F.out_rgba[slot0 + (size_t) j]; pq[k] = F.out_pos[slot0 + (size_t) j]; }
+                if (j < n_spp) { pv[k] = MTS_FILM_LOAD(F.out_rgba + slot0 + (size_t) j); pq[k] = MTS_FILM_LOAD(F.out_pos + slot0 + (size_t) j); }
             }
             if (!(rec.w >= 0.0f)) continue;                  // (X, Y, Z, alpha); alpha < 0: invalid or absent sample
             float wxs[kFilmTaps], wys[kFilmTaps];

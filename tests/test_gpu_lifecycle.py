@@ -164,3 +164,40 @@ def test_config5_per_rank_shape_adds_up(gpu):
             assert float(part[far.cuda()].abs().max()) == 0.0
             total += part
     assert torch.allclose(total, whole, rtol=2e-5, atol=1e-4)
+
+
+def _rccl_worker(rank, world, port, out_path):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+    from mitsuba2_amd import dist as mdist, render, scenes
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    scene = render.Scene(scenes.cornell_box(), device=0)
+    sensor = render.make_sensor(scenes.cornell_box_sensor(96, 64, 8, seed=2))
+    film = mdist.render_distributed(render.PathIntegrator(), scene, sensor, all_ranks=True)      # all_reduce on the device tensor
+    t = torch.ones(4, device="cuda") * (rank + 1)
+    dist.all_reduce(t)
+    torch.save({"film": film.cpu(), "sum": t.cpu()}, out_path)
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_runs_the_film_reduce(gpu, tmp_path):
+    """The `nccl` backend of torch.distributed IS RCCL on ROCm.  The GPU box has one card, so this is a one-rank group -- but it is the
+    code path of the N-GPU bench: process-group initialisation on the device, the film reduce on a device tensor without host
+    staging, and a plain all_reduce.  (Two ranks on one card are refused by RCCL; the two-rank logic runs over gloo.)"""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "rccl.pt")
+    mp.spawn(_rccl_worker, args=(1, port, out), nprocs=1, join=True)
+    got = torch.load(out, weights_only=True)
+    scene = gpu.Scene(scenes.cornell_box())
+    ref, _ = _film(gpu, gpu.PathIntegrator(), scene, scenes.cornell_box_sensor(96, 64, 8, seed=2))
+    assert torch.equal(got["film"], ref.cpu()) and torch.equal(got["sum"], torch.ones(4))
