@@ -70,7 +70,8 @@ typedef struct {
  *   `twosided` = wrapped in the TwoSidedBRDF adapter (twosided.cpp). */
 typedef enum { MTSAMD_BSDF_DIFFUSE = 0, MTSAMD_BSDF_CONDUCTOR = 1, MTSAMD_BSDF_ROUGHCONDUCTOR = 2, MTSAMD_BSDF_DIELECTRIC = 3,
                MTSAMD_BSDF_PLASTIC = 4, MTSAMD_BSDF_ROUGHPLASTIC = 5,
-               MTSAMD_BSDF_ROUGHDIELECTRIC = 6 } mtsamd_bsdf_type;
+               MTSAMD_BSDF_ROUGHDIELECTRIC = 6,
+               MTSAMD_BSDF_THINDIELECTRIC = 7 /* src/bsdfs/thindielectric.cpp: delta reflection + null transmission of a thin slab */ } mtsamd_bsdf_type;
 typedef struct {
     int32_t type;              /* mtsamd_bsdf_type */
     float reflectance[3];      /* diffuse.reflectance / plastic.diffuse_reflectance: constant `srgb` value (src/spectra/srgb.cpp:27-52) */

@@ -6,11 +6,12 @@ takes (``mtsamd_bsdf_desc``; also `roughplastic`, ``roughplastic.cpp:146-178``, 
 """
 import numpy as np
 
-DIFFUSE, CONDUCTOR, ROUGHCONDUCTOR, DIELECTRIC, PLASTIC, ROUGHPLASTIC, ROUGHDIELECTRIC = range(7)
+DIFFUSE, CONDUCTOR, ROUGHCONDUCTOR, DIELECTRIC, PLASTIC, ROUGHPLASTIC, ROUGHDIELECTRIC, THINDIELECTRIC = range(8)
 TYPE_IDS = {"diffuse": DIFFUSE, "conductor": CONDUCTOR, "roughconductor": ROUGHCONDUCTOR, "dielectric": DIELECTRIC, "plastic": PLASTIC,
-            "roughplastic": ROUGHPLASTIC, "roughdielectric": ROUGHDIELECTRIC}
-SMOOTH = {DIFFUSE: True, CONDUCTOR: False, ROUGHCONDUCTOR: True, DIELECTRIC: False, PLASTIC: True, ROUGHPLASTIC: True, ROUGHDIELECTRIC: True}      # BSDFFlags::Smooth
-TRANSMISSIVE = {DIELECTRIC, ROUGHDIELECTRIC}
+            "roughplastic": ROUGHPLASTIC, "roughdielectric": ROUGHDIELECTRIC, "thindielectric": THINDIELECTRIC}
+SMOOTH = {DIFFUSE: True, CONDUCTOR: False, ROUGHCONDUCTOR: True, DIELECTRIC: False, PLASTIC: True, ROUGHPLASTIC: True, ROUGHDIELECTRIC: True,
+          THINDIELECTRIC: False}      # BSDFFlags::Smooth
+TRANSMISSIVE = {DIELECTRIC, ROUGHDIELECTRIC, THINDIELECTRIC}
 
 # ior.h:23-50
 IOR = {"vacuum": 1.0, "helium": 1.000036, "hydrogen": 1.000132, "air": 1.000277, "carbon dioxide": 1.00045, "water": 1.3330,
@@ -73,7 +74,7 @@ def normalize(b):
             out["id"] = b["id"]
         return out
     if t not in TYPE_IDS:
-        raise RuntimeError("BSDF plugin '%s' is not supported by this backend (diffuse, conductor, roughconductor, dielectric, roughdielectric, plastic, roughplastic, twosided)" % t)
+        raise RuntimeError("BSDF plugin '%s' is not supported by this backend (diffuse, conductor, roughconductor, dielectric, roughdielectric, thindielectric, plastic, roughplastic, twosided)" % t)
     tid = TYPE_IDS[t]
     out = dict(type=tid, twosided=twosided, reflectance=[0.5, 0.5, 0.5], specular_reflectance=[1.0] * 3, specular_transmittance=[1.0] * 3,
                eta=[0.0] * 3, k=[1.0] * 3, int_ior=1.0, ext_ior=1.0, alpha_u=0.1, alpha_v=0.1, distribution=0, sample_visible=True,
@@ -114,8 +115,8 @@ def normalize(b):
         known |= {"distribution", "sample_visible", "alpha", "alpha_u", "alpha_v"}
         if tid == ROUGHPLASTIC and out["alpha_u"] != out["alpha_v"]:
             raise RuntimeError("The 'roughplastic' plugin currently does not support anisotropic microfacet distributions!")
-    if tid in (DIELECTRIC, PLASTIC, ROUGHPLASTIC, ROUGHDIELECTRIC):
-        out["int_ior"] = lookup_ior(b.get("int_ior"), "bk7" if tid in (DIELECTRIC, ROUGHDIELECTRIC) else "polypropylene")
+    if tid in (DIELECTRIC, PLASTIC, ROUGHPLASTIC, ROUGHDIELECTRIC, THINDIELECTRIC):
+        out["int_ior"] = lookup_ior(b.get("int_ior"), "bk7" if tid in (DIELECTRIC, ROUGHDIELECTRIC, THINDIELECTRIC) else "polypropylene")
         out["ext_ior"] = lookup_ior(b.get("ext_ior"), "air")
         if out["int_ior"] < 0 or out["ext_ior"] < 0:
             raise RuntimeError("The interior and exterior indices of refraction must be positive!")
@@ -124,7 +125,7 @@ def normalize(b):
         out["specular_reflectance"] = _rgb(b.get("specular_reflectance"), 1.0)
         out["uniform_mask"] |= 2 if _is_uniform(b.get("specular_reflectance"), 1.0) else 0
         known |= {"int_ior", "ext_ior", "specular_reflectance"}
-    if tid in (DIELECTRIC, ROUGHDIELECTRIC):
+    if tid in (DIELECTRIC, ROUGHDIELECTRIC, THINDIELECTRIC):
         out["specular_transmittance"] = _rgb(b.get("specular_transmittance"), 1.0)
         out["uniform_mask"] |= 4 if _is_uniform(b.get("specular_transmittance"), 1.0) else 0
         known |= {"specular_transmittance"}

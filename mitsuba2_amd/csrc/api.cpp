@@ -257,7 +257,7 @@ static void fill_bsdf_model(const mtsamd_bsdf_desc &bd, DevBsdf &d) {
     if (bd.type == MTSAMD_BSDF_CONDUCTOR || bd.type == MTSAMD_BSDF_ROUGHCONDUCTOR) {
         d.er = bd.eta[0]; d.eg = bd.eta[1]; d.eb = bd.eta[2];
         d.kr = bd.k[0]; d.kg = bd.k[1]; d.kb = bd.k[2];
-    } else if (bd.type == MTSAMD_BSDF_DIELECTRIC || bd.type == MTSAMD_BSDF_ROUGHDIELECTRIC) {
+    } else if (bd.type == MTSAMD_BSDF_DIELECTRIC || bd.type == MTSAMD_BSDF_ROUGHDIELECTRIC || bd.type == MTSAMD_BSDF_THINDIELECTRIC) {
         d.er = bd.int_ior / bd.ext_ior;
         d.kr = bd.specular_transmittance[0]; d.kg = bd.specular_transmittance[1]; d.kb = bd.specular_transmittance[2];
     } else if (bd.type == MTSAMD_BSDF_PLASTIC || bd.type == MTSAMD_BSDF_ROUGHPLASTIC) {
@@ -421,7 +421,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     }
     for (uint32_t b = 0; b < desc->bsdf_count; ++b) {
         const mtsamd_bsdf_desc &bd = desc->bsdfs[b];
-        if (bd.type < MTSAMD_BSDF_DIFFUSE || bd.type > MTSAMD_BSDF_ROUGHDIELECTRIC) return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u: unknown BSDF type %d", b, bd.type);
+        if (bd.type < MTSAMD_BSDF_DIFFUSE || bd.type > MTSAMD_BSDF_THINDIELECTRIC) return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u: unknown BSDF type %d", b, bd.type);
         if (desc->spectral && (bd.type == MTSAMD_BSDF_CONDUCTOR || bd.type == MTSAMD_BSDF_ROUGHCONDUCTOR) &&
             (bd.eta[0] != bd.eta[1] || bd.eta[0] != bd.eta[2] || bd.k[0] != bd.k[1] || bd.k[0] != bd.k[2]))
             return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u: the spectral variant needs uniform (constant) eta and k spectra", b);
@@ -432,10 +432,11 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
                                                                       : "The 'roughplastic' plugin currently does not support anisotropic microfacet distributions!");
         if (bd.type == MTSAMD_BSDF_ROUGHDIELECTRIC && (bd.int_ior < 0.0f || bd.ext_ior < 0.0f || bd.int_ior == bd.ext_ior))
             return fail(MTSAMD_ERR_INVALID, "The interior and exterior indices of refraction must be positive and differ!");      // roughdielectric.cpp:153-155
-        if ((bd.type == MTSAMD_BSDF_DIELECTRIC || bd.type == MTSAMD_BSDF_PLASTIC || bd.type == MTSAMD_BSDF_ROUGHPLASTIC || bd.type == MTSAMD_BSDF_ROUGHDIELECTRIC) &&
+        if ((bd.type == MTSAMD_BSDF_DIELECTRIC || bd.type == MTSAMD_BSDF_PLASTIC || bd.type == MTSAMD_BSDF_ROUGHPLASTIC || bd.type == MTSAMD_BSDF_ROUGHDIELECTRIC ||
+             bd.type == MTSAMD_BSDF_THINDIELECTRIC) &&
             (bd.int_ior < 0.0f || bd.ext_ior < 0.0f || bd.ext_ior == 0.0f))
             return fail(MTSAMD_ERR_INVALID, "The interior and exterior indices of refraction must be positive!");      // dielectric.cpp:183-185
-        if ((bd.type == MTSAMD_BSDF_DIELECTRIC || bd.type == MTSAMD_BSDF_ROUGHDIELECTRIC) && bd.twosided)
+        if ((bd.type == MTSAMD_BSDF_DIELECTRIC || bd.type == MTSAMD_BSDF_ROUGHDIELECTRIC || bd.type == MTSAMD_BSDF_THINDIELECTRIC) && bd.twosided)
             return fail(MTSAMD_ERR_INVALID, "Only materials without a transmission component can be nested!");          // twosided.cpp:90-91
         if (desc->bsdfs[b].texture >= (int32_t) desc->texture_count) return fail(MTSAMD_ERR_INVALID, "bsdf %u: invalid texture index %d", b, desc->bsdfs[b].texture);
     }

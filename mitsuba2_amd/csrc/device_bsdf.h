@@ -15,7 +15,7 @@
 namespace mtsamd {
 
 constexpr int kBsdfDiffuse = 0, kBsdfConductor = 1, kBsdfRoughConductor = 2, kBsdfDielectric = 3, kBsdfPlastic = 4, kBsdfRoughPlastic = 5,
-              kBsdfRoughDielectric = 6;
+              kBsdfRoughDielectric = 6, kBsdfThinDielectric = 7;
 constexpr uint32_t kBsdfTwoSided = 1u, kBsdfGGX = 2u, kBsdfSampleVisible = 4u, kBsdfNonlinear = 8u;
 // spectral variant: the parameter is a `uniform` spectrum (its constant sits in the first colour channel) instead of `srgb`
 constexpr uint32_t kBsdfUniformRefl = 16u, kBsdfUniformSpec = 32u, kBsdfUniformTrans = 64u;
@@ -300,6 +300,18 @@ MTS_DEV bool bsdf_sample_n(const DevBsdf &b, const BsdfChannels<N> &c, f3 wi, fl
         const float q = sqr(f.eta_ti);
 #pragma unroll
         for (int i = 0; i < N; ++i) weight[i] = selected_r ? 1.0f * c.spec[i] : (1.0f * c.trans[i]) * q;
+        ok = true;
+    } else if (b.type == kBsdfThinDielectric) {                // thindielectric.cpp:100-148
+        float r = fresnel(fabsf(wi.z), b.er).r;
+        r *= 2.0f / (1.0f + r);                                // internal reflections: r' = r + trt + tr^3t + ..
+        const float t = 1.0f - r;
+        const bool selected_r = sample1 <= r;
+        bs.pdf = selected_r ? r : t;
+        bs.wo = selected_r ? reflect_z(wi) : mk3(-wi.x, -wi.y, -wi.z);
+        bs.eta = 1.0f;
+        bs.delta = true;                                       // DeltaReflection or Null: both are in BSDFFlags::Delta (bsdf.h:117)
+#pragma unroll
+        for (int i = 0; i < N; ++i) weight[i] = selected_r ? 1.0f * c.spec[i] : 1.0f * c.trans[i];
         ok = true;
     } else if (b.type == kBsdfPlastic) {
         const float cos_theta_i = wi.z;

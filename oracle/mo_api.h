@@ -52,7 +52,7 @@ int mo_scene_update_texture(mo_scene *s, uint32_t texture, const float *rgb);
 int mo_scene_set_reflectance(mo_scene *s, uint32_t shape, const float *rgb);
 /* BSDF models beyond `diffuse` (oracle/mo_bsdf.c).  `twosided` wraps the model in the TwoSidedBRDF adapter. */
 enum { MO_BSDF_DIFFUSE = 0, MO_BSDF_CONDUCTOR = 1, MO_BSDF_ROUGHCONDUCTOR = 2, MO_BSDF_DIELECTRIC = 3, MO_BSDF_PLASTIC = 4,
-       MO_BSDF_ROUGHPLASTIC = 5, MO_BSDF_ROUGHDIELECTRIC = 6 };
+       MO_BSDF_ROUGHPLASTIC = 5, MO_BSDF_ROUGHDIELECTRIC = 6, MO_BSDF_THINDIELECTRIC = 7 };
 typedef struct {
     int32_t type, twosided;
     float reflectance[3];              /* diffuse.reflectance / plastic.diffuse_reflectance (constant part) */

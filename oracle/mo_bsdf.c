@@ -210,7 +210,8 @@ static void roughplastic_tables(mo_bsdf *b);
 /* derived constants (plastic.cpp:162-176, roughplastic.cpp:365-399) */
 void mo_bsdf_prepare(mo_bsdf *b) {
     b->eta_rel = 1.0f;
-    if (b->d.type == MO_BSDF_DIELECTRIC || b->d.type == MO_BSDF_PLASTIC || b->d.type == MO_BSDF_ROUGHPLASTIC || b->d.type == MO_BSDF_ROUGHDIELECTRIC) b->eta_rel = b->d.int_ior / b->d.ext_ior;
+    if (b->d.type == MO_BSDF_DIELECTRIC || b->d.type == MO_BSDF_PLASTIC || b->d.type == MO_BSDF_ROUGHPLASTIC || b->d.type == MO_BSDF_ROUGHDIELECTRIC ||
+        b->d.type == MO_BSDF_THINDIELECTRIC) b->eta_rel = b->d.int_ior / b->d.ext_ior;
     if (b->d.type == MO_BSDF_ROUGHPLASTIC) roughplastic_tables(b);
     if (b->d.type == MO_BSDF_PLASTIC || b->d.type == MO_BSDF_ROUGHPLASTIC) {
         b->inv_eta_2 = 1.0f / (b->eta_rel * b->eta_rel);
@@ -406,6 +407,20 @@ int mo_bsdf_sample_n(const mo_bsdf *b, int n, const mo_bsdf_chan *c, mo_v3 wi, f
             if (!selected_r) wk *= sqr(f[3]);
             weight[k] = wk;
         }
+        ok = 1;
+    } break;
+    case MO_BSDF_THINDIELECTRIC: {                           /* thindielectric.cpp:100-148 (both lobes enabled) */
+        float f[4];
+        mo_fresnel(fabsf(wi.z), b->eta_rel, f);
+        float r = f[0];
+        r *= 2.0f / (1.0f + r);                              /* internal reflections: r' = r + trt + tr^3t + .. */
+        float t = 1.0f - r;
+        int selected_r = sample1 <= r;
+        bs->pdf = selected_r ? r : t;
+        bs->wo = selected_r ? reflect_z(wi) : mo_neg(wi);
+        bs->eta = 1.0f;
+        bs->delta = 1;                                       /* DeltaReflection or Null: both in BSDFFlags::Delta (bsdf.h:117) */
+        for (int k = 0; k < n; ++k) weight[k] = 1.0f * (selected_r ? c->spec[k] : c->trans[k]);
         ok = 1;
     } break;
     case MO_BSDF_PLASTIC: {                                  /* plastic.cpp:178-240 */

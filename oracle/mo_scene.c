@@ -221,7 +221,7 @@ int mo_scene_set_reflectance(mo_scene *s, uint32_t shape, const float *rgb) {
     return 0;
 }
 int mo_scene_set_bsdf(mo_scene *s, uint32_t shape, const mo_bsdf_desc *desc) {
-    if (!s || shape >= s->n_meshes || !desc || desc->type < MO_BSDF_DIFFUSE || desc->type > MO_BSDF_ROUGHDIELECTRIC) return -1;
+    if (!s || shape >= s->n_meshes || !desc || desc->type < MO_BSDF_DIFFUSE || desc->type > MO_BSDF_THINDIELECTRIC) return -1;
     if (s->spectral) return -2;                                       /* set the BSDFs before mo_scene_set_spectral */
     mo_mesh *m = &s->meshes[shape];
     m->bsdf.d = *desc;

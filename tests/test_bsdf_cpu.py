@@ -181,6 +181,32 @@ def test_dielectric_sample():
         ob.bsdf_desc({"type": "dielectric", "int_ior": -0.5})
 
 
+def test_thindielectric_sample():
+    """thindielectric.cpp:100-148: a slab with internal reflections -- r' = 2 r / (1 + r) of the Fresnel reflectance r at
+    |cos theta_i| -- reflects specularly with probability r' and lets light pass straight through (wo = -wi, eta = 1, null lobe)
+    with 1 - r'; both lobes are in BSDFFlags::Delta (bsdf.h:117); eval() and pdf() are zero (thindielectric.cpp:152-160).  The same
+    from either side.  No reference test file exists for this plugin: pinned to these closed forms."""
+    b = {"type": "thindielectric", "specular_reflectance": 0.3, "specular_transmittance": 0.6, "int_ior": 1.5, "ext_ior": 1}
+    r0 = 0.04                                  # Fresnel at normal incidence, eta = 1.5
+    rp = 2 * r0 / (1 + r0)
+    for wz in (1.0, -1.0):
+        r = ob.bsdf_kat(b, [[0, 0, wz]] * 2, [[0, 0, 1]] * 2, [[0, 0, 0], [rp + 1e-3, 0, 0]])
+        assert np.allclose(r["s_weight"][0], 0.3) and np.isclose(r["s_pdf"][0], rp) and r["s_eta"][0] == 1 and np.allclose(r["s_wo"][0], [0, 0, wz])
+        assert np.allclose(r["s_weight"][1], 0.6) and np.isclose(r["s_pdf"][1], 1 - rp) and r["s_eta"][1] == 1 and np.allclose(r["s_wo"][1], [0, 0, -wz])
+        assert r["s_delta"].all() and (r["eval"] == 0).all() and (r["pdf"] == 0).all()
+    # oblique incidence: r from the oracle's Fresnel routine (pinned by test_fresnel.py's values above)
+    wi = np.array([math.sin(1.2), 0, math.cos(1.2)], np.float32)
+    fr = ob.fresnel(float(wi[2]), 1.5)[0]
+    rr = fr * 2 / (1 + fr)
+    r = ob.bsdf_kat({"type": "thindielectric", "int_ior": 1.5, "ext_ior": 1.0}, [wi, wi], [[0, 0, 1]] * 2, [[0.5 * rr, 0, 0], [0.5 * (1 + rr), 0, 0]])
+    assert np.isclose(r["s_pdf"][0], rr, rtol=1e-5) and np.allclose(r["s_wo"][0], [-wi[0], 0, wi[2]]) and np.allclose(r["s_weight"][0], 1.0)
+    assert np.isclose(r["s_pdf"][1], 1 - rr, rtol=1e-5) and np.allclose(r["s_wo"][1], -wi) and np.allclose(r["s_weight"][1], 1.0)
+    d, _ = ob.bsdf_desc({"type": "thindielectric"})                 # defaults: bk7 / air (thindielectric.cpp:80-82)
+    assert abs(d.int_ior - 1.5046) < 1e-6 and abs(d.ext_ior - 1.000277) < 1e-6
+    with pytest.raises(RuntimeError):
+        ob.bsdf_desc({"type": "twosided", "bsdf": {"type": "thindielectric"}})
+
+
 def test_conductor_mirror():
     """conductor.cpp:185-252: a delta reflection weighted by the conductor Fresnel term (test_conductor.py:47-50 checks the
     same identity through the Mueller matrix)"""

@@ -19,6 +19,7 @@ MATERIALS = {
     "rough_ggx_all": {"type": "roughconductor", "alpha": 0.25, "distribution": "ggx", "sample_visible": False, "eta": 0.0, "k": 1.0},
     "rough_beckmann_all": {"type": "roughconductor", "alpha": 0.25, "distribution": "beckmann", "sample_visible": False, "eta": 0.0, "k": 1.0},
     "glass": {"type": "dielectric", "int_ior": "bk7", "ext_ior": "air", "specular_transmittance": [0.9, 0.95, 1.0]},
+    "thin_glass": {"type": "thindielectric", "int_ior": "bk7", "ext_ior": "air", "specular_transmittance": [0.9, 0.95, 1.0], "specular_reflectance": 0.8},
     "plastic": {"type": "plastic", "diffuse_reflectance": [0.1, 0.27, 0.36], "int_ior": 1.9},
     "plastic_nl": {"type": "plastic", "diffuse_reflectance": [0.5, 0.2, 0.1], "nonlinear": True, "specular_reflectance": 0.8},
     "roughplastic": {"type": "roughplastic", "alpha": 0.15, "diffuse_reflectance": [0.1, 0.27, 0.36], "int_ior": 1.9},
@@ -83,7 +84,7 @@ def test_unsupported_combinations():
     with pytest.raises(RuntimeError, match="uniform"):
         R.Scene(cb, variant="spectral")
     with pytest.raises(RuntimeError, match="not supported by this backend"):
-        R.Scene(dict(cb, bsdfs=[{"type": "thindielectric"}] * len(cb["bsdfs"])))
+        R.Scene(dict(cb, bsdfs=[{"type": "blendbsdf"}] * len(cb["bsdfs"])))
     with pytest.raises(RuntimeError, match="positive and differ"):
         R.Scene(dict(cb, bsdfs=[{"type": "roughdielectric", "int_ior": 1.2, "ext_ior": 1.2}] * len(cb["bsdfs"])))
 

@@ -67,6 +67,7 @@ SPECTRAL_MATERIALS = {
     "rough_beckmann": {"type": "roughconductor", "alpha_u": 0.3, "alpha_v": 0.1, "distribution": "beckmann", "eta": 0.0, "k": 1.0,
                        "specular_reflectance": 0.8},
     "glass": {"type": "dielectric", "int_ior": "bk7", "specular_transmittance": [0.9, 0.95, 1.0]},
+    "thin_glass": {"type": "thindielectric", "specular_transmittance": [0.9, 0.95, 1.0], "specular_reflectance": 0.8},
     "frosted_glass": {"type": "roughdielectric", "alpha": 0.2, "specular_transmittance": [0.9, 0.95, 1.0], "specular_reflectance": 0.9},
     "plastic": {"type": "plastic", "diffuse_reflectance": [0.1, 0.27, 0.36], "int_ior": 1.9},
     "plastic_uniform": {"type": "plastic", "diffuse_reflectance": 0.3, "specular_reflectance": 0.7, "nonlinear": True},
