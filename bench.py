@@ -8,7 +8,7 @@ before anything touches the GPU); under `python -m torch.distributed.run ... ben
 
 Configurations (BASELINE.json `configs`):
   cbox      [1] synthetic Cornell box, RGB, 1024x1024 @ 256 spp per GPU -- the headline line.  N > 1: the film is cut into
-            interleaved 32-row tiles (mitsuba2_amd/dist.py), every rank keeps 2^28 camera samples (weak scaling: 256 N spp),
+            interleaved 16-row tiles (mitsuba2_amd/dist.py), every rank keeps 2^28 camera samples (weak scaling: 256 N spp),
             the per-rank XYZAW films are summed with one RCCL reduce.
   mesh      [2] 261 k-triangle displaced sphere, spectral variant, 1920x1080 @ 1024 spp, 1 GPU.
   autodiff  [3] one inverse-rendering iteration (primal + derivative render + adjoint + Adam) on the Cornell box, the setup of
@@ -284,7 +284,7 @@ def run_cbox(args, R, strong=False):
         "data": "synthetic",
         "config": {"workload": "synthetic Cornell box (36 triangles, diffuse, 1 area light), %dx%d film, %d spp total%s, "
                                "gaussian rfilter, independent sampler" % (width, height, spp_total, "" if strong else " (%d per GPU)" % args.spp),
-                   "partition": "interleaved 32-row film tiles + RCCL reduce" if n > 1 else "single GPU",
+                   "partition": "interleaved 16-row film tiles + RCCL reduce" if n > 1 else "single GPU",
                    "backend": (args.backend if n > 1 else None)},
         "mray_per_s": (tot_closest + tot_any) / dt / 1e6,
         "segments_per_sample": acc["segments"] / max(acc["samples"], 1),

@@ -1421,8 +1421,11 @@ int mtsamd_render(mtsamd_scene *s, const mtsamd_render_desc *d, float *film, uin
     if (tiled) {          // scratch tiles of the largest pass
         FilmParams f{};
         f.crop_w = d->crop_width; f.pass_rows = (int32_t) std::min<uint64_t>(rows_per_pass, (uint64_t) rows.local_rows); f.tile_h = film_tile_h;
+        f.spp = d->sample_count;
         film_tile_grid(f);
-        const size_t need = film_partial_floats(f);
+        size_t need = film_partial_floats(f);
+        const uint64_t last_rows = (uint64_t) rows.local_rows % rows_per_pass;      // a shorter last pass has fewer tiles but more sample runs
+        if (last_rows) { f.pass_rows = (int32_t) last_rows; film_tile_grid(f); need = std::max(need, film_partial_floats(f)); }
         if (need > ws.film_partial_floats) {
             (void) hipFree(ws.film_partials); ws.film_partials = nullptr; ws.film_partial_floats = 0;
             HIP_TRY(hipMalloc((void **) &ws.film_partials, need * sizeof(float)));

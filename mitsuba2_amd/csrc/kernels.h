@@ -94,6 +94,7 @@ struct FilmParams {
     // accumulates the film pixels it reaches into its scratch tile of `partials`
     int32_t pass_lr0, pass_rows, tiles_x, tiles_y;
     int32_t tile_h;             // local rows per source tile (<= 16; 16 unless a partitioned film forces less)
+    int32_t slices;             // the samples of a pixel are cut into this many runs, each accumulated by a workgroup of its own (few tiles, many samples)
     float *partials;
 };
 

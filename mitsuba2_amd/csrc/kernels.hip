@@ -1544,13 +1544,15 @@ __global__ __launch_bounds__(kBlock) void k_film_accum(const FilmParams F) {
 #pragma unroll
             for (int c = 0; c < 5; ++c) acc[ky][kx][c] = 0.0f;
     float4 pv[kFilmPrefetch]; float2 pq[kFilmPrefetch];
-    const int n_spp = have ? F.spp : 0;
+    // blockIdx.y: which run of the pixel's samples (runs start on multiples of 4: whole 64-byte sectors)
+    const int run = ((F.spp + F.slices - 1) / F.slices + 3) & ~3;
+    const int s_begin = min((int) blockIdx.y * run, F.spp), n_spp = have ? min(s_begin + run, F.spp) : s_begin;
 #pragma unroll
     for (int k = 0; k < kFilmPrefetch; ++k) {
         pv[k] = make_float4(0.0f, 0.0f, 0.0f, -1.0f); pq[k] = make_float2(0.0f, 0.0f);
-        if (k < n_spp) { pv[k] = MTS_FILM_LOAD(F.out_rgba + slot0 + (size_t) k); pq[k] = MTS_FILM_LOAD(F.out_pos + slot0 + (size_t) k); }
+        if (s_begin + k < n_spp) { pv[k] = MTS_FILM_LOAD(F.out_rgba + slot0 + (size_t) (s_begin + k)); pq[k] = MTS_FILM_LOAD(F.out_pos + slot0 + (size_t) (s_begin + k)); }
     }
-    for (int s0 = 0; s0 < n_spp; s0 += kFilmPrefetch) {
+    for (int s0 = s_begin; s0 < n_spp; s0 += kFilmPrefetch) {
 #pragma unroll
         for (int k = 0; k < kFilmPrefetch; ++k) {
             const float4 rec = pv[k]; const float2 rp = pq[k];
@@ -1605,7 +1607,7 @@ __global__ __launch_bounds__(kBlock) void k_film_accum(const FilmParams F) {
         collect(d0, ky, out0);
         if (d1 < n_dest) collect(d1, ky, out1);
     }
-    float *dst = F.partials + (size_t) blockIdx.x * kFilmPartial;
+    float *dst = F.partials + ((size_t) blockIdx.y * gridDim.x + blockIdx.x) * kFilmPartial;
     if (d0 < n_dest)
 #pragma unroll
         for (int k = 0; k < 5; ++k) dst[5 * d0 + k] = out0[k];
@@ -1635,9 +1637,11 @@ __global__ __launch_bounds__(kBlock) void k_film_merge(const FilmParams F) {
         for (int tc = tc0; tc <= tc1; ++tc) {
             const int dx = x - (tc * kFilmTile - R);
             if (dx < 0 || dx >= DW || dy < 0 || dy >= DW) continue;
-            const float *p = F.partials + (size_t) (tr * F.tiles_x + tc) * kFilmPartial + 5 * (dy * DW + dx);
+            for (int sl = 0; sl < F.slices; ++sl) {
+                const float *p = F.partials + ((size_t) sl * (size_t) (F.tiles_x * F.tiles_y) + (size_t) (tr * F.tiles_x + tc)) * kFilmPartial + 5 * (dy * DW + dx);
 #pragma unroll
-            for (int k = 0; k < 5; ++k) acc[k] += p[k];
+                for (int k = 0; k < 5; ++k) acc[k] += p[k];
+            }
         }
     }
     if (prev < 0) return;                  // a film row between two of this rank's row tiles: nothing of this pass reaches it
@@ -1647,15 +1651,19 @@ __global__ __launch_bounds__(kBlock) void k_film_merge(const FilmParams F) {
 }
 
 bool film_tiles_supported(const FilterView &f) { return f.taps <= 4 && (int) ceilf(f.radius) <= 2; }
-size_t film_partial_floats(const FilmParams &p) { return (size_t) p.tiles_x * (size_t) p.tiles_y * kFilmPartial; }
+size_t film_partial_floats(const FilmParams &p) { return (size_t) p.slices * (size_t) p.tiles_x * (size_t) p.tiles_y * kFilmPartial; }
 void film_tile_grid(FilmParams &p) {
     p.tiles_x = (p.crop_w + kFilmTile - 1) / kFilmTile;
     p.tiles_y = (p.pass_rows + p.tile_h - 1) / p.tile_h;
+    // few tiles with many samples each (a rank's share of a partitioned film, a pass of a large film): cut the samples of a pixel
+    // into runs of >= 64 so that about 2048 workgroups share the stream
+    const int tiles = std::max(p.tiles_x * p.tiles_y, 1);
+    p.slices = std::max(1, std::min({ 2048 / tiles, p.spp / 64, 64 }));
 }
 
 hipError_t launch_film_tiles(const FilmParams &p, hipStream_t s) {
     if (p.row1 <= p.row0 || p.pass_rows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_film_accum, dim3((uint32_t) (p.tiles_x * p.tiles_y)), dim3(kBlock), 0, s, p);
+    hipLaunchKernelGGL(k_film_accum, dim3((uint32_t) (p.tiles_x * p.tiles_y), (uint32_t) p.slices), dim3(kBlock), 0, s, p);
     const uint64_t n = (uint64_t) (p.row1 - p.row0) * (uint64_t) p.crop_w;
     hipLaunchKernelGGL(k_film_merge, dim3((uint32_t) ((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, p);
     return hipGetLastError();

@@ -6,9 +6,11 @@ normalisation deferred to ``HDRFilm::bitmap``), so any partition of the camera s
 exact up to fp32 addition order.
 
 * one process per GPU (``torch.distributed``, backend ``nccl`` = RCCL over xGMI; ``gloo`` in the CPU tests);
-* the film is cut into tiles of ``tile_rows`` rows (32 = ``MTS_BLOCK_SIZE``, ``include/mitsuba/render/spiral.h:10``)
-  dealt round-robin to the ranks -- interleaving keeps the per-rank work balanced although path length varies
-  over the image; RNG streams are seeded with the *global* sample index, so the image is independent of the
+* the film is cut into tiles of ``tile_rows`` rows dealt round-robin to the ranks -- interleaving keeps the per-rank
+  work balanced although path length varies over the image.  16 rows (half of ``MTS_BLOCK_SIZE``,
+  ``include/mitsuba/render/spiral.h:10``, and the height of the film kernel's source tiles): on the 1024-row headline
+  film cut over 8 ranks the slowest rank then takes 1.026 x the mean (32-row tiles: 1.055 x, 8-row tiles: 1.022 x;
+  ``scripts/rank_balance.py``); RNG streams are seeded with the *global* sample index, so the image is independent of the
   number of ranks (up to the summation order of the final reduce);
 * every rank splats its samples into a full-size XYZAW film (its tiles plus the filter apron), the scene is
   replicated, and the films are summed with ONE ``reduce`` (root 0) or ``all_reduce``.
@@ -16,7 +18,7 @@ exact up to fp32 addition order.
 import torch
 import torch.distributed as dist
 
-TILE_ROWS = 32
+TILE_ROWS = 16
 
 
 def film_partition(rank, world_size, tile_rows=TILE_ROWS):

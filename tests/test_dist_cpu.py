@@ -79,7 +79,7 @@ def test_owned_rows_edge_cases():
     for h, w, tr in ((1080, 8, 32), (33, 4, 32), (4096, 8, 32)):
         allr = sorted(r for k in range(w) for r in mdist.owned_rows(h, k, w, tr))
         assert allr == list(range(h))
-    # balance on the headline config: 1024 rows over 8 ranks in 32-row tiles -> 128 rows each
+    # balance on the headline config: 1024 rows over 8 ranks in 16-row tiles -> 128 rows each
     assert {len(mdist.owned_rows(1024, k, 8)) for k in range(8)} == {128}
 
 
