@@ -10,7 +10,8 @@ Configurations (BASELINE.json `configs`):
   cbox      [1] synthetic Cornell box, RGB, 1024x1024 @ 256 spp per GPU -- the headline line.  N > 1: the film is cut into
             interleaved 16-row tiles (mitsuba2_amd/dist.py), every rank keeps 2^28 camera samples (weak scaling: 256 N spp),
             the per-rank XYZAW films are summed with one RCCL reduce.
-  mesh      [2] 261 k-triangle displaced sphere, spectral variant, 1920x1080 @ 1024 spp, 1 GPU.
+  mesh      [2] 261 k-triangle displaced sphere, spectral variant, 1920x1080 @ 1024 spp, 1 GPU, all-diffuse materials;
+            mesh_matpreview: the same with a roughplastic object, a checkerboard ground and an envmap sky (general BSDF / emitter kernels).
   autodiff  [3] one inverse-rendering iteration (primal + derivative render + adjoint + Adam) on the Cornell box, the setup of
             docs/examples/10_inverse_rendering/invert_cbox.py; metric = ms per iteration.
   cbox4k    [4] 4096x4096 @ 4096 spp Cornell box, film tile-partitioned over the N ranks (strong scaling: the work is fixed).
@@ -311,16 +312,18 @@ def run_cbox(args, R, strong=False):
 SAMPLE_RECORD_BYTES = 24       # per finished camera sample: 16 B (X, Y, Z, alpha) + 8 B film position
 
 
-def run_mesh(args, R):
-    """configs[2]: ~250 k-triangle matpreview-style mesh, spectral variant, 1920x1080 @ 1024 spp on one GPU (8 passes of 136 film
-    rows).  Roofline of the BVH traversal kernel k_trace<false,false>: 48 B per closest-hit ray + the geometry
-    once per launch, over the average launch duration measured with HIP events on the stream of each launch."""
+def run_mesh(args, R, matpreview=False):
+    """configs[2]: ~250 k-triangle matpreview-style mesh, spectral variant, 1920x1080 @ 1024 spp on one GPU (2 passes).  Roofline of
+    the BVH traversal kernel k_trace<false,false>: 48 B per closest-hit ray + the geometry once per launch, over the
+    average launch duration measured with HIP events on the stream of each launch.  Two material sets on the same geometry, camera and
+    area light: all-diffuse (`mesh`: the kernels specialised for one-sided diffuse BSDFs and area lights) and the materials of a
+    material-preview scene (`mesh_matpreview`: roughplastic object, checkerboard ground, envmap sky: the general BSDF / emitter kernels)."""
     import numpy as np
     from mitsuba2_amd import render, scenes
-    explicit = args.config == "mesh"
-    steps, warmup = (args.steps, args.warmup) if explicit else (2, 1)
+    explicit = args.config in ("mesh", "mesh_matpreview")
+    steps, warmup = (args.steps, args.warmup) if explicit else ((1, 1) if matpreview else (2, 1))
     variant = args.variant
-    sd = scenes.bumpy_sphere(256, 512)
+    sd = scenes.matpreview(256, 512) if matpreview else scenes.bumpy_sphere(256, 512)
     scene = render.Scene(sd, device=R.device, variant=variant)
     info = scene.info()
     w, h, spp = args.mesh_width, args.mesh_height, args.mesh_spp
@@ -338,8 +341,9 @@ def run_mesh(args, R):
         "metric": "Msample/s, %d k-triangle mesh, %s variant, %dx%d@%dspp, path integrator (max_depth=-1, rr_depth=5)" % (info["primitives"] // 1000, variant, w, h, spp),
         "value": acc["samples"] / dt / 1e6, "unit": "Msample/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
         "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "procedural displaced sphere (%d triangles, vertex normals) over a ground quad, one area light, diffuse BSDFs, %s variant, "
-                               "%dx%d film, %d spp, gaussian rfilter, independent sampler" % (info["primitives"], variant, w, h, spp),
+        "config": {"workload": "procedural displaced sphere (%d triangles, vertex normals) over a ground quad, one area light, %s, %s variant, "
+                               "%dx%d film, %d spp, gaussian rfilter, independent sampler" % (info["primitives"],
+                               "roughplastic (GGX) object, checkerboard ground, 256x512 envmap sky" if matpreview else "diffuse BSDFs", variant, w, h, spp),
                    "bvh_nodes": info["bvh_nodes"], "bvh_depth": info["bvh_depth"]},
         "mray_per_s": (acc["closest_hit_rays"] + acc["any_hit_rays"]) / dt / 1e6,
         "segments_per_sample": acc["segments"] / max(acc["samples"], 1),
@@ -357,8 +361,8 @@ def run_mesh(args, R):
     }
     if not args.no_cpu_baseline:
         path = render.srgb_coeff_path() if variant == "spectral" else None
-        out["cpu_baseline"] = cpu_baseline(sd, lambda s: scenes.bumpy_sphere_sensor(w, h, s), "mesh %s" % variant, spectral_path=path,
-                                           seconds=args.cpu_seconds, max_spp=8)
+        out["cpu_baseline"] = cpu_baseline(sd, lambda s: scenes.bumpy_sphere_sensor(w, h, s), "mesh %s%s" % ("matpreview " if matpreview else "", variant),
+                                           spectral_path=path, seconds=args.cpu_seconds, max_spp=4 if matpreview else 8)
     if not args.no_parity:
         # same kernels, a 96x64 @ 64 spp render of the same scene against the oracle with the same per-sample seeds
         ob = _oracle()
@@ -492,7 +496,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="cbox", choices=["cbox", "mesh", "autodiff", "cbox4k", "launcher-selftest"])
+    ap.add_argument("--config", default="cbox", choices=["cbox", "mesh", "mesh_matpreview", "autodiff", "cbox4k", "launcher-selftest"])
     ap.add_argument("--only", action="store_true", help="--config cbox without the other configurations")
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=1024)
@@ -516,15 +520,15 @@ def main():
         ap.error("--gpus must be positive")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
-    if args.config in ("mesh", "autodiff") and args.gpus != 1:
+    if args.config in ("mesh", "mesh_matpreview", "autodiff") and args.gpus != 1:
         ap.error("--config %s is a single-GPU configuration" % args.config)
 
     R = Ranks(args)
     if args.config == "launcher-selftest":
         R.barrier()
         out = {"n_gpus": R.world, "backend": args.backend, "ranks": R.gather(R.rank), "sum": R.sum([R.rank + 1])[0], "max": R.max(R.rank)}
-    elif args.config == "mesh":
-        out = run_mesh(args, R)
+    elif args.config in ("mesh", "mesh_matpreview"):
+        out = run_mesh(args, R, matpreview=args.config == "mesh_matpreview")
     elif args.config == "autodiff":
         out = run_autodiff(args, R)
     elif args.config == "cbox4k":
@@ -535,6 +539,7 @@ def main():
             others = {}
             if R.world == 1:
                 others["mesh"] = run_mesh(args, R)
+                others["mesh_matpreview"] = run_mesh(args, R, matpreview=True)
                 others["autodiff"] = run_autodiff(args, R)
             strong = run_cbox(args, R, strong=True)
             if R.rank == 0:

@@ -191,6 +191,24 @@ def bumpy_sphere(n_theta=64, n_phi=128, with_normals=True, seed=1):
     return dict(meshes=meshes, bsdfs=bsdfs, emitters=emitters)
 
 
+def matpreview(n_theta=256, n_phi=512, env_res=(256, 512)):
+    """Material-preview style scene (BASELINE config 3 with the materials of a matpreview scene): the displaced sphere as a `roughplastic`
+    object on a `checkerboard` ground plane, lit by a procedural sky `envmap` (smooth gradient + a sun lobe) and the area light."""
+    sd = bumpy_sphere(n_theta, n_phi)
+    sd["bsdfs"][0] = dict(type="roughplastic", alpha=0.1, distribution="ggx", diffuse_reflectance=np.array([0.1, 0.27, 0.36], dtype=F32), int_ior=1.49)
+    sd["bsdfs"][1] = dict(type="diffuse", reflectance=dict(type="checkerboard", color0=[0.4, 0.4, 0.4], color1=[0.2, 0.2, 0.2],
+                                                            to_uv=np.array([[8, 0, 0, 0], [0, 8, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=F32)))
+    h, w = env_res
+    v, u = np.meshgrid((np.arange(h) + 0.5) / h, (np.arange(w) + 0.5) / w, indexing="ij")
+    theta, phi = v * np.pi, u * 2 * np.pi
+    d = np.stack([np.sin(theta) * np.sin(phi), np.cos(theta), -np.sin(theta) * np.cos(phi)], -1)
+    sun = np.array([0.4, 0.7, -0.6]); sun /= np.linalg.norm(sun)
+    sky = 0.25 + 0.55 * np.clip(d[..., 1], 0, 1)[..., None] * np.array([0.55, 0.7, 1.0]) + 0.08 * np.clip(-d[..., 1], 0, 1)[..., None] * np.array([0.5, 0.45, 0.4])
+    sky = sky + 12.0 * np.exp(-(1 - np.clip(d @ sun, -1, 1)) * 200.0)[..., None] * np.array([1.0, 0.9, 0.75])
+    sd["emitters"].append(dict(type="envmap", data=np.ascontiguousarray(sky, dtype=F32), scale=1.0))
+    return sd
+
+
 def bumpy_sphere_sensor(width=128, height=96, spp=8, seed=0, max_depth=-1, rr_depth=5):
     return dict(to_world=look_at([0, 2.5, -5.5], [0, 1.0, 0], [0, 1, 0]), fov=40.0, near_clip=0.01, far_clip=1e4,
                 width=width, height=height, crop=(0, 0, width, height), rfilter="gaussian", rfilter_param=0.5,

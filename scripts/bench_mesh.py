@@ -21,9 +21,10 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--variant", default="rgb", choices=["rgb", "spectral"])
+    ap.add_argument("--scene", default="diffuse", choices=["diffuse", "matpreview"], help="matpreview: roughplastic object, checkerboard ground, envmap")
     args = ap.parse_args()
     t0 = time.perf_counter()
-    sd = scenes.bumpy_sphere(args.theta, args.phi)
+    sd = scenes.matpreview(args.theta, args.phi) if args.scene == "matpreview" else scenes.bumpy_sphere(args.theta, args.phi)
     t1 = time.perf_counter()
     scene = render.Scene(sd, variant=args.variant)
     t2 = time.perf_counter()
