@@ -275,10 +275,13 @@ int mtsamd_sample_radiance(mtsamd_scene *scene, const mtsamd_render_desc *desc, 
  * and 'bsdf.reflectance.data' (src/textures/bitmap.cpp:295-299).  The image is values / (weight + 1e-8) of a film
  * rendered with `desc` and desc->film_rgb = 1 (channels R,G,B,A,W); dloss_dimage_dev holds dLoss/dImage
  * (crop_height*crop_width*3), film_dev that primal film.  Paths are replayed with the same per-sample PCG32 streams.
- * grad_bsdf_dev (bsdf_count*3) and grad_textures_dev (all textures concatenated in index order, see
- * mtsamd_scene_texture_info) are ACCUMULATED into; either may be NULL.  Needs 0 <= max_depth <= 16. */
+ * grad_bsdf_dev (bsdf_count*3), grad_textures_dev (all textures concatenated in index order, see
+ * mtsamd_scene_texture_info) and grad_emitters_dev (emitter_count*3: the radiance of area lights,
+ * 'shape.emitter.radiance.value', docs/src/inverse_rendering/diff_render.rst:76) are ACCUMULATED into; each may be NULL.
+ * Needs 0 <= max_depth <= 16. */
 int mtsamd_render_adjoint(mtsamd_scene *scene, const mtsamd_render_desc *desc, const float *dloss_dimage_dev,
-                          const float *film_dev, float *grad_bsdf_dev, float *grad_textures_dev, void *stream);
+                          const float *film_dev, float *grad_bsdf_dev, float *grad_textures_dev, float *grad_emitters_dev,
+                          void *stream);
 /* Size of a bitmap texture and its float offset inside the concatenated texture-gradient buffer. */
 /* RoughPlastic precomputation (roughplastic.cpp:380-399) of BSDF `bsdf`: out65[0..63] = external transmittance at
  * cos(theta) = i / 63, out65[64] = internal diffuse reflectance.  Host pointer. */

@@ -13,6 +13,7 @@ import ctypes as C
 import math
 from contextlib import contextmanager
 
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -45,6 +46,15 @@ class ParameterMap:
                 key = name + ".reflectance.value"
                 self.properties[key] = torch.as_tensor([float(x) for x in refl], dtype=torch.float32, device=dev)
                 self._kind[key] = ("bsdf", i, i)
+        # 'shape.emitter.radiance.value' of area lights (docs/src/inverse_rendering/diff_render.rst:76)
+        for i, m in enumerate(scene._dict["meshes"]):
+            e = m.get("emitter", -1)
+            if e is None or e < 0 or scene._dict["emitters"][e].get("type", "area") != "area":
+                continue
+            key = m.get("id", "shape_%d" % i) + ".emitter.radiance.value"
+            rad = np.broadcast_to(np.asarray(scene._dict["emitters"][e]["radiance"], np.float32), (3,))
+            self.properties[key] = torch.as_tensor(rad.copy(), dtype=torch.float32, device=dev)
+            self._kind[key] = ("emitter", e, i)
 
     def __getitem__(self, k): return self.properties[k]
     def __contains__(self, k): return k in self.properties
@@ -74,6 +84,8 @@ class ParameterMap:
             kind, idx, _ = self._kind[k]
             if kind == "texture":
                 self._scene.update_texture(idx, v)
+            elif kind == "emitter":
+                self._scene.set_emitter_radiance(idx, v.detach().cpu().tolist())
             else:
                 self._scene.set_bsdf_reflectance(idx, v.detach().cpu().tolist())
 
@@ -123,13 +135,16 @@ class _Render(torch.autograd.Function):
         tex_floats = sum(h * w * 3 for (h, w, _) in scene._texture_shapes)
         g_bsdf = torch.zeros((n_bsdf, 3), dtype=torch.float32, device=dev)
         g_tex = torch.zeros(max(tex_floats, 1), dtype=torch.float32, device=dev)
+        g_em = torch.zeros((max(len(scene._dict.get("emitters", [])), 1), 3), dtype=torch.float32, device=dev)
         gi = grad_image.to(dev, torch.float32).contiguous()
-        L.check(L.lib().mtsamd_render_adjoint(scene._handle, C.byref(d), _ptr(gi), _ptr(film), _ptr(g_bsdf), _ptr(g_tex), _stream()))
+        L.check(L.lib().mtsamd_render_adjoint(scene._handle, C.byref(d), _ptr(gi), _ptr(film), _ptr(g_bsdf), _ptr(g_tex), _ptr(g_em), _stream()))
         grads = []
         for k in keys:
             kind, idx, _ = pmap._kind[k]
             if kind == "bsdf":
                 grads.append(g_bsdf[idx].clone())
+            elif kind == "emitter":
+                grads.append(g_em[idx].clone())
             else:
                 off, w, h = C.c_uint64(), C.c_int32(), C.c_int32()
                 L.check(L.lib().mtsamd_scene_texture_info(scene._handle, idx, C.byref(w), C.byref(h), C.byref(off)))

@@ -1508,7 +1508,7 @@ int mtsamd_render(mtsamd_scene *s, const mtsamd_render_desc *d, float *film, uin
 }
 
 int mtsamd_render_adjoint(mtsamd_scene *s, const mtsamd_render_desc *d, const float *dimage, const float *film, float *grad_bsdf,
-                          float *grad_tex, void *stream_) {
+                          float *grad_tex, float *grad_emitter, void *stream_) {
     if (!s || !dimage || !film) return fail(MTSAMD_ERR_INVALID, "null argument");
     if (int rc = check_desc(d)) return rc;
     if (d->max_depth < 0 || d->max_depth > 16)
@@ -1518,6 +1518,7 @@ int mtsamd_render_adjoint(mtsamd_scene *s, const mtsamd_render_desc *d, const fl
     if (s->general_bsdfs) return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass is implemented for one-sided diffuse BSDFs only");
     if (s->environment >= 0 || s->delta_emitters) return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass handles area emitters only");
     if (s->bsdfs.size() > 32 && grad_bsdf) return fail(MTSAMD_ERR_UNSUPPORTED, "at most 32 BSDFs with constant-reflectance gradients");
+    if (s->emitters.size() > 32 && grad_emitter) return fail(MTSAMD_ERR_UNSUPPORTED, "at most 32 emitters with radiance gradients");
     HIP_TRY(hipSetDevice(s->device));
     AdjointParams a{};
     if (int rc = make_camera(*d, a.rp.cam)) return rc;
@@ -1530,7 +1531,7 @@ int mtsamd_render_adjoint(mtsamd_scene *s, const mtsamd_render_desc *d, const fl
     a.rp.rows = RowMap{ 0, d->crop_height, std::max(d->crop_height, 1), 0, 1 };
     a.rp.store_xyz = 0; a.rp.out_pos = nullptr; a.rp.out_rgba = nullptr;
     a.n_samples = (uint64_t) d->crop_width * d->crop_height * (uint64_t) d->sample_count;
-    a.dimage = dimage; a.film = film; a.grad_bsdf = grad_bsdf; a.grad_tex = grad_tex;
+    a.dimage = dimage; a.film = film; a.grad_bsdf = grad_bsdf; a.grad_tex = grad_tex; a.grad_emitter = grad_emitter;
     HIP_TRY(launch_adjoint(a, (hipStream_t) stream_));
     return MTSAMD_OK;
 }

@@ -106,6 +106,7 @@ struct AdjointParams {
     const float *film;          // primal film (5 channels; only the weight channel is read)
     float *grad_bsdf;           // n_bsdfs * 3, accumulated (may be null)
     float *grad_tex;            // all textures concatenated in index order, accumulated (may be null)
+    float *grad_emitter;        // n_emitters * 3 (radiance of area lights), accumulated (may be null)
 };
 
 struct RayStreams {

@@ -59,6 +59,8 @@ struct VertexRec {
     f3 E, Nc, Tp, rho; float invq;
     f3 T; int32_t rr_channel;       // throughput before Russian roulette; channel that sets q (-1: none / q clamped)
     uint32_t texel; f2 w1; int32_t bsdf; uint32_t has_bsdf;
+    // radiance-free coefficients for d/d(emitter radiance): E = ew * Le[em_hit], Nc = nk * Le[em_nee] (-1: none)
+    float ew, nk; int32_t em_hit, em_nee;
 };
 
 // Split ("wavefront") pipeline: the two ray queries of a segment run in their own kernels.  `hit` / `found` carry the
@@ -84,7 +86,8 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
     const SceneView &sv = P.sv;
     if (REC) {
         rec->E = rec->Nc = rec->Tp = rec->rho = mk3(0.0f, 0.0f, 0.0f);
-        rec->invq = 1.0f; rec->rr_channel = -1; rec->T = mk3(0.0f, 0.0f, 0.0f); rec->texel = kNoPrim; rec->w1.x = rec->w1.y = 0.0f; rec->bsdf = -1; rec->has_bsdf = 0u;
+        rec->invq = 1.0f; rec->rr_channel = -1; rec->T = s.thr; rec->texel = kNoPrim; rec->w1.x = rec->w1.y = 0.0f; rec->bsdf = -1; rec->has_bsdf = 0u;
+        rec->ew = rec->nk = 0.0f; rec->em_hit = rec->em_nee = -1;
     }
     const Geo<FLAT> geo{ sv, lds };
     Hit hit;
@@ -112,7 +115,7 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
             }
             if (si.wi.z > 0.0f) {                           // AreaLight::eval (area.cpp:71-79)
                 s.res.x += (ew * s.thr.x) * e.r; s.res.y += (ew * s.thr.y) * e.g; s.res.z += (ew * s.thr.z) * e.b;
-                if (REC) rec->E = mk3(ew * e.r, ew * e.g, ew * e.b);
+                if (REC) { rec->E = mk3(ew * e.r, ew * e.g, ew * e.b); rec->ew = ew; rec->em_hit = emitter; }
             }
         }
     }
@@ -132,7 +135,7 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
         if (active) active = pcg_next_f32(s.rng) < q;
         float rq = rcp(q);
         if (REC) {
-            rec->invq = rq; rec->T = s.thr;
+            rec->invq = rq;
             if (hm * (s.eta * s.eta) < 0.95f) rec->rr_channel = s.thr.x == hm ? 0 : (s.thr.y == hm ? 1 : 2);
         }
         s.thr = s.thr * rq;
@@ -148,7 +151,18 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
     if (!GENERAL || bsdf_is_smooth(bsdf)) {                  // active_e: only BSDFs with a smooth component (path.cpp:154)
         f2 s2; s2.x = pcg_next_f32(s.rng); s2.y = pcg_next_f32(s.rng);
         DirectionSample ds; f3 spec;
-        sample_emitter_direction<FLAT, GENERAL>(geo, si.p, s2, ds, spec);
+        float em_geo = 0.0f;                                 // REC: spec / radiance of an area light
+        if (REC) {
+            float r1, r2;
+            sample_emitter_direction<FLAT, GENERAL>(geo, si.p, s2, ds, r1, r2);
+            spec = mk3(0.0f, 0.0f, 0.0f);
+            if (sv.n_emitters != 0u) {
+                const DevEmitter e = geo.emitter(ds.emitter);
+                spec = mk3(e.r * r1, e.g * r1, e.b * r1);
+                if (sv.n_emitters > 1u) spec = spec * r2;
+                em_geo = r1 * r2;
+            }
+        } else sample_emitter_direction<FLAT, GENERAL>(geo, si.p, s2, ds, spec);
         if (ds.pdf != 0.0f) {
             f3 wo = to_local(si.sh, ds.d);
             f3 bv; float bp;
@@ -166,7 +180,7 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
                     df->smint = kRayEpsilon * (1.0f + hmax_abs(si.p)); df->smaxt = ds.dist * (1.0f - kShadowEpsilon);
                     df->nee[0] = contrib.x; df->nee[1] = contrib.y; df->nee[2] = contrib.z; df->nee[3] = 0.0f;
                 }
-            } else if (contrib.x != 0.0f || contrib.y != 0.0f || contrib.z != 0.0f) {
+            } else if (contrib.x != 0.0f || contrib.y != 0.0f || contrib.z != 0.0f || (REC && em_geo != 0.0f)) {
                 Hit sh;
                 ++c.any;
 #if defined(MTS_ABLATE_SHADOW)   // diagnostic build only: wrong image, used to price the any-hit loop in situ
@@ -180,6 +194,7 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
                     if (REC && si.wi.z > 0.0f && wo.z > 0.0f) {     // d(contrib)/d(rho) / T'_k
                         float k = mis * (kInvPi * wo.z);
                         rec->Nc = mk3(k * spec.x, k * spec.y, k * spec.z);
+                        if (em_geo != 0.0f) { rec->nk = k * em_geo; rec->em_nee = (int32_t) ds.emitter; }
                     }
                 }
             }
@@ -1300,7 +1315,8 @@ __global__ __launch_bounds__(kBlock) void k_adjoint(const AdjointParams A) {
     const RenderParams &P = A.rp;
     const LdsView lds = lds_stage<FLAT>(P.sv, smem);
     __shared__ float s_grad[3 * 32];                       // per-workgroup sums for constant reflectances
-    for (uint32_t i = threadIdx.x; i < 3u * 32u; i += kBlock) s_grad[i] = 0.0f;
+    __shared__ float s_grad_em[3 * 32];                    // ... and for the radiance of area lights
+    for (uint32_t i = threadIdx.x; i < 3u * 32u; i += kBlock) s_grad[i] = s_grad_em[i] = 0.0f;
     __syncthreads();
     const FilterView &f = A.filter;
     const uint32_t spp = (uint32_t) P.spp;
@@ -1344,6 +1360,16 @@ __global__ __launch_bounds__(kBlock) void k_adjoint(const AdjointParams A) {
         f3 a = mk3(0.0f, 0.0f, 0.0f);
         for (int v = n - 1; v >= 0; --v) {
             const VertexRec &r = rec[v];
+            if (A.grad_emitter) {     // radiance is linear in Le: delta * T_v * ew (emitter hit) + delta * T'_v rho_v nk (emitter sampled)
+                if (r.em_hit >= 0 && r.em_hit < 32) {
+                    atomicAdd(&s_grad_em[3 * r.em_hit], delta.x * r.T.x * r.ew); atomicAdd(&s_grad_em[3 * r.em_hit + 1], delta.y * r.T.y * r.ew);
+                    atomicAdd(&s_grad_em[3 * r.em_hit + 2], delta.z * r.T.z * r.ew);
+                }
+                if (r.em_nee >= 0 && r.em_nee < 32) {
+                    atomicAdd(&s_grad_em[3 * r.em_nee], delta.x * (r.Tp.x * r.rho.x) * r.nk); atomicAdd(&s_grad_em[3 * r.em_nee + 1], delta.y * (r.Tp.y * r.rho.y) * r.nk);
+                    atomicAdd(&s_grad_em[3 * r.em_nee + 2], delta.z * (r.Tp.z * r.rho.z) * r.nk);
+                }
+            }
             if (!r.has_bsdf) { a = mk3(delta.x * r.E.x, delta.y * r.E.y, delta.z * r.E.z); continue; }
             const f3 Y = mk3(delta.x * r.Nc.x + a.x, delta.y * r.Nc.y + a.y, delta.z * r.Nc.z + a.z);
             const f3 g = mk3(r.Tp.x * Y.x, r.Tp.y * Y.y, r.Tp.z * Y.z);
@@ -1375,6 +1401,9 @@ __global__ __launch_bounds__(kBlock) void k_adjoint(const AdjointParams A) {
     if (A.grad_bsdf)
         for (uint32_t i = threadIdx.x; i < 3u * min(P.sv.n_bsdfs, 32u); i += kBlock)
             if (s_grad[i] != 0.0f) atomicAdd(A.grad_bsdf + i, s_grad[i]);
+    if (A.grad_emitter)
+        for (uint32_t i = threadIdx.x; i < 3u * min(P.sv.n_emitters, 32u); i += kBlock)
+            if (s_grad_em[i] != 0.0f) atomicAdd(A.grad_emitter + i, s_grad_em[i]);
 }
 
 hipError_t launch_adjoint(const AdjointParams &a, hipStream_t s) {

@@ -40,6 +40,7 @@ void mo_kat_envmap(int w, int h, const float *rgb, float scale, const float *to_
 int mo_scene_add_delta_emitter(mo_scene *s, int type, const float *rgb, const float *position3, const float *direction3,
                                const float *to_world9, float cutoff_angle_deg, float beam_width_deg);
 int mo_scene_set_emitter_order(mo_scene *s, uint32_t n, const uint32_t *order);
+int mo_scene_set_emitter_radiance(mo_scene *s, uint32_t emitter, const float *rgb);
 /* Bitmap texture (src/textures/bitmap.cpp, linear RGB data, identity to_uv): returns its index.  A texture is
  * attached to the reflectance of a shape's diffuse BSDF with mo_scene_set_texture (-1 detaches). */
 int mo_scene_add_texture(mo_scene *s, int width, int height, const float *rgb);
@@ -159,9 +160,10 @@ int mo_render_rows(const mo_scene *s, const mo_render_desc *d, int row0, int row
 /* Reverse-mode derivative of Image = RGB / (W + 1e-8) (autodiff.py:80-91) w.r.t. diffuse reflectances, by path replay
  * (restatement of what ek.backward() does through PathIntegrator::sample for these parameters; RR probabilities detached).
  * dimage: crop_h*crop_w*3 = dLoss/dImage; film: the primal R,G,B,A,W film of the same desc (weights);
- * grad_shape: n_shapes*3 (constant reflectance of each shape's BSDF), grad_tex: textures concatenated; both accumulated. */
+ * grad_shape: n_shapes*3 (constant reflectance of each shape's BSDF), grad_tex: textures concatenated, grad_emitter:
+ * n_emitters*3 (radiance of area lights, 'shape.emitter.radiance.value'); all accumulated, any may be NULL. */
 int mo_render_adjoint(const mo_scene *s, const mo_render_desc *d, const float *dimage, const float *film,
-                      float *grad_shape, float *grad_tex);
+                      float *grad_shape, float *grad_tex, float *grad_emitter);
 /* HDRFilm::bitmap(): XYZAW -> RGBA float32 (hdrfilm.cpp:249-320, struct.cpp:1761-1811) */
 void mo_film_develop(const float *xyzaw, uint64_t n_pixels, float *rgba);
 

@@ -1069,6 +1069,8 @@ typedef struct {
     float E[3], Nc[3], Tp[3], rho[3], invq;
     float T[3]; int rr_channel;      /* throughput before Russian roulette; channel that sets q (-1: none / q clamped) */
     uint32_t texel; float w1[2]; uint32_t shape; int has_bsdf;
+    /* radiance-free coefficients for d/d(emitter radiance): E = ew * Le[em_hit], Nc = nk * Le[em_nee] (-1: none) */
+    float ew, nk; int em_hit, em_nee;
 } vertex_rec;
 #define MO_ADJ_MAX_DEPTH 16
 
@@ -1086,10 +1088,12 @@ static int path_sample_rec(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_i
     for (int depth = 1; n < MO_ADJ_MAX_DEPTH; ++depth) {
         vertex_rec *r = &rec[n++];
         memset(r, 0, sizeof(*r));
-        r->invq = 1.0f; r->texel = 0xffffffffu; r->rr_channel = -1;
+        r->invq = 1.0f; r->texel = 0xffffffffu; r->rr_channel = -1; r->em_hit = r->em_nee = -1;
+        for (int k = 0; k < 3; ++k) r->T[k] = throughput[k];
         if (emitter >= 0 && active && si.wi.z > 0.0f) {
             const float *le = s->emitters[emitter].radiance;
             for (int k = 0; k < 3; ++k) r->E[k] = emission_weight * le[k];
+            r->ew = emission_weight; r->em_hit = emitter;
         }
         active = active && si_valid;
         if (depth > rr_depth) {
@@ -1097,7 +1101,6 @@ static int path_sample_rec(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_i
             float q = fminf(hm * (eta * eta), 0.95f);
             if (active) active = mo_pcg32_next_f32(rng) < q;
             float rq = mo_rcp(q);
-            for (int k = 0; k < 3; ++k) r->T[k] = throughput[k];
             if (hm * (eta * eta) < 0.95f) r->rr_channel = throughput[0] == hm ? 0 : (throughput[1] == hm ? 1 : 2);
             for (int k = 0; k < 3; ++k) throughput[k] *= rq;
             r->invq = rq;
@@ -1117,12 +1120,18 @@ static int path_sample_rec(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_i
                 sr.o = si.p; sr.d = ds.d;
                 sr.mint = MO_RAY_EPSILON * (1.0f + mo_hmax_abs(si.p));
                 sr.maxt = ds.dist * (1.0f - MO_SHADOW_EPSILON);
-                if (mo_intersect(s, &sr, 1, 0, NULL)) emitter_val[0] = emitter_val[1] = emitter_val[2] = 0.0f;
+                const int occluded = mo_intersect(s, &sr, 1, 0, NULL);
+                if (occluded) emitter_val[0] = emitter_val[1] = emitter_val[2] = 0.0f;
                 mo_v3 wo = mo_to_local(&si.sh, ds.d);
                 if (si.wi.z > 0.0f && wo.z > 0.0f) {
                     float bsdf_pdf = mo_square_to_cosine_hemisphere_pdf(wo);
                     float k = (ds.delta ? 1.0f : mis_weight(ds.pdf, bsdf_pdf)) * (MO_INV_PI * wo.z);
                     for (int c = 0; c < 3; ++c) r->Nc[c] = k * emitter_val[c];
+                    /* area light: emitter_val = (Le / pdf_single) * n_emitters for a sample on the front side (scene.cpp:141-189) */
+                    if (!occluded && s->emitters[ds.emitter].type == 0 && mo_dot(ds.d, ds.n) < 0.0f) {
+                        r->nk = k * mo_rcp(ds.pdf_single) * (s->n_emitters > 1 ? (float) s->n_emitters : 1.0f);
+                        r->em_nee = (int) ds.emitter;
+                    }
                 }
             }
         }
@@ -1151,7 +1160,7 @@ static int path_sample_rec(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_i
 }
 
 int mo_render_adjoint(const mo_scene *s, const mo_render_desc *d, const float *dimage, const float *film,
-                      float *grad_shape, float *grad_tex) {
+                      float *grad_shape, float *grad_tex, float *grad_emitter) {
     if (desc_check(d) || d->max_depth < 0 || d->max_depth > MO_ADJ_MAX_DEPTH) return -1;
     camera cam; camera_init(d, &cam);
     rfilter f; rfilter_init(&f, d->rfilter, d->rfilter_param, d->rfilter_param2);
@@ -1207,6 +1216,11 @@ int mo_render_adjoint(const mo_scene *s, const mo_render_desc *d, const float *d
         float a[3] = { 0, 0, 0 };
         for (int v = n - 1; v >= 0; --v) {
             const vertex_rec *r = &rec[v];
+            /* radiance is linear in the emitters' radiance: d/dLe = delta * T_v * ew (emitter hit) + delta * T'_v rho_v nk (emitter sampled) */
+            if (grad_emitter && r->em_hit >= 0)
+                for (int c = 0; c < 3; ++c) grad_emitter[3 * r->em_hit + c] += delta[c] * r->T[c] * r->ew;
+            if (grad_emitter && r->em_nee >= 0)
+                for (int c = 0; c < 3; ++c) grad_emitter[3 * r->em_nee + c] += delta[c] * (r->Tp[c] * r->rho[c]) * r->nk;
             if (!r->has_bsdf) { for (int c = 0; c < 3; ++c) a[c] = delta[c] * r->E[c]; continue; }
             float Y[3], g[3], b[3];
             for (int c = 0; c < 3; ++c) { Y[c] = delta[c] * r->Nc[c] + a[c]; g[c] = r->Tp[c] * Y[c]; b[c] = r->rho[c] * Y[c]; }

@@ -148,6 +148,12 @@ int mo_scene_set_emitter_order(mo_scene *s, uint32_t n, const uint32_t *order) {
     return 0;
 }
 
+int mo_scene_set_emitter_radiance(mo_scene *s, uint32_t emitter, const float *rgb) {
+    if (!s || emitter >= s->n_emitters || !rgb) return -1;
+    for (int k = 0; k < 3; ++k) s->emitters[emitter].radiance[k] = rgb[k];
+    return 0;
+}
+
 int mo_scene_add_texture(mo_scene *s, int width, int height, const float *rgb) {
     if (!s || width < 2 || height < 2 || !rgb) return -1;
     s->textures = (mo_texture *) realloc(s->textures, sizeof(mo_texture) * (s->n_textures + 1));

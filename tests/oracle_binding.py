@@ -83,7 +83,8 @@ def lib():
         L.mo_sample_radiance.argtypes = [vp, C.POINTER(RenderDesc), C.c_uint64, C.c_uint64, vp, vp]
         L.mo_render_rows.argtypes = [vp, C.POINTER(RenderDesc), C.c_int, C.c_int, vp]
         L.mo_film_develop.argtypes = [vp, C.c_uint64, vp]
-        L.mo_render_adjoint.argtypes = [vp, C.POINTER(RenderDesc), vp, vp, vp, vp]
+        L.mo_render_adjoint.argtypes = [vp, C.POINTER(RenderDesc), vp, vp, vp, vp, vp]
+        L.mo_scene_set_emitter_radiance.argtypes = [vp, C.c_uint32, vp]
         L.mo_camera_rays.argtypes = [C.POINTER(RenderDesc), C.c_uint64] + [vp] * 7
         L.mo_imageblock_put.argtypes = [C.c_int] * 6 + [C.c_float, C.c_float, C.c_int, C.c_int, C.c_uint64, vp, vp, vp]
         L.mo_rfilter_table.argtypes = [C.c_int, C.c_float, C.c_float, vp, f32p, C.POINTER(C.c_int)]
@@ -286,13 +287,21 @@ class OracleScene:
         film, _ = self.render(desc, mode=1)
         return film[..., :3] / (film[..., 4:5] + np.float32(1e-8)), film
 
-    def render_adjoint(self, desc, dimage, film, n_shapes, tex_floats):
+    def render_adjoint(self, desc, dimage, film, n_shapes, tex_floats, n_emitters=None):
+        """gradients w.r.t. constant reflectances (per shape), texels, and -- with n_emitters -- area-light radiances"""
         dimage = _f(dimage); film = _f(film)
         gs = np.zeros((n_shapes, 3), np.float32); gt = np.zeros(max(tex_floats, 1), np.float32)
-        rc = lib().mo_render_adjoint(self.h, C.byref(desc), _p(dimage), _p(film), _p(gs), _p(gt))
+        ge = np.zeros((max(n_emitters or 0, 1), 3), np.float32)
+        rc = lib().mo_render_adjoint(self.h, C.byref(desc), _p(dimage), _p(film), _p(gs), _p(gt), _p(ge) if n_emitters is not None else None)
         if rc != 0:
             raise RuntimeError("oracle adjoint failed (%d)" % rc)
+        if n_emitters is not None:
+            return gs, gt[:tex_floats], ge[:n_emitters]
         return gs, gt[:tex_floats]
+
+    def set_emitter_radiance(self, emitter, rgb):
+        rgb = _f(rgb)
+        assert lib().mo_scene_set_emitter_radiance(self.h, emitter, rgb.ctypes.data_as(f32p)) == 0
 
     def sample_radiance(self, desc, first, count):
         rgba = np.empty((count, 4), np.float32); pos = np.empty((count, 2), np.float32)

@@ -58,6 +58,34 @@ def test_oracle_adjoint_matches_finite_differences(oracle, rfilter, max_depth):
         assert abs(fd - g) <= 5e-3 * max(abs(fd), 1e-3) + 1e-5, (bsdf, c, fd, g)
 
 
+@pytest.mark.parametrize("rfilter,max_depth,two_lights", [("box", 3, False), ("gaussian", 6, True)])
+def test_oracle_emitter_radiance_gradient(oracle, rfilter, max_depth, two_lights):
+    """'shape.emitter.radiance.value' (diff_render.rst:76): the image is linear in every area light's radiance, so central
+    differences are exact up to rounding; the second case has two lights (emitter selection, scene.cpp:141-189) and
+    Russian roulette"""
+    sd, tex, desc = _setup(oracle, rfilter, max_depth)
+    if two_lights:
+        sd["emitters"] = list(sd["emitters"]) + [dict(type="area", radiance=np.array([2.0, 3.0, 4.0], np.float32))]
+        sd["meshes"][7] = dict(sd["meshes"][7], emitter=1)                 # one of the boxes glows too
+    S = oracle.OracleScene(sd, naive=True)
+    image, film = S.render_image(desc)
+    dimage = np.random.RandomState(3).randn(*image.shape).astype(np.float32)
+    _, _, ge = S.render_adjoint(desc, dimage, film, len(sd["meshes"]), tex.size, n_emitters=len(sd["emitters"]))
+    loss = lambda img: float(np.sum(img.astype(np.float64) * dimage))
+    assert np.abs(ge).min() > 0
+    for e in range(len(sd["emitters"])):
+        base = np.array(sd["emitters"][e]["radiance"], np.float32)
+        for c in range(3):
+            eps = 0.05 * base[c]
+            vp, vm = base.copy(), base.copy()
+            vp[c] += eps; vm[c] -= eps
+            S.set_emitter_radiance(e, vp); lp = loss(S.render_image(desc)[0])
+            S.set_emitter_radiance(e, vm); lm = loss(S.render_image(desc)[0])
+            S.set_emitter_radiance(e, base)
+            fd = (lp - lm) / (2 * eps)
+            assert abs(fd - ge[e, c]) <= 2e-3 * max(abs(fd), np.abs(ge).max()) + 1e-5, (e, c, fd, ge[e, c])
+
+
 def test_adjoint_argument_checks(oracle):
     sd, tex, desc = _setup(oracle, "box", 3)
     S = oracle.OracleScene(sd, naive=True)

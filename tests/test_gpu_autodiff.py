@@ -12,8 +12,12 @@ from mitsuba2_amd import scenes
 pytestmark = pytest.mark.gpu
 
 
-def _scene(gpu, tex, w, h, spp, max_depth, rfilter="box", seed=5):
+def _scene(gpu, tex, w, h, spp, max_depth, rfilter="box", seed=5, two_lights=False):
     sd = scenes.cornell_box(texture=tex)
+    sd["meshes"][5]["id"] = "lamp"
+    if two_lights:                                     # a second area light: the emitter-selection branch of scene.cpp:141-189
+        sd["emitters"] = list(sd["emitters"]) + [dict(type="area", radiance=np.array([2.0, 3.0, 4.0], np.float32))]
+        sd["meshes"][7] = dict(sd["meshes"][7], emitter=1, id="glowing_box")
     names = ["white", "red", "green", "light", "textured"]
     for b, n in zip(sd["bsdfs"], names):
         b["id"] = n
@@ -28,7 +32,7 @@ def test_adjoint_matches_oracle(gpu, oracle, rfilter, max_depth):
     from mitsuba2_amd import autodiff, _lib as L
     rng = np.random.RandomState(1)
     tex = (0.3 + 0.5 * rng.rand(4, 5, 3)).astype(np.float32)
-    sd, p, scene = _scene(gpu, tex, 24, 20, 4, max_depth, rfilter)
+    sd, p, scene = _scene(gpu, tex, 24, 20, 4, max_depth, rfilter, two_lights=max_depth == 8)
     d = autodiff._desc(scene, scene.sensors()[0], scene.integrator(), None, p["seed"])
     film = autodiff._render_film(scene, d)
     desc = oracle.make_desc(p, analytic=True, film_rgb=True)
@@ -37,13 +41,16 @@ def test_adjoint_matches_oracle(gpu, oracle, rfilter, max_depth):
     assert np.allclose(film.cpu().numpy()[..., 4], film_o[..., 4], rtol=1e-5, atol=1e-6)
     assert np.mean((film.cpu().numpy()[..., :3] - film_o[..., :3]) ** 2 / (film_o[..., :3] ** 2 + 1e-2)) < 1e-5
     dimage = np.random.RandomState(2).randn(20, 24, 3).astype(np.float32)
-    gs_o, gt_o = S.render_adjoint(desc, dimage, film_o, len(sd["meshes"]), tex.size)
+    gs_o, gt_o, ge_o = S.render_adjoint(desc, dimage, film_o, len(sd["meshes"]), tex.size, n_emitters=len(sd["emitters"]))
     g_bsdf = torch.zeros((len(sd["bsdfs"]), 3), device="cuda")
     g_tex = torch.zeros(tex.size, device="cuda")
+    g_em = torch.zeros((len(sd["emitters"]), 3), device="cuda")
     di = torch.from_numpy(dimage).cuda()
     L.check(L.lib().mtsamd_render_adjoint(scene._handle, C.byref(d), C.c_void_p(di.data_ptr()), C.c_void_p(film.data_ptr()),
-                                          C.c_void_p(g_bsdf.data_ptr()), C.c_void_p(g_tex.data_ptr()), None))
+                                          C.c_void_p(g_bsdf.data_ptr()), C.c_void_p(g_tex.data_ptr()), C.c_void_p(g_em.data_ptr()), None))
     torch.cuda.synchronize()
+    assert np.abs(ge_o).min() > 1e-3                   # 'shape.emitter.radiance.value' of every area light
+    assert np.allclose(g_em.cpu().numpy(), ge_o, rtol=2e-2, atol=2e-3 * np.abs(ge_o).max())
     gt = g_tex.cpu().numpy()
     assert np.abs(gt_o).max() > 1e-3
     assert np.allclose(gt, gt_o, rtol=2e-2, atol=2e-3 * np.abs(gt_o).max())
@@ -63,8 +70,8 @@ def test_autograd_and_finite_differences(gpu):
     sd, p, scene = _scene(gpu, tex, 32, 32, 8, 4, "gaussian")
     params = autodiff.traverse(scene)
     assert set(params.keys()) == {"white.reflectance.value", "red.reflectance.value", "green.reflectance.value",
-                                  "light.reflectance.value", "textured.reflectance.data"}
-    params.keep(["red.reflectance.value", "textured.reflectance.data"])
+                                  "light.reflectance.value", "textured.reflectance.data", "lamp.emitter.radiance.value"}
+    params.keep(["red.reflectance.value", "textured.reflectance.data", "lamp.emitter.radiance.value"])
     for k in list(params.keys()):
         params[k].requires_grad_(True)
     target = torch.from_numpy(np.random.RandomState(4).rand(32 * 32 * 3).astype(np.float32)).cuda()
@@ -79,18 +86,21 @@ def test_autograd_and_finite_differences(gpu):
     loss.backward()
     g_red = params["red.reflectance.value"].grad.clone()
     g_tex = params["textured.reflectance.data"].grad.clone()
-    assert g_tex.shape == (6, 6, 3) and g_tex.abs().max() > 0 and g_red.abs().max() > 0
+    g_lamp = params["lamp.emitter.radiance.value"].grad.clone()
+    assert g_tex.shape == (6, 6, 3) and g_tex.abs().max() > 0 and g_red.abs().max() > 0 and g_lamp.abs().min() > 0
     eps = 2e-2
     with torch.no_grad():
         for key, idx, g in (("red.reflectance.value", (0,), g_red), ("red.reflectance.value", (2,), g_red),
+                            ("lamp.emitter.radiance.value", (0,), g_lamp), ("lamp.emitter.radiance.value", (2,), g_lamp),
                             ("textured.reflectance.data", (2, 3, 1), g_tex), ("textured.reflectance.data", (4, 1, 0), g_tex)):
             base = params[key].detach().clone()
             vp, vm = base.clone(), base.clone()
-            vp[idx] += eps; vm[idx] -= eps
+            h = 0.5 if "radiance" in key else eps          # the loss is quadratic in the radiance: central differences are exact
+            vp[idx] += h; vm[idx] -= h
             params[key] = vp; lp, _ = loss_at(7)
             params[key] = vm; lm, _ = loss_at(7)
             params[key] = base
-            fd = (lp.item() - lm.item()) / (2 * eps)
+            fd = (lp.item() - lm.item()) / (2 * h)
             assert abs(fd - g[idx].item()) <= 3e-2 * max(abs(fd), abs(g[idx].item())) + 1e-6, (key, idx, fd, g[idx].item())
     # unbiased mode: value of the primal render, gradient of a decorrelated one
     params["red.reflectance.value"].requires_grad_(True)
