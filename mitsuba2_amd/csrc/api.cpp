@@ -806,7 +806,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     // BVH2: one deferred subtree per level; BVH4: up to three
     v.stack_depth = MTS_BVH4 ? 3u * s->bvh.wdepth + 2u : std::max<uint32_t>(s->bvh.depth, 2);
     // standalone ray streams: 8 persistent workgroups per CU, the first 12 (BVH2: 16) stack entries of a lane in LDS
-    v.walk_lds_depth = std::min<uint32_t>(v.stack_depth, MTS_BVH4 ? 12u : 16u);
+    v.walk_lds_depth = std::min<uint32_t>(v.stack_depth, MTS_BVH4 ? 8u : 16u);      // 16 KB per workgroup: 8 workgroups (k_ray_walk: 8 waves per SIMD) per CU
     v.walk_blocks = 8u * (uint32_t) s->cu_count;
     if (!flat && v.stack_depth > v.walk_lds_depth) {
         const size_t entries = (size_t) v.walk_blocks * (v.stack_depth - v.walk_lds_depth) * 256u;

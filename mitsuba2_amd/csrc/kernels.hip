@@ -1073,15 +1073,25 @@ void k_shade(const RenderParams P) {
 #define MTS_TRACE_GROUP 8
 #endif
 constexpr uint32_t kShadowGroup = MTS_TRACE_GROUP;
-// LDS part of k_trace's per-lane stack: 16 entries = 16 KB per workgroup, 8 workgroups (32 waves) per CU; a full 25-entry stack
-// (261 k-triangle mesh) caps the CU at 6 workgroups
+// LDS part of k_trace's per-lane stack: 8 entries of 8 bytes (BVH4: reference + entry distance) = 16 KB per workgroup, 8 workgroups
+// (32 waves) per CU; the full 41-entry stack of the 261 k-triangle mesh would cap the CU at one workgroup
 #ifndef MTS_TRACE_LDS_DEPTH
-#define MTS_TRACE_LDS_DEPTH (MTS_BVH4 ? 12 : 16)
+#define MTS_TRACE_LDS_DEPTH (MTS_BVH4 ? 8 : 16)
 #endif
 constexpr uint32_t kTraceLdsDepth = MTS_TRACE_LDS_DEPTH;
 
+// Register budget of k_trace: 64 VGPRs = 8 waves per SIMD.  The walks are bound by the latency of their node / triangle fetches
+// (L2 and beyond for a 261 k-triangle scene), which only more waves in flight hide: 5 waves (84 VGPRs, the compiler's own choice)
+// -> 8 waves: +7.5 % on the whole render (RGB and spectral); the closest-hit kernel then spills 20 bytes per lane.
+#ifndef MTS_TRACE_WAVES
+#define MTS_TRACE_WAVES 8
+#endif
 template <bool ANY, bool FLAT = false>
-__global__ __launch_bounds__(kBlock) void k_trace(const RenderParams P) {
+__global__ __launch_bounds__(kBlock)
+#if MTS_TRACE_WAVES > 0
+__attribute__((amdgpu_waves_per_eu(MTS_TRACE_WAVES, MTS_TRACE_WAVES)))
+#endif
+void k_trace(const RenderParams P) {
     extern __shared__ float4 smem[];
     LdsView lds = {};
     if (FLAT) {
@@ -1778,7 +1788,11 @@ static uint32_t stream_grid(uint64_t n) {
 // lanes fetch the next ray of the chunk as soon as their walk ends (dynamic ray fetch, as k_trace does for the path pool).
 constexpr uint32_t kRayChunk = 16u * kBlock;
 template <bool ANY>
-__global__ __launch_bounds__(kBlock) void k_ray_walk(const SceneView sv, uint64_t n, const RayStreams r, float *t, uint32_t *prim,
+__global__ __launch_bounds__(kBlock)
+#if MTS_TRACE_WAVES > 0
+__attribute__((amdgpu_waves_per_eu(MTS_TRACE_WAVES, MTS_TRACE_WAVES)))
+#endif
+void k_ray_walk(const SceneView sv, uint64_t n, const RayStreams r, float *t, uint32_t *prim,
                                                      uint32_t *shape, float *u, float *v, uint8_t *hit) {
     extern __shared__ float4 smem[];
     __shared__ uint32_t s_next;
