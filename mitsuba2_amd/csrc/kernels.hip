@@ -850,9 +850,18 @@ MTS_DEV void start_path(const RenderParams &P, uint64_t ordinal, uint32_t lp, ui
 
 // FLAT = false: hierarchy scene, closest hits precomputed by k_trace<false>; FLAT = true: LDS-resident scene, closest hit
 // inline (wave-uniform primitive loop), only the shadow rays are queued
+// Register budget of k_shade on hierarchy scenes (waves per SIMD the compiler must reach): the kernel streams the path state through
+// HBM and gathers vertex data, so it lives on waves in flight.  5 waves (96 VGPRs) fit the RGB diffuse-only variant without spilling
+// (+1.5 %); the others get 4 waves (128 VGPRs; the compiler's own choice was 136-185 VGPRs = 2-3 waves): spectral diffuse +2 %,
+// general BSDFs +5 % (RGB) / +10 % (spectral, 128 bytes of scratch per lane) on the 261 k-triangle scenes.
 #ifndef MTS_SHADE_WAVES_MIN
-#define MTS_SHADE_WAVES_MIN 1
+#define MTS_SHADE_WAVES_MIN 4
 #endif
+#ifndef MTS_SHADE_WAVES_MIN_RGB_DIFFUSE
+#define MTS_SHADE_WAVES_MIN_RGB_DIFFUSE 5
+#endif
+template <typename State, bool GENERAL> struct ShadeWaves { static constexpr int kMin = MTS_SHADE_WAVES_MIN; };
+template <> struct ShadeWaves<PathState, false> { static constexpr int kMin = MTS_SHADE_WAVES_MIN_RGB_DIFFUSE; };
 // INLINE (flat scenes only): the shadow rays of consecutive 64-path chunks are collected in a per-wave LDS ring and resolved
 // 64 at a time inside this kernel -- the any-hit loop then always runs on full waves (only about two thirds of the paths cast
 // a shadow ray) -- and `nee` is added to the radiance the wave has already stored in its output segment.
@@ -880,7 +889,7 @@ MTS_DEV void drain_shadow_ring(const RenderParams &P, const LdsView &lds, const 
 }
 
 template <typename State, bool GENERAL, bool FLAT, bool INLINE = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FLAT ? MTS_BOUNCE_WAVES : MTS_SHADE_WAVES_MIN, FLAT ? MTS_BOUNCE_WAVES : 8)))
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FLAT ? MTS_BOUNCE_WAVES : ShadeWaves<State, GENERAL>::kMin, FLAT ? MTS_BOUNCE_WAVES : 8)))
 void k_shade(const RenderParams P) {
     static_assert(FLAT || !INLINE, "the in-kernel shadow queue is for LDS-resident scenes");
     extern __shared__ float4 smem[];
