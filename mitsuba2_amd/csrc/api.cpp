@@ -1045,10 +1045,14 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     // one chunk per wave (consecutive pixels) for hierarchy scenes
     const uint64_t chunk = j.s->view.flat ? 64u : std::max<uint64_t>((n + nw - 1) / nw, 1u);
     const uint64_t n_chunks = (n + chunk - 1u) / chunk, last_size = n - (n_chunks - 1u) * chunk;
+    // hierarchy scenes run two launch chains over the halves of the scheduling waves: their chunks alternate (kernels.h, chunk_owner)
+    uint32_t chain_split = 0;
+    if (!j.s->view.flat && j.split && nw >= 256u && !getenv("MTSAMD_ONE_CHAIN") && !getenv("MTSAMD_NO_CHAIN_INTERLEAVE")) chain_split = (nw / 2u + 7u) & ~7u;
     for (uint32_t k = 0; k < nw; ++k) {
-        const uint64_t mine = k < n_chunks ? (n_chunks - 1u - k) / nw + 1u : 0u;
+        const uint64_t c0 = chunk_owner(k, nw, chain_split);      // this wave owns the chunks c0, c0 + nw, ...
+        const uint64_t mine = c0 < n_chunks ? (n_chunks - 1u - c0) / nw + 1u : 0u;
         uint64_t samples = mine * chunk;
-        if (mine && (n_chunks - 1u) % nw == k) samples -= chunk - last_size;       // the last, partial chunk of the pass
+        if (mine && (n_chunks - 1u) % nw == c0) samples -= chunk - last_size;       // the last, partial chunk of the pass
         w.h_cursor[k] = 0; w.h_cursor[nw + k] = samples;
     }
     if (n >= (1ull << 31)) return fail(MTSAMD_ERR_INVALID, "a pass holds fewer than 2^31 samples");
@@ -1065,6 +1069,7 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     p.count_shadow = w.count_shadow;
     p.first_ordinal = first; p.first_pix = (uint32_t) (first / spp); p.first_rem = (uint32_t) (first % spp);
     p.chunk = (uint32_t) (j.s->view.flat ? 64u : std::max<uint64_t>((n + nw - 1) / nw, 1u)); p.base_seed = j.d->seed;
+    p.chain_split = chain_split;
     p.rows = j.rows; p.store_xyz = j.store_xyz;
     p.plane_pix0 = j.plane_pix0; p.plane_pixels = j.plane_pixels;
     p.n_waves = nw; p.seg_cap = w.seg_cap; p.target = j.target;
@@ -1100,7 +1105,10 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     int cur = 0;
     // Termination test without stalling the device: every `stride` launches the per-wave path counts are copied to
     // pinned memory; the copy issued at the previous checkpoint (long complete) is inspected before issuing a new one.
-    const uint64_t stride = 4;
+    // While samples are left to generate a checkpoint every fourth launch round does; once the cursors are dry the pool only shrinks,
+    // the rounds get short and every round is checked (against the counts of the round before), so that k_finish takes over as soon
+    // as the pool is small enough
+    uint64_t stride = 4, next_check = 0;
     int pending = -1, slot = 0;
     HIP_TRY(hipEventRecord(w.tev[0], j.stream));
     uint32_t n_parts = 2;
@@ -1112,6 +1120,13 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     // Pool drain of LDS-resident scenes: once every cursor is dry, a workgroup gathers the paths of gather_w consecutive scheduling
     // waves at the front of the group (k_shade).  gather_w grows by powers of four as the pool empties -- decided on the counts read
     // back every `stride` launches; they are upper bounds, counts only shrink from then on -- and its groups lie inside one part.
+    // pool size below which k_finish ends the pass (0: never).  Hierarchy scenes: measured flat between 2^20 and 2^24 (the fused kernel
+    // keeps up with the launch rounds of the split pipeline once they are no longer full): 2^22; LDS-resident scenes, whose drain is
+    // already compacted by the gathering below: 2^18
+    uint64_t finish_at = p.split == 1 ? (1ull << 22) : (p.split == 3 ? (1ull << 18) : 0ull);
+    if (const char *e = getenv("MTSAMD_FINISH_AT")) finish_at = (uint64_t) std::max(0ll, atoll(e));      // experiment switch
+    bool finish = false;
+    uint64_t finish_alive = 0;
     uint32_t gather_max = 4u, gather_w = 4u;
     if (p.split == 3 && !getenv("MTSAMD_NO_GATHER")) {
         gather_max = 1024u;
@@ -1223,17 +1238,25 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
                     (unsigned long long) busy_waves, it > 1 ? std::chrono::duration<double, std::micro>(t_now - t_prev).count() : 0.0, gather_w);
             t_prev = std::chrono::steady_clock::now();
         }
-        if (it >= min_iters && (it - min_iters) % stride == 0) {
+        if (it >= min_iters && it >= next_check) {
+            next_check = it + stride;
             if (pending >= 0) {
                 HIP_TRY(hipEventSynchronize(w.ev[pending]));
                 uint64_t alive = 0;
                 const uint32_t *hc = w.h_counts + (size_t) pending * nw;
                 for (uint32_t k = 0; k < nw; ++k) alive += hc[k];
                 if (alive == 0) break;
-                if (gather_w < gather_max) {
-                    const uint64_t *hcur = w.h_cursor_rb + (size_t) pending * nw;
-                    bool dry = true;
+                bool dry = false;
+                const uint64_t *hcur = w.h_cursor_rb + (size_t) pending * nw;
+                if (gather_w < gather_max || finish_at) {
+                    dry = true;
                     for (uint32_t k = 0; k < nw && dry; ++k) dry = hcur[k] >= w.h_cursor[nw + k];
+                }
+                // every sample has been generated and few paths are left (the counts are a few launches old: an upper bound): one
+                // k_finish launch instead of the dozens of near-empty launch rounds the deepest paths would still need
+                if (dry && alive <= finish_at) { finish = true; finish_alive = alive; break; }
+                if (dry && finish_at) { stride = 1; next_check = it + 1; }
+                if (gather_w < gather_max) {
                     if (getenv("MTSAMD_TRACE_ITERS")) {
                         uint32_t wet = 0, first_wet = 0;
                         for (uint32_t k = 0; k < nw; ++k) if (hcur[k] < w.h_cursor[nw + k]) { if (!wet) first_wet = k; ++wet; }
@@ -1251,7 +1274,7 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
                 HIP_TRY(hipStreamWaitEvent(j.stream, w.part_ev[2], 0));
             }
             HIP_TRY(hipMemcpyAsync(w.h_counts + (size_t) slot * nw, w.count[cur], nw * sizeof(uint32_t), hipMemcpyDeviceToHost, j.stream));
-            if (gather_w < gather_max) HIP_TRY(hipMemcpyAsync(w.h_cursor_rb + (size_t) slot * nw, w.cursor, nw * sizeof(uint64_t), hipMemcpyDeviceToHost, j.stream));
+            if (gather_w < gather_max || finish_at) HIP_TRY(hipMemcpyAsync(w.h_cursor_rb + (size_t) slot * nw, w.cursor, nw * sizeof(uint64_t), hipMemcpyDeviceToHost, j.stream));
             HIP_TRY(hipEventRecord(w.ev[slot], j.stream));
             pending = slot; slot ^= 1;
         }
@@ -1266,6 +1289,13 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
         }
     }
     if (n_parts > 1) { if (int rc = join_parts()) return rc; }
+    if (finish) {          // every stream of the loop has been joined into j.stream
+        RenderParams h = p;
+        h.in = w.pool[cur]; h.out = w.pool[cur ^ 1];
+        h.count_in = w.count[cur]; h.count_out = w.count[cur ^ 1];
+        HIP_TRY(launch_finish(h, finish_alive, j.stream));
+        ++it;
+    }
     HIP_TRY(hipEventRecord(w.tev[1], j.stream));
     HIP_TRY(hipEventSynchronize(w.tev[1]));
     float ms = 0.0f;

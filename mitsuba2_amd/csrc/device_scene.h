@@ -113,6 +113,8 @@ struct LdsView {
     const float4 *tris;
     uint32_t *stack;           // [depth][blockDim]
     uint32_t stride;           // blockDim.x
+    StackEntry *spill;         // null: the whole traversal stack lives in LDS; else this thread's column of a global spill area ...
+    uint32_t spill_stride, stack_lds_depth;      // ... that takes the entries beyond the first stack_lds_depth
     const float4 *flat;        // 4 per prim (shading records)
     const float4 *pairs;       // 5 per primitive pair (intersection records), + 1 all-zero pair
     const DevShape *shapes;
@@ -454,7 +456,8 @@ MTS_DEV bool traverse_bvh(const SceneView &sv, const LdsView &lds, f3 o, f3 d, f
                           Hit &hit, uint32_t &tri_tests) {
     BvhWalk w;
     walk_begin(w, sv, o, d, mint, maxt);
-    const WalkStack st = { reinterpret_cast<StackEntry *>(lds.stack) + threadIdx.x, lds.stride, 0xffffffffu, nullptr, 0u };      // whole stack in LDS
+    const WalkStack st = { reinterpret_cast<StackEntry *>(lds.stack) + threadIdx.x, lds.stride, lds.spill ? lds.stack_lds_depth : 0xffffffffu,
+                           lds.spill, lds.spill_stride };      // k_bounce: whole stack in LDS; k_finish: short LDS part + spill
     while (w.cur != kNoNode) {
         if (w.far) walk_round<ANY, true>(w, sv, st, tri_tests);
         else walk_round<ANY, false>(w, sv, st, tri_tests);

@@ -56,6 +56,8 @@ struct RenderParams {
     float4 *out_rgba;           // per sample ordinal: radiance rgb + valid_ray
     float2 *out_pos;            // per sample ordinal: film position sample
     uint32_t chunk;             // samples per chunk dealt to a scheduling wave (kernels.hip, cursor_sample)
+    uint32_t chain_split;       // 0, or the first scheduling wave of the second launch chain (hierarchy scenes): the chunks are dealt to the
+                                // two chains alternately (chunk_owner), so that both halves of the waves see the same mix of pixels
     uint32_t first_pix, first_rem;       // first_ordinal = first_pix * spp + first_rem (film renders: passes start on a pixel, first_rem == 0)
     uint64_t first_ordinal;     // local sample ordinal of slot 0 of out_rgba / out_pos
     uint64_t base_seed;
@@ -79,6 +81,15 @@ struct RenderParams {
     uint32_t trace_lds_depth;   // k_trace: stack entries per lane kept in LDS; deeper ones go to trace_spill
     uint32_t *trace_spill;      // k_trace: [workgroup][entry][thread]
 };
+
+// Index of the (first) chunk owned by scheduling wave `wave`: the identity, or -- two launch chains [0, h) and [h, n), h >= n - h --
+// even chunks to the first chain and odd ones to the second as long as the second has waves left.  A bijection of [0, n).
+__host__ __device__ inline uint32_t chunk_owner(uint32_t wave, uint32_t n, uint32_t h) {
+    if (h == 0u || h >= n) return wave;
+    const uint32_t m = n - h;                      // waves of the second chain
+    if (wave >= h) return 2u * (wave - h) + 1u;
+    return wave < m ? 2u * wave : m + wave;
+}
 
 struct FilmParams {
     const float4 *out_rgba;
@@ -122,6 +133,8 @@ size_t trace_spill_words(const SceneView &sv, uint32_t n_waves);
 // `direct` / `depth` integrators: every sample of [first_ordinal, first_ordinal + n) is finished by one thread
 hipError_t launch_direct(const RenderParams &p, uint64_t n, hipStream_t s);
 hipError_t launch_adjoint(const AdjointParams &a, hipStream_t s);
+// end of a pass: every path of p.in (counts p.count_in) is run to its end in one launch; needs dry sample cursors (kernels.hip, k_finish)
+hipError_t launch_finish(const RenderParams &p, uint64_t alive, hipStream_t s);
 // CIE x, y, z and D65 tables (95 floats each) -> device; call once before the first spectral launch
 hipError_t upload_spectral_tables(const float *x, const float *y, const float *z, const float *d65);
 hipError_t launch_film_gather(const FilmParams &p, hipStream_t s);

@@ -274,7 +274,7 @@ MTS_DEV void store_result(const RenderParams &P, const PathState &s) {
 // sample has no influence on the result: its RNG stream and its slot in the sample stream depend on the ordinal alone.
 MTS_DEV void cursor_sample(const RenderParams &P, uint32_t wave, uint64_t v, uint64_t &ordinal, uint32_t &lp, uint32_t &j) {
     const uint32_t t = (uint32_t) v / P.chunk, within = (uint32_t) v - t * P.chunk;
-    const uint32_t in_pass = (t * P.n_waves + wave) * P.chunk + within;      // < 2^31
+    const uint32_t in_pass = (t * P.n_waves + chunk_owner(wave, P.n_waves, P.chain_split)) * P.chunk + within;      // < 2^31
     ordinal = P.first_ordinal + in_pass;
     const uint32_t r = in_pass + P.first_rem, q = r / (uint32_t) P.spp;
     lp = P.first_pix + q; j = r - q * (uint32_t) P.spp;
@@ -1072,6 +1072,100 @@ void k_shade(const RenderParams P) {
         ws[0] += tot[0]; ws[1] += tot[1]; ws[2] += tot[2];
         if (FLAT) ws[3] += tot[3];
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// End of a pass.  Once the sample cursors are dry the pool only shrinks, and a launch round (two or three dependent kernels per
+// chain, every one spanning all scheduling waves) costs its fixed ~0.1 ms however few paths are left; the deepest paths need dozens
+// of such rounds.  k_finish takes the pool as it stands and runs every remaining path to its end inside ONE launch: a workgroup of
+// one hardware wave gathers the paths of `per` consecutive scheduling waves (prefix sums in LDS), a lane that finishes a path takes
+// the next one of the workgroup's list at once, every loop trip is one path.cpp iteration (both ray queries inline, as in k_bounce:
+// the floating-point operations on a sample and their order are those of the other schedules, the film is unchanged).
+constexpr uint32_t kFinishMaxPer = 1024u, kFinishLdsDepth = 8u;
+template <bool GENERAL, bool FLAT>
+MTS_DEV bool step_fused(const RenderParams &P, const LdsView &lds, PathState &s, Counters &c) { return bounce_step<FLAT, false, 0, GENERAL>(P, lds, s, c); }
+template <bool GENERAL, bool FLAT>
+MTS_DEV bool step_fused(const RenderParams &P, const LdsView &lds, PathStateS &s, Counters &c) { return bounce_step_spectral<FLAT, false, GENERAL>(P, lds, s, c); }
+
+template <typename State, bool GENERAL, bool FLAT>
+__global__ __launch_bounds__(64) void k_finish(const RenderParams P, uint32_t per) {
+    extern __shared__ float4 smem[];
+    __shared__ uint32_t s_pre[kFinishMaxPer + 1];
+    const uint32_t lane = threadIdx.x, w0 = blockIdx.x * per;
+    const uint32_t n_w = min(per, P.n_waves - min(P.n_waves, w0));
+    {   // s_pre[k] = paths in the workgroup's scheduling waves before the k-th (a run of entries per lane + a wave scan)
+        const uint32_t run = (n_w + 63u) / 64u;
+        uint32_t local = 0u;
+        for (uint32_t i = 0; i < run; ++i) { const uint32_t k = lane * run + i; if (k < n_w) local += P.count_in[w0 + k]; }
+        uint32_t incl = local;
+        for (uint32_t off = 1u; off < 64u; off <<= 1) { const uint32_t v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+        uint32_t sum = incl - local;
+        if (lane == 0u) s_pre[0] = 0u;
+        for (uint32_t i = 0; i < run; ++i) { const uint32_t k = lane * run + i; if (k < n_w) { sum += P.count_in[w0 + k]; s_pre[k + 1u] = sum; } }
+    }
+    __syncthreads();
+    const uint32_t total = s_pre[n_w];
+    if (total == 0u) return;
+    for (uint32_t k = lane; k < n_w; k += 64u) P.count_out[w0 + k] = 0u;
+    LdsView lds = {};
+    if (FLAT) lds = lds_stage<true>(P.sv, smem);
+    else {          // the BVH walks keep the first entries of their stack in LDS, the rest in this workgroup's slice of the k_trace spill area
+        lds.stride = 64u; lds.stack = reinterpret_cast<uint32_t *>(smem);
+        lds.stack_lds_depth = min(P.sv.stack_depth, kFinishLdsDepth);
+        lds.spill = reinterpret_cast<StackEntry *>(P.trace_spill) + (size_t) blockIdx.x * (P.sv.stack_depth - lds.stack_lds_depth) * 64u + lane;
+        lds.spill_stride = 64u;
+    }
+    Counters c = { 0u, 0u, 0u, 0u };
+    State s;
+    bool busy = false;
+    uint32_t next = 0u;
+    while (true) {
+        const uint64_t m = __ballot(!busy);
+        if (m != 0ull && next < total) {
+            const uint32_t idx = next + mask_rank(m);
+            if (!busy && idx < total) {
+                uint32_t k = 0u;          // s_pre[k] <= idx < s_pre[k + 1]
+                for (uint32_t step = kFinishMaxPer >> 1; step; step >>= 1) if (k + step < n_w && s_pre[k + step] <= idx) k += step;
+                load_state(P.in, (size_t) (w0 + k) * P.seg_cap + (idx - s_pre[k]), s);
+                if (s.flags & kFlagZombie) finish_path(P, s);      // only its shadow ray was outstanding
+                else busy = true;
+            }
+            next += (uint32_t) __popcll(m);
+        }
+        if (__ballot(busy) == 0ull) {
+            if (next >= total) break;
+            continue;
+        }
+        if (busy && !step_fused<GENERAL, FLAT>(P, lds, s, c)) { finish_path(P, s); busy = false; }
+    }
+    uint32_t tot[4] = { c.closest, c.any, c.segments, c.tri_tests };
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        for (int off = 32; off > 0; off >>= 1) tot[k] += __shfl_xor(tot[k], off);
+    if (lane == 0u) {                  // the workgroup owns its scheduling waves: no atomics
+        uint64_t *ws = P.wave_stats + 4u * (size_t) w0;
+        ws[0] += tot[0]; ws[1] += tot[1]; ws[2] += tot[2]; ws[3] += tot[3];
+    }
+}
+
+hipError_t launch_finish(const RenderParams &p, uint64_t alive, hipStream_t s) {
+    // about four paths per lane (alive: upper bound of the paths left), at least 2048 workgroups if there are that many scheduling waves
+    const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(alive / 256u, 2048u), p.n_waves);
+    const uint32_t per = std::min((uint32_t) ((p.n_waves + want - 1u) / want), kFinishMaxPer);
+    const uint32_t blocks = (p.n_waves + per - 1u) / per;
+    const size_t lds = p.sv.flat ? lds_bytes(p.sv, 64u) : sizeof(StackEntry) * std::min(p.sv.stack_depth, kFinishLdsDepth) * 64u;
+    if (p.sv.flat) {
+        if (p.spectral && p.sv.general) hipLaunchKernelGGL((k_finish<PathStateS, true, true>), dim3(blocks), dim3(64), lds, s, p, per);
+        else if (p.spectral) hipLaunchKernelGGL((k_finish<PathStateS, false, true>), dim3(blocks), dim3(64), lds, s, p, per);
+        else if (p.sv.general) hipLaunchKernelGGL((k_finish<PathState, true, true>), dim3(blocks), dim3(64), lds, s, p, per);
+        else hipLaunchKernelGGL((k_finish<PathState, false, true>), dim3(blocks), dim3(64), lds, s, p, per);
+    } else {
+        if (p.spectral && p.sv.general) hipLaunchKernelGGL((k_finish<PathStateS, true, false>), dim3(blocks), dim3(64), lds, s, p, per);
+        else if (p.spectral) hipLaunchKernelGGL((k_finish<PathStateS, false, false>), dim3(blocks), dim3(64), lds, s, p, per);
+        else if (p.sv.general) hipLaunchKernelGGL((k_finish<PathState, true, false>), dim3(blocks), dim3(64), lds, s, p, per);
+        else hipLaunchKernelGGL((k_finish<PathState, false, false>), dim3(blocks), dim3(64), lds, s, p, per);
+    }
+    return hipGetLastError();
 }
 
 // k_trace<false>: closest hit of every path's ray (input pool), one workgroup per scheduling wave, one thread per slot.

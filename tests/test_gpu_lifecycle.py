@@ -114,6 +114,30 @@ def test_cancel_from_another_thread(gpu):
     assert torch.equal(again2, fresh)
 
 
+@pytest.mark.parametrize("what", ["cbox", "cbox_spectral", "mesh", "mesh_spectral", "mesh_glossy"])
+def test_finish_kernel_leaves_the_film_unchanged(gpu, what):
+    """End of a pass (kernels.hip, k_finish): once every sample has been generated the remaining paths are run to their end by one
+    fused launch instead of further launch rounds.  A path performs the same floating-point operations in the same order either way:
+    with the switch taken as early as possible (threshold = the whole pool) and never (0), film and ray counts must be identical."""
+    variant = "spectral" if what.endswith("spectral") else "rgb"
+    if what.startswith("cbox"):
+        sd, p = scenes.cornell_box(), scenes.cornell_box_sensor(160, 128, 32, seed=3)
+    else:
+        sd, p = scenes.bumpy_sphere(64, 128), scenes.bumpy_sphere_sensor(192, 128, 16)
+        if what == "mesh_glossy":
+            sd["bsdfs"][0] = {"type": "roughplastic", "alpha": 0.2, "diffuse_reflectance": [0.3, 0.4, 0.5]}
+    scene = gpu.Scene(sd, variant=variant)
+    integ = gpu.PathIntegrator(max_depth=12)
+    with _env(MTSAMD_FINISH_AT=0):
+        never, st0 = _film(gpu, integ, scene, p)
+    with _env(MTSAMD_FINISH_AT=1 << 40):
+        early, st1 = _film(gpu, integ, scene, p)
+    assert st1["iterations"] < st0["iterations"]                 # the fused launch really replaced launch rounds
+    for k in ("samples", "segments", "closest_hit_rays", "any_hit_rays"):
+        assert st0[k] == st1[k], (k, st0[k], st1[k])
+    assert torch.equal(never, early)
+
+
 def test_timeout_stops_between_passes(gpu):
     """`timeout` (integrator.cpp:38, should_stop integrator.h:143-146): work stops being scheduled once the timer runs out;
     render() still returns true (only cancel() sets m_stop) and the film holds what was put before."""
