@@ -1103,6 +1103,16 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
         return 0;
     }
 
+    if (getenv("MTSAMD_MEGA") && (p.split == 1 || p.split == 3)) {          // experiment: one persistent launch, no pool
+        HIP_TRY(hipEventRecord(w.tev[0], j.stream));
+        HIP_TRY(launch_mega(p, j.stream));
+        HIP_TRY(hipEventRecord(w.tev[1], j.stream));
+        HIP_TRY(hipEventSynchronize(w.tev[1]));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, w.tev[0], w.tev[1]));
+        j.bounce_ms += ms; j.iterations += 1;
+        return 0;
+    }
     // the sample cursors cannot run dry before this many launches
     const uint64_t min_iters = (n + (uint64_t) nw * j.target - 1) / ((uint64_t) nw * j.target);
     uint64_t it = 0;

@@ -1148,6 +1148,72 @@ __global__ __launch_bounds__(64) void k_finish(const RenderParams P, uint32_t pe
     }
 }
 
+// Experiment (MTSAMD_MEGA=1): the whole pass as ONE launch of persistent lanes -- no pool, no launch rounds.  A workgroup (one hardware
+// wave) owns the samples of one scheduling wave; a lane whose path ends starts the next sample at once.
+template <typename State, bool GENERAL, bool FLAT>
+__global__ __launch_bounds__(64) void k_mega(const RenderParams P) {
+    extern __shared__ float4 smem[];
+    const uint32_t lane = threadIdx.x, wave = blockIdx.x;
+    uint64_t cursor = P.cursor[wave];
+    const uint64_t end = P.cursor_end[wave];
+    if (cursor >= end) return;
+    LdsView lds = {};
+    if (FLAT) lds = lds_stage<true>(P.sv, smem);
+    else {
+        lds.stride = 64u; lds.stack = reinterpret_cast<uint32_t *>(smem);
+        lds.stack_lds_depth = min(P.sv.stack_depth, kFinishLdsDepth);
+        lds.spill = reinterpret_cast<StackEntry *>(P.trace_spill) + (size_t) blockIdx.x * (P.sv.stack_depth - lds.stack_lds_depth) * 64u + lane;
+        lds.spill_stride = 64u;
+    }
+    Counters c = { 0u, 0u, 0u, 0u };
+    State s;
+    bool busy = false;
+    while (true) {
+        const uint64_t m = __ballot(!busy);
+        if (m != 0ull && cursor < end) {
+            const uint64_t v = cursor + mask_rank(m);
+            if (!busy && v < end) {
+                uint64_t ordinal; uint32_t lp, sj;
+                cursor_sample(P, wave, v, ordinal, lp, sj);
+                start_path(P, ordinal, lp, sj, s);
+                busy = true;
+            }
+            cursor += (uint64_t) __popcll(m);
+        }
+        if (__ballot(busy) == 0ull) {
+            if (cursor >= end) break;
+            continue;
+        }
+        if (busy && !step_fused<GENERAL, FLAT>(P, lds, s, c)) { finish_path(P, s); busy = false; }
+    }
+    uint32_t tot[4] = { c.closest, c.any, c.segments, c.tri_tests };
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        for (int off = 32; off > 0; off >>= 1) tot[k] += __shfl_xor(tot[k], off);
+    if (lane == 0u) {
+        P.cursor[wave] = end;
+        uint64_t *ws = P.wave_stats + 4u * (size_t) wave;
+        ws[0] += tot[0]; ws[1] += tot[1]; ws[2] += tot[2]; ws[3] += tot[3];
+    }
+}
+
+hipError_t launch_mega(const RenderParams &p, hipStream_t s) {
+    const size_t lds = p.sv.flat ? lds_bytes(p.sv, 64u) : sizeof(StackEntry) * std::min(p.sv.stack_depth, kFinishLdsDepth) * 64u;
+    const uint32_t blocks = p.n_waves;
+    if (p.sv.flat) {
+        if (p.spectral && p.sv.general) hipLaunchKernelGGL((k_mega<PathStateS, true, true>), dim3(blocks), dim3(64), lds, s, p);
+        else if (p.spectral) hipLaunchKernelGGL((k_mega<PathStateS, false, true>), dim3(blocks), dim3(64), lds, s, p);
+        else if (p.sv.general) hipLaunchKernelGGL((k_mega<PathState, true, true>), dim3(blocks), dim3(64), lds, s, p);
+        else hipLaunchKernelGGL((k_mega<PathState, false, true>), dim3(blocks), dim3(64), lds, s, p);
+    } else {
+        if (p.spectral && p.sv.general) hipLaunchKernelGGL((k_mega<PathStateS, true, false>), dim3(blocks), dim3(64), lds, s, p);
+        else if (p.spectral) hipLaunchKernelGGL((k_mega<PathStateS, false, false>), dim3(blocks), dim3(64), lds, s, p);
+        else if (p.sv.general) hipLaunchKernelGGL((k_mega<PathState, true, false>), dim3(blocks), dim3(64), lds, s, p);
+        else hipLaunchKernelGGL((k_mega<PathState, false, false>), dim3(blocks), dim3(64), lds, s, p);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_finish(const RenderParams &p, uint64_t alive, hipStream_t s) {
     // about four paths per lane (alive: upper bound of the paths left), at least 2048 workgroups if there are that many scheduling waves
     const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(alive / 256u, 2048u), p.n_waves);

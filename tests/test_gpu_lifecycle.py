@@ -136,6 +136,11 @@ def test_finish_kernel_leaves_the_film_unchanged(gpu, what):
     for k in ("samples", "segments", "closest_hit_rays", "any_hit_rays"):
         assert st0[k] == st1[k], (k, st0[k], st1[k])
     assert torch.equal(never, early)
+    # the ablation schedule of DESIGN section 7 (one launch of persistent lanes, no path pool) computes the same film, too
+    with _env(MTSAMD_MEGA=1):
+        mega, stm = _film(gpu, integ, scene, p)
+    assert stm["iterations"] == 1 and stm["segments"] == st0["segments"]
+    assert torch.equal(never, mega)
 
 
 def test_timeout_stops_between_passes(gpu):
