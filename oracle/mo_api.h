@@ -157,6 +157,13 @@ int mo_sample_radiance(const mo_scene *s, const mo_render_desc *d, uint64_t firs
  * [row0,row1) are traced; splats land in the full crop-sized film (for multi-GPU tests). */
 int mo_render_rows(const mo_scene *s, const mo_render_desc *d, int row0, int row1,
                    float *film_xyzaw);
+/* Derivative of the same image w.r.t. the texels of the `envmap` emitter ('data', envmap.cpp:214-218; the inverse-rendering example
+ * docs/examples/10_inverse_rendering/invert_bunny.py): radiance is linear in them, the sampling distribution built from their
+ * luminances is not differentiated (envmap.cpp:220-253 rebuilds it from plain floats).  Any BSDF, any depth.  grad_env: h*w*3,
+ * accumulated. */
+int mo_render_adjoint_envmap(const mo_scene *s, const mo_render_desc *d, const float *dimage, const float *film, float *grad_env);
+/* new envmap texels (h*w*3); rebuild_warp = 0 keeps the sampling distribution (a render is then exactly linear in the texels) */
+int mo_scene_update_envmap(mo_scene *s, const float *rgb, int rebuild_warp);
 /* Reverse-mode derivative of Image = RGB / (W + 1e-8) (autodiff.py:80-91) w.r.t. diffuse reflectances, by path replay
  * (restatement of what ek.backward() does through PathIntegrator::sample for these parameters; RR probabilities detached).
  * dimage: crop_h*crop_w*3 = dLoss/dImage; film: the primal R,G,B,A,W film of the same desc (weights);

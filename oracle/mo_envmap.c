@@ -229,6 +229,41 @@ static void dir_to_uv(mo_v3 v, float *u, float *vv) {                    /* envm
     *u = a - floorf(a); *vv = b - floorf(b);
 }
 
+/* bilinear footprint of envmap_lookup: radiance[k] = sum_i w[i] * texel[idx[i]][k] (weights include `scale`) -- d radiance / d texel */
+void mo_envmap_footprint(const mo_envmap *e, float u, float v, uint32_t idx[4], float w[4]) {
+    u *= (float) (e->w - 1); v *= (float) (e->h - 1);
+    uint32_t px = (uint32_t) u, py = (uint32_t) v;
+    if (px > (uint32_t) (e->w - 2)) px = (uint32_t) (e->w - 2);
+    if (py > (uint32_t) (e->h - 2)) py = (uint32_t) (e->h - 2);
+    float w1x = u - (float) px, w1y = v - (float) py, w0x = 1.0f - w1x, w0y = 1.0f - w1y;
+    idx[0] = py * (uint32_t) e->w + px; idx[1] = idx[0] + 1; idx[2] = idx[0] + (uint32_t) e->w; idx[3] = idx[2] + 1;
+    w[0] = (w0y * w0x) * e->scale; w[1] = (w0y * w1x) * e->scale; w[2] = (w1y * w0x) * e->scale; w[3] = (w1y * w1x) * e->scale;
+}
+void mo_envmap_dir_to_uv(const mo_envmap *e, mo_v3 d_world, float *u, float *v) {
+    dir_to_uv(mat3_apply(e->to_local, d_world), u, v);
+}
+/* new texel values ('data' of envmap.cpp:214-218); rebuild_warp: parameters_changed() (envmap.cpp:220-253) rebuilds the sampling
+ * distribution from the new luminances; 0 keeps it, so that a render is exactly linear in the texels (finite-difference tests) */
+int mo_envmap_update(mo_envmap *e, const float *rgb, int rebuild_warp) {
+    float *lum = rebuild_warp ? (float *) malloc(sizeof(float) * (size_t) e->w * e->h) : NULL;
+    for (int y = 0; y < e->h; ++y) {
+        float sin_theta = sinf((float) y / (float) (e->h - 1) * MO_PI_F);
+        for (int x = 0; x < e->w; ++x) {
+            const float *p = rgb + 3 * ((size_t) y * e->w + x);
+            float *o = e->data + 4 * ((size_t) y * e->w + x);
+            o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = 1.0f;
+            if (lum) lum[(size_t) y * e->w + x] = luminance(p) * sin_theta;
+        }
+    }
+    int rc = 0;
+    if (lum) {
+        mo_hier2d_free(&e->warp);
+        rc = mo_hier2d_build(&e->warp, lum, (uint32_t) e->w, (uint32_t) e->h, 1);
+        free(lum);
+    }
+    return rc;
+}
+
 /* EnvironmentMapEmitter::eval for the world-space direction `d` the ray travels in (si.wi = -d) */
 void mo_envmap_eval(const mo_envmap *e, mo_v3 d, float out[3]) {
     mo_v3 v = mat3_apply(e->to_local, d);

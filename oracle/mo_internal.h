@@ -52,6 +52,9 @@ void mo_envmap_sample(const mo_envmap *e, mo_v2 sample, mo_v3 *d_out, float *pdf
 void mo_envmap_lookup_spectral(const mo_envmap *e, float u, float v, const float *wav, float *out);   /* 4 wavelengths */
 void mo_envmap_eval_spectral(const mo_envmap *e, mo_v3 d, const float *wav, float *out);
 float mo_envmap_pdf(const mo_envmap *e, mo_v3 d_world);
+void mo_envmap_footprint(const mo_envmap *e, float u, float v, uint32_t idx[4], float w[4]);
+void mo_envmap_dir_to_uv(const mo_envmap *e, mo_v3 d_world, float *u, float *v);
+int mo_envmap_update(mo_envmap *e, const float *rgb, int rebuild_warp);
 
 /* type 0: `area` (src/emitters/area.cpp) attached to `shape`; type 1: `constant` environment (src/emitters/constant.cpp)
  * with the scene's bounding sphere (set_scene, constant.cpp:47-51); type 2: `envmap` (src/emitters/envmap.cpp) */

@@ -407,8 +407,17 @@ static int scene_intersect(const mo_scene *s, const mo_ray *ray, mo_si *si, ray_
     return 0;
 }
 
+/* eg != NULL: besides the radiance, d(loss)/d(envmap texels) = delta * d(radiance)/d(texels) is scattered into eg->grad (h*w*3):
+ * the radiance is linear in the texels at its two uses, the emission picked up by an escaped ray and the emitter sample */
+typedef struct { const float *delta; float *grad; } env_grad;
+static void env_grad_add(const mo_envmap *env, float u, float v, const float coeff[3], const env_grad *eg) {
+    uint32_t idx[4]; float w[4];
+    mo_envmap_footprint(env, u, v, idx, w);
+    for (int i = 0; i < 4; ++i)
+        for (int k = 0; k < 3; ++k) eg->grad[3 * (size_t) idx[i] + k] += (eg->delta[k] * coeff[k]) * w[i];
+}
 static void path_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, int max_depth,
-                        int rr_depth, float result[3], int *valid_ray, ray_stats *st) {
+                        int rr_depth, float result[3], int *valid_ray, ray_stats *st, const env_grad *eg) {
     mo_ray ray = *ray_in;
     float eta = 1.0f, emission_weight = 1.0f;
     float throughput[3] = { 1.0f, 1.0f, 1.0f };
@@ -429,6 +438,12 @@ static void path_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, 
                 const float *le = s->emitters[emitter].radiance;
                 if (s->emitters[emitter].type == 2) { mo_envmap_eval(s->emitters[emitter].env, mo_neg(si.wi), le_env); le = le_env; }
                 for (int k = 0; k < 3; ++k) result[k] += (emission_weight * throughput[k]) * le[k];
+                if (eg && s->emitters[emitter].type == 2) {
+                    float u, v, coeff[3];
+                    mo_envmap_dir_to_uv(s->emitters[emitter].env, mo_neg(si.wi), &u, &v);
+                    for (int k = 0; k < 3; ++k) coeff[k] = emission_weight * throughput[k];
+                    env_grad_add(s->emitters[emitter].env, u, v, coeff, eg);
+                }
             }
         }
         active = active && si_valid;
@@ -452,7 +467,7 @@ static void path_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, 
             mo_v2 s2; s2.x = mo_pcg32_next_f32(rng); s2.y = mo_pcg32_next_f32(rng);
             mo_dsample ds; float emitter_val[3];
             mo_sample_emitter_direction(s, si.p, s2, &ds, emitter_val);
-            int active_e = ds.pdf != 0.0f;
+            int active_e = ds.pdf != 0.0f, occluded = 0;
             if (active_e && s->n_emitters > 0) {
                 /* visibility test (scene.cpp:178-182) */
                 mo_ray sr;
@@ -460,7 +475,7 @@ static void path_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, 
                 sr.mint = MO_RAY_EPSILON * (1.0f + mo_hmax_abs(si.p));
                 sr.maxt = ds.dist * (1.0f - MO_SHADOW_EPSILON);
                 st->any++;
-                if (mo_intersect(s, &sr, 1, 0, NULL)) emitter_val[0] = emitter_val[1] = emitter_val[2] = 0.0f;
+                if (mo_intersect(s, &sr, 1, 0, NULL)) { emitter_val[0] = emitter_val[1] = emitter_val[2] = 0.0f; occluded = 1; }
             }
             if (active_e) {
                 mo_v3 wo = mo_to_local(&si.sh, ds.d);
@@ -469,6 +484,12 @@ static void path_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, 
                 float mis = ds.delta ? 1.0f : mis_weight(ds.pdf, bsdf_pdf);      /* path.cpp:170 */
                 for (int k = 0; k < 3; ++k)
                     result[k] += ((mis * throughput[k]) * bsdf_val[k]) * emitter_val[k];
+                if (eg && !occluded && s->emitters[ds.emitter].type == 2) {
+                    /* emitter_val = lookup(uv) / pdf_single * emitter count (envmap.cpp:186-189, scene.cpp:160-163) */
+                    float g = mo_rcp(ds.pdf_single) * (s->n_emitters > 1 ? (float) s->n_emitters : 1.0f), coeff[3];
+                    for (int k = 0; k < 3; ++k) coeff[k] = ((mis * throughput[k]) * bsdf_val[k]) * g;
+                    env_grad_add(s->emitters[ds.emitter].env, ds.uv.x, ds.uv.y, coeff, eg);
+                }
             }
         }
 
@@ -839,7 +860,7 @@ static void render_sample(const mo_scene *s, const mo_render_desc *d, const came
     } else {
     if (d->integrator == 1) direct_sample(s, rng, &ray, d->emitter_samples, d->bsdf_samples, d->hide_emitters, L, &valid, st);
     else if (d->integrator == 2) depth_sample(s, &ray, L, &valid, st);
-    else path_sample(s, rng, &ray, d->max_depth, d->rr_depth, L, &valid, st);
+    else path_sample(s, rng, &ray, d->max_depth, d->rr_depth, L, &valid, st, NULL);
     /* ray_weight == 1 in RGB mode (spectrum.h:304-309) */
     srgb_to_xyz(L, xyz);
     }
@@ -1159,6 +1180,50 @@ static int path_sample_rec(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_i
     return n;
 }
 
+/* camera sample i of the wavefront order: its RNG stream (advanced past the camera sample), its ray and
+ * delta = dLoss/dRadiance of the sample = sum over its filter footprint of w * dLoss/dImage / (W + 1e-8) (autodiff.py:80-91) */
+static void adjoint_sample(const mo_render_desc *d, const camera *cam, const rfilter *f, uint32_t taps, uint64_t i, const float *dimage,
+                           const float *film, mo_pcg32 *rng, mo_ray *ray, float delta[3]) {
+    seed_wavefront(rng, i, d->base_seed);
+    uint64_t pixel = i / (uint64_t) d->spp;
+    float px0 = (float) (uint32_t) (pixel % (uint64_t) d->crop_w) + (float) d->crop_x, py0 = (float) (uint32_t) (pixel / (uint64_t) d->crop_w) + (float) d->crop_y;
+    float jx = mo_pcg32_next_f32(rng), jy = mo_pcg32_next_f32(rng);
+    float psx = px0 + jx, psy = py0 + jy;
+    float apx = 0.5f, apy = 0.5f;
+    if (cam->aperture_radius > 0.0f) { apx = mo_pcg32_next_f32(rng); apy = mo_pcg32_next_f32(rng); }
+    (void) mo_pcg32_next_f32(rng);
+    float ax = (psx - (float) d->crop_x) / (float) d->crop_w, ay = (psy - (float) d->crop_y) / (float) d->crop_h;
+    camera_sample_ray(cam, ax, ay, apx, apy, ray);
+    /* delta = dLoss/dRadiance of this sample */
+    delta[0] = delta[1] = delta[2] = 0.0f;
+    float px = psx - ((float) d->crop_x + 0.5f), py = psy - ((float) d->crop_y + 0.5f);
+    if (f->radius > 1.0f) {
+        int lox = (int) ceilf(px - f->radius), loy = (int) ceilf(py - f->radius);
+        int hix = (int) floorf(px + f->radius), hiy = (int) floorf(py + f->radius);
+        if (lox < 0) lox = 0;
+        if (loy < 0) loy = 0;
+        if (hix > d->crop_w - 1) hix = d->crop_w - 1;
+        if (hiy > d->crop_h - 1) hiy = d->crop_h - 1;
+        float bx = (float) (uint32_t) lox - px, by = (float) (uint32_t) loy - py;
+        for (uint32_t yr = 0; yr < taps && loy + (int) yr <= hiy; ++yr) {
+            float wy = d->filter_analytic ? rfilter_eval(f, by + (float) yr) : rfilter_eval_discretized(f, by + (float) yr);
+            for (uint32_t xr = 0; xr < taps && lox + (int) xr <= hix; ++xr) {
+                float wx = d->filter_analytic ? rfilter_eval(f, bx + (float) xr) : rfilter_eval_discretized(f, bx + (float) xr);
+                size_t pix = (size_t) (loy + (int) yr) * d->crop_w + (size_t) (lox + (int) xr);
+                float iw = (wy * wx) / (film[5 * pix + 4] + 1e-8f);
+                for (int c = 0; c < 3; ++c) delta[c] += iw * dimage[3 * pix + c];
+            }
+        }
+    } else {
+        int lox = (int) ceilf(px - 0.5f), loy = (int) ceilf(py - 0.5f);
+        if (lox >= 0 && loy >= 0 && lox < d->crop_w && loy < d->crop_h) {
+            size_t pix = (size_t) loy * d->crop_w + (size_t) lox;
+            float iw = 1.0f / (film[5 * pix + 4] + 1e-8f);
+            for (int c = 0; c < 3; ++c) delta[c] = iw * dimage[3 * pix + c];
+        }
+    }
+}
+
 int mo_render_adjoint(const mo_scene *s, const mo_render_desc *d, const float *dimage, const float *film,
                       float *grad_shape, float *grad_tex, float *grad_emitter) {
     if (desc_check(d) || d->max_depth < 0 || d->max_depth > MO_ADJ_MAX_DEPTH) return -1;
@@ -1170,44 +1235,8 @@ int mo_render_adjoint(const mo_scene *s, const mo_render_desc *d, const float *d
     for (uint32_t t = 0; t < s->n_textures; ++t) toff[t + 1] = toff[t] + 3 * (size_t) s->textures[t].w * s->textures[t].h;
     uint64_t total = (uint64_t) d->crop_w * d->crop_h * (uint64_t) d->spp;
     for (uint64_t i = 0; i < total; ++i) {
-        mo_pcg32 rng; seed_wavefront(&rng, i, d->base_seed);
-        uint64_t pixel = i / (uint64_t) d->spp;
-        float px0 = (float) (uint32_t) (pixel % (uint64_t) d->crop_w) + (float) d->crop_x, py0 = (float) (uint32_t) (pixel / (uint64_t) d->crop_w) + (float) d->crop_y;
-        float jx = mo_pcg32_next_f32(&rng), jy = mo_pcg32_next_f32(&rng);
-        float psx = px0 + jx, psy = py0 + jy;
-        float apx = 0.5f, apy = 0.5f;
-        if (cam.aperture_radius > 0.0f) { apx = mo_pcg32_next_f32(&rng); apy = mo_pcg32_next_f32(&rng); }
-        (void) mo_pcg32_next_f32(&rng);
-        float ax = (psx - (float) d->crop_x) / (float) d->crop_w, ay = (psy - (float) d->crop_y) / (float) d->crop_h;
-        mo_ray ray; camera_sample_ray(&cam, ax, ay, apx, apy, &ray);
-        /* delta = dLoss/dRadiance of this sample */
-        float delta[3] = { 0, 0, 0 };
-        float px = psx - ((float) d->crop_x + 0.5f), py = psy - ((float) d->crop_y + 0.5f);
-        if (f.radius > 1.0f) {
-            int lox = (int) ceilf(px - f.radius), loy = (int) ceilf(py - f.radius);
-            int hix = (int) floorf(px + f.radius), hiy = (int) floorf(py + f.radius);
-            if (lox < 0) lox = 0;
-            if (loy < 0) loy = 0;
-            if (hix > d->crop_w - 1) hix = d->crop_w - 1;
-            if (hiy > d->crop_h - 1) hiy = d->crop_h - 1;
-            float bx = (float) (uint32_t) lox - px, by = (float) (uint32_t) loy - py;
-            for (uint32_t yr = 0; yr < taps && loy + (int) yr <= hiy; ++yr) {
-                float wy = d->filter_analytic ? rfilter_eval(&f, by + (float) yr) : rfilter_eval_discretized(&f, by + (float) yr);
-                for (uint32_t xr = 0; xr < taps && lox + (int) xr <= hix; ++xr) {
-                    float wx = d->filter_analytic ? rfilter_eval(&f, bx + (float) xr) : rfilter_eval_discretized(&f, bx + (float) xr);
-                    size_t pix = (size_t) (loy + (int) yr) * d->crop_w + (size_t) (lox + (int) xr);
-                    float iw = (wy * wx) / (film[5 * pix + 4] + 1e-8f);
-                    for (int c = 0; c < 3; ++c) delta[c] += iw * dimage[3 * pix + c];
-                }
-            }
-        } else {
-            int lox = (int) ceilf(px - 0.5f), loy = (int) ceilf(py - 0.5f);
-            if (lox >= 0 && loy >= 0 && lox < d->crop_w && loy < d->crop_h) {
-                size_t pix = (size_t) loy * d->crop_w + (size_t) lox;
-                float iw = 1.0f / (film[5 * pix + 4] + 1e-8f);
-                for (int c = 0; c < 3; ++c) delta[c] = iw * dimage[3 * pix + c];
-            }
-        }
+        mo_pcg32 rng; mo_ray ray; float delta[3];
+        adjoint_sample(d, &cam, &f, taps, i, dimage, film, &rng, &ray, delta);
         vertex_rec rec[MO_ADJ_MAX_DEPTH];
         int n = path_sample_rec(s, &rng, &ray, d->max_depth, d->rr_depth, rec);
         /* backward sweep; a = dLoss/dT_v (throughput arriving at vertex v).  q = min(hmax(T) eta^2, .95) is
@@ -1326,4 +1355,21 @@ void mo_kat_sample_emitter(const mo_scene *s, const float *ref_p3, const float *
     out[5] = ds.n.x; out[6] = ds.n.y; out[7] = ds.n.z; out[8] = ds.p.x; out[9] = ds.p.y; out[10] = ds.p.z;
     out[11] = spec[0]; out[12] = spec[1]; out[13] = spec[2];
     out[14] = s->n_emitters ? mo_pdf_emitter_direction(s, ds.emitter, ds.d, ds.n, ds.dist) : 0.0f;
+}
+
+int mo_render_adjoint_envmap(const mo_scene *s, const mo_render_desc *d, const float *dimage, const float *film, float *grad_env) {
+    if (desc_check(d) || !grad_env || s->spectral || s->environment < 0 || s->emitters[s->environment].type != 2) return -1;
+    camera cam; camera_init(d, &cam);
+    rfilter f; rfilter_init(&f, d->rfilter, d->rfilter_param, d->rfilter_param2);
+    uint32_t taps = (uint32_t) ceilf((f.radius - 2.0f * MO_RAY_EPSILON) * 2.0f);
+    uint64_t total = (uint64_t) d->crop_w * d->crop_h * (uint64_t) d->spp;
+    ray_stats st = { 0, 0 };
+    for (uint64_t i = 0; i < total; ++i) {
+        mo_pcg32 rng; mo_ray ray; float delta[3], L[3];
+        adjoint_sample(d, &cam, &f, taps, i, dimage, film, &rng, &ray, delta);
+        env_grad eg = { delta, grad_env };
+        int valid;
+        path_sample(s, &rng, &ray, d->max_depth, d->rr_depth, L, &valid, &st, &eg);
+    }
+    return 0;
 }

@@ -108,6 +108,10 @@ int mo_scene_add_envmap_emitter(mo_scene *s, int w, int h, const float *rgb, flo
     s->environment = (int) s->n_emitters;
     return (int) s->n_emitters++;
 }
+int mo_scene_update_envmap(mo_scene *s, const float *rgb, int rebuild_warp) {
+    if (!s || !rgb || s->environment < 0 || s->emitters[s->environment].type != 2 || s->spectral) return -1;
+    return mo_envmap_update(s->emitters[s->environment].env, rgb, rebuild_warp);
+}
 int mo_scene_add_delta_emitter(mo_scene *s, int type, const float *rgb, const float *position3, const float *direction3,
                                const float *to_world9, float cutoff_angle_deg, float beam_width_deg) {
     if (!s || !rgb || type < 3 || type > 5) return -1;

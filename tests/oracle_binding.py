@@ -85,6 +85,8 @@ def lib():
         L.mo_film_develop.argtypes = [vp, C.c_uint64, vp]
         L.mo_render_adjoint.argtypes = [vp, C.POINTER(RenderDesc), vp, vp, vp, vp, vp]
         L.mo_scene_set_emitter_radiance.argtypes = [vp, C.c_uint32, vp]
+        L.mo_render_adjoint_envmap.argtypes = [vp, C.POINTER(RenderDesc), vp, vp, vp]
+        L.mo_scene_update_envmap.argtypes = [vp, vp, C.c_int]
         L.mo_camera_rays.argtypes = [C.POINTER(RenderDesc), C.c_uint64] + [vp] * 7
         L.mo_imageblock_put.argtypes = [C.c_int] * 6 + [C.c_float, C.c_float, C.c_int, C.c_int, C.c_uint64, vp, vp, vp]
         L.mo_rfilter_table.argtypes = [C.c_int, C.c_float, C.c_float, vp, f32p, C.POINTER(C.c_int)]
@@ -298,6 +300,19 @@ class OracleScene:
         if n_emitters is not None:
             return gs, gt[:tex_floats], ge[:n_emitters]
         return gs, gt[:tex_floats]
+
+    def render_adjoint_envmap(self, desc, dimage, film, shape):
+        """gradient w.r.t. the texels of the envmap emitter (`shape` = (h, w, 3))"""
+        dimage = _f(dimage); film = _f(film)
+        g = np.zeros(shape, np.float32)
+        rc = lib().mo_render_adjoint_envmap(self.h, C.byref(desc), _p(dimage), _p(film), _p(g))
+        if rc != 0:
+            raise RuntimeError("oracle envmap adjoint failed (%d)" % rc)
+        return g
+
+    def update_envmap(self, data, rebuild_warp=True):
+        data = _f(data)
+        assert lib().mo_scene_update_envmap(self.h, _p(data), 1 if rebuild_warp else 0) == 0
 
     def set_emitter_radiance(self, emitter, rgb):
         rgb = _f(rgb)

@@ -86,6 +86,60 @@ def test_oracle_emitter_radiance_gradient(oracle, rfilter, max_depth, two_lights
             assert abs(fd - ge[e, c]) <= 2e-3 * max(abs(fd), np.abs(ge).max()) + 1e-5, (e, c, fd, ge[e, c])
 
 
+def _envmap_scene(with_area):
+    """open Cornell box (no ceiling / back wall) with a glossy and a glass box under an `envmap` emitter, optionally the area light"""
+    cb = scenes.cornell_box()
+    keep = [i for i, m in enumerate(cb["meshes"]) if i not in (1, 2) and (with_area or m.get("emitter", -1) < 0)]
+    cb["meshes"] = [dict(cb["meshes"][i]) for i in keep]
+    cb["bsdfs"] = list(cb["bsdfs"]) + [{"type": "roughconductor", "alpha": 0.2, "distribution": "ggx", "eta": 0.0, "k": 1.0}, {"type": "dielectric"}]
+    cb["meshes"][-1]["bsdf"] = len(cb["bsdfs"]) - 2
+    cb["meshes"][-2]["bsdf"] = len(cb["bsdfs"]) - 1
+    rng = np.random.RandomState(7)
+    img = rng.uniform(0.2, 1.0, size=(6, 10, 3)).astype(np.float32)
+    img[1:3, 6:8] += 8.0
+    env = {"type": "envmap", "id": "my_envmap", "data": img, "scale": 0.8, "to_world": scenes.look_at([0, 0, 0], [1, 0.2, 0.3], [0, 1, 0])}
+    if with_area:
+        cb["emitters"] = [env] + list(cb["emitters"])
+        for m in cb["meshes"]:
+            if m.get("emitter", -1) >= 0:
+                m["emitter"] = 1
+    else:
+        cb["emitters"] = [env]
+    return cb, img
+
+
+@pytest.mark.parametrize("with_area,rfilter,max_depth", [(False, "box", 4), (True, "gaussian", 6)])
+def test_oracle_envmap_gradient(oracle, with_area, rfilter, max_depth):
+    """'my_envmap.data' (docs/examples/10_inverse_rendering/invert_bunny.py): with the sampling distribution held fixed the image
+    is linear in the texels, so central differences of the oracle's forward render are exact up to rounding -- through glossy and
+    dielectric BSDFs, MIS with BSDF sampling, Russian roulette and (second case) emitter selection"""
+    sd, img = _envmap_scene(with_area)
+    p = scenes.cornell_box_sensor(14, 12, 8, seed=9, max_depth=max_depth, rfilter=rfilter)
+    desc = oracle.make_desc(p, analytic=True, film_rgb=True)
+    S = oracle.OracleScene(sd, naive=True)
+    image, film = S.render_image(desc)
+    dimage = np.random.RandomState(3).randn(*image.shape).astype(np.float32)
+    g = S.render_adjoint_envmap(desc, dimage, film, img.shape)
+    loss = lambda im: float(np.sum(im.astype(np.float64) * dimage))
+    assert (np.abs(g) > 0).mean() > 0.5
+    checked = 0
+    for (ty, tx, c) in [(1, 6, 0), (2, 7, 1), (0, 0, 2), (4, 3, 1), (5, 9, 0), (3, 5, 2)]:
+        h = 0.25
+        tp, tm = img.copy(), img.copy()
+        tp[ty, tx, c] += h; tm[ty, tx, c] -= h
+        S.update_envmap(tp, rebuild_warp=False); lp = loss(S.render_image(desc)[0])
+        S.update_envmap(tm, rebuild_warp=False); lm = loss(S.render_image(desc)[0])
+        fd = (lp - lm) / (2 * h)
+        assert abs(fd - g[ty, tx, c]) <= 2e-3 * max(abs(fd), np.abs(g).max()) + 1e-5, (ty, tx, c, fd, g[ty, tx, c])
+        checked += abs(fd) > 1e-6
+    assert checked >= 4
+    S.update_envmap(img, rebuild_warp=False)
+    assert np.array_equal(S.render_image(desc)[0], image)
+    # parameters_changed() (envmap.cpp:220-253): rebuilding the distribution from the same texels changes nothing
+    S.update_envmap(img, rebuild_warp=True)
+    assert np.array_equal(S.render_image(desc)[0], image)
+
+
 def test_adjoint_argument_checks(oracle):
     sd, tex, desc = _setup(oracle, "box", 3)
     S = oracle.OracleScene(sd, naive=True)
