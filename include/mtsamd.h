@@ -282,6 +282,16 @@ int mtsamd_sample_radiance(mtsamd_scene *scene, const mtsamd_render_desc *desc, 
 int mtsamd_render_adjoint(mtsamd_scene *scene, const mtsamd_render_desc *desc, const float *dloss_dimage_dev,
                           const float *film_dev, float *grad_bsdf_dev, float *grad_textures_dev, float *grad_emitters_dev,
                           void *stream);
+/* The same derivative with respect to the texels of the `envmap` emitter -- 'my_envmap.data' (src/emitters/envmap.cpp:214-218), the
+ * parameter docs/examples/10_inverse_rendering/invert_bunny.py optimises.  The radiance is linear in the texels; the sampling
+ * distribution built from their luminances is not differentiated (envmap.cpp:220-253 rebuilds it from plain floats).  Any BSDF,
+ * any max_depth, RGB variant.  grad_envmap_dev: envmap height * width * 3 floats, ACCUMULATED into. */
+int mtsamd_render_adjoint_envmap(mtsamd_scene *scene, const mtsamd_render_desc *desc, const float *dloss_dimage_dev,
+                                 const float *film_dev, float *grad_envmap_dev, void *stream);
+/* New texels for the envmap emitter (host pointer, height * width * 3 linear RGB; parameters_changed of envmap.cpp:220-253).
+ * rebuild_distribution = 0 keeps the importance-sampling hierarchy of the previous texels (a render is then exactly linear in the
+ * texels: finite-difference tests); the reference always rebuilds.  Synchronises the device.  RGB variant. */
+int mtsamd_scene_update_envmap(mtsamd_scene *scene, const float *rgb, int32_t rebuild_distribution);
 /* Size of a bitmap texture and its float offset inside the concatenated texture-gradient buffer. */
 /* RoughPlastic precomputation (roughplastic.cpp:380-399) of BSDF `bsdf`: out65[0..63] = external transmittance at
  * cos(theta) = i / 63, out65[64] = internal diffuse reflectance.  Host pointer. */

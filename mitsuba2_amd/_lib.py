@@ -87,6 +87,8 @@ SYMBOLS = {
     "mtsamd_rgb2spec_build": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32]),
     "mtsamd_srgb_model_fetch": (C.c_int, [C.c_char_p, f32p, f32p]),
     "mtsamd_render_adjoint": (C.c_int, [vp, C.POINTER(RenderDesc), vp, vp, vp, vp, vp, vp]),
+    "mtsamd_render_adjoint_envmap": (C.c_int, [vp, C.POINTER(RenderDesc), vp, vp, vp, vp]),
+    "mtsamd_scene_update_envmap": (C.c_int, [vp, f32p, C.c_int32]),
     "mtsamd_scene_roughplastic_tables": (C.c_int, [vp, C.c_uint32, f32p]),
     "mtsamd_scene_texture_info": (C.c_int, [vp, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), u64p]),
     "mtsamd_sample_radiance": (C.c_int, [vp, C.POINTER(RenderDesc), C.c_uint64, C.c_uint64, vp, vp, vp]),

@@ -28,10 +28,22 @@ class ParameterMap:
 
     def __init__(self, scene):
         self._scene = scene
+        self.rebuild_envmap_distribution = True      # what parameters_changed() does (envmap.cpp:220-253); False: tests of linearity
         self.properties = {}
         self._kind = {}
         dev = torch.device("cuda", scene._device_index)
-        for i, b in enumerate(scene._bsdf_records):
+        emitters = scene._dict.get("emitters", [])
+        # 'my_envmap.data' (envmap.cpp:214-218): differentiable in any scene (any BSDF); shape (H, W, 3) linear RGB
+        for e, em in enumerate(emitters):
+            if em.get("type", "area") == "envmap":
+                key = em.get("id", "emitter_%d" % e) + ".data"
+                self.properties[key] = torch.as_tensor(np.ascontiguousarray(em["data"], np.float32), dtype=torch.float32, device=dev).clone()
+                self._kind[key] = ("envmap", e, e)
+        # reflectances and area-light radiances are differentiated by the diffuse path replay (mtsamd_render_adjoint): scenes of
+        # one-sided diffuse BSDFs lit by area lights only
+        diffuse_scene = all(b["type"] == 0 and not b["twosided"] for b in scene._bsdf_records) and \
+            all(em.get("type", "area") == "area" for em in emitters)
+        for i, b in enumerate(scene._bsdf_records if diffuse_scene else []):
             if b["type"] != 0:            # only diffuse reflectances are exposed (the adjoint pass covers those)
                 continue
             name = b.get("id", "bsdf_%d" % i)
@@ -47,7 +59,7 @@ class ParameterMap:
                 self.properties[key] = torch.as_tensor([float(x) for x in refl], dtype=torch.float32, device=dev)
                 self._kind[key] = ("bsdf", i, i)
         # 'shape.emitter.radiance.value' of area lights (docs/src/inverse_rendering/diff_render.rst:76)
-        for i, m in enumerate(scene._dict["meshes"]):
+        for i, m in enumerate(scene._dict["meshes"] if diffuse_scene else []):
             e = m.get("emitter", -1)
             if e is None or e < 0 or scene._dict["emitters"][e].get("type", "area") != "area":
                 continue
@@ -86,6 +98,8 @@ class ParameterMap:
                 self._scene.update_texture(idx, v)
             elif kind == "emitter":
                 self._scene.set_emitter_radiance(idx, v.detach().cpu().tolist())
+            elif kind == "envmap":
+                self._scene.update_envmap(v, rebuild_distribution=self.rebuild_envmap_distribution)
             else:
                 self._scene.set_bsdf_reflectance(idx, v.detach().cpu().tolist())
 
@@ -137,11 +151,19 @@ class _Render(torch.autograd.Function):
         g_tex = torch.zeros(max(tex_floats, 1), dtype=torch.float32, device=dev)
         g_em = torch.zeros((max(len(scene._dict.get("emitters", [])), 1), 3), dtype=torch.float32, device=dev)
         gi = grad_image.to(dev, torch.float32).contiguous()
-        L.check(L.lib().mtsamd_render_adjoint(scene._handle, C.byref(d), _ptr(gi), _ptr(film), _ptr(g_bsdf), _ptr(g_tex), _ptr(g_em), _stream()))
+        kinds = {pmap._kind[k][0] for k in keys}
+        if kinds - {"envmap"}:
+            L.check(L.lib().mtsamd_render_adjoint(scene._handle, C.byref(d), _ptr(gi), _ptr(film), _ptr(g_bsdf), _ptr(g_tex), _ptr(g_em), _stream()))
+        g_env = None
+        if "envmap" in kinds:
+            g_env = torch.zeros_like(next(pmap[k] for k in keys if pmap._kind[k][0] == "envmap"))
+            L.check(L.lib().mtsamd_render_adjoint_envmap(scene._handle, C.byref(d), _ptr(gi), _ptr(film), _ptr(g_env), _stream()))
         grads = []
         for k in keys:
             kind, idx, _ = pmap._kind[k]
-            if kind == "bsdf":
+            if kind == "envmap":
+                grads.append(g_env)
+            elif kind == "bsdf":
                 grads.append(g_bsdf[idx].clone())
             elif kind == "emitter":
                 grads.append(g_em[idx].clone())

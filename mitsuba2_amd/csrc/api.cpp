@@ -330,6 +330,7 @@ struct mtsamd_scene {
     float *d_area_pmf = nullptr, *d_area_cdf = nullptr;
     float *d_rough_tables = nullptr;     // roughplastic: 64 floats per BSDF that needs them
     float *d_env_texels = nullptr, *d_env_warp = nullptr; DevEnvmap *d_envmap = nullptr;      // envmap emitter
+    int32_t env_w = 0, env_h = 0;
     float4 *d_flat = nullptr, *d_pairs = nullptr;
     std::vector<DevTexture> textures;       // device data pointers, owned
     std::vector<float> spec_mean;           // per BSDF: mean of specular_reflectance
@@ -752,6 +753,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         std::vector<DevEnvmap> one(1);
         if ((rc = upload(&s->d_env_texels, eh.texels)) || (rc = upload(&s->d_env_warp, eh.warp))) { mtsamd_scene_destroy(s); return rc; }
         de.data = reinterpret_cast<const float4 *>(s->d_env_texels); de.warp = s->d_env_warp;
+        s->env_w = ed.envmap_width; s->env_h = ed.envmap_height;
         de.w = ed.envmap_width; de.h = ed.envmap_height; de.n_levels = (int32_t) eh.lv_offset.size(); de.scale = ed.envmap_scale;
         for (size_t k = 0; k < eh.lv_offset.size(); ++k) { de.lv_offset[k] = eh.lv_offset[k]; de.lv_width[k] = eh.lv_width[k]; }
         for (int k = 0; k < 2; ++k) { de.patch_size[k] = eh.patch_size[k]; de.inv_patch_size[k] = eh.inv_patch_size[k]; de.max_patch_index[k] = eh.max_patch_index[k]; }
@@ -1551,32 +1553,65 @@ int mtsamd_render(mtsamd_scene *s, const mtsamd_render_desc *d, float *film, uin
     return MTSAMD_OK;
 }
 
-int mtsamd_render_adjoint(mtsamd_scene *s, const mtsamd_render_desc *d, const float *dimage, const float *film, float *grad_bsdf,
-                          float *grad_tex, float *grad_emitter, void *stream_) {
+// sensor / sampler / film part of an adjoint launch: the whole crop window of `d`, the primal film's weights, dLoss/dImage
+static int fill_adjoint(mtsamd_scene *s, const mtsamd_render_desc *d, const float *dimage, const float *film, AdjointParams &a) {
     if (!s || !dimage || !film) return fail(MTSAMD_ERR_INVALID, "null argument");
     if (int rc = check_desc(d)) return rc;
-    if (d->max_depth < 0 || d->max_depth > 16)
-        return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass needs a finite max_depth <= 16 (got %d)", d->max_depth);
     if (d->part_count > 1 || d->row_begin != 0 || d->row_end > 0) return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass renders the whole crop window");
     if (s->spectral) return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass is implemented for the RGB variant only");
-    if (s->general_bsdfs) return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass is implemented for one-sided diffuse BSDFs only");
-    if (s->environment >= 0 || s->delta_emitters) return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass handles area emitters only");
-    if (s->bsdfs.size() > 32 && grad_bsdf) return fail(MTSAMD_ERR_UNSUPPORTED, "at most 32 BSDFs with constant-reflectance gradients");
-    if (s->emitters.size() > 32 && grad_emitter) return fail(MTSAMD_ERR_UNSUPPORTED, "at most 32 emitters with radiance gradients");
     HIP_TRY(hipSetDevice(s->device));
-    AdjointParams a{};
     if (int rc = make_camera(*d, a.rp.cam)) return rc;
     if (int rc = make_filter(d->rfilter, d->rfilter_param, d->rfilter_param2, d->rfilter_analytic, a.filter)) return rc;
     if (a.filter.taps > 8) return fail(MTSAMD_ERR_UNSUPPORTED, "reconstruction filter too wide for the adjoint pass");
     a.rp.sv = s->view;
+    if (a.rp.cam.aperture_radius > 0.0f) a.rp.sv.general = 1u;
     a.rp.base_seed = d->seed; a.rp.spp = d->sample_count;
     a.rp.crop_x = d->crop_x; a.rp.crop_y = d->crop_y; a.rp.crop_w = d->crop_width; a.rp.crop_h = d->crop_height;
     a.rp.max_depth = d->max_depth; a.rp.rr_depth = d->rr_depth;
     a.rp.rows = RowMap{ 0, d->crop_height, std::max(d->crop_height, 1), 0, 1 };
     a.rp.store_xyz = 0; a.rp.out_pos = nullptr; a.rp.out_rgba = nullptr;
     a.n_samples = (uint64_t) d->crop_width * d->crop_height * (uint64_t) d->sample_count;
-    a.dimage = dimage; a.film = film; a.grad_bsdf = grad_bsdf; a.grad_tex = grad_tex; a.grad_emitter = grad_emitter;
+    a.dimage = dimage; a.film = film;
+    return 0;
+}
+
+int mtsamd_render_adjoint(mtsamd_scene *s, const mtsamd_render_desc *d, const float *dimage, const float *film, float *grad_bsdf,
+                          float *grad_tex, float *grad_emitter, void *stream_) {
+    AdjointParams a{};
+    if (int rc = fill_adjoint(s, d, dimage, film, a)) return rc;
+    if (d->max_depth < 0 || d->max_depth > 16)
+        return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass needs a finite max_depth <= 16 (got %d)", d->max_depth);
+    if (s->general_bsdfs) return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass is implemented for one-sided diffuse BSDFs only");
+    if (s->environment >= 0 || s->delta_emitters) return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass handles area emitters only");
+    if (s->bsdfs.size() > 32 && grad_bsdf) return fail(MTSAMD_ERR_UNSUPPORTED, "at most 32 BSDFs with constant-reflectance gradients");
+    if (s->emitters.size() > 32 && grad_emitter) return fail(MTSAMD_ERR_UNSUPPORTED, "at most 32 emitters with radiance gradients");
+    a.grad_bsdf = grad_bsdf; a.grad_tex = grad_tex; a.grad_emitter = grad_emitter;
     HIP_TRY(launch_adjoint(a, (hipStream_t) stream_));
+    return MTSAMD_OK;
+}
+
+int mtsamd_render_adjoint_envmap(mtsamd_scene *s, const mtsamd_render_desc *d, const float *dimage, const float *film, float *grad_envmap,
+                                 void *stream_) {
+    AdjointParams a{};
+    if (int rc = fill_adjoint(s, d, dimage, film, a)) return rc;
+    if (!grad_envmap) return fail(MTSAMD_ERR_INVALID, "null argument");
+    if (s->environment < 0 || !s->d_envmap) return fail(MTSAMD_ERR_UNSUPPORTED, "the scene has no envmap emitter");
+    if (d->integrator != 0) return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass differentiates the path integrator");
+    a.grad_env = grad_envmap;
+    HIP_TRY(launch_adjoint_env(a, (hipStream_t) stream_));
+    return MTSAMD_OK;
+}
+
+int mtsamd_scene_update_envmap(mtsamd_scene *s, const float *rgb, int32_t rebuild_distribution) {
+    if (!s || !rgb) return fail(MTSAMD_ERR_INVALID, "null argument");
+    if (s->environment < 0 || !s->d_envmap) return fail(MTSAMD_ERR_UNSUPPORTED, "the scene has no envmap emitter");
+    if (s->spectral) return fail(MTSAMD_ERR_UNSUPPORTED, "envmap updates are implemented for the RGB variant only");
+    HIP_TRY(hipSetDevice(s->device));
+    EnvmapHost eh;
+    if (!build_envmap(rgb, s->env_w, s->env_h, eh)) return fail(MTSAMD_ERR_INVALID, "envmap: unsupported image size");
+    HIP_TRY(hipDeviceSynchronize());           // renders in flight read the old texels
+    HIP_TRY(hipMemcpy(s->d_env_texels, eh.texels.data(), eh.texels.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (rebuild_distribution) HIP_TRY(hipMemcpy(s->d_env_warp, eh.warp.data(), eh.warp.size() * sizeof(float), hipMemcpyHostToDevice));
     return MTSAMD_OK;
 }
 

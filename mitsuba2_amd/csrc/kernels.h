@@ -118,6 +118,7 @@ struct AdjointParams {
     float *grad_bsdf;           // n_bsdfs * 3, accumulated (may be null)
     float *grad_tex;            // all textures concatenated in index order, accumulated (may be null)
     float *grad_emitter;        // n_emitters * 3 (radiance of area lights), accumulated (may be null)
+    float *grad_env;            // k_adjoint_env: envmap height * width * 3, accumulated
 };
 
 struct RayStreams {
@@ -133,6 +134,7 @@ size_t trace_spill_words(const SceneView &sv, uint32_t n_waves);
 // `direct` / `depth` integrators: every sample of [first_ordinal, first_ordinal + n) is finished by one thread
 hipError_t launch_direct(const RenderParams &p, uint64_t n, hipStream_t s);
 hipError_t launch_adjoint(const AdjointParams &a, hipStream_t s);
+hipError_t launch_adjoint_env(const AdjointParams &a, hipStream_t s);
 // end of a pass: every path of p.in (counts p.count_in) is run to its end in one launch; needs dry sample cursors (kernels.hip, k_finish)
 hipError_t launch_finish(const RenderParams &p, uint64_t alive, hipStream_t s);
 hipError_t launch_mega(const RenderParams &p, hipStream_t s);      // experiment: the whole pass in one launch of persistent lanes

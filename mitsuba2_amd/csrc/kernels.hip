@@ -79,10 +79,29 @@ constexpr uint32_t kFlagDelta = 4u;       // the ray was spawned by a delta lobe
 
 // DEFER: 0 = both ray queries inline (fused kernel); 1 = closest hit precomputed + shadow ray queued (split pipeline of
 // hierarchy scenes); 2 = closest hit inline, shadow ray queued (flat scenes: the any-hit loop then runs on dense batches)
-template <bool FLAT, bool REC = false, int DEFER = 0, bool GENERAL = false>
+// ENVGRAD (k_adjoint_env): besides the radiance, d(loss)/d(envmap texels) = delta * d(radiance)/d(texels) is scattered into `grad`
+// (h * w * 3) -- the radiance is linear in the texels at its two uses, the emission an escaped ray picks up and the emitter sample;
+// the sampling distribution built from their luminances is not differentiated (envmap.cpp:220-253 rebuilds it from plain floats)
+struct EnvGradCtx { f3 delta; float *grad; };
+MTS_DEV void env_grad_add(const DevEnvmap &e, float u, float v, f3 coeff, const EnvGradCtx &eg) {
+    u *= (float) (e.w - 1); v *= (float) (e.h - 1);                  // the bilinear footprint of envmap_lookup
+    const uint32_t px = min((uint32_t) u, (uint32_t) (e.w - 2)), py = min((uint32_t) v, (uint32_t) (e.h - 2));
+    const float w1x = u - (float) px, w1y = v - (float) py, w0x = 1.0f - w1x, w0y = 1.0f - w1y;
+    const float wt[4] = { (w0y * w0x) * e.scale, (w0y * w1x) * e.scale, (w1y * w0x) * e.scale, (w1y * w1x) * e.scale };
+    const uint32_t idx[4] = { py * (uint32_t) e.w + px, py * (uint32_t) e.w + px + 1u, (py + 1u) * (uint32_t) e.w + px, (py + 1u) * (uint32_t) e.w + px + 1u };
+    const f3 c = mk3(eg.delta.x * coeff.x, eg.delta.y * coeff.y, eg.delta.z * coeff.z);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float *g = eg.grad + 3u * (size_t) idx[i];
+        atomicAdd(g, c.x * wt[i]); atomicAdd(g + 1, c.y * wt[i]); atomicAdd(g + 2, c.z * wt[i]);
+    }
+}
+
+template <bool FLAT, bool REC = false, int DEFER = 0, bool GENERAL = false, bool ENVGRAD = false>
 MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s, Counters &c, VertexRec *rec = nullptr,
-                         Deferred *df = nullptr) {
+                         Deferred *df = nullptr, const EnvGradCtx *eg = nullptr) {
     static_assert(!(REC && GENERAL), "the adjoint replay handles diffuse BSDFs only");
+    static_assert(!ENVGRAD || (GENERAL && DEFER == 0), "the envmap gradient rides on the general fused step");
     const SceneView &sv = P.sv;
     if (REC) {
         rec->E = rec->Nc = rec->Tp = rec->rho = mk3(0.0f, 0.0f, 0.0f);
@@ -125,6 +144,11 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
         if (s.depth > 1u) ew = mis_weight(s.bs_pdf, (GENERAL && (s.flags & kFlagDelta)) ? 0.0f : pdf_environment(sv, e, s.d));
         const f3 le = environment_radiance(sv, e, s.d);
         s.res.x += (ew * s.thr.x) * le.x; s.res.y += (ew * s.thr.y) * le.y; s.res.z += (ew * s.thr.z) * le.z;
+        if (ENVGRAD && e.pad0 == kEmitterEnvmap) {
+            float u, v;
+            env_dir_to_uv(mat3_apply(sv.envmap->to_local, s.d), u, v);
+            env_grad_add(*sv.envmap, u, v, mk3(ew * s.thr.x, ew * s.thr.y, ew * s.thr.z), *eg);
+        }
     }
     bool active = found;
 
@@ -162,6 +186,18 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
                 if (sv.n_emitters > 1u) spec = spec * r2;
                 em_geo = r1 * r2;
             }
+        } else if (ENVGRAD) {          // the wrapper below, keeping spec / radiance
+            float r1, r2;
+            sample_emitter_direction<FLAT, GENERAL>(geo, si.p, s2, ds, r1, r2);
+            spec = mk3(0.0f, 0.0f, 0.0f);
+            if (sv.n_emitters != 0u) {
+                const DevEmitter e = geo.emitter(ds.emitter);
+                f3 rad = mk3(e.r, e.g, e.b);
+                if (e.pad0 == kEmitterEnvmap) { rad = envmap_lookup(*sv.envmap, ds.uv.x, ds.uv.y); em_geo = sv.n_emitters > 1u ? r1 * r2 : r1; }
+                if (ds.delta) rad = mk3(rad.x * ds.falloff, rad.y * ds.falloff, rad.z * ds.falloff);
+                spec = mk3(rad.x * r1, rad.y * r1, rad.z * r1);
+                if (sv.n_emitters > 1u) spec = spec * r2;
+            }
         } else sample_emitter_direction<FLAT, GENERAL>(geo, si.p, s2, ds, spec);
         if (ds.pdf != 0.0f) {
             f3 wo = to_local(si.sh, ds.d);
@@ -180,7 +216,7 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
                     df->smint = kRayEpsilon * (1.0f + hmax_abs(si.p)); df->smaxt = ds.dist * (1.0f - kShadowEpsilon);
                     df->nee[0] = contrib.x; df->nee[1] = contrib.y; df->nee[2] = contrib.z; df->nee[3] = 0.0f;
                 }
-            } else if (contrib.x != 0.0f || contrib.y != 0.0f || contrib.z != 0.0f || (REC && em_geo != 0.0f)) {
+            } else if (contrib.x != 0.0f || contrib.y != 0.0f || contrib.z != 0.0f || ((REC || ENVGRAD) && em_geo != 0.0f)) {
                 Hit sh;
                 ++c.any;
 #if defined(MTS_ABLATE_SHADOW)   // diagnostic build only: wrong image, used to price the any-hit loop in situ
@@ -191,6 +227,9 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
 #endif
                 if (!occluded) {
                     s.res = s.res + contrib;
+                    if (ENVGRAD && em_geo != 0.0f)
+                        env_grad_add(*sv.envmap, ds.uv.x, ds.uv.y, mk3(((mis * s.thr.x) * bv.x) * em_geo, ((mis * s.thr.y) * bv.y) * em_geo,
+                                                                         ((mis * s.thr.z) * bv.z) * em_geo), *eg);
                     if (REC && si.wi.z > 0.0f && wo.z > 0.0f) {     // d(contrib)/d(rho) / T'_k
                         float k = mis * (kInvPi * wo.z);
                         rec->Nc = mk3(k * spec.x, k * spec.y, k * spec.z);
@@ -1488,6 +1527,37 @@ MTS_DEV float filter_weight(const FilterView &f, float x) {
 // Russian-roulette factor 1/q(T) (path.cpp:137-141), as Enoki's autodiff does.
 constexpr int kAdjointMaxDepth = 16;
 
+// dLoss/dRadiance of the camera sample at film position `pos`: the adjoint of ImageBlock::put (imageblock.cpp:117-169, block = the
+// crop window, no border) followed by Image = values / (weight + 1e-8) (autodiff.py:80-91)
+MTS_DEV f3 adjoint_delta(const AdjointParams &A, float2 pos) {
+    const RenderParams &P = A.rp;
+    const FilterView &f = A.filter;
+    f3 delta = mk3(0.0f, 0.0f, 0.0f);
+    const float px = pos.x - ((float) P.crop_x + 0.5f), py = pos.y - ((float) P.crop_y + 0.5f);
+    if (f.radius > 1.0f) {
+        const int lox = max((int) ceilf(px - f.radius), 0), loy = max((int) ceilf(py - f.radius), 0);
+        const int hix = min((int) floorf(px + f.radius), P.crop_w - 1), hiy = min((int) floorf(py + f.radius), P.crop_h - 1);
+        const float bx = (float) (uint32_t) lox - px, by = (float) (uint32_t) loy - py;
+        for (int yr = 0; yr < f.taps && loy + yr <= hiy; ++yr) {
+            const float wy = filter_weight(f, by + (float) yr);
+            for (int xr = 0; xr < f.taps && lox + xr <= hix; ++xr) {
+                const float w = wy * filter_weight(f, bx + (float) xr);
+                const size_t pix = (size_t) (loy + yr) * P.crop_w + (size_t) (lox + xr);
+                const float iw = w / (A.film[5 * pix + 4] + 1e-8f);
+                delta.x += iw * A.dimage[3 * pix]; delta.y += iw * A.dimage[3 * pix + 1]; delta.z += iw * A.dimage[3 * pix + 2];
+            }
+        }
+    } else {
+        const int lox = (int) ceilf(px - 0.5f), loy = (int) ceilf(py - 0.5f);
+        if (lox >= 0 && loy >= 0 && lox < P.crop_w && loy < P.crop_h) {
+            const size_t pix = (size_t) loy * P.crop_w + (size_t) lox;
+            const float iw = 1.0f / (A.film[5 * pix + 4] + 1e-8f);
+            delta = mk3(iw * A.dimage[3 * pix], iw * A.dimage[3 * pix + 1], iw * A.dimage[3 * pix + 2]);
+        }
+    }
+    return delta;
+}
+
 template <bool FLAT>
 __global__ __launch_bounds__(kBlock) void k_adjoint(const AdjointParams A) {
     extern __shared__ float4 smem[];
@@ -1497,37 +1567,11 @@ __global__ __launch_bounds__(kBlock) void k_adjoint(const AdjointParams A) {
     __shared__ float s_grad_em[3 * 32];                    // ... and for the radiance of area lights
     for (uint32_t i = threadIdx.x; i < 3u * 32u; i += kBlock) s_grad[i] = s_grad_em[i] = 0.0f;
     __syncthreads();
-    const FilterView &f = A.filter;
     const uint32_t spp = (uint32_t) P.spp;
     for (uint64_t k = (uint64_t) blockIdx.x * kBlock + threadIdx.x; k < A.n_samples; k += (uint64_t) gridDim.x * kBlock) {
         PathState s; float2 pos;
         generate_path(P, k, (uint32_t) (k / spp), (uint32_t) (k % spp), s, &pos);
-        // ---- delta: adjoint of ImageBlock::put (imageblock.cpp:117-169, block = the crop window, no border)
-        f3 delta = mk3(0.0f, 0.0f, 0.0f);
-        {
-            const float px = pos.x - ((float) P.crop_x + 0.5f), py = pos.y - ((float) P.crop_y + 0.5f);
-            if (f.radius > 1.0f) {
-                const int lox = max((int) ceilf(px - f.radius), 0), loy = max((int) ceilf(py - f.radius), 0);
-                const int hix = min((int) floorf(px + f.radius), P.crop_w - 1), hiy = min((int) floorf(py + f.radius), P.crop_h - 1);
-                const float bx = (float) (uint32_t) lox - px, by = (float) (uint32_t) loy - py;
-                for (int yr = 0; yr < f.taps && loy + yr <= hiy; ++yr) {
-                    const float wy = filter_weight(f, by + (float) yr);
-                    for (int xr = 0; xr < f.taps && lox + xr <= hix; ++xr) {
-                        const float w = wy * filter_weight(f, bx + (float) xr);
-                        const size_t pix = (size_t) (loy + yr) * P.crop_w + (size_t) (lox + xr);
-                        const float iw = w / (A.film[5 * pix + 4] + 1e-8f);
-                        delta.x += iw * A.dimage[3 * pix]; delta.y += iw * A.dimage[3 * pix + 1]; delta.z += iw * A.dimage[3 * pix + 2];
-                    }
-                }
-            } else {
-                const int lox = (int) ceilf(px - 0.5f), loy = (int) ceilf(py - 0.5f);
-                if (lox >= 0 && loy >= 0 && lox < P.crop_w && loy < P.crop_h) {
-                    const size_t pix = (size_t) loy * P.crop_w + (size_t) lox;
-                    const float iw = 1.0f / (A.film[5 * pix + 4] + 1e-8f);
-                    delta = mk3(iw * A.dimage[3 * pix], iw * A.dimage[3 * pix + 1], iw * A.dimage[3 * pix + 2]);
-                }
-            }
-        }
+        const f3 delta = adjoint_delta(A, pos);
         // ---- replay the path, remembering its vertices
         VertexRec rec[kAdjointMaxDepth];
         int n = 0;
@@ -1591,6 +1635,33 @@ hipError_t launch_adjoint(const AdjointParams &a, hipStream_t s) {
     if (blocks > 2048) blocks = 2048;
     if (a.rp.sv.flat) hipLaunchKernelGGL(k_adjoint<true>, dim3((uint32_t) blocks), dim3(kBlock), bounce_lds_bytes(a.rp.sv), s, a);
     else hipLaunchKernelGGL(k_adjoint<false>, dim3((uint32_t) blocks), dim3(kBlock), bounce_lds_bytes(a.rp.sv), s, a);
+    return hipGetLastError();
+}
+
+// Derivative w.r.t. the texels of the `envmap` emitter ('data', envmap.cpp:214-218; docs/examples/10_inverse_rendering/invert_bunny.py):
+// one thread replays one camera sample with the PCG32 stream of the primal pass through the general fused step -- any BSDF, any depth
+// -- and scatters delta * d(radiance)/d(texel) at every use of the map (bounce_step, ENVGRAD).
+template <bool FLAT>
+__global__ __launch_bounds__(kBlock) void k_adjoint_env(const AdjointParams A) {
+    extern __shared__ float4 smem[];
+    const RenderParams &P = A.rp;
+    const LdsView lds = lds_stage<FLAT>(P.sv, smem);
+    const uint32_t spp = (uint32_t) P.spp;
+    for (uint64_t k = (uint64_t) blockIdx.x * kBlock + threadIdx.x; k < A.n_samples; k += (uint64_t) gridDim.x * kBlock) {
+        PathState s; float2 pos;
+        generate_path(P, k, (uint32_t) (k / spp), (uint32_t) (k % spp), s, &pos);
+        const EnvGradCtx eg = { adjoint_delta(A, pos), A.grad_env };
+        Counters c = { 0u, 0u, 0u, 0u };
+        while (bounce_step<FLAT, false, 0, true, true>(P, lds, s, c, nullptr, nullptr, &eg)) { }
+    }
+}
+
+hipError_t launch_adjoint_env(const AdjointParams &a, hipStream_t s) {
+    if (a.n_samples == 0) return hipSuccess;
+    uint64_t blocks = (a.n_samples + kBlock - 1) / kBlock;
+    if (blocks > 2048) blocks = 2048;
+    if (a.rp.sv.flat) hipLaunchKernelGGL(k_adjoint_env<true>, dim3((uint32_t) blocks), dim3(kBlock), bounce_lds_bytes(a.rp.sv), s, a);
+    else hipLaunchKernelGGL(k_adjoint_env<false>, dim3((uint32_t) blocks), dim3(kBlock), bounce_lds_bytes(a.rp.sv), s, a);
     return hipGetLastError();
 }
 

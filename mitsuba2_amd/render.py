@@ -595,6 +595,14 @@ class Scene:
             L.check(L.lib().mtsamd_scene_update_texture(self._handle, int(texture), a.ctypes.data_as(C.c_void_p), _stream()))
             torch.cuda.current_stream().synchronize()
 
+    def update_envmap(self, data, rebuild_distribution=True):
+        """parameters_changed() for the envmap emitter's `data` (envmap.cpp:220-253); data: (H, W, 3) linear RGB tensor or array.
+        ``rebuild_distribution=False`` keeps the importance-sampling hierarchy of the previous texels."""
+        if isinstance(data, torch.Tensor):
+            data = data.detach().cpu().numpy()
+        a = _f32(data)
+        L.check(L.lib().mtsamd_scene_update_envmap(self._handle, a.ctypes.data_as(L.f32p), 1 if rebuild_distribution else 0))
+
     def set_emitter_radiance(self, index, rgb):
         L.check(L.lib().mtsamd_scene_set_emitter_radiance(self._handle, int(index), (C.c_float * 3)(*[float(x) for x in rgb])))
 

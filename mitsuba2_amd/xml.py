@@ -647,6 +647,8 @@ def _instantiate(ctx, root, base_dir):
                     raise XMLError('"%s": file does not exist!' % path)
                 entry = dict(type="envmap", data=bitmap.read_rgb(path), scale=it.get("scale", 1.0, "float"),
                              to_world=it.get("to_world", np.eye(4, dtype=F32), "transform"))
+                if it.id is not None:
+                    entry["id"] = it.id                  # 'my_envmap.data' of mitsuba.python.util.traverse
                 it.check_unqueried()
                 desc.scene_dict["emitters"].append(entry)
             elif it.type in ("point", "spot", "directional"):       # point.cpp:52-65, spot.cpp:68-91, directional.cpp:43-63
