@@ -17,3 +17,10 @@ if [ "$2" = "pmc" ]; then
   done
   echo collected $OUT
 fi
+# the mesh line of bench.py itself (spectral, 1920x1080@1024 spp): kernel-trace summary whose k_trace<false,false> average must agree with the
+# line's k_trace_closest_avg_launch_us -> profiles/<tag>_mesh_bench_kernel_stats.csv, profiles/<tag>_mesh_bench.json
+if [ "$2" = "bench" ] || [ "$3" = "bench" ]; then
+  mkdir -p $OUT/bench
+  timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -- python3 bench.py --config mesh --no-cpu-baseline --no-parity --steps 1 --warmup 1 > $OUT/bench.log 2>&1 || exit 1
+  echo collected $OUT/bench
+fi
