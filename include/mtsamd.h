@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MTSAMD_ABI_VERSION 4
+#define MTSAMD_ABI_VERSION 5
 
 typedef enum {
     MTSAMD_OK = 0,
@@ -71,7 +71,12 @@ typedef struct {
 typedef enum { MTSAMD_BSDF_DIFFUSE = 0, MTSAMD_BSDF_CONDUCTOR = 1, MTSAMD_BSDF_ROUGHCONDUCTOR = 2, MTSAMD_BSDF_DIELECTRIC = 3,
                MTSAMD_BSDF_PLASTIC = 4, MTSAMD_BSDF_ROUGHPLASTIC = 5,
                MTSAMD_BSDF_ROUGHDIELECTRIC = 6,
-               MTSAMD_BSDF_THINDIELECTRIC = 7 /* src/bsdfs/thindielectric.cpp: delta reflection + null transmission of a thin slab */ } mtsamd_bsdf_type;
+               MTSAMD_BSDF_THINDIELECTRIC = 7 /* src/bsdfs/thindielectric.cpp: delta reflection + null transmission of a thin slab */,
+               /* src/bsdfs/blendbsdf.cpp (weight * nested[1] + (1 - weight) * nested[0]) and src/bsdfs/mask.cpp (opacity * nested[0] +
+                * a null lobe): `nested` index plain records of the same table whose parameters are constants; the weight / opacity
+                * is reflectance[0], or Texture::eval_1 of `texture` (luminance of a bitmap texel, bitmap.cpp:215-231; first colour
+                * channel of a checkerboard cell).  `twosided` wraps a whole blend (mask transmits: twosided.cpp:78-80 refuses it). */
+               MTSAMD_BSDF_BLEND = 8, MTSAMD_BSDF_MASK = 9 } mtsamd_bsdf_type;
 typedef struct {
     int32_t type;              /* mtsamd_bsdf_type */
     float reflectance[3];      /* diffuse.reflectance / plastic.diffuse_reflectance: constant `srgb` value (src/spectra/srgb.cpp:27-52) */
@@ -88,6 +93,7 @@ typedef struct {
     int32_t uniform_mask;      /* spectral variant: bit 0 / 1 / 2 = reflectance / specular_reflectance / specular_transmittance is a
                                   constant (`uniform` spectrum, xml.cpp:1069-1083) rather than an RGB colour (`srgb`, upsampled);
                                   conductors need the same eta and k in all three channels (uniform) */
+    int32_t nested[2];         /* MTSAMD_BSDF_BLEND: bsdf_0, bsdf_1; MTSAMD_BSDF_MASK: nested_bsdf, -1; otherwise ignored (ABI 5) */
 } mtsamd_bsdf_desc;
 
 /* area: src/emitters/area.cpp (attached to a mesh); constant: src/emitters/constant.cpp and envmap: src/emitters/envmap.cpp

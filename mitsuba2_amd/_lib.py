@@ -26,7 +26,8 @@ class BsdfDesc(C.Structure):
     _fields_ = [("type", C.c_int32), ("reflectance", C.c_float * 3), ("texture", C.c_int32), ("twosided", C.c_int32),
                 ("specular_reflectance", C.c_float * 3), ("specular_transmittance", C.c_float * 3), ("eta", C.c_float * 3),
                 ("k", C.c_float * 3), ("int_ior", C.c_float), ("ext_ior", C.c_float), ("alpha_u", C.c_float), ("alpha_v", C.c_float),
-                ("distribution", C.c_int32), ("sample_visible", C.c_int32), ("nonlinear", C.c_int32), ("uniform_mask", C.c_int32)]
+                ("distribution", C.c_int32), ("sample_visible", C.c_int32), ("nonlinear", C.c_int32), ("uniform_mask", C.c_int32),
+                ("nested", C.c_int32 * 2)]
 
 
 class EmitterDesc(C.Structure):
@@ -115,7 +116,7 @@ def lib():
             fn = getattr(handle, name)      # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if handle.mtsamd_abi_version() != 4:
+        if handle.mtsamd_abi_version() != 5:
             raise RuntimeError("libmtsamd.so ABI version mismatch")
         _lib = handle
     return _lib

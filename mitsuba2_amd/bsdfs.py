@@ -6,7 +6,8 @@ takes (``mtsamd_bsdf_desc``; also `roughplastic`, ``roughplastic.cpp:146-178``, 
 """
 import numpy as np
 
-DIFFUSE, CONDUCTOR, ROUGHCONDUCTOR, DIELECTRIC, PLASTIC, ROUGHPLASTIC, ROUGHDIELECTRIC, THINDIELECTRIC = range(8)
+DIFFUSE, CONDUCTOR, ROUGHCONDUCTOR, DIELECTRIC, PLASTIC, ROUGHPLASTIC, ROUGHDIELECTRIC, THINDIELECTRIC, BLEND, MASK = range(10)
+NESTING = {"blendbsdf": BLEND, "mask": MASK}      # src/bsdfs/blendbsdf.cpp, src/bsdfs/mask.cpp: over plain child BSDFs
 TYPE_IDS = {"diffuse": DIFFUSE, "conductor": CONDUCTOR, "roughconductor": ROUGHCONDUCTOR, "dielectric": DIELECTRIC, "plastic": PLASTIC,
             "roughplastic": ROUGHPLASTIC, "roughdielectric": ROUGHDIELECTRIC, "thindielectric": THINDIELECTRIC}
 SMOOTH = {DIFFUSE: True, CONDUCTOR: False, ROUGHCONDUCTOR: True, DIELECTRIC: False, PLASTIC: True, ROUGHPLASTIC: True, ROUGHDIELECTRIC: True,
@@ -53,6 +54,78 @@ def _rgb(v, default):
     return [float(x) for x in a]
 
 
+def is_transmissive(n):
+    """a normalised record has a transmission component (what TwoSidedBRDF refuses, twosided.cpp:78-80)"""
+    if n["type"] == MASK:
+        return True
+    if n["type"] == BLEND:
+        return any(is_transmissive(c) for c in n["children"])
+    return n["type"] in TRANSMISSIVE
+
+
+def is_smooth(n):
+    """BSDFFlags::Smooth of a normalised record (blend / mask: union of the nested flags)"""
+    if n["type"] in (BLEND, MASK):
+        return any(is_smooth(c) for c in n["children"])
+    return SMOOTH[n["type"]]
+
+
+def _normalize_nesting(b, t):
+    """blendbsdf.cpp:57-79 / mask.cpp:67-91: child BSDFs in the order they are given, `weight` (required) / `opacity` (default 0.5) as
+    a constant or a texture.  This backend nests one level: the children are plain BSDFs with constant parameters."""
+    pname = "weight" if t == "blendbsdf" else "opacity"
+    bsdf_types = set(TYPE_IDS) | set(NESTING) | {"twosided"}
+    children = [v for k, v in b.items() if k not in ("type", "id", pname) and isinstance(v, dict) and v.get("type", "diffuse") in bsdf_types]
+    extra = [k for k, v in b.items() if k not in ("type", "id", pname) and not (isinstance(v, dict) and v.get("type", "diffuse") in bsdf_types)]
+    if t == "blendbsdf":
+        if len(children) > 2:
+            raise RuntimeError("BlendBSDF: Cannot specify more than two child BSDFs")
+        if pname not in b:
+            raise RuntimeError('Property "weight" has not been specified!')
+        if len(children) != 2:
+            raise RuntimeError("BlendBSDF: Two child BSDFs must be specified!")
+    else:
+        if len(children) > 1:
+            raise RuntimeError("Cannot specify more than one child BSDF")
+        if not children:
+            raise RuntimeError("Child BSDF not specified")
+    if extra:
+        raise RuntimeError('Error while loading: unreferenced property "%s" in bsdf plugin of type "%s"' % (extra[0], t))
+    kids = [normalize(c) for c in children]
+    for k in kids:
+        if k["type"] in (BLEND, MASK):
+            raise RuntimeError("%s: nested blendbsdf / mask children are not supported by this backend (one level of nesting)" % t)
+        if isinstance(k["reflectance"], dict):
+            raise RuntimeError("%s: textured parameters of a child BSDF are not supported by this backend (constants only)" % t)
+    w = b.get(pname, 0.5)
+    if isinstance(w, dict):
+        if w.get("type") not in ("bitmap", "checkerboard"):
+            raise RuntimeError("Texture plugin '%s' is not supported by this backend (bitmap, checkerboard)" % w.get("type"))
+        weight = w
+    else:
+        a = np.asarray(w, dtype=np.float32).reshape(-1)
+        if a.size != 1:
+            raise RuntimeError("%s: '%s' is a scalar (Texture::eval_1): a constant or a texture" % (t, pname))
+        weight = [float(a[0])] * 3
+    out = dict(type=NESTING[t], twosided=False, reflectance=weight, specular_reflectance=[1.0] * 3, specular_transmittance=[1.0] * 3,
+               eta=[0.0] * 3, k=[1.0] * 3, int_ior=1.0, ext_ior=1.0, alpha_u=0.1, alpha_v=0.1, distribution=0, sample_visible=True,
+               nonlinear=False, uniform_mask=1, children=kids)
+    if "id" in b:
+        out["id"] = b["id"]
+    return out
+
+
+def flatten(records):
+    """Top-level records followed by the children of blend / mask records; every nesting record gets `nested` = the table indices of
+    its children (mtsamd_bsdf_desc::nested).  Shapes keep referring to the top-level indices."""
+    flat = list(records)
+    for r in records:
+        if r["type"] in (BLEND, MASK):
+            r["nested"] = [len(flat) + i for i in range(len(r["children"]))] + [-1] * (2 - len(r["children"]))
+            flat.extend(r["children"])
+    return flat
+
+
 def normalize(b):
     """Plugin dictionary -> flat record: dict(type, twosided, reflectance (rgb list or bitmap dict), specular_reflectance,
     specular_transmittance, eta, k, int_ior, ext_ior, alpha_u, alpha_v, distribution, sample_visible, nonlinear)."""
@@ -67,14 +140,16 @@ def normalize(b):
         if len(nested) == 2 and nested[0] != nested[1]:
             raise RuntimeError("twosided: two different nested BSDFs are not supported by this backend")
         out = normalize(nested[0])
-        if out["type"] in TRANSMISSIVE:
+        if is_transmissive(out):
             raise RuntimeError("Only materials without a transmission component can be nested!")
         out["twosided"] = True
         if "id" in b:
             out["id"] = b["id"]
         return out
+    if t in NESTING:
+        return _normalize_nesting(b, t)
     if t not in TYPE_IDS:
-        raise RuntimeError("BSDF plugin '%s' is not supported by this backend (diffuse, conductor, roughconductor, dielectric, roughdielectric, thindielectric, plastic, roughplastic, twosided)" % t)
+        raise RuntimeError("BSDF plugin '%s' is not supported by this backend (diffuse, conductor, roughconductor, dielectric, roughdielectric, thindielectric, plastic, roughplastic, twosided, blendbsdf, mask)" % t)
     tid = TYPE_IDS[t]
     out = dict(type=tid, twosided=twosided, reflectance=[0.5, 0.5, 0.5], specular_reflectance=[1.0] * 3, specular_transmittance=[1.0] * 3,
                eta=[0.0] * 3, k=[1.0] * 3, int_ior=1.0, ext_ior=1.0, alpha_u=0.1, alpha_v=0.1, distribution=0, sample_visible=True,

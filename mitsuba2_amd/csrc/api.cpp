@@ -422,11 +422,12 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     }
     for (uint32_t b = 0; b < desc->bsdf_count; ++b) {
         const mtsamd_bsdf_desc &bd = desc->bsdfs[b];
-        if (bd.type < MTSAMD_BSDF_DIFFUSE || bd.type > MTSAMD_BSDF_THINDIELECTRIC) return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u: unknown BSDF type %d", b, bd.type);
+        if (bd.type < MTSAMD_BSDF_DIFFUSE || bd.type > MTSAMD_BSDF_MASK) return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u: unknown BSDF type %d", b, bd.type);
         if (desc->spectral && (bd.type == MTSAMD_BSDF_CONDUCTOR || bd.type == MTSAMD_BSDF_ROUGHCONDUCTOR) &&
             (bd.eta[0] != bd.eta[1] || bd.eta[0] != bd.eta[2] || bd.k[0] != bd.k[1] || bd.k[0] != bd.k[2]))
             return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u: the spectral variant needs uniform (constant) eta and k spectra", b);
-        if (bd.texture >= 0 && bd.type != MTSAMD_BSDF_DIFFUSE && bd.type != MTSAMD_BSDF_PLASTIC && bd.type != MTSAMD_BSDF_ROUGHPLASTIC)
+        if (bd.texture >= 0 && bd.type != MTSAMD_BSDF_DIFFUSE && bd.type != MTSAMD_BSDF_PLASTIC && bd.type != MTSAMD_BSDF_ROUGHPLASTIC &&
+            bd.type != MTSAMD_BSDF_BLEND && bd.type != MTSAMD_BSDF_MASK)
             return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u: textures are implemented for diffuse.reflectance and (rough)plastic.diffuse_reflectance only", b);
         if (bd.type == MTSAMD_BSDF_ROUGHPLASTIC && (bd.int_ior == bd.ext_ior || bd.alpha_u != bd.alpha_v))
             return fail(MTSAMD_ERR_INVALID, bd.int_ior == bd.ext_ior ? "The interior and exterior indices of refraction must be positive and differ!"
@@ -559,6 +560,30 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         d.type = desc->bsdfs[b].type; d.texture = desc->bsdfs[b].texture < 0 ? -1 : desc->bsdfs[b].texture;
         fill_bsdf_model(desc->bsdfs[b], d);
         if (d.type != kBsdfDiffuse || (d.flags & kBsdfTwoSided)) s->general_bsdfs = true;
+        if (d.type == kBsdfBlend || d.type == kBsdfMask) {
+            // blendbsdf.cpp:57-79 / mask.cpp:67-91 over plain records of this table (one level of nesting)
+            const mtsamd_bsdf_desc &bd = desc->bsdfs[b];
+            const int n_child = d.type == kBsdfBlend ? 2 : 1;
+            bool smooth = false;
+            for (int k = 0; k < n_child; ++k) {
+                const int32_t c = bd.nested[k];
+                if (c < 0 || (uint32_t) c >= desc->bsdf_count || desc->bsdfs[c].type < MTSAMD_BSDF_DIFFUSE || desc->bsdfs[c].type > MTSAMD_BSDF_THINDIELECTRIC ||
+                    desc->bsdfs[c].texture >= 0) {
+                    delete s;
+                    return fail(MTSAMD_ERR_INVALID, "bsdf %u: nested[%d] must index a plain BSDF record with constant parameters", b, k);
+                }
+                const int ct = desc->bsdfs[c].type;
+                smooth = smooth || ct == kBsdfDiffuse || ct == kBsdfRoughConductor || ct == kBsdfPlastic || ct == kBsdfRoughPlastic || ct == kBsdfRoughDielectric;
+            }
+            if (d.type == kBsdfMask && bd.twosided) { delete s; return fail(MTSAMD_ERR_INVALID, "Only materials without a transmission component can be nested!"); }
+            if (desc->spectral && d.texture >= 0) {
+                delete s;
+                return fail(MTSAMD_ERR_UNSUPPORTED, "eval_1(): a bitmap / checkerboard weight is converted into spectra in the spectral variant (bitmap.cpp:218-222); use a constant");
+            }
+            d.nested0 = (uint32_t) bd.nested[0]; d.nested1 = (uint32_t) (n_child == 2 ? bd.nested[1] : bd.nested[0]);
+            d.flags = (bd.twosided ? kBsdfTwoSided : 0u) | kBsdfUniformRefl | (smooth ? kBsdfNestSmooth : 0u) |
+                      ((d.texture >= 0 && desc->textures[d.texture].kind == 0) ? kBsdfWeightLum : 0u);
+        }
         if (desc->spectral) {
             // every colour-valued parameter is a `uniform` constant or an `srgb` texture: range check + coefficient fetch
             // (srgb.cpp:31-41); Texture::mean() of either kind feeds the plastic lobe-selection weight (plastic.cpp:170-175)
@@ -567,6 +592,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
             float *coeffs[3] = { &d.c0, &d.sc0, &d.tc0 };
             float means[3] = { 0.0f, 0.0f, 0.0f };
             for (int p = 0; p < 3; ++p) {
+                if (d.type == kBsdfBlend || d.type == kBsdfMask) break;   // the weight is a scalar; the children are records of their own
                 if (p == 0 && d.texture >= 0) continue;               // textured: coefficients per texel, mean from the texture (below)
                 if (bd.uniform_mask & (1 << p)) { means[p] = vals[p][0]; continue; }
                 const float *c = vals[p];

@@ -15,8 +15,12 @@
 namespace mtsamd {
 
 constexpr int kBsdfDiffuse = 0, kBsdfConductor = 1, kBsdfRoughConductor = 2, kBsdfDielectric = 3, kBsdfPlastic = 4, kBsdfRoughPlastic = 5,
-              kBsdfRoughDielectric = 6, kBsdfThinDielectric = 7;
+              kBsdfRoughDielectric = 6, kBsdfThinDielectric = 7,
+              kBsdfBlend = 8, kBsdfMask = 9;      // blendbsdf.cpp / mask.cpp over plain records of the same table (DevBsdf::nested0/1)
 constexpr uint32_t kBsdfTwoSided = 1u, kBsdfGGX = 2u, kBsdfSampleVisible = 4u, kBsdfNonlinear = 8u;
+// blend / mask: some child has a smooth component (BSDFFlags::Smooth of the union of the nested flags); the weight / opacity texture
+// is a bitmap, whose eval_1 is the luminance of the texel (bitmap.cpp:215-231)
+constexpr uint32_t kBsdfNestSmooth = 128u, kBsdfWeightLum = 256u;
 // spectral variant: the parameter is a `uniform` spectrum (its constant sits in the first colour channel) instead of `srgb`
 constexpr uint32_t kBsdfUniformRefl = 16u, kBsdfUniformSpec = 32u, kBsdfUniformTrans = 64u;
 constexpr float kInvSqrtPi = 0.56418958354775628695f, kEps = kEpsilon;
@@ -201,7 +205,7 @@ struct DevBsdf {
     float kr, kg, kb, alpha_v;
     float sc0, sc1, sc2, pad0;               // spectral variant: srgb_model coefficients of specular_reflectance
     float tc0, tc1, tc2, pad1;               //                   ... of specular_transmittance
-    const float *table; uint64_t pad2;       // roughplastic: external transmittance table (device memory)
+    const float *table; uint32_t nested0, nested1;      // roughplastic: external transmittance table (device memory); blend / mask: child records
 };
 constexpr int kRoughTableRes = 64;           // MTS_ROUGH_TRANSMITTANCE_RES
 
@@ -216,7 +220,7 @@ struct BsdfSample { f3 wo; float pdf, eta; bool delta; };
 
 MTS_DEV bool bsdf_is_smooth(const DevBsdf &b) {          // BSDFFlags::Smooth: any diffuse / glossy component
     return b.type == kBsdfDiffuse || b.type == kBsdfRoughConductor || b.type == kBsdfPlastic || b.type == kBsdfRoughPlastic ||
-           b.type == kBsdfRoughDielectric;
+           b.type == kBsdfRoughDielectric || (b.flags & kBsdfNestSmooth) != 0u;
 }
 
 // Per-channel inputs of a BSDF evaluation: N = 3 colour channels (RGB variant) or N = 4 wavelengths (spectral variant).
@@ -543,7 +547,106 @@ MTS_DEV float rough_reflectance(const Mdf &d, f3 wi, float eta, int res, const f
     return accum * 0.25f;
 }
 
+// ---------------------------------------------------------------------------------------------
+// blendbsdf (blendbsdf.cpp:82-179) and mask (mask.cpp:92-172) over plain child records, and the plain BSDFs themselves, behind one
+// entry point: the record that is actually sampled / evaluated is resolved first (a child, or `b` itself), so the model code above
+// is instantiated once.  `table(i)` returns record i of the scene's BSDF table, `chan_of(rec)` the per-channel inputs of a child
+// (its own constant parameters); `c` are the inputs of `b` -- for a blend / mask c.refl[0..2] carries what Texture::eval_1 of the
+// weight / opacity reads (the constant, or the texture lookup).
+template <int N>
+MTS_DEV float nest_weight(const DevBsdf &b, const BsdfChannels<N> &c) {
+    float w = c.refl[0];
+    if (b.flags & kBsdfWeightLum) w = fmaf(0.072169f, c.refl[2], fmaf(0.715160f, c.refl[1], 0.212671f * c.refl[0]));      // luminance (spectrum.h:239-241)
+    return fminf(fmaxf(w, 0.0f), 1.0f);
+}
+template <int N, typename Table, typename ChanOf>
+MTS_DEV bool surface_bsdf_sample(const DevBsdf &b, const BsdfChannels<N> &c, const Table &table, const ChanOf &chan_of, f3 wi, float sample1,
+                                 f2 sample2, BsdfSample &bs, float (&weight)[N]) {
+    if (b.type < kBsdfBlend) return bsdf_sample_n<N>(b, c, wi, sample1, sample2, bs, weight);
+    bs.wo = mk3(0.0f, 0.0f, 0.0f); bs.pdf = 0.0f; bs.eta = 0.0f; bs.delta = false;
+#pragma unroll
+    for (int i = 0; i < N; ++i) weight[i] = 0.0f;
+    const bool two = (b.flags & kBsdfTwoSided) != 0u;       // twosided.cpp:94-123 around the whole nest
+    if (two && wi.z == 0.0f) return false;
+    const bool flip = two && wi.z < 0.0f;
+    if (flip) wi.z = -wi.z;
+    const float w = nest_weight<N>(b, c);
+    uint32_t child = b.nested0; float s1 = sample1; bool nested = true;
+    if (b.type == kBsdfBlend) {
+        if (sample1 > w) s1 = (sample1 - w) / (1.0f - w);
+        else if (sample1 <= w) { child = b.nested1; s1 = sample1 / w; }
+        else nested = false;                                 // NaN sample: neither mask of blendbsdf.cpp:108-109
+    } else {
+        nested = sample1 < w;
+        s1 = sample1 / w;
+    }
+    bool ok = false;
+    if (nested) {
+        const DevBsdf rec = table(child);
+        ok = bsdf_sample_n<N>(rec, chan_of(rec), wi, s1, sample2, bs, weight);
+    } else if (b.type == kBsdfMask) {                        // the null lobe: straight through (mask.cpp:116-121); Null is part of Delta
+        bs.wo = mk3(-wi.x, -wi.y, -wi.z); bs.eta = 1.0f; bs.pdf = 1.0f - w; bs.delta = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) weight[i] = 1.0f;
+        ok = true;
+    }
+    if (flip) bs.wo.z = -bs.wo.z;
+    return ok;
+}
+template <int N, typename Table, typename ChanOf>
+MTS_DEV void surface_bsdf_eval_pdf(const DevBsdf &b, const BsdfChannels<N> &c, const Table &table, const ChanOf &chan_of, f3 wi, f3 wo,
+                                   float (&value)[N], float &pdf) {
+    if (b.type < kBsdfBlend) { bsdf_eval_pdf_n<N>(b, c, wi, wo, value, pdf); return; }
+#pragma unroll
+    for (int i = 0; i < N; ++i) value[i] = 0.0f;
+    pdf = 0.0f;
+    if (b.flags & kBsdfTwoSided) {
+        if (wi.z == 0.0f) return;
+        if (wi.z < 0.0f) { wi.z = -wi.z; wo.z = -wo.z; }
+    }
+    const float w = nest_weight<N>(b, c);
+    const bool blend = b.type == kBsdfBlend;
+    float v0[N], p0 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) v0[i] = 0.0f;
+#pragma unroll 1
+    for (uint32_t k = 0; k < (blend ? 2u : 1u); ++k) {      // one instance of the model code for both children
+        const DevBsdf rec = table(k == 0u ? b.nested0 : b.nested1);
+        float v[N], p;
+        bsdf_eval_pdf_n<N>(rec, chan_of(rec), wi, wo, v, p);
+        if (k == 0u) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) v0[i] = v[i];
+            p0 = p;
+        } else {                                             // eval0 * (1 - weight) + eval1 * weight (blendbsdf.cpp:141-142,157-158)
+#pragma unroll
+            for (int i = 0; i < N; ++i) value[i] = fmaf(v[i], w, v0[i] * (1.0f - w));
+            pdf = fmaf(p, w, p0 * (1.0f - w));
+        }
+    }
+    if (!blend) {                                            // mask.cpp:133-159
+#pragma unroll
+        for (int i = 0; i < N; ++i) value[i] = v0[i] * w;
+        pdf = p0 * w;
+    }
+}
+
 // RGB variant
+template <typename Table>
+MTS_DEV bool surface_bsdf_sample(const DevBsdf &b, f3 refl, const Table &table, f3 wi, float sample1, f2 sample2, BsdfSample &bs, f3 &weight) {
+    float w[3];
+    auto chan_of = [](const DevBsdf &rec) { return rgb_channels(rec, mk3(rec.r, rec.g, rec.b)); };
+    const bool ok = surface_bsdf_sample<3>(b, rgb_channels(b, refl), table, chan_of, wi, sample1, sample2, bs, w);
+    weight = mk3(w[0], w[1], w[2]);
+    return ok;
+}
+template <typename Table>
+MTS_DEV void surface_bsdf_eval_pdf(const DevBsdf &b, f3 refl, const Table &table, f3 wi, f3 wo, f3 &value, float &pdf) {
+    float v[3];
+    auto chan_of = [](const DevBsdf &rec) { return rgb_channels(rec, mk3(rec.r, rec.g, rec.b)); };
+    surface_bsdf_eval_pdf<3>(b, rgb_channels(b, refl), table, chan_of, wi, wo, v, pdf);
+    value = mk3(v[0], v[1], v[2]);
+}
 MTS_DEV bool bsdf_sample(const DevBsdf &b, f3 refl, f3 wi, float sample1, f2 sample2, BsdfSample &bs, f3 &weight) {
     float w[3];
     const bool ok = bsdf_sample_n<3>(b, rgb_channels(b, refl), wi, sample1, sample2, bs, w);

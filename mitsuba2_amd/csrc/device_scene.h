@@ -32,8 +32,10 @@ constexpr uint32_t kNoPrim = 0xffffffffu;
 // BVH4 walk: an entry is (child reference, distance at which the ray enters the child's box): a popped subtree whose entry distance
 // lies beyond the closest hit found meanwhile is dropped without touching its node.
 typedef uint2 StackEntry;
+typedef uint64_t StackRaw;      // the same entry as one LDS word
 #else
 typedef uint32_t StackEntry;
+typedef uint32_t StackRaw;
 #endif
 
 // BVH2 node, 64 B: both child boxes + child references.
@@ -249,34 +251,73 @@ MTS_DEV void walk_begin(BvhWalk &w, const SceneView &sv, f3 o, f3 d, float mint,
 // ends (cur = kNoNode, found = true) at the first hit.
 // Traversal stack of one lane: the first `lds_depth` entries live in LDS ([depth][lane], conflict-free), deeper ones -- rare:
 // a walk seldom defers more than a dozen subtrees -- in a global spill area, so that the LDS footprint does not cap occupancy.
-struct WalkStack { StackEntry *lds; uint32_t stride, lds_depth; StackEntry *spill; uint32_t spill_stride; };
+struct WalkStack { StackEntry *lds; uint32_t shift, lds_depth; StackEntry *spill; uint32_t spill_stride; };      // shift: log2 of the row stride (threads per workgroup, a power of two)
+// The LDS part is addressed through an explicit LDS pointer (ds_read / ds_write of a whole entry; a pointer select between LDS and
+// the spill area compiles to flat accesses of half entries).  Row min(sp, lds_depth) is touched unconditionally: with a spill area
+// the row after the lds_depth real ones is a scratch row, so the deep (rare) case only adds the spill access behind a branch that
+// is almost never taken; lds_depth = 0xffffffff: the whole stack is in LDS.
+typedef __attribute__((address_space(3))) StackRaw LdsStackRaw;
+MTS_DEV LdsStackRaw *stack_row(const WalkStack &st, uint32_t sp) {
+    return reinterpret_cast<LdsStackRaw *>((uint32_t) reinterpret_cast<uintptr_t>(st.lds)) + (min(sp, st.lds_depth) << st.shift);
+}
+MTS_DEV uint32_t log2_stride(uint32_t stride) { return 31u - (uint32_t) __builtin_clz(stride); }
+#if MTS_BVH4
+MTS_DEV StackRaw stack_raw(StackEntry v) { return (uint64_t) v.x | ((uint64_t) v.y << 32); }
+MTS_DEV StackEntry stack_entry(StackRaw r) { return make_uint2((uint32_t) r, (uint32_t) (r >> 32)); }
+#else
+MTS_DEV StackRaw stack_raw(StackEntry v) { return v; }
+MTS_DEV StackEntry stack_entry(StackRaw r) { return r; }
+#endif
 MTS_DEV void stack_push(const WalkStack &st, uint32_t sp, StackEntry v) {
-    if (sp < st.lds_depth) st.lds[sp * st.stride] = v;
-    else st.spill[(size_t) (sp - st.lds_depth) * st.spill_stride] = v;
+    *stack_row(st, sp) = stack_raw(v);
+    if (sp >= st.lds_depth) st.spill[(size_t) (sp - st.lds_depth) * st.spill_stride] = v;
+}
+// Branch-free push: the entry is written above the top in any case and only counted when `take` (the next push overwrites it).
+MTS_DEV void stack_push_if(const WalkStack &st, uint32_t &sp, bool take, StackEntry v) {
+    *stack_row(st, sp) = stack_raw(v);
+    if (take && sp >= st.lds_depth) st.spill[(size_t) (sp - st.lds_depth) * st.spill_stride] = v;
+    sp += take ? 1u : 0u;
 }
 MTS_DEV StackEntry stack_pop(const WalkStack &st, uint32_t sp) {
-    return sp < st.lds_depth ? st.lds[sp * st.stride] : st.spill[(size_t) (sp - st.lds_depth) * st.spill_stride];
+    // volatile: keeps the LDS read a ds_read of the whole entry (otherwise it is merged with the spill read into flat loads)
+    StackEntry e = stack_entry(*const_cast<const volatile LdsStackRaw *>(stack_row(st, sp)));
+    if (sp >= st.lds_depth) e = st.spill[(size_t) (sp - st.lds_depth) * st.spill_stride];
+    return e;
 }
 
 #if MTS_BVH4
 // Triangle tests of the leaf a lane holds (all lanes of the wave together), then the next subtree from the stack.
+#ifndef MTS_LEAF_STEP
+#define MTS_LEAF_STEP 0
+#endif
 template <bool ANY>
-MTS_DEV void walk_leaf(BvhWalk &w, const SceneView &sv, uint32_t cur, uint32_t &tri_tests) {
-    const uint32_t start = cur & kLeafStartMask, count = (cur >> kLeafCountShift) & 0xfu;
-    for (uint32_t i = 0; i < count; ++i) {
-        const float4 *p = sv.tris + 3u * (start + i);
+MTS_DEV void walk_leaf(BvhWalk &w, const SceneView &sv, uint32_t &cur, uint32_t &tri_tests) {
+    const uint32_t start = cur & kLeafStartMask, total = (cur >> kLeafCountShift) & 0xfu;
+    auto test_one = [&](uint32_t slot) -> bool {
+        const float4 *p = sv.tris + 3u * slot;
         const float4 t0 = p[0], t1 = p[1], t2 = p[2];
         float u, v, t;
         ++tri_tests;
         if (tri_test(mk3(t0.x, t0.y, t0.z), mk3(t0.w, t1.x, t1.y), mk3(t1.z, t1.w, t2.x), w.o, w.d, w.mint, w.maxt, u, v, t)) {
-            if (ANY) { w.found = true; return; }
+            if (ANY) { w.found = true; return true; }
             const uint32_t prim = __float_as_uint(t2.y);
             if (!w.found || t < w.best || (t == w.best && prim > w.best_prim)) {
                 w.found = true; w.best = t; w.best_prim = prim;
                 w.hit.t = t; w.hit.prim = prim; w.hit.u = u; w.hit.v = v;
             }
         }
-    }
+        return false;
+    };
+#if MTS_LEAF_STEP == 1
+    // one triangle per leaf phase; the rest of the leaf stays in `cur` for the next round: the wave's leaf phase has no trip-count
+    // divergence and a lane with a long leaf does not hold the others
+    cur = total > 1u ? cur - (1u << kLeafCountShift) + 1u : kNoNode;
+    test_one(start);
+#else
+    cur = kNoNode;
+    for (uint32_t i = 0; i < total; ++i)
+        if (test_one(start + i)) return;
+#endif
 }
 
 // One round of the "while-while" traversal over the BVH4: the lane descends until it holds a leaf (or nothing), then the wave tests
@@ -335,16 +376,16 @@ MTS_DEV void walk_round(BvhWalk &w, const SceneView &sv, const WalkStack &st, ui
             ta = tlo; tb = thi; ra = rlo; rb = rhi;
         };
         cswap(t0, r0, t1, r1); cswap(t2, r2, t3, r3); cswap(t0, r0, t2, r2); cswap(t1, r1, t3, r3); cswap(t1, r1, t2, r2);
-        if (t3 < kInf) { stack_push(st, sp, make_uint2(r3, __float_as_uint(t3))); ++sp; }
-        if (t2 < kInf) { stack_push(st, sp, make_uint2(r2, __float_as_uint(t2))); ++sp; }
-        if (t1 < kInf) { stack_push(st, sp, make_uint2(r1, __float_as_uint(t1))); ++sp; }
+        stack_push_if(st, sp, t3 < kInf, make_uint2(r3, __float_as_uint(t3)));
+        stack_push_if(st, sp, t2 < kInf, make_uint2(r2, __float_as_uint(t2)));
+        stack_push_if(st, sp, t1 < kInf, make_uint2(r1, __float_as_uint(t1)));
         if (t0 < kInf) cur = r0;
         else pop_next();
     }
     if (cur & kLeafFlag) {
         walk_leaf<ANY>(w, sv, cur, tri_tests);
         if (ANY && w.found) { w.cur = kNoNode; w.sp = 0; return; }
-        pop_next();
+        if (cur == kNoNode) pop_next();
     }
     w.cur = cur; w.sp = sp;
 }
@@ -456,7 +497,7 @@ MTS_DEV bool traverse_bvh(const SceneView &sv, const LdsView &lds, f3 o, f3 d, f
                           Hit &hit, uint32_t &tri_tests) {
     BvhWalk w;
     walk_begin(w, sv, o, d, mint, maxt);
-    const WalkStack st = { reinterpret_cast<StackEntry *>(lds.stack) + threadIdx.x, lds.stride, lds.spill ? lds.stack_lds_depth : 0xffffffffu,
+    const WalkStack st = { reinterpret_cast<StackEntry *>(lds.stack) + threadIdx.x, log2_stride(lds.stride), lds.spill ? lds.stack_lds_depth : 0xffffffffu,
                            lds.spill, lds.spill_stride };      // k_bounce: whole stack in LDS; k_finish: short LDS part + spill
     while (w.cur != kNoNode) {
         if (w.far) walk_round<ANY, true>(w, sv, st, tri_tests);

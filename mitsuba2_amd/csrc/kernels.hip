@@ -202,7 +202,7 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
         if (ds.pdf != 0.0f) {
             f3 wo = to_local(si.sh, ds.d);
             f3 bv; float bp;
-            if (GENERAL) bsdf_eval_pdf(bsdf, refl, si.wi, wo, bv, bp);
+            if (GENERAL) surface_bsdf_eval_pdf(bsdf, refl, [&](uint32_t i) { return geo.bsdf(i); }, si.wi, wo, bv, bp);
             else diffuse_eval_pdf(refl, si.wi, wo, bv, bp);
             float mis = (GENERAL && ds.delta) ? 1.0f : mis_weight(ds.pdf, bp);      // path.cpp:170
             f3 contrib = mk3(((mis * s.thr.x) * bv.x) * spec.x, ((mis * s.thr.y) * bv.y) * spec.y,
@@ -246,7 +246,7 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
     f3 wo, weight; float pdf;
     if (GENERAL) {
         BsdfSample bs;
-        bsdf_sample(bsdf, refl, si.wi, s1, s2, bs, weight);
+        surface_bsdf_sample(bsdf, refl, [&](uint32_t i) { return geo.bsdf(i); }, si.wi, s1, s2, bs, weight);
         wo = bs.wo; pdf = bs.pdf;
         s.eta *= bs.eta;                                     // harmless for a failed sample: the path ends below
         s.flags = bs.delta ? (s.flags | kFlagDelta) : (s.flags & ~kFlagDelta);
@@ -581,6 +581,8 @@ MTS_DEV bool bounce_step_spectral(const RenderParams &P, const LdsView &lds, Pat
 #pragma unroll
         for (int k = 0; k < kWav; ++k) chan.refl[k] = refl.v[k];
     }
+    // blend / mask: per-wavelength inputs of a child record (its own constant parameters)
+    auto child_chan = [&](const DevBsdf &rec) { return spectral_channels(rec, s.wav); };
 
     if (!GENERAL || bsdf_is_smooth(bsdf)) {
         f2 s2; s2.x = pcg_next_f32(s.rng); s2.y = pcg_next_f32(s.rng);
@@ -592,7 +594,7 @@ MTS_DEV bool bounce_step_spectral(const RenderParams &P, const LdsView &lds, Pat
             bool front = si.wi.z > 0.0f && wo.z > 0.0f;
             float bp = front ? kInvPi * wo.z : 0.0f;
             float bvs[kWav];
-            if (GENERAL) bsdf_eval_pdf_n<kWav>(bsdf, chan, si.wi, wo, bvs, bp);
+            if (GENERAL) surface_bsdf_eval_pdf<kWav>(bsdf, chan, [&](uint32_t i) { return geo.bsdf(i); }, child_chan, si.wi, wo, bvs, bp);
             float mis = (GENERAL && ds.delta) ? 1.0f : mis_weight(ds.pdf, bp);
             Spec4 contrib; bool nz = false;
             const Spec4 le4 = emitter_spectrum(sv, e, s.wav, ds.uv);
@@ -632,7 +634,7 @@ MTS_DEV bool bounce_step_spectral(const RenderParams &P, const LdsView &lds, Pat
     bool nz = false;
     if (GENERAL) {
         BsdfSample bs; float w[kWav];
-        bsdf_sample_n<kWav>(bsdf, chan, si.wi, s1, s2, bs, w);
+        surface_bsdf_sample<kWav>(bsdf, chan, [&](uint32_t i) { return geo.bsdf(i); }, child_chan, si.wi, s1, s2, bs, w);
         wo = bs.wo; pdf = bs.pdf;
         s.eta *= bs.eta;
         s.flags = bs.delta ? (s.flags | kFlagDelta) : (s.flags & ~kFlagDelta);
@@ -791,7 +793,7 @@ __global__ __launch_bounds__(kBlock) void k_direct(const RenderParams P, uint64_
                     if (ds.pdf == 0.0f) continue;
                     const f3 wo = to_local(si.sh, ds.d);
                     f3 bv; float bp;
-                    if (GENERAL) bsdf_eval_pdf(bsdf, refl, si.wi, wo, bv, bp);
+                    if (GENERAL) surface_bsdf_eval_pdf(bsdf, refl, [&](uint32_t i) { return geo.bsdf(i); }, si.wi, wo, bv, bp);
                     else diffuse_eval_pdf(refl, si.wi, wo, bv, bp);
                     const float mis = (GENERAL && ds.delta) ? 1.0f : mis_weight(ds.pdf * frac_lum, bp * frac_bsdf) * weight_lum;      // direct.cpp:155-156
                     const f3 contrib = mk3((mis * bv.x) * spec.x, (mis * bv.y) * spec.y, (mis * bv.z) * spec.z);
@@ -810,7 +812,7 @@ __global__ __launch_bounds__(kBlock) void k_direct(const RenderParams P, uint64_
                 f3 wo, weight; float pdf; bool delta = false;
                 if (GENERAL) {
                     BsdfSample bs;
-                    bsdf_sample(bsdf, refl, si.wi, s1, s2, bs, weight);
+                    surface_bsdf_sample(bsdf, refl, [&](uint32_t i) { return geo.bsdf(i); }, si.wi, s1, s2, bs, weight);
                     wo = bs.wo; pdf = bs.pdf; delta = bs.delta;
                 } else {
                     diffuse_sample(refl, si.wi, s2, wo, pdf, weight);
@@ -1237,7 +1239,7 @@ __global__ __launch_bounds__(64) void k_mega(const RenderParams P) {
 }
 
 hipError_t launch_mega(const RenderParams &p, hipStream_t s) {
-    const size_t lds = p.sv.flat ? lds_bytes(p.sv, 64u) : sizeof(StackEntry) * std::min(p.sv.stack_depth, kFinishLdsDepth) * 64u;
+    const size_t lds = p.sv.flat ? lds_bytes(p.sv, 64u) : sizeof(StackEntry) * (std::min(p.sv.stack_depth, kFinishLdsDepth) + 1u) * 64u;
     const uint32_t blocks = p.n_waves;
     if (p.sv.flat) {
         if (p.spectral && p.sv.general) hipLaunchKernelGGL((k_mega<PathStateS, true, true>), dim3(blocks), dim3(64), lds, s, p);
@@ -1258,7 +1260,7 @@ hipError_t launch_finish(const RenderParams &p, uint64_t alive, hipStream_t s) {
     const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(alive / 256u, 2048u), p.n_waves);
     const uint32_t per = std::min((uint32_t) ((p.n_waves + want - 1u) / want), kFinishMaxPer);
     const uint32_t blocks = (p.n_waves + per - 1u) / per;
-    const size_t lds = p.sv.flat ? lds_bytes(p.sv, 64u) : sizeof(StackEntry) * std::min(p.sv.stack_depth, kFinishLdsDepth) * 64u;
+    const size_t lds = p.sv.flat ? lds_bytes(p.sv, 64u) : sizeof(StackEntry) * (std::min(p.sv.stack_depth, kFinishLdsDepth) + 1u) * 64u;
     if (p.sv.flat) {
         if (p.spectral && p.sv.general) hipLaunchKernelGGL((k_finish<PathStateS, true, true>), dim3(blocks), dim3(64), lds, s, p, per);
         else if (p.spectral) hipLaunchKernelGGL((k_finish<PathStateS, false, true>), dim3(blocks), dim3(64), lds, s, p, per);
@@ -1351,7 +1353,7 @@ void k_trace(const RenderParams P) {
         // LDS holds the first P.trace_lds_depth stack entries of every lane; deeper entries spill to this workgroup's slice of
         // P.trace_spill ([entry][thread])
         const uint32_t spill_depth = P.sv.stack_depth > P.trace_lds_depth ? P.sv.stack_depth - P.trace_lds_depth : 0u;
-        const WalkStack st = { reinterpret_cast<StackEntry *>(lds.stack) + threadIdx.x, lds.stride, P.trace_lds_depth,
+        const WalkStack st = { reinterpret_cast<StackEntry *>(lds.stack) + threadIdx.x, log2_stride(lds.stride), P.trace_lds_depth,
                                reinterpret_cast<StackEntry *>(P.trace_spill) + ((size_t) (ANY ? (P.n_waves + kShadowGroup - 1u) / kShadowGroup : 0u) + group) * spill_depth * kBlock + threadIdx.x, blockDim.x };
         BvhWalk w;
         w.cur = kNoNode; w.sp = 0u; w.found = false;
@@ -1410,7 +1412,7 @@ void k_trace(const RenderParams P) {
 #define MTS_TRACE_BLOCK 256
 #endif
 constexpr uint32_t kTraceBlock = MTS_TRACE_BLOCK;      // threads per k_trace workgroup (hierarchy scenes)
-size_t trace_lds_bytes(const SceneView &sv) { return sizeof(StackEntry) * std::min(sv.stack_depth, kTraceLdsDepth) * kTraceBlock; }
+size_t trace_lds_bytes(const SceneView &sv) { return sizeof(StackEntry) * (std::min(sv.stack_depth, kTraceLdsDepth) + 1u) * kTraceBlock; }      // + the scratch row of stack_row()
 uint32_t trace_lds_depth(const SceneView &sv) { return std::min(sv.stack_depth, kTraceLdsDepth); }
 size_t trace_spill_words(const SceneView &sv, uint32_t n_waves) {
     const uint32_t spill = sv.stack_depth > kTraceLdsDepth ? sv.stack_depth - kTraceLdsDepth : 0u;
@@ -2039,7 +2041,7 @@ void k_ray_walk(const SceneView sv, uint64_t n, const RayStreams r, float *t, ui
     const uint32_t lane = lane_id();
     // the first sv.walk_lds_depth stack entries of a lane live in LDS, deeper ones in this workgroup's slice of sv.walk_spill
     const uint32_t spill_depth = sv.stack_depth > sv.walk_lds_depth ? sv.stack_depth - sv.walk_lds_depth : 0u;
-    const WalkStack st = { reinterpret_cast<StackEntry *>(smem) + threadIdx.x, kBlock, sv.walk_lds_depth,
+    const WalkStack st = { reinterpret_cast<StackEntry *>(smem) + threadIdx.x, log2_stride(kBlock), sv.walk_lds_depth,
                            sv.walk_spill + (size_t) blockIdx.x * spill_depth * kBlock + threadIdx.x, kBlock };
     const LdsView lds = {};
     const Geo<false> geo{ sv, lds };
@@ -2101,7 +2103,7 @@ void k_ray_walk(const SceneView sv, uint64_t n, const RayStreams r, float *t, ui
 static uint32_t walk_grid(const SceneView &sv, uint64_t n) {
     return (uint32_t) std::min<uint64_t>((n + kRayChunk - 1) / kRayChunk, sv.walk_blocks);
 }
-static size_t walk_lds(const SceneView &sv) { return sizeof(StackEntry) * std::min(sv.stack_depth, sv.walk_lds_depth) * kBlock; }
+static size_t walk_lds(const SceneView &sv) { return sizeof(StackEntry) * (std::min(sv.stack_depth, sv.walk_lds_depth) + 1u) * kBlock; }
 
 hipError_t launch_ray_intersect(const SceneView &sv, uint64_t n, const RayStreams &r, int mode, float *t,
                                 uint32_t *prim, uint32_t *shape, float *u, float *v, float *si26, hipStream_t s) {

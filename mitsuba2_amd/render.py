@@ -478,15 +478,15 @@ class Scene:
             md[i].normals = nrm.ctypes.data_as(L.f32p) if nrm is not None else None
             md[i].texcoords = uv.ctypes.data_as(L.f32p) if uv is not None else None
             md[i].bsdf, md[i].emitter = int(m["bsdf"]), int(m.get("emitter", -1))
-        bd = (L.BsdfDesc * max(len(bsdfs), 1))()
         tex = []                       # bitmap textures (src/textures/bitmap.cpp): reflectance = dict(type="bitmap", data=(H,W,3))
         self._bsdf_texture = {}
         from . import bsdfs as B
-        self._bsdf_records = []
-        for i, b in enumerate(bsdfs):
-            n = B.normalize(b)             # plugin defaults / validation (src/bsdfs/*.cpp constructors)
-            self._bsdf_records.append(n)
+        self._bsdf_records = [B.normalize(b) for b in bsdfs]      # plugin defaults / validation (src/bsdfs/*.cpp constructors)
+        flat = B.flatten(self._bsdf_records)                      # + the children of blendbsdf / mask records
+        bd = (L.BsdfDesc * max(len(flat), 1))()
+        for i, n in enumerate(flat):
             bd[i].type, bd[i].twosided = n["type"], int(n["twosided"])
+            bd[i].nested = (C.c_int32 * 2)(*n.get("nested", [-1, -1]))
             refl = n["reflectance"]
             if isinstance(refl, dict):
                 kind = refl.get("type")
@@ -539,7 +539,7 @@ class Scene:
                 ed[i].envmap_data = img.ctypes.data_as(L.f32p)
                 ed[i].envmap_height, ed[i].envmap_width = img.shape[0], img.shape[1]
                 ed[i].envmap_scale = n["scale"]
-        sd = L.SceneDesc(md, len(meshes), bd, len(bsdfs), ed, len(emitters), td, len(tex), 0, None)
+        sd = L.SceneDesc(md, len(meshes), bd, len(flat), ed, len(emitters), td, len(tex), 0, None)
         if variant == "spectral":
             sd.spectral = 1
             sd.rgb2spec_path = srgb_coeff_path().encode()

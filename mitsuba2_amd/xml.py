@@ -739,7 +739,7 @@ def load_file(path, device=0, variant="rgb", **params):
 
 
 # -------------------------------------------------------------------------------------------- load_dict
-_PLUGIN_CLASS = {"twosided": "bsdf", "conductor": "bsdf", "roughconductor": "bsdf", "dielectric": "bsdf", "plastic": "bsdf", "roughplastic": "bsdf", "roughdielectric": "bsdf", "thindielectric": "bsdf", "path": "integrator", "perspective": "sensor", "thinlens": "sensor", "hdrfilm": "film", "independent": "sampler", "gaussian": "rfilter", "box": "rfilter", "tent": "rfilter", "catmullrom": "rfilter", "mitchell": "rfilter", "lanczos": "rfilter",
+_PLUGIN_CLASS = {"twosided": "bsdf", "blendbsdf": "bsdf", "mask": "bsdf", "conductor": "bsdf", "roughconductor": "bsdf", "dielectric": "bsdf", "plastic": "bsdf", "roughplastic": "bsdf", "roughdielectric": "bsdf", "thindielectric": "bsdf", "path": "integrator", "perspective": "sensor", "thinlens": "sensor", "hdrfilm": "film", "independent": "sampler", "gaussian": "rfilter", "box": "rfilter", "tent": "rfilter", "catmullrom": "rfilter", "mitchell": "rfilter", "lanczos": "rfilter",
                  "direct": "integrator", "depth": "integrator", "moment": "integrator", "obj": "shape", "ply": "shape", "serialized": "shape", "rectangle": "shape", "diffuse": "bsdf", "area": "emitter", "constant": "emitter", "envmap": "emitter", "point": "emitter", "spot": "emitter", "directional": "emitter", "bitmap": "texture", "checkerboard": "texture", "scene": "scene"}
 
 

@@ -71,6 +71,15 @@ typedef struct {
 } mo_bsdf_desc;
 /* Replaces the BSDF of a shape (keeps an attached reflectance texture). */
 int mo_scene_set_bsdf(mo_scene *s, uint32_t shape, const mo_bsdf_desc *desc);
+/* blendbsdf (src/bsdfs/blendbsdf.cpp) and mask (src/bsdfs/mask.cpp) over plain child BSDFs with constant parameters.  The blend
+ * weight / opacity is `weight`, or -- after mo_scene_set_texture on the shape -- Texture::eval_1 of that texture: the luminance of
+ * the interpolated bitmap texel (bitmap.cpp:215-231) or the (constant, first-channel) colour of the checkerboard cell
+ * (checkerboard.cpp:67-86).  `twosided` wraps the whole nest in the TwoSidedBRDF adapter (blend only: mask transmits). */
+enum { MO_NEST_BLEND = 1, MO_NEST_MASK = 2 };
+int mo_scene_set_nested_bsdf(mo_scene *s, uint32_t shape, int kind, float weight, int twosided, const mo_bsdf_desc *child0, const mo_bsdf_desc *child1);
+/* one BSDF query per row as mo_kat_bsdf, on a blend / mask with constant weight */
+void mo_kat_nested_bsdf(int kind, float weight, int twosided, const mo_bsdf_desc *child0, const mo_bsdf_desc *child1, uint64_t n,
+                        const float *wi3, const float *wo3, const float *sample3, float *out14);
 void mo_kat_fresnel(float cos_theta_i, float eta, float *out4);
 float mo_kat_fresnel_conductor(float cos_theta_i, float eta_r, float eta_i);
 float mo_kat_fresnel_diffuse(float eta);

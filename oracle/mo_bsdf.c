@@ -322,6 +322,8 @@ static inline float lerp_gather(const float *data, float x, int size) {         
 
 /* BSDFFlags::Smooth = any diffuse / glossy component (bsdf.h:106-112) */
 int mo_bsdf_is_smooth(const mo_bsdf *b) {
+    if (b->nest == MO_NEST_BLEND) return mo_bsdf_is_smooth(b->child[0]) || mo_bsdf_is_smooth(b->child[1]);      /* flags = union (blendbsdf.cpp:66-79) */
+    if (b->nest == MO_NEST_MASK) return mo_bsdf_is_smooth(b->child[0]);                                         /* nested flags + Null (mask.cpp:69-84) */
     return b->d.type == MO_BSDF_DIFFUSE || b->d.type == MO_BSDF_ROUGHCONDUCTOR || b->d.type == MO_BSDF_PLASTIC || b->d.type == MO_BSDF_ROUGHPLASTIC ||
            b->d.type == MO_BSDF_ROUGHDIELECTRIC;
 }
@@ -610,14 +612,92 @@ void mo_bsdf_eval_pdf_n(const mo_bsdf *b, int n, const mo_bsdf_chan *c, mo_v3 wi
     }
 }
 
+/* ------------------------------------------------------------------ blendbsdf / mask */
+/* Texture::eval_1 of the weight / opacity, clamped (blendbsdf.cpp:177-179, mask.cpp:170-172).  `value` is what a plain BSDF would
+ * receive as its reflectance: the constant (first channel) or the texture lookup. */
+static float nest_weight(const mo_bsdf *b, const float *value) {
+    float w = value[0];
+    if (b->weight_lum) w = fmaf(0.072169f, value[2], fmaf(0.715160f, value[1], 0.212671f * value[0]));      /* luminance (spectrum.h:239-241) */
+    return fminf(fmaxf(w, 0.0f), 1.0f);
+}
+/* per-channel inputs of child k: its own constant parameters */
+static void child_channels(const mo_bsdf *c, int n, const float *wav, mo_bsdf_chan *out) {
+    if (n == 3) rgb_channels(c, c->d.reflectance, out);
+    else mo_bsdf_spectral_channels(c, wav, out);
+}
+/* blendbsdf.cpp:82-123 (ctx.component == -1) and mask.cpp:92-131 (both the null and the nested components enabled) */
+static int nest_sample(const mo_bsdf *b, int n, const float *wav, float w, mo_v3 wi, float sample1, mo_v2 sample2, mo_bsample *bs, float *weight) {
+    bs->wo = mo_v3_make(0.0f, 0.0f, 0.0f); bs->pdf = 0.0f; bs->eta = 0.0f; bs->delta = 0;
+    for (int k = 0; k < n; ++k) weight[k] = 0.0f;
+    int flip = 0;
+    if (b->d.twosided) {                                    /* twosided.cpp:94-123 around the whole nest */
+        if (wi.z == 0.0f) return 0;
+        flip = wi.z < 0.0f;
+        if (flip) wi.z = -wi.z;
+    }
+    mo_bsdf_chan c; int ok = 0;
+    if (b->nest == MO_NEST_BLEND) {
+        if (sample1 > w) {
+            child_channels(b->child[0], n, wav, &c);
+            ok = mo_bsdf_sample_n(b->child[0], n, &c, wi, (sample1 - w) / (1.0f - w), sample2, bs, weight);
+        } else if (sample1 <= w) {
+            child_channels(b->child[1], n, wav, &c);
+            ok = mo_bsdf_sample_n(b->child[1], n, &c, wi, sample1 / w, sample2, bs, weight);
+        }
+    } else {
+        bs->wo = mo_neg(wi); bs->eta = 1.0f; bs->pdf = 1.0f - w; bs->delta = 1;      /* BSDFFlags::Null is part of BSDFFlags::Delta (bsdf.h:98) */
+        for (int k = 0; k < n; ++k) weight[k] = 1.0f;
+        ok = 1;
+        if (sample1 < w) {                                  /* the nested sample replaces the record as it is (mask.cpp:123-128) */
+            child_channels(b->child[0], n, wav, &c);
+            ok = mo_bsdf_sample_n(b->child[0], n, &c, wi, sample1 / w, sample2, bs, weight);
+        }
+    }
+    if (flip) bs->wo.z = -bs->wo.z;
+    return ok;
+}
+/* blendbsdf.cpp:125-158, mask.cpp:133-159 */
+static void nest_eval_pdf(const mo_bsdf *b, int n, const float *wav, float w, mo_v3 wi, mo_v3 wo, float *value, float *pdf) {
+    for (int k = 0; k < n; ++k) value[k] = 0.0f;
+    *pdf = 0.0f;
+    if (b->d.twosided) {
+        if (wi.z == 0.0f) return;
+        if (wi.z < 0.0f) { wi.z = -wi.z; wo.z = -wo.z; }
+    }
+    mo_bsdf_chan c; float v0[4], p0;
+    child_channels(b->child[0], n, wav, &c);
+    mo_bsdf_eval_pdf_n(b->child[0], n, &c, wi, wo, v0, &p0);
+    if (b->nest == MO_NEST_MASK) {
+        for (int k = 0; k < n; ++k) value[k] = v0[k] * w;
+        *pdf = p0 * w;
+        return;
+    }
+    float v1[4], p1;
+    child_channels(b->child[1], n, wav, &c);
+    mo_bsdf_eval_pdf_n(b->child[1], n, &c, wi, wo, v1, &p1);
+    for (int k = 0; k < n; ++k) value[k] = fmaf(v1[k], w, v0[k] * (1.0f - w));
+    *pdf = fmaf(p1, w, p0 * (1.0f - w));
+}
+
 /* RGB variant */
 int mo_bsdf_sample(const mo_bsdf *b, const float refl[3], mo_v3 wi, float sample1, mo_v2 sample2, mo_bsample *bs, float weight[3]) {
+    if (b->nest) return nest_sample(b, 3, NULL, nest_weight(b, refl), wi, sample1, sample2, bs, weight);
     mo_bsdf_chan c; rgb_channels(b, refl, &c);
     return mo_bsdf_sample_n(b, 3, &c, wi, sample1, sample2, bs, weight);
 }
 void mo_bsdf_eval_pdf(const mo_bsdf *b, const float refl[3], mo_v3 wi, mo_v3 wo, float value[3], float *pdf) {
+    if (b->nest) { nest_eval_pdf(b, 3, NULL, nest_weight(b, refl), wi, wo, value, pdf); return; }
     mo_bsdf_chan c; rgb_channels(b, refl, &c);
     mo_bsdf_eval_pdf_n(b, 3, &c, wi, wo, value, pdf);
+}
+/* spectral variant */
+int mo_bsdf_sample_spec(const mo_bsdf *b, const float *wav, const mo_bsdf_chan *c, mo_v3 wi, float sample1, mo_v2 sample2, mo_bsample *bs, float *weight) {
+    if (b->nest) return nest_sample(b, MO_WAV, wav, nest_weight(b, c->refl), wi, sample1, sample2, bs, weight);
+    return mo_bsdf_sample_n(b, MO_WAV, c, wi, sample1, sample2, bs, weight);
+}
+void mo_bsdf_eval_pdf_spec(const mo_bsdf *b, const float *wav, const mo_bsdf_chan *c, mo_v3 wi, mo_v3 wo, float *value, float *pdf) {
+    if (b->nest) { nest_eval_pdf(b, MO_WAV, wav, nest_weight(b, c->refl), wi, wo, value, pdf); return; }
+    mo_bsdf_eval_pdf_n(b, MO_WAV, c, wi, wo, value, pdf);
 }
 
 /* ------------------------------------------------------------------ known-answer entry points */
@@ -655,6 +735,23 @@ void mo_kat_bsdf(const mo_bsdf_desc *desc, uint64_t n, const float *wi3, const f
         mo_bsdf_eval_pdf(&b, desc->reflectance, wi, wo, o, o + 3);
         mo_bsample bs; mo_v2 s2 = { sample3[3 * i + 1], sample3[3 * i + 2] };
         int ok = mo_bsdf_sample(&b, desc->reflectance, wi, sample3[3 * i], s2, &bs, o + 10);
+        o[4] = bs.wo.x; o[5] = bs.wo.y; o[6] = bs.wo.z; o[7] = bs.pdf; o[8] = bs.eta; o[9] = (float) bs.delta; o[13] = (float) ok;
+    }
+}
+void mo_kat_nested_bsdf(int kind, float weight, int twosided, const mo_bsdf_desc *child0, const mo_bsdf_desc *child1, uint64_t n,
+                        const float *wi3, const float *wo3, const float *sample3, float *out14) {
+    mo_bsdf top, c0, c1;
+    memset(&top, 0, sizeof(top)); memset(&c0, 0, sizeof(c0)); memset(&c1, 0, sizeof(c1));
+    c0.d = *child0; mo_bsdf_prepare(&c0);
+    if (child1) { c1.d = *child1; mo_bsdf_prepare(&c1); }
+    top.nest = kind; top.d.twosided = twosided; top.child[0] = &c0; top.child[1] = child1 ? &c1 : NULL;
+    const float wv[3] = { weight, weight, weight };
+    for (uint64_t i = 0; i < n; ++i) {
+        mo_v3 wi = mo_v3_make(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]), wo = mo_v3_make(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]);
+        float *o = out14 + 14 * i;
+        mo_bsdf_eval_pdf(&top, wv, wi, wo, o, o + 3);
+        mo_bsample bs; mo_v2 s2 = { sample3[3 * i + 1], sample3[3 * i + 2] };
+        int ok = mo_bsdf_sample(&top, wv, wi, sample3[3 * i], s2, &bs, o + 10);
         o[4] = bs.wo.x; o[5] = bs.wo.y; o[6] = bs.wo.z; o[7] = bs.pdf; o[8] = bs.eta; o[9] = (float) bs.delta; o[13] = (float) ok;
     }
 }

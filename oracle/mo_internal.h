@@ -17,10 +17,14 @@ typedef struct {
 typedef struct { mo_v3 p, n, d; float dist, pdf; uint32_t emitter; float pdf_single; mo_v2 uv; int delta; float falloff, scale; } mo_dsample;   /* delta emitters: spec = (L * falloff) * scale */   /* pdf_single: before the emitter-selection probability; uv: envmap samples */
 
 /* a BSDF instance: the descriptor plus the constants its constructor derives (plastic.cpp:162-176) */
-typedef struct {
+typedef struct mo_bsdf {
     mo_bsdf_desc d; float eta_rel, inv_eta_2, fdr_int, fdr_ext, spec_weight;
     float refl_coeff[3], spec_coeff[3], trans_coeff[3];      /* spectral variant: srgb_model coefficients */
     float ext_trans[64], internal_reflectance;               /* roughplastic (roughplastic.cpp:380-399) */
+    /* nest = MO_NEST_BLEND / MO_NEST_MASK: blendbsdf.cpp / mask.cpp over child[0..1] (mask: child[0]); the weight / opacity
+     * arrives where a plain BSDF receives its reflectance (the shape's constant or texture); weight_lum: it is a bitmap
+     * texel whose eval_1 is the luminance (bitmap.cpp:215-231) */
+    int nest, weight_lum; struct mo_bsdf *child[2];
 } mo_bsdf;
 /* per-channel inputs of a BSDF evaluation: 3 colour channels or MO_WAV wavelengths */
 typedef struct { float refl[4], spec[4], trans[4], eta[4], k[4]; } mo_bsdf_chan;
@@ -113,6 +117,10 @@ void mo_bsdf_eval_pdf(const mo_bsdf *b, const float refl[3], mo_v3 wi, mo_v3 wo,
 int mo_bsdf_sample_n(const mo_bsdf *b, int n, const mo_bsdf_chan *c, mo_v3 wi, float sample1, mo_v2 sample2, mo_bsample *bs, float *weight);
 void mo_bsdf_eval_pdf_n(const mo_bsdf *b, int n, const mo_bsdf_chan *c, mo_v3 wi, mo_v3 wo, float *value, float *pdf);
 void mo_bsdf_spectral_channels(const mo_bsdf *b, const float *wav, mo_bsdf_chan *c);
+/* spectral variant of mo_bsdf_sample / mo_bsdf_eval_pdf: `c` = mo_bsdf_spectral_channels(b, wav) (+ textured reflectance); nested
+ * BSDFs build the channels of their children from `wav` */
+int mo_bsdf_sample_spec(const mo_bsdf *b, const float *wav, const mo_bsdf_chan *c, mo_v3 wi, float sample1, mo_v2 sample2, mo_bsample *bs, float *weight);
+void mo_bsdf_eval_pdf_spec(const mo_bsdf *b, const float *wav, const mo_bsdf_chan *c, mo_v3 wi, mo_v3 wo, float *value, float *pdf);
 float mo_srgb_model_mean(const float coeff[3]);
 
 /* spectral variant (mo_spectral.c) */

@@ -789,7 +789,7 @@ static void path_sample_spectral(const mo_scene *s, mo_pcg32 *rng, const mo_ray 
                 int occluded = mo_intersect(s, &sr, 1, 0, NULL);
                 mo_v3 wo = mo_to_local(&si.sh, ds.d);
                 float bv[MO_WAV], bsdf_pdf, le[MO_WAV];
-                mo_bsdf_eval_pdf_n(bsdf, MO_WAV, &chan, si.wi, wo, bv, &bsdf_pdf);
+                mo_bsdf_eval_pdf_spec(bsdf, wav, &chan, si.wi, wo, bv, &bsdf_pdf);
                 float mis = ds.delta ? 1.0f : mis_weight(ds.pdf, bsdf_pdf);
                 emitter_spectrum(e, wav, &ds.d, &ds.uv, le);
                 for (int k = 0; k < MO_WAV; ++k) {
@@ -803,7 +803,7 @@ static void path_sample_spectral(const mo_scene *s, mo_pcg32 *rng, const mo_ray 
         float s1 = mo_pcg32_next_f32(rng);
         mo_v2 s2; s2.x = mo_pcg32_next_f32(rng); s2.y = mo_pcg32_next_f32(rng);
         mo_bsample bs; float bsdf_w[MO_WAV];
-        mo_bsdf_sample_n(bsdf, MO_WAV, &chan, si.wi, s1, s2, &bs, bsdf_w);
+        mo_bsdf_sample_spec(bsdf, wav, &chan, si.wi, s1, s2, &bs, bsdf_w);
         int nz = 0;
         for (int k = 0; k < MO_WAV; ++k) { throughput[k] = throughput[k] * bsdf_w[k]; nz = nz || throughput[k] != 0.0f; }
         active = active && nz;

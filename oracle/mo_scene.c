@@ -37,6 +37,7 @@ void mo_scene_free(mo_scene *s) {
         mo_mesh *m = &s->meshes[i];
         free(m->pos); free(m->nrm); free(m->uv); free(m->faces);
         free(m->area_pmf); free(m->area_cdf);
+        free(m->bsdf.child[0]); free(m->bsdf.child[1]);
     }
     for (uint32_t i = 0; i < s->n_textures; ++i) free(s->textures[i].data);
     free(s->textures);
@@ -207,6 +208,7 @@ int mo_scene_set_texture(mo_scene *s, uint32_t shape, int texture) {
     if (!s || shape >= s->n_meshes || texture >= (int) s->n_textures) return -1;
     mo_mesh *m = &s->meshes[shape];
     m->texture = texture;
+    if (m->bsdf.nest) m->bsdf.weight_lum = texture >= 0 && s->textures[texture].kind == 0;      /* eval_1 of a bitmap: luminance */
     if (texture >= 0 && (m->bsdf.d.type == MO_BSDF_PLASTIC || m->bsdf.d.type == MO_BSDF_ROUGHPLASTIC)) {
         /* plastic.cpp:170-175: specular sampling weight from Texture::mean() of both reflectances */
         const float *sr = m->bsdf.d.specular_reflectance;
@@ -238,6 +240,32 @@ int mo_scene_set_bsdf(mo_scene *s, uint32_t shape, const mo_bsdf_desc *desc) {
     m->bsdf_kind = desc->type;
     for (int k = 0; k < 3; ++k) m->refl[k] = desc->reflectance[k];
     mo_bsdf_prepare(&m->bsdf);
+    return 0;
+}
+
+/* blendbsdf / mask over plain children (see mo_api.h).  The weight takes the place of the shape's reflectance: constant, or the
+ * texture attached with mo_scene_set_texture afterwards. */
+int mo_scene_set_nested_bsdf(mo_scene *s, uint32_t shape, int kind, float weight, int twosided, const mo_bsdf_desc *child0, const mo_bsdf_desc *child1) {
+    if (!s || shape >= s->n_meshes || !child0 || (kind != MO_NEST_BLEND && kind != MO_NEST_MASK)) return -1;
+    if ((kind == MO_NEST_BLEND) != (child1 != NULL) || (kind == MO_NEST_MASK && twosided)) return -1;
+    if (s->spectral) return -2;
+    const mo_bsdf_desc *cd[2] = { child0, child1 };
+    for (int k = 0; k < 2; ++k)
+        if (cd[k] && (cd[k]->type < MO_BSDF_DIFFUSE || cd[k]->type > MO_BSDF_THINDIELECTRIC)) return -1;
+    mo_mesh *m = &s->meshes[shape];
+    free(m->bsdf.child[0]); free(m->bsdf.child[1]);
+    memset(&m->bsdf, 0, sizeof(m->bsdf));
+    m->bsdf.nest = kind; m->bsdf.d.twosided = twosided; m->bsdf.d.type = -kind; m->bsdf.d.uniform_mask = 1;
+    for (int k = 0; k < 2; ++k) {
+        if (!cd[k]) continue;
+        mo_bsdf *c = (mo_bsdf *) calloc(1, sizeof(mo_bsdf));
+        if (!c) return -1;
+        c->d = *cd[k]; mo_bsdf_prepare(c);
+        m->bsdf.child[k] = c;
+    }
+    m->bsdf_kind = 100 + kind;                          /* not `diffuse`: the adjoint pass rejects the scene */
+    for (int k = 0; k < 3; ++k) m->refl[k] = m->bsdf.d.reflectance[k] = weight;
+    m->bsdf.weight_lum = m->texture >= 0 && s->textures[m->texture].kind == 0;
     return 0;
 }
 

@@ -140,22 +140,31 @@ int mo_scene_set_spectral(mo_scene *s, const char *coeff_path) {
             tx->mean = (float) (mean / (double) ((size_t) tx->w * tx->h));
         }
     }
-    for (uint32_t i = 0; i < s->n_meshes; ++i) {
+    for (uint32_t i = 0; i < s->n_meshes; ++i)
+      for (int nest_k = 0; nest_k < 2; ++nest_k) {
         mo_mesh *m = &s->meshes[i];
         mo_bsdf *b = &m->bsdf;
+        if (b->nest) {
+            /* blendbsdf / mask: the weight is a scalar (a bitmap without raw = true throws in eval_1, bitmap.cpp:218-222);
+             * the children upsample their own constant colours */
+            if (m->texture >= 0) { free(t.scale); free(t.data); return -5; }
+            b = b->child[nest_k];
+            if (!b) continue;
+        } else if (nest_k) continue;
+        const int is_child = m->bsdf.nest != 0;
         /* every colour-valued parameter is either `uniform` (a constant) or an `srgb` texture, whose constructor rejects
          * values outside [0, 1] (srgb.cpp:34-35) and fetches the model coefficients */
-        const float *vals[3] = { m->refl, b->d.specular_reflectance, b->d.specular_transmittance };
+        const float *vals[3] = { is_child ? b->d.reflectance : m->refl, b->d.specular_reflectance, b->d.specular_transmittance };
         float *coeffs[3] = { b->refl_coeff, b->spec_coeff, b->trans_coeff };
         float means[3] = { 0.0f, 0.0f, 0.0f };
         for (int p = 0; p < 3; ++p) {
-            if (p == 0 && m->texture >= 0) { means[0] = s->textures[m->texture].mean; continue; }
+            if (p == 0 && !is_child && m->texture >= 0) { means[0] = s->textures[m->texture].mean; continue; }
             if (b->d.uniform_mask & (1 << p)) { means[p] = vals[p][0]; continue; }
             for (int k = 0; k < 3; ++k) if (vals[p][k] < 0.0f || vals[p][k] > 1.0f) { free(t.scale); free(t.data); return -3; }
             model_fetch(&t, vals[p], coeffs[p]);
             means[p] = mo_srgb_model_mean(coeffs[p]);
         }
-        for (int k = 0; k < 3; ++k) m->refl_coeff[k] = b->refl_coeff[k];
+        if (!is_child) for (int k = 0; k < 3; ++k) m->refl_coeff[k] = b->refl_coeff[k];
         if ((b->d.type == MO_BSDF_CONDUCTOR || b->d.type == MO_BSDF_ROUGHCONDUCTOR) &&
             (b->d.eta[0] != b->d.eta[1] || b->d.eta[0] != b->d.eta[2] || b->d.k[0] != b->d.k[1] || b->d.k[0] != b->d.k[2])) {
             free(t.scale); free(t.data); return -4;          /* RGB eta / k cannot be upsampled (values > 1): uniform spectra only */

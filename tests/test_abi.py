@@ -26,7 +26,7 @@ def test_header_symbols_are_exported():
     handle = C.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(handle, name), "libmtsamd.so does not export %s" % name
-    assert _lib.lib().mtsamd_abi_version() == 4
+    assert _lib.lib().mtsamd_abi_version() == 5
     # the two symbols PluginManager reads from a plugin .so (class.h:205-211, plugin.cpp:19-31)
     assert _lib.lib().plugin_name() == b"path_amd" and len(_lib.lib().plugin_descr()) > 0
 

@@ -393,3 +393,105 @@ def test_rough_dielectric_parameters():
         ob.bsdf_desc({"type": "twosided", "bsdf": {"type": "roughdielectric"}})
     d, n = ob.bsdf_desc({"type": "roughdielectric"})                # defaults: bk7 / air, beckmann, alpha = 0.1
     assert n["int_ior"] == 1.5046 and n["ext_ior"] == 1.000277 and n["alpha_u"] == n["alpha_v"] == 0.1 and n["distribution"] == 0
+
+
+# ------------------------------------------------------------------ blendbsdf / mask
+def test_blendbsdf_reference_values():
+    """src/bsdfs/tests/test_blendbsdf.py: test02_eval_all (:32-63) -- eval of a 0 / 1 diffuse blend at normal incidence is
+    weight / pi -- and the sampling branch of test04 (:110-158): sample1 above the weight selects the first child"""
+    w = 0.2
+    b = {"type": "blendbsdf", "weight": w, "bsdf_0": {"type": "diffuse", "reflectance": 0.0}, "bsdf_1": {"type": "diffuse", "reflectance": 1.0}}
+    up = [[0.0, 0.0, 1.0]]
+    r = ob.bsdf_kat(b, up, up, [[0.5, 0.5, 0.5]])
+    assert np.allclose(r["eval"], (1 - w) * 0.0 / math.pi + w * 1.0 / math.pi, rtol=1e-6)
+    assert np.allclose(r["pdf"], 1.0 / math.pi, rtol=1e-6)            # both children: cosine pdf, blended with (1 - w) + w
+    # sample1 = 0.3 > weight: first child (reflectance 0: zero weight), sample1 = 0.1 <= weight: second child (weight 1)
+    hi = ob.bsdf_kat(b, up, up, [[0.3, 0.5, 0.5]])
+    lo = ob.bsdf_kat(b, up, up, [[0.1, 0.5, 0.5]])
+    assert np.all(hi["s_weight"] == 0.0) and np.allclose(lo["s_weight"], 1.0)
+    assert np.allclose(lo["s_wo"], hi["s_wo"]) and lo["s_pdf"][0] > 0
+
+
+def test_blendbsdf_against_its_children():
+    """blendbsdf.cpp:82-158: eval / pdf are the weighted sums of the children's, sample() hands a rescaled sample1 to one child"""
+    rng = np.random.default_rng(3)
+    c0 = {"type": "roughconductor", "alpha": 0.3, "distribution": "ggx", "eta": [0.2, 0.92, 1.1], "k": [3.9, 2.45, 2.14]}
+    c1 = {"type": "plastic", "diffuse_reflectance": [0.1, 0.27, 0.36]}
+    w = 0.35
+    b = {"type": "blendbsdf", "weight": w, "a": c0, "b": c1}
+    n = 4000
+    wi = rng.normal(size=(n, 3)).astype(np.float32); wi[:, 2] = np.abs(wi[:, 2]); wi /= np.linalg.norm(wi, axis=1, keepdims=True)
+    wo = rng.normal(size=(n, 3)).astype(np.float32); wo /= np.linalg.norm(wo, axis=1, keepdims=True)
+    s3 = rng.uniform(size=(n, 3)).astype(np.float32)
+    r, r0, r1 = ob.bsdf_kat(b, wi, wo, s3), ob.bsdf_kat(c0, wi, wo, s3), ob.bsdf_kat(c1, wi, wo, s3)
+    assert np.allclose(r["eval"], r0["eval"] * (1 - w) + r1["eval"] * w, rtol=1e-5, atol=1e-7)
+    assert np.allclose(r["pdf"], r0["pdf"] * (1 - w) + r1["pdf"] * w, rtol=1e-5, atol=1e-7)
+    first = s3[:, 0] > np.float32(w)
+    s_a = s3.copy(); s_a[:, 0] = (s3[:, 0] - np.float32(w)) / (np.float32(1) - np.float32(w))
+    s_b = s3.copy(); s_b[:, 0] = s3[:, 0] / np.float32(w)
+    ra, rb = ob.bsdf_kat(c0, wi, wo, s_a), ob.bsdf_kat(c1, wi, wo, s_b)
+    for k in ("s_wo", "s_pdf", "s_eta", "s_weight", "s_delta", "s_valid"):
+        assert np.array_equal(r[k][first], ra[k][first]) and np.array_equal(r[k][~first], rb[k][~first]), k
+    # twosided around the blend: the back side scatters like the front side, mirrored
+    t = {"type": "twosided", "bsdf": b}
+    back = ob.bsdf_kat(t, wi * [1, 1, -1], wo * [1, 1, -1], s3)
+    assert np.array_equal(back["eval"], r["eval"]) and np.array_equal(back["s_wo"], r["s_wo"] * np.float32([1, 1, -1]))
+    assert np.array_equal(ob.bsdf_kat(t, wi, wo, s3)["eval"], r["eval"])
+
+
+def test_mask_semantics():
+    """mask.cpp:92-159: with probability (1 - opacity) the ray continues straight (null lobe, weight 1, pdf 1 - opacity, a Delta
+    event); otherwise the nested sample is returned AS IS with sample1 / opacity; eval and pdf are the nested ones times opacity"""
+    rng = np.random.default_rng(4)
+    c = {"type": "diffuse", "reflectance": [0.2, 0.4, 0.6]}
+    o = 0.3
+    m = {"type": "mask", "opacity": o, "nested": c}
+    n = 2000
+    wi = rng.normal(size=(n, 3)).astype(np.float32); wi /= np.linalg.norm(wi, axis=1, keepdims=True)
+    wo = rng.normal(size=(n, 3)).astype(np.float32); wo /= np.linalg.norm(wo, axis=1, keepdims=True)
+    s3 = rng.uniform(size=(n, 3)).astype(np.float32)
+    r, rc = ob.bsdf_kat(m, wi, wo, s3), ob.bsdf_kat(c, wi, wo, s3)
+    assert np.array_equal(r["eval"], rc["eval"] * np.float32(o)) and np.array_equal(r["pdf"], rc["pdf"] * np.float32(o))
+    null = ~(s3[:, 0] < np.float32(o))
+    assert np.array_equal(r["s_wo"][null], -wi[null]) and np.all(r["s_weight"][null] == 1.0) and np.all(r["s_delta"][null])
+    assert np.allclose(r["s_pdf"][null], 1 - o) and np.all(r["s_eta"][null] == 1.0) and np.all(r["s_valid"][null])
+    s_n = s3.copy(); s_n[:, 0] = s3[:, 0] / np.float32(o)
+    rn = ob.bsdf_kat(c, wi, wo, s_n)
+    for k in ("s_wo", "s_pdf", "s_eta", "s_weight", "s_delta", "s_valid"):
+        assert np.array_equal(r[k][~null], rn[k][~null]), k
+    assert abs(null.mean() - (1 - o)) < 0.04
+    d, nrm = ob.bsdf_desc({"type": "mask", "nested": c})               # opacity defaults to 0.5 (mask.cpp:69)
+    assert nrm["reflectance"] == [0.5] * 3 and nrm["type"] == 9
+
+
+def test_nested_bsdf_constructor_errors():
+    d = {"type": "diffuse"}
+    for bad, msg in (({"type": "blendbsdf", "a": d, "b": d}, "weight"), ({"type": "blendbsdf", "weight": 0.5, "a": d}, "Two child BSDFs"),
+                     ({"type": "blendbsdf", "weight": 0.5, "a": d, "b": d, "c": d}, "more than two"), ({"type": "mask"}, "Child BSDF not specified"),
+                     ({"type": "mask", "a": d, "b": d}, "more than one"), ({"type": "twosided", "bsdf": {"type": "mask", "a": d}}, "transmission"),
+                     ({"type": "twosided", "bsdf": {"type": "blendbsdf", "weight": 0.1, "a": d, "b": {"type": "dielectric"}}}, "transmission")):
+        with pytest.raises(RuntimeError, match=msg):
+            ob.bsdf_desc(bad)
+
+
+def test_oracle_renders_nested_bsdfs():
+    """white furnace style check through the whole path: a mask of opacity 0 is an empty scene object, opacity 1 its child; a blend
+    of weight 0 / 1 is one of its children (same random numbers only where sample1 is not consumed differently: compare means)"""
+    from mitsuba2_amd import scenes
+    sp = dict(scenes.cornell_box_sensor(24, 24, spp=32, seed=3), max_depth=5)
+    def render(mat):
+        cb = scenes.cornell_box()
+        cb["bsdfs"] = list(cb["bsdfs"]) + [mat]
+        cb["meshes"][6] = dict(cb["meshes"][6], bsdf=len(cb["bsdfs"]) - 1)
+        film, _ = ob.OracleScene(cb, naive=True).render(ob.make_desc(sp), mode=1)
+        return ob.film_develop(film)[..., :3]
+    c0, c1 = {"type": "diffuse", "reflectance": [0.7, 0.2, 0.1]}, {"type": "diffuse", "reflectance": [0.1, 0.3, 0.8]}
+    a, b = render(c0), render(c1)
+    b0 = render({"type": "blendbsdf", "weight": 0.0, "x": c0, "y": c1})
+    b1 = render({"type": "blendbsdf", "weight": 1.0, "x": c0, "y": c1})
+    # weight 0: child 0 with sample1' = sample1 (diffuse ignores sample1) -> the same image bit for bit; weight 1: child 1 likewise
+    assert np.array_equal(a, b0) and np.array_equal(b, b1)
+    m1 = render({"type": "mask", "opacity": 1.0, "n": c0})
+    assert np.array_equal(a, m1)
+    half = render({"type": "blendbsdf", "weight": 0.5, "x": c0, "y": c1})
+    assert abs(half.mean() - 0.5 * (a.mean() + b.mean())) < 0.05 * a.mean()

@@ -31,6 +31,22 @@ MATERIALS = {
     "frosted_beckmann_all": {"type": "roughdielectric", "alpha": 0.3, "sample_visible": False, "int_ior": 1.0, "ext_ior": 1.5},
     "twosided_diffuse": {"type": "twosided", "bsdf": {"type": "diffuse", "reflectance": [0.6, 0.3, 0.2]}},
     "twosided_rough": {"type": "twosided", "bsdf": {"type": "roughconductor", "alpha": 0.15, "distribution": "ggx", "eta": 0.0, "k": 1.0}},
+    # src/bsdfs/blendbsdf.cpp / mask.cpp over plain children; constant and textured (Texture::eval_1) weights
+    "blend_rough_diffuse": {"type": "blendbsdf", "weight": 0.3,
+                            "bsdf_0": {"type": "roughconductor", "alpha": 0.2, "distribution": "ggx", "eta": [0.2, 0.92, 1.1], "k": [3.9, 2.45, 2.14]},
+                            "bsdf_1": {"type": "diffuse", "reflectance": [0.2, 0.5, 0.7]}},
+    "blend_plastic_glass": {"type": "blendbsdf", "weight": 0.6, "a": {"type": "plastic", "diffuse_reflectance": [0.1, 0.27, 0.36]},
+                            "b": {"type": "dielectric", "int_ior": "bk7", "specular_transmittance": [0.9, 0.95, 1.0]}},
+    "twosided_blend_checker": {"type": "twosided", "bsdf": {"type": "blendbsdf",
+                               "weight": {"type": "checkerboard", "color0": 0.9, "color1": 0.15, "to_uv": [[4.0, 0, 0.1, 0], [0, 3.0, 0.2, 0], [0, 0, 1, 0], [0, 0, 0, 1]]},
+                               "bsdf_0": {"type": "diffuse", "reflectance": [0.7, 0.2, 0.1]}, "bsdf_1": {"type": "conductor"}}},
+    "blend_bitmap_weight": {"type": "blendbsdf", "weight": {"type": "bitmap", "data": np.random.default_rng(5).uniform(0.0, 1.3, size=(6, 5, 3)).astype(np.float32)},
+                            "bsdf_0": {"type": "diffuse", "reflectance": [0.7, 0.2, 0.1]},
+                            "bsdf_1": {"type": "roughplastic", "alpha": 0.2, "diffuse_reflectance": [0.1, 0.3, 0.6]}},
+    "mask_diffuse": {"type": "mask", "opacity": 0.4, "nested": {"type": "twosided", "bsdf": {"type": "diffuse", "reflectance": [0.6, 0.3, 0.2]}}},
+    "mask_checker_glass": {"type": "mask", "opacity": {"type": "checkerboard", "color0": 1.0, "color1": 0.0, "to_uv": [[5.0, 0, 0, 0], [0, 5.0, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]]},
+                           "nested": {"type": "roughdielectric", "alpha": 0.2}},
+    "mask_default_opacity": {"type": "mask", "nested": {"type": "roughconductor", "alpha": 0.3, "eta": 0.0, "k": 1.0}},
 }
 
 
@@ -84,7 +100,17 @@ def test_unsupported_combinations():
     with pytest.raises(RuntimeError, match="uniform"):
         R.Scene(cb, variant="spectral")
     with pytest.raises(RuntimeError, match="not supported by this backend"):
-        R.Scene(dict(cb, bsdfs=[{"type": "blendbsdf"}] * len(cb["bsdfs"])))
+        R.Scene(dict(cb, bsdfs=[{"type": "measured"}] * len(cb["bsdfs"])))
+    # constructor errors of the nesting plugins (blendbsdf.cpp:57-72, mask.cpp:71-82, twosided.cpp:78-80)
+    d = {"type": "diffuse"}
+    for bad, msg in (({"type": "blendbsdf", "a": d, "b": d}, "weight"), ({"type": "blendbsdf", "weight": 0.5, "a": d}, "Two child BSDFs"),
+                     ({"type": "blendbsdf", "weight": 0.5, "a": d, "b": d, "c": d}, "more than two"), ({"type": "mask"}, "Child BSDF not specified"),
+                     ({"type": "mask", "a": d, "b": d}, "more than one"), ({"type": "twosided", "bsdf": {"type": "mask", "a": d}}, "transmission"),
+                     ({"type": "mask", "a": {"type": "mask", "a": d}}, "one level")):
+        with pytest.raises(RuntimeError, match=msg):
+            R.Scene(dict(cb, bsdfs=[bad] * len(cb["bsdfs"])))
+    with pytest.raises(RuntimeError, match="eval_1"):      # a textured weight is converted into spectra in the spectral variant
+        R.Scene(dict(cb, bsdfs=[{"type": "blendbsdf", "weight": {"type": "checkerboard"}, "a": d, "b": d}] * len(cb["bsdfs"])), variant="spectral")
     with pytest.raises(RuntimeError, match="positive and differ"):
         R.Scene(dict(cb, bsdfs=[{"type": "roughdielectric", "int_ior": 1.2, "ext_ior": 1.2}] * len(cb["bsdfs"])))
 

@@ -71,6 +71,9 @@ SPECTRAL_MATERIALS = {
     "frosted_glass": {"type": "roughdielectric", "alpha": 0.2, "specular_transmittance": [0.9, 0.95, 1.0], "specular_reflectance": 0.9},
     "plastic": {"type": "plastic", "diffuse_reflectance": [0.1, 0.27, 0.36], "int_ior": 1.9},
     "plastic_uniform": {"type": "plastic", "diffuse_reflectance": 0.3, "specular_reflectance": 0.7, "nonlinear": True},
+    "blend": {"type": "blendbsdf", "weight": 0.35, "bsdf_0": {"type": "diffuse", "reflectance": [0.6, 0.3, 0.2]},
+              "bsdf_1": {"type": "roughconductor", "alpha": 0.2, "eta": 0.2, "k": 3.9, "specular_reflectance": [0.9, 0.7, 0.3]}},
+    "mask": {"type": "mask", "opacity": 0.6, "nested": {"type": "plastic", "diffuse_reflectance": [0.1, 0.27, 0.36]}},
 }
 
 

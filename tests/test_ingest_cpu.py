@@ -157,7 +157,8 @@ def test_xml_invalid_roots():
     ('<integer name="n" value="1.5"/>', 'could not parse integer value "1.5".'),
     ('<float name="n" value="a"/>', 'could not parse floating point value "a".'),
     ('<shape type="sphere"/>', 'Shape plugin "sphere" is not supported'),
-    ('<shape type="rectangle"><bsdf type="blendbsdf"/></shape>', "BSDF plugin 'blendbsdf' is not supported"),
+    ('<shape type="rectangle"><bsdf type="hair"/></shape>', "BSDF plugin 'hair' is not supported"),
+    ('<shape type="rectangle"><bsdf type="blendbsdf"><bsdf type="diffuse"/><bsdf type="diffuse"/></bsdf></shape>', 'Property "weight" has not been specified'),
     ('<shape type="rectangle"><bsdf type="roughconductor"/></shape>', 'measured IOR tables'),
     ('<shape type="rectangle"><bsdf type="twosided"><bsdf type="dielectric"/></bsdf></shape>', 'Only materials without a transmission component can be nested'),
     ('<shape type="rectangle"><bsdf type="dielectric"><float name="int_ior" value="-0.5"/></bsdf></shape>', 'indices of refraction must be positive'),
