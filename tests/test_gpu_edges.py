@@ -12,6 +12,12 @@ pytestmark = pytest.mark.gpu
 def test_empty_scene_renders_zero():
     from mitsuba2_amd import render as R, scenes
     sd = dict(meshes=[], bsdfs=[], emitters=[])
+    # device memory that was used before is not zero: the scene's (empty) node and triangle arrays must never be read.  (Round 2: the
+    # split pipeline started its walks at node 0 instead of the empty root leaf -- harmless on the zero pages of a fresh process, a
+    # memory fault after other scenes had used the memory.)
+    junk = torch.full((1 << 27,), 0x7f7f7f7f, dtype=torch.int32, device="cuda")
+    del junk
+    torch.cuda.empty_cache()
     scene = R.Scene(sd)
     sensor = R.make_sensor(scenes.cornell_box_sensor(24, 17, spp=3, seed=1))
     for integ in (R.PathIntegrator(), R.DirectIntegrator(), R.DepthIntegrator(), R.PathIntegrator(pipeline=2)):
