@@ -40,13 +40,15 @@ class ParameterMap:
                 self.properties[key] = torch.as_tensor(np.ascontiguousarray(em["data"], np.float32), dtype=torch.float32, device=dev).clone()
                 self._kind[key] = ("envmap", e, e)
         # reflectances and area-light radiances are differentiated by the diffuse path replay (mtsamd_render_adjoint): scenes of
-        # one-sided diffuse BSDFs lit by area lights only
-        diffuse_scene = all(b["type"] == 0 and not b["twosided"] for b in scene._bsdf_records) and \
+        # diffuse BSDFs (plain or inside `twosided`) lit by area lights only
+        diffuse_scene = all(b["type"] == 0 for b in scene._bsdf_records) and \
             all(em.get("type", "area") == "area" for em in emitters)
         for i, b in enumerate(scene._bsdf_records if diffuse_scene else []):
             if b["type"] != 0:            # only diffuse reflectances are exposed (the adjoint pass covers those)
                 continue
             name = b.get("id", "bsdf_%d" % i)
+            if b["twosided"]:             # TwoSidedBRDF::traverse exposes its nested BSDF as "brdf_0" (twosided.cpp:183-186)
+                name += ".brdf_0"
             refl = b["reflectance"]
             if isinstance(refl, dict) and refl.get("type") != "bitmap":
                 continue                  # procedural textures have no differentiable texels

@@ -314,6 +314,8 @@ static void gauss_legendre(int n, float *nodes, float *weights) {
 struct mtsamd_scene {
     int32_t environment = -1;        // index of the `constant` emitter
     bool general_bsdfs = false;      // any BSDF other than one-sided `diffuse`: the kernels with the BSDF switch are used
+    bool nested_bsdfs = false;       // blendbsdf / mask: the fused schedule (k_bounce*, k_direct) is the one that carries the nesting code
+    bool non_diffuse_bsdfs = false;  // any BSDF other than `diffuse` (one- or two-sided): what the adjoint path replay cannot differentiate
     bool delta_emitters = false;     // point / spot / directional emitters: handled by the same general kernels
     int device = 0;
     int cu_count = 256;
@@ -560,7 +562,9 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         d.type = desc->bsdfs[b].type; d.texture = desc->bsdfs[b].texture < 0 ? -1 : desc->bsdfs[b].texture;
         fill_bsdf_model(desc->bsdfs[b], d);
         if (d.type != kBsdfDiffuse || (d.flags & kBsdfTwoSided)) s->general_bsdfs = true;
+        if (d.type != kBsdfDiffuse) s->non_diffuse_bsdfs = true;
         if (d.type == kBsdfBlend || d.type == kBsdfMask) {
+            s->nested_bsdfs = true;
             // blendbsdf.cpp:57-79 / mask.cpp:67-91 over plain records of this table (one level of nesting)
             const mtsamd_bsdf_desc &bd = desc->bsdfs[b];
             const int n_child = d.type == kBsdfBlend ? 2 : 1;
@@ -849,7 +853,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     v.n_shapes = desc->mesh_count; v.n_bsdfs = desc->bsdf_count;
     v.textures = s->d_textures; v.n_textures = desc->texture_count;
     v.flat_recs = s->d_flat; v.flat = flat ? 1u : 0u;
-    v.general = (s->general_bsdfs || s->delta_emitters || s->environment >= 0) ? 1u : 0u;       // the diffuse / area-light fast path (kernels.hip) handles none of these
+    v.general = s->nested_bsdfs ? 2u : (s->general_bsdfs || s->delta_emitters || s->environment >= 0) ? 1u : 0u;       // the diffuse / area-light fast path (kernels.hip) handles none of these
     v.flat_pairs = s->d_pairs; v.n_pairs = n_pairs;
     if (bounce_lds_bytes(v) > 150 * 1024) {
         mtsamd_scene_destroy(s);
@@ -1095,7 +1099,7 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
 
     RenderParams p{};
     p.sv = j.s->view; p.cam = j.cam;
-    if (p.cam.aperture_radius > 0.0f) p.sv.general = 1u;      // thin lens: aperture sampling lives in the general kernels
+    if (p.cam.aperture_radius > 0.0f) p.sv.general = std::max(p.sv.general, 1u);      // thin lens: aperture sampling lives in the general kernels
     p.cursor = w.cursor; p.cursor_end = w.cursor_end; p.wave_stats = w.wave_stats;
     p.out_rgba = j.buf ? w.out_rgba2 : w.out_rgba; p.out_pos = j.buf ? w.out_pos2 : w.out_pos;
     p.count_shadow = w.count_shadow;
@@ -1367,6 +1371,9 @@ int setup_job(Job &j, mtsamd_scene *s, const mtsamd_render_desc *d, hipStream_t 
     j.split = d->integrator == 0 && (d->pipeline == 2 || (d->pipeline == 0 && !s->view.flat));
     j.shadow_queue = d->integrator == 0 && s->view.flat && d->pipeline == 3;
     j.shadow_ring = d->integrator == 0 && s->view.flat && (d->pipeline == 4 || d->pipeline == 0);
+    // scenes with a blendbsdf / mask run the fused schedule whatever was asked for: only its kernels carry the nesting code (inside the
+    // kernels of the other schedules, capped at 128 VGPRs, it cost every general scene up to 20 %)
+    if (s->nested_bsdfs) j.split = j.shadow_queue = j.shadow_ring = false;
     if ((d->pipeline == 3 || d->pipeline == 4) && !s->view.flat) return fail(MTSAMD_ERR_INVALID, "pipelines 3 and 4 (queued shadow rays) apply to LDS-resident scenes only");
     // Paths in flight.  A launch advances every in-flight path by one segment and ends with a tail in which the CUs run
     // dry one by one; the tails (and, for the split pipeline, the gaps between its three launches) only amortise over large
@@ -1590,7 +1597,7 @@ static int fill_adjoint(mtsamd_scene *s, const mtsamd_render_desc *d, const floa
     if (int rc = make_filter(d->rfilter, d->rfilter_param, d->rfilter_param2, d->rfilter_analytic, a.filter)) return rc;
     if (a.filter.taps > 8) return fail(MTSAMD_ERR_UNSUPPORTED, "reconstruction filter too wide for the adjoint pass");
     a.rp.sv = s->view;
-    if (a.rp.cam.aperture_radius > 0.0f) a.rp.sv.general = 1u;
+    if (a.rp.cam.aperture_radius > 0.0f) a.rp.sv.general = std::max(a.rp.sv.general, 1u);
     a.rp.base_seed = d->seed; a.rp.spp = d->sample_count;
     a.rp.crop_x = d->crop_x; a.rp.crop_y = d->crop_y; a.rp.crop_w = d->crop_width; a.rp.crop_h = d->crop_height;
     a.rp.max_depth = d->max_depth; a.rp.rr_depth = d->rr_depth;
@@ -1607,7 +1614,7 @@ int mtsamd_render_adjoint(mtsamd_scene *s, const mtsamd_render_desc *d, const fl
     if (int rc = fill_adjoint(s, d, dimage, film, a)) return rc;
     if (d->max_depth < 0 || d->max_depth > 16)
         return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass needs a finite max_depth <= 16 (got %d)", d->max_depth);
-    if (s->general_bsdfs) return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass is implemented for one-sided diffuse BSDFs only");
+    if (s->non_diffuse_bsdfs) return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass is implemented for diffuse BSDFs (one- or two-sided) only");
     if (s->environment >= 0 || s->delta_emitters) return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass handles area emitters only");
     if (s->bsdfs.size() > 32 && grad_bsdf) return fail(MTSAMD_ERR_UNSUPPORTED, "at most 32 BSDFs with constant-reflectance gradients");
     if (s->emitters.size() > 32 && grad_emitter) return fail(MTSAMD_ERR_UNSUPPORTED, "at most 32 emitters with radiance gradients");
@@ -1622,6 +1629,7 @@ int mtsamd_render_adjoint_envmap(mtsamd_scene *s, const mtsamd_render_desc *d, c
     if (int rc = fill_adjoint(s, d, dimage, film, a)) return rc;
     if (!grad_envmap) return fail(MTSAMD_ERR_INVALID, "null argument");
     if (s->environment < 0 || !s->d_envmap) return fail(MTSAMD_ERR_UNSUPPORTED, "the scene has no envmap emitter");
+    if (s->nested_bsdfs) return fail(MTSAMD_ERR_UNSUPPORTED, "the envmap adjoint does not handle blendbsdf / mask materials");
     if (d->integrator != 0) return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass differentiates the path integrator");
     a.grad_env = grad_envmap;
     HIP_TRY(launch_adjoint_env(a, (hipStream_t) stream_));

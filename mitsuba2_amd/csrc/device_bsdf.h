@@ -553,39 +553,53 @@ MTS_DEV float rough_reflectance(const Mdf &d, f3 wi, float eta, int res, const f
 // is instantiated once.  `table(i)` returns record i of the scene's BSDF table, `chan_of(rec)` the per-channel inputs of a child
 // (its own constant parameters); `c` are the inputs of `b` -- for a blend / mask c.refl[0..2] carries what Texture::eval_1 of the
 // weight / opacity reads (the constant, or the texture lookup).
-template <int N>
-MTS_DEV float nest_weight(const DevBsdf &b, const BsdfChannels<N> &c) {
-    float w = c.refl[0];
-    if (b.flags & kBsdfWeightLum) w = fmaf(0.072169f, c.refl[2], fmaf(0.715160f, c.refl[1], 0.212671f * c.refl[0]));      // luminance (spectrum.h:239-241)
-    return fminf(fmaxf(w, 0.0f), 1.0f);
+// What the entry points below keep of a blend / mask record; kind = 0: a plain BSDF.  The record variable of the caller is working
+// storage: for a nest it is overwritten with the child that is evaluated / sampled, so only ONE 128-byte record is ever live (two of
+// them -- parent and child -- cost the general kernels 200+ bytes of scratch per lane and 20 % of their speed).  NEST = false compiles
+// all of it out: only the kernels of the schedule that scenes with a blend / mask run (k_bounce*, k_direct) carry the nesting code.
+struct NestInfo { int kind; uint32_t n0, n1; float w; bool two; };
+// `value` = what Texture::eval_1 of the weight / opacity reads: the constant, or the texture lookup (first three channels)
+template <bool NEST>
+MTS_DEV NestInfo nest_info(const DevBsdf &b, float v0, float v1, float v2) {
+    NestInfo ni = { 0, 0u, 0u, 1.0f, false };
+    if (NEST && b.type >= kBsdfBlend) {
+        float w = v0;
+        if (b.flags & kBsdfWeightLum) w = fmaf(0.072169f, v2, fmaf(0.715160f, v1, 0.212671f * v0));      // luminance (spectrum.h:239-241)
+        ni.kind = b.type; ni.n0 = b.nested0; ni.n1 = b.nested1; ni.two = (b.flags & kBsdfTwoSided) != 0u;
+        ni.w = fminf(fmaxf(w, 0.0f), 1.0f);                  // blendbsdf.cpp:177-179, mask.cpp:170-172
+    }
+    return ni;
 }
-template <int N, typename Table, typename ChanOf>
-MTS_DEV bool surface_bsdf_sample(const DevBsdf &b, const BsdfChannels<N> &c, const Table &table, const ChanOf &chan_of, f3 wi, float sample1,
+// `table(i)` returns record i of the scene's BSDF table; `chan_of(rec, child)` the per-channel inputs of the record that is used: the
+// caller's own (child = false) or those of a child record (its constant parameters).
+template <bool NEST, int N, typename Table, typename ChanOf>
+MTS_DEV bool surface_bsdf_sample(DevBsdf &cur, const NestInfo &ni, const Table &table, const ChanOf &chan_of, f3 wi, float sample1,
                                  f2 sample2, BsdfSample &bs, float (&weight)[N]) {
-    if (b.type < kBsdfBlend) return bsdf_sample_n<N>(b, c, wi, sample1, sample2, bs, weight);
-    bs.wo = mk3(0.0f, 0.0f, 0.0f); bs.pdf = 0.0f; bs.eta = 0.0f; bs.delta = false;
+    float s1 = sample1;
+    bool model = true, flip = false;
+    if (NEST && ni.kind != 0) {
+        bs.wo = mk3(0.0f, 0.0f, 0.0f); bs.pdf = 0.0f; bs.eta = 0.0f; bs.delta = false;
 #pragma unroll
-    for (int i = 0; i < N; ++i) weight[i] = 0.0f;
-    const bool two = (b.flags & kBsdfTwoSided) != 0u;       // twosided.cpp:94-123 around the whole nest
-    if (two && wi.z == 0.0f) return false;
-    const bool flip = two && wi.z < 0.0f;
-    if (flip) wi.z = -wi.z;
-    const float w = nest_weight<N>(b, c);
-    uint32_t child = b.nested0; float s1 = sample1; bool nested = true;
-    if (b.type == kBsdfBlend) {
-        if (sample1 > w) s1 = (sample1 - w) / (1.0f - w);
-        else if (sample1 <= w) { child = b.nested1; s1 = sample1 / w; }
-        else nested = false;                                 // NaN sample: neither mask of blendbsdf.cpp:108-109
-    } else {
-        nested = sample1 < w;
-        s1 = sample1 / w;
+        for (int i = 0; i < N; ++i) weight[i] = 0.0f;
+        if (ni.two && wi.z == 0.0f) return false;            // twosided.cpp:94-123 around the whole nest
+        flip = ni.two && wi.z < 0.0f;
+        if (flip) wi.z = -wi.z;
+        const float w = ni.w;
+        uint32_t child = ni.n0;
+        if (ni.kind == kBsdfBlend) {
+            if (sample1 > w) s1 = (sample1 - w) / (1.0f - w);
+            else if (sample1 <= w) { child = ni.n1; s1 = sample1 / w; }
+            else model = false;                              // NaN sample: neither mask of blendbsdf.cpp:108-109
+        } else {
+            model = sample1 < w;
+            s1 = sample1 / w;
+        }
+        if (model) cur = table(child);
     }
     bool ok = false;
-    if (nested) {
-        const DevBsdf rec = table(child);
-        ok = bsdf_sample_n<N>(rec, chan_of(rec), wi, s1, sample2, bs, weight);
-    } else if (b.type == kBsdfMask) {                        // the null lobe: straight through (mask.cpp:116-121); Null is part of Delta
-        bs.wo = mk3(-wi.x, -wi.y, -wi.z); bs.eta = 1.0f; bs.pdf = 1.0f - w; bs.delta = true;
+    if (model) ok = bsdf_sample_n<N>(cur, chan_of(cur, NEST && ni.kind != 0), wi, s1, sample2, bs, weight);      // the one call site of the model code
+    else if (NEST && ni.kind == kBsdfMask) {                 // the null lobe: straight through (mask.cpp:116-121); Null is part of Delta
+        bs.wo = mk3(-wi.x, -wi.y, -wi.z); bs.eta = 1.0f; bs.pdf = 1.0f - ni.w; bs.delta = true;
 #pragma unroll
         for (int i = 0; i < N; ++i) weight[i] = 1.0f;
         ok = true;
@@ -593,28 +607,37 @@ MTS_DEV bool surface_bsdf_sample(const DevBsdf &b, const BsdfChannels<N> &c, con
     if (flip) bs.wo.z = -bs.wo.z;
     return ok;
 }
-template <int N, typename Table, typename ChanOf>
-MTS_DEV void surface_bsdf_eval_pdf(const DevBsdf &b, const BsdfChannels<N> &c, const Table &table, const ChanOf &chan_of, f3 wi, f3 wo,
+template <bool NEST, int N, typename Table, typename ChanOf>
+MTS_DEV void surface_bsdf_eval_pdf(DevBsdf &cur, const NestInfo &ni, const Table &table, const ChanOf &chan_of, f3 wi, f3 wo,
                                    float (&value)[N], float &pdf) {
-    if (b.type < kBsdfBlend) { bsdf_eval_pdf_n<N>(b, c, wi, wo, value, pdf); return; }
+    const bool nest = NEST && ni.kind != 0, blend = nest && ni.kind == kBsdfBlend;
+    const float w = ni.w;
+    if (nest) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) value[i] = 0.0f;
-    pdf = 0.0f;
-    if (b.flags & kBsdfTwoSided) {
-        if (wi.z == 0.0f) return;
-        if (wi.z < 0.0f) { wi.z = -wi.z; wo.z = -wo.z; }
+        for (int i = 0; i < N; ++i) value[i] = 0.0f;
+        pdf = 0.0f;
+        if (ni.two) {
+            if (wi.z == 0.0f) return;
+            if (wi.z < 0.0f) { wi.z = -wi.z; wo.z = -wo.z; }
+        }
     }
-    const float w = nest_weight<N>(b, c);
-    const bool blend = b.type == kBsdfBlend;
     float v0[N], p0 = 0.0f;
 #pragma unroll
     for (int i = 0; i < N; ++i) v0[i] = 0.0f;
 #pragma unroll 1
-    for (uint32_t k = 0; k < (blend ? 2u : 1u); ++k) {      // one instance of the model code for both children
-        const DevBsdf rec = table(k == 0u ? b.nested0 : b.nested1);
+    for (uint32_t k = 0; k < (blend ? 2u : 1u); ++k) {      // one call site of the model code: the record itself, or its children in turn
+        if (nest) cur = table(k == 0u ? ni.n0 : ni.n1);
         float v[N], p;
-        bsdf_eval_pdf_n<N>(rec, chan_of(rec), wi, wo, v, p);
-        if (k == 0u) {
+        bsdf_eval_pdf_n<N>(cur, chan_of(cur, nest), wi, wo, v, p);
+        if (!nest) {                                         // plain BSDF: unchanged values
+#pragma unroll
+            for (int i = 0; i < N; ++i) value[i] = v[i];
+            pdf = p;
+        } else if (!blend) {                                 // mask.cpp:133-159
+#pragma unroll
+            for (int i = 0; i < N; ++i) value[i] = v[i] * w;
+            pdf = p * w;
+        } else if (k == 0u) {
 #pragma unroll
             for (int i = 0; i < N; ++i) v0[i] = v[i];
             p0 = p;
@@ -624,27 +647,22 @@ MTS_DEV void surface_bsdf_eval_pdf(const DevBsdf &b, const BsdfChannels<N> &c, c
             pdf = fmaf(p, w, p0 * (1.0f - w));
         }
     }
-    if (!blend) {                                            // mask.cpp:133-159
-#pragma unroll
-        for (int i = 0; i < N; ++i) value[i] = v0[i] * w;
-        pdf = p0 * w;
-    }
 }
 
 // RGB variant
-template <typename Table>
-MTS_DEV bool surface_bsdf_sample(const DevBsdf &b, f3 refl, const Table &table, f3 wi, float sample1, f2 sample2, BsdfSample &bs, f3 &weight) {
+template <bool NEST, typename Table>
+MTS_DEV bool surface_bsdf_sample(DevBsdf &cur, const NestInfo &ni, f3 refl, const Table &table, f3 wi, float sample1, f2 sample2, BsdfSample &bs, f3 &weight) {
     float w[3];
-    auto chan_of = [](const DevBsdf &rec) { return rgb_channels(rec, mk3(rec.r, rec.g, rec.b)); };
-    const bool ok = surface_bsdf_sample<3>(b, rgb_channels(b, refl), table, chan_of, wi, sample1, sample2, bs, w);
+    auto chan_of = [&](const DevBsdf &rec, bool child) { return rgb_channels(rec, child ? mk3(rec.r, rec.g, rec.b) : refl); };
+    const bool ok = surface_bsdf_sample<NEST, 3>(cur, ni, table, chan_of, wi, sample1, sample2, bs, w);
     weight = mk3(w[0], w[1], w[2]);
     return ok;
 }
-template <typename Table>
-MTS_DEV void surface_bsdf_eval_pdf(const DevBsdf &b, f3 refl, const Table &table, f3 wi, f3 wo, f3 &value, float &pdf) {
+template <bool NEST, typename Table>
+MTS_DEV void surface_bsdf_eval_pdf(DevBsdf &cur, const NestInfo &ni, f3 refl, const Table &table, f3 wi, f3 wo, f3 &value, float &pdf) {
     float v[3];
-    auto chan_of = [](const DevBsdf &rec) { return rgb_channels(rec, mk3(rec.r, rec.g, rec.b)); };
-    surface_bsdf_eval_pdf<3>(b, rgb_channels(b, refl), table, chan_of, wi, wo, v, pdf);
+    auto chan_of = [&](const DevBsdf &rec, bool child) { return rgb_channels(rec, child ? mk3(rec.r, rec.g, rec.b) : refl); };
+    surface_bsdf_eval_pdf<NEST, 3>(cur, ni, table, chan_of, wi, wo, v, pdf);
     value = mk3(v[0], v[1], v[2]);
 }
 MTS_DEV bool bsdf_sample(const DevBsdf &b, f3 refl, f3 wi, float sample1, f2 sample2, BsdfSample &bs, f3 &weight) {

@@ -97,11 +97,12 @@ MTS_DEV void env_grad_add(const DevEnvmap &e, float u, float v, f3 coeff, const 
     }
 }
 
-template <bool FLAT, bool REC = false, int DEFER = 0, bool GENERAL = false, bool ENVGRAD = false>
+template <bool FLAT, bool REC = false, int DEFER = 0, bool GENERAL = false, bool ENVGRAD = false, bool NEST = false>
 MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s, Counters &c, VertexRec *rec = nullptr,
                          Deferred *df = nullptr, const EnvGradCtx *eg = nullptr) {
     static_assert(!(REC && GENERAL), "the adjoint replay handles diffuse BSDFs only");
     static_assert(!ENVGRAD || (GENERAL && DEFER == 0), "the envmap gradient rides on the general fused step");
+    static_assert(!NEST || (GENERAL && DEFER == 0 && !ENVGRAD), "blendbsdf / mask run the general fused step");
     const SceneView &sv = P.sv;
     if (REC) {
         rec->E = rec->Nc = rec->Tp = rec->rho = mk3(0.0f, 0.0f, 0.0f);
@@ -166,13 +167,20 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
     }
     if (s.depth >= (uint32_t) P.max_depth || !active) return false;
 
-    const DevBsdf bsdf = geo.bsdf((uint32_t) si.shape_rec.bsdf);
+    DevBsdf bsdf = geo.bsdf((uint32_t) si.shape_rec.bsdf);      // blend / mask: overwritten with the child in use (surface_bsdf_*)
     uint32_t texel; f2 tw1;
     const f3 refl = eval_reflectance(sv, bsdf, si.uv, texel, tw1);
+    const NestInfo ni = nest_info<NEST>(bsdf, refl.x, refl.y, refl.z);
+    const bool smooth = !GENERAL || bsdf_is_smooth(bsdf);
     if (REC) { rec->Tp = s.thr; rec->rho = refl; rec->texel = texel; rec->w1 = tw1; rec->bsdf = si.shape_rec.bsdf; rec->has_bsdf = 1u; }
+    // adjoint replay of a `twosided` diffuse BSDF (twosided.cpp:94-175; the primal render of such a scene runs the GENERAL kernels, whose
+    // diffuse branch does the same arithmetic): the back side scatters like the front side, mirrored
+    f3 wi_b = si.wi;
+    const bool flip = REC && (bsdf.flags & kBsdfTwoSided) != 0u && wi_b.z < 0.0f;
+    if (flip) wi_b.z = -wi_b.z;
 
     // --------------------- Emitter sampling (path.cpp:153-172) ---------------------
-    if (!GENERAL || bsdf_is_smooth(bsdf)) {                  // active_e: only BSDFs with a smooth component (path.cpp:154)
+    if (smooth) {                                            // active_e: only BSDFs with a smooth component (path.cpp:154)
         f2 s2; s2.x = pcg_next_f32(s.rng); s2.y = pcg_next_f32(s.rng);
         DirectionSample ds; f3 spec;
         float em_geo = 0.0f;                                 // REC: spec / radiance of an area light
@@ -202,8 +210,8 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
         if (ds.pdf != 0.0f) {
             f3 wo = to_local(si.sh, ds.d);
             f3 bv; float bp;
-            if (GENERAL) surface_bsdf_eval_pdf(bsdf, refl, [&](uint32_t i) { return geo.bsdf(i); }, si.wi, wo, bv, bp);
-            else diffuse_eval_pdf(refl, si.wi, wo, bv, bp);
+            if (GENERAL) surface_bsdf_eval_pdf<NEST>(bsdf, ni, refl, [&](uint32_t i) { return geo.bsdf(i); }, si.wi, wo, bv, bp);
+            else diffuse_eval_pdf(refl, wi_b, flip ? mk3(wo.x, wo.y, -wo.z) : wo, bv, bp);
             float mis = (GENERAL && ds.delta) ? 1.0f : mis_weight(ds.pdf, bp);      // path.cpp:170
             f3 contrib = mk3(((mis * s.thr.x) * bv.x) * spec.x, ((mis * s.thr.y) * bv.y) * spec.y,
                              ((mis * s.thr.z) * bv.z) * spec.z);
@@ -230,8 +238,9 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
                     if (ENVGRAD && em_geo != 0.0f)
                         env_grad_add(*sv.envmap, ds.uv.x, ds.uv.y, mk3(((mis * s.thr.x) * bv.x) * em_geo, ((mis * s.thr.y) * bv.y) * em_geo,
                                                                          ((mis * s.thr.z) * bv.z) * em_geo), *eg);
-                    if (REC && si.wi.z > 0.0f && wo.z > 0.0f) {     // d(contrib)/d(rho) / T'_k
-                        float k = mis * (kInvPi * wo.z);
+                    const float wo_bz = flip ? -wo.z : wo.z;      // the BSDF's side of the surface (twosided)
+                    if (REC && wi_b.z > 0.0f && wo_bz > 0.0f) {     // d(contrib)/d(rho) / T'_k
+                        float k = mis * (kInvPi * wo_bz);
                         rec->Nc = mk3(k * spec.x, k * spec.y, k * spec.z);
                         if (em_geo != 0.0f) { rec->nk = k * em_geo; rec->em_nee = (int32_t) ds.emitter; }
                     }
@@ -246,12 +255,13 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
     f3 wo, weight; float pdf;
     if (GENERAL) {
         BsdfSample bs;
-        surface_bsdf_sample(bsdf, refl, [&](uint32_t i) { return geo.bsdf(i); }, si.wi, s1, s2, bs, weight);
+        surface_bsdf_sample<NEST>(bsdf, ni, refl, [&](uint32_t i) { return geo.bsdf(i); }, si.wi, s1, s2, bs, weight);
         wo = bs.wo; pdf = bs.pdf;
         s.eta *= bs.eta;                                     // harmless for a failed sample: the path ends below
         s.flags = bs.delta ? (s.flags | kFlagDelta) : (s.flags & ~kFlagDelta);
     } else {
-        diffuse_sample(refl, si.wi, s2, wo, pdf, weight);    // eta *= bs.eta (== 1)
+        diffuse_sample(refl, wi_b, s2, wo, pdf, weight);     // eta *= bs.eta (== 1)
+        if (flip) wo.z = -wo.z;
     }
     s.thr = mk3(s.thr.x * weight.x, s.thr.y * weight.y, s.thr.z * weight.z);
     if (!(s.thr.x != 0.0f || s.thr.y != 0.0f || s.thr.z != 0.0f)) return false;
@@ -322,7 +332,7 @@ MTS_DEV void cursor_sample(const RenderParams &P, uint32_t wave, uint64_t v, uin
 #ifndef MTS_BOUNCE_WAVES
 #define MTS_BOUNCE_WAVES 4
 #endif
-template <bool FLAT, bool GENERAL>
+template <bool FLAT, bool GENERAL, bool NEST = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MTS_BOUNCE_WAVES, MTS_BOUNCE_WAVES)))
 void k_bounce(const RenderParams P) {
     extern __shared__ float4 smem[];
@@ -347,7 +357,7 @@ void k_bounce(const RenderParams P) {
         bool alive = false;
         if (i0 + lane < n_in) {
             load_state(P.in, base + i0 + lane, s);
-            alive = bounce_step<FLAT, false, false, GENERAL>(P, lds, s, c);
+            alive = bounce_step<FLAT, false, 0, GENERAL, false, NEST>(P, lds, s, c);
             if (!alive) store_result(P, s);
         }
         // wavefront ballot + prefix rank: compact the survivors to the front of the output segment
@@ -512,7 +522,7 @@ MTS_DEV Spec4 emitter_spectrum(const SceneView &sv, const DevEmitter &e, const S
     return r;
 }
 
-template <bool FLAT, int DEFER = 0, bool GENERAL = false>
+template <bool FLAT, int DEFER = 0, bool GENERAL = false, bool NEST = false>
 MTS_DEV bool bounce_step_spectral(const RenderParams &P, const LdsView &lds, PathStateS &s, Counters &c, Deferred *df = nullptr) {
     const SceneView &sv = P.sv;
     const Geo<FLAT> geo{ sv, lds };
@@ -569,7 +579,7 @@ MTS_DEV bool bounce_step_spectral(const RenderParams &P, const LdsView &lds, Pat
     }
     if (s.depth >= (uint32_t) P.max_depth || !active) return false;
 
-    const DevBsdf bsdf = geo.bsdf((uint32_t) si.shape_rec.bsdf);
+    DevBsdf bsdf = geo.bsdf((uint32_t) si.shape_rec.bsdf);      // blend / mask: overwritten with the child in use (surface_bsdf_*)
     Spec4 refl;
 #pragma unroll
     for (int k = 0; k < kWav; ++k)       // srgb.cpp:45-52 / uniform.cpp
@@ -582,9 +592,12 @@ MTS_DEV bool bounce_step_spectral(const RenderParams &P, const LdsView &lds, Pat
         for (int k = 0; k < kWav; ++k) chan.refl[k] = refl.v[k];
     }
     // blend / mask: per-wavelength inputs of a child record (its own constant parameters)
-    auto child_chan = [&](const DevBsdf &rec) { return spectral_channels(rec, s.wav); };
+    // a scalar weight in the spectral variant is a constant (a textured one is refused at scene creation)
+    const NestInfo ni = nest_info<NEST>(bsdf, refl.v[0], refl.v[1], refl.v[2]);
+    const bool smooth = !GENERAL || bsdf_is_smooth(bsdf);
+    auto chan_of = [&](const DevBsdf &rec, bool child) { return child ? spectral_channels(rec, s.wav) : chan; };
 
-    if (!GENERAL || bsdf_is_smooth(bsdf)) {
+    if (smooth) {
         f2 s2; s2.x = pcg_next_f32(s.rng); s2.y = pcg_next_f32(s.rng);
         DirectionSample ds; float r1, r2;
         sample_emitter_direction<FLAT, GENERAL>(geo, si.p, s2, ds, r1, r2);
@@ -594,7 +607,7 @@ MTS_DEV bool bounce_step_spectral(const RenderParams &P, const LdsView &lds, Pat
             bool front = si.wi.z > 0.0f && wo.z > 0.0f;
             float bp = front ? kInvPi * wo.z : 0.0f;
             float bvs[kWav];
-            if (GENERAL) surface_bsdf_eval_pdf<kWav>(bsdf, chan, [&](uint32_t i) { return geo.bsdf(i); }, child_chan, si.wi, wo, bvs, bp);
+            if (GENERAL) surface_bsdf_eval_pdf<NEST, kWav>(bsdf, ni, [&](uint32_t i) { return geo.bsdf(i); }, chan_of, si.wi, wo, bvs, bp);
             float mis = (GENERAL && ds.delta) ? 1.0f : mis_weight(ds.pdf, bp);
             Spec4 contrib; bool nz = false;
             const Spec4 le4 = emitter_spectrum(sv, e, s.wav, ds.uv);
@@ -634,7 +647,7 @@ MTS_DEV bool bounce_step_spectral(const RenderParams &P, const LdsView &lds, Pat
     bool nz = false;
     if (GENERAL) {
         BsdfSample bs; float w[kWav];
-        surface_bsdf_sample<kWav>(bsdf, chan, [&](uint32_t i) { return geo.bsdf(i); }, child_chan, si.wi, s1, s2, bs, w);
+        surface_bsdf_sample<NEST, kWav>(bsdf, ni, [&](uint32_t i) { return geo.bsdf(i); }, chan_of, si.wi, s1, s2, bs, w);
         wo = bs.wo; pdf = bs.pdf;
         s.eta *= bs.eta;
         s.flags = bs.delta ? (s.flags | kFlagDelta) : (s.flags & ~kFlagDelta);
@@ -691,7 +704,7 @@ MTS_DEV void store_result_spectral(const RenderParams &P, const PathStateS &s) {
     P.out_rgba[s.ordinal] = make_float4(xyz.x, xyz.y, xyz.z, (valid || !P.store_xyz) ? alpha : -1.0f);
 }
 
-template <bool FLAT, bool GENERAL>
+template <bool FLAT, bool GENERAL, bool NEST = false>
 __global__ __launch_bounds__(kBlock) void k_bounce_spectral(const RenderParams P) {
     extern __shared__ float4 smem[];
     const LdsView lds = lds_stage<FLAT>(P.sv, smem);
@@ -707,7 +720,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce_spectral(const RenderParams P
         bool alive = false;
         if (i0 + lane < n_in) {
             load_state(P.in, base + i0 + lane, s);
-            alive = bounce_step_spectral<FLAT, false, GENERAL>(P, lds, s, c);
+            alive = bounce_step_spectral<FLAT, 0, GENERAL, NEST>(P, lds, s, c);
             if (!alive) store_result_spectral(P, s);
         }
         const uint64_t m = __ballot(alive);
@@ -744,7 +757,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce_spectral(const RenderParams P
 // ---------------------------------------------------------------------------------------------
 // `direct` (src/integrators/direct.cpp:105-196) and `depth` (depth.cpp:19-33): no path state survives a sample, so one
 // thread carries a camera sample from the sensor to its result.
-template <bool FLAT, bool GENERAL>
+template <bool FLAT, bool GENERAL, bool NEST = false>
 __global__ __launch_bounds__(kBlock) void k_direct(const RenderParams P, uint64_t n) {
     extern __shared__ float4 smem[];
     const LdsView lds = lds_stage<FLAT>(P.sv, smem);
@@ -782,9 +795,10 @@ __global__ __launch_bounds__(kBlock) void k_direct(const RenderParams P, uint64_
                 const DevEmitter e = geo.emitter((uint32_t) si.shape_rec.emitter);
                 s.res = mk3(s.res.x + e.r, s.res.y + e.g, s.res.z + e.b);
             }
-            const DevBsdf bsdf = geo.bsdf((uint32_t) si.shape_rec.bsdf);
+            DevBsdf bsdf = geo.bsdf((uint32_t) si.shape_rec.bsdf);      // blend / mask: overwritten with the child in use (surface_bsdf_*)
             uint32_t texel; f2 tw1;
             const f3 refl = eval_reflectance(sv, bsdf, si.uv, texel, tw1);
+            const NestInfo ni = nest_info<NEST>(bsdf, refl.x, refl.y, refl.z);
             if (!GENERAL || bsdf_is_smooth(bsdf)) {
                 for (int32_t i = 0; i < ne; ++i) {
                     f2 s2; s2.x = pcg_next_f32(s.rng); s2.y = pcg_next_f32(s.rng);
@@ -793,7 +807,7 @@ __global__ __launch_bounds__(kBlock) void k_direct(const RenderParams P, uint64_
                     if (ds.pdf == 0.0f) continue;
                     const f3 wo = to_local(si.sh, ds.d);
                     f3 bv; float bp;
-                    if (GENERAL) surface_bsdf_eval_pdf(bsdf, refl, [&](uint32_t i) { return geo.bsdf(i); }, si.wi, wo, bv, bp);
+                    if (GENERAL) surface_bsdf_eval_pdf<NEST>(bsdf, ni, refl, [&](uint32_t i) { return geo.bsdf(i); }, si.wi, wo, bv, bp);
                     else diffuse_eval_pdf(refl, si.wi, wo, bv, bp);
                     const float mis = (GENERAL && ds.delta) ? 1.0f : mis_weight(ds.pdf * frac_lum, bp * frac_bsdf) * weight_lum;      // direct.cpp:155-156
                     const f3 contrib = mk3((mis * bv.x) * spec.x, (mis * bv.y) * spec.y, (mis * bv.z) * spec.z);
@@ -812,7 +826,7 @@ __global__ __launch_bounds__(kBlock) void k_direct(const RenderParams P, uint64_
                 f3 wo, weight; float pdf; bool delta = false;
                 if (GENERAL) {
                     BsdfSample bs;
-                    surface_bsdf_sample(bsdf, refl, [&](uint32_t i) { return geo.bsdf(i); }, si.wi, s1, s2, bs, weight);
+                    surface_bsdf_sample<NEST>(bsdf, ni, refl, [&](uint32_t i) { return geo.bsdf(i); }, si.wi, s1, s2, bs, weight);
                     wo = bs.wo; pdf = bs.pdf; delta = bs.delta;
                 } else {
                     diffuse_sample(refl, si.wi, s2, wo, pdf, weight);
@@ -857,7 +871,10 @@ __global__ __launch_bounds__(kBlock) void k_direct(const RenderParams P, uint64_
 hipError_t launch_direct(const RenderParams &p, uint64_t n, hipStream_t s) {
     const uint32_t blocks = (uint32_t) ((n + kBlock - 1) / kBlock);
     const size_t lds = bounce_lds_bytes(p.sv);
-    if (p.sv.general) {
+    if (p.sv.general == 2u) {      // scenes with blendbsdf / mask
+        if (p.sv.flat) hipLaunchKernelGGL((k_direct<true, true, true>), dim3(blocks), dim3(kBlock), lds, s, p, n);
+        else hipLaunchKernelGGL((k_direct<false, true, true>), dim3(blocks), dim3(kBlock), lds, s, p, n);
+    } else if (p.sv.general) {
         if (p.sv.flat) hipLaunchKernelGGL((k_direct<true, true>), dim3(blocks), dim3(kBlock), lds, s, p, n);
         else hipLaunchKernelGGL((k_direct<false, true>), dim3(blocks), dim3(kBlock), lds, s, p, n);
     } else {
@@ -1469,7 +1486,10 @@ hipError_t launch_bounce(const RenderParams &p_, hipStream_t s) {
     }
     uint32_t blocks = (p.n_waves * 64u + kBlock - 1) / kBlock;
     if (p.spectral) {
-        if (p.sv.general) {
+        if (p.sv.general == 2u) {
+            if (p.sv.flat) hipLaunchKernelGGL((k_bounce_spectral<true, true, true>), dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);
+            else hipLaunchKernelGGL((k_bounce_spectral<false, true, true>), dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);
+        } else if (p.sv.general) {
             if (p.sv.flat) hipLaunchKernelGGL((k_bounce_spectral<true, true>), dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);
             else hipLaunchKernelGGL((k_bounce_spectral<false, true>), dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);
         } else {
@@ -1478,7 +1498,10 @@ hipError_t launch_bounce(const RenderParams &p_, hipStream_t s) {
         }
         return hipGetLastError();
     }
-    if (p.sv.general) {
+    if (p.sv.general == 2u) {
+        if (p.sv.flat) hipLaunchKernelGGL((k_bounce<true, true, true>), dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);
+        else hipLaunchKernelGGL((k_bounce<false, true, true>), dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);
+    } else if (p.sv.general) {
         if (p.sv.flat) hipLaunchKernelGGL((k_bounce<true, true>), dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);
         else hipLaunchKernelGGL((k_bounce<false, true>), dim3(blocks), dim3(kBlock), bounce_lds_bytes(p.sv), s, p);
     } else {

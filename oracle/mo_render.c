@@ -1131,6 +1131,10 @@ static int path_sample_rec(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_i
         float refl[3];
         mo_reflectance(s, mesh, si.uv, refl, &r->texel, r->w1);
         r->has_bsdf = 1; r->shape = si.shape;
+        /* `twosided` around the diffuse BSDF (twosided.cpp:94-175): the back side scatters like the front side, mirrored */
+        mo_v3 wi_b = si.wi;
+        const int flip = mesh->bsdf.d.twosided && wi_b.z < 0.0f;
+        if (flip) wi_b.z = -wi_b.z;
         for (int k = 0; k < 3; ++k) { r->Tp[k] = throughput[k]; r->rho[k] = refl[k]; }
         {
             mo_v2 s2; s2.x = mo_pcg32_next_f32(rng); s2.y = mo_pcg32_next_f32(rng);
@@ -1144,7 +1148,8 @@ static int path_sample_rec(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_i
                 const int occluded = mo_intersect(s, &sr, 1, 0, NULL);
                 if (occluded) emitter_val[0] = emitter_val[1] = emitter_val[2] = 0.0f;
                 mo_v3 wo = mo_to_local(&si.sh, ds.d);
-                if (si.wi.z > 0.0f && wo.z > 0.0f) {
+                if (flip) wo.z = -wo.z;
+                if (wi_b.z > 0.0f && wo.z > 0.0f) {
                     float bsdf_pdf = mo_square_to_cosine_hemisphere_pdf(wo);
                     float k = (ds.delta ? 1.0f : mis_weight(ds.pdf, bsdf_pdf)) * (MO_INV_PI * wo.z);
                     for (int c = 0; c < 3; ++c) r->Nc[c] = k * emitter_val[c];
@@ -1159,7 +1164,8 @@ static int path_sample_rec(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_i
         float s1 = mo_pcg32_next_f32(rng); (void) s1;
         mo_v2 s2; s2.x = mo_pcg32_next_f32(rng); s2.y = mo_pcg32_next_f32(rng);
         mo_v3 bs_wo; float bs_pdf, bsdf_w[3];
-        mo_diffuse_sample(refl, si.wi, s2, &bs_wo, &bs_pdf, bsdf_w);
+        mo_diffuse_sample(refl, wi_b, s2, &bs_wo, &bs_pdf, bsdf_w);
+        if (flip) bs_wo.z = -bs_wo.z;
         for (int k = 0; k < 3; ++k) throughput[k] = throughput[k] * bsdf_w[k];
         active = active && (throughput[0] != 0.0f || throughput[1] != 0.0f || throughput[2] != 0.0f);
         if (!active) break;
@@ -1227,6 +1233,8 @@ static void adjoint_sample(const mo_render_desc *d, const camera *cam, const rfi
 int mo_render_adjoint(const mo_scene *s, const mo_render_desc *d, const float *dimage, const float *film,
                       float *grad_shape, float *grad_tex, float *grad_emitter) {
     if (desc_check(d) || d->max_depth < 0 || d->max_depth > MO_ADJ_MAX_DEPTH) return -1;
+    for (uint32_t m = 0; m < s->n_meshes; ++m)          /* the path replay knows `diffuse` (one- or two-sided) only */
+        if (s->meshes[m].bsdf_kind != MO_BSDF_DIFFUSE || s->meshes[m].bsdf.nest) return -2;
     camera cam; camera_init(d, &cam);
     rfilter f; rfilter_init(&f, d->rfilter, d->rfilter_param, d->rfilter_param2);
     uint32_t taps = (uint32_t) ceilf((f.radius - 2.0f * MO_RAY_EPSILON) * 2.0f);

@@ -8,7 +8,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB_PATH = os.path.join(ORACLE_DIR, "libmts_oracle.so")
+LIB_PATH = os.environ.get("MTS_ORACLE_LIB", os.path.join(ORACLE_DIR, "libmts_oracle.so"))   # override: sanitizer builds of the oracle
 
 f32p = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)

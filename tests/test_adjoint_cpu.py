@@ -147,3 +147,50 @@ def test_adjoint_argument_checks(oracle):
     desc.max_depth = -1
     with pytest.raises(RuntimeError):
         S.render_adjoint(desc, np.zeros_like(image), film, len(sd["meshes"]), tex.size)
+
+
+def _twosided_cbox(tex=None):
+    """Cornell box whose red wall is wound the other way (every hit on it is a back-face hit) with all diffuse BSDFs inside `twosided`"""
+    sd = scenes.cornell_box(texture=tex)
+    sd["bsdfs"] = [dict(type="twosided", id=b.get("id", "b%d" % i), bsdf=dict(b, id="inner%d" % i)) if b.get("type", "diffuse") == "diffuse" else b
+                   for i, b in enumerate(sd["bsdfs"])]
+    wall = next(i for i, m in enumerate(sd["meshes"]) if m["bsdf"] == 1)
+    sd["meshes"][wall] = dict(sd["meshes"][wall], faces=np.ascontiguousarray(np.asarray(sd["meshes"][wall]["faces"]).reshape(-1, 3)[:, ::-1]))
+    return sd, wall
+
+
+def test_oracle_adjoint_twosided_diffuse(oracle):
+    """`twosided` around `diffuse` (twosided.cpp:94-175) in the adjoint path replay: finite differences of the forward render, and the
+    flipped wall really is lit (a one-sided wall seen from behind is black and has a zero gradient)"""
+    sd, wall = _twosided_cbox()
+    p = scenes.cornell_box_sensor(12, 10, 4, seed=5, max_depth=4, rfilter="box")
+    desc = oracle.make_desc(p, analytic=True, film_rgb=True)
+    S = oracle.OracleScene(sd, naive=True)
+    image, film = S.render_image(desc)
+    dimage = np.random.RandomState(2).randn(*image.shape).astype(np.float32)
+    gs, _ = S.render_adjoint(desc, dimage, film, len(sd["meshes"]), 0)
+    loss = lambda img: float(np.sum(img.astype(np.float64) * dimage))
+    eps = 1e-2
+    assert np.abs(gs[wall]).max() > 1e-3                     # the back-facing wall scatters
+    for bsdf, c in ((1, 0), (1, 2), (0, 1)):
+        base = np.array(sd["bsdfs"][bsdf]["bsdf"]["reflectance"], np.float32)
+        shapes = [i for i, m in enumerate(sd["meshes"]) if m["bsdf"] == bsdf]
+        vp, vm = base.copy(), base.copy()
+        vp[c] += eps; vm[c] -= eps
+        S.set_bsdf_reflectance(bsdf, vp); lp = loss(S.render_image(desc)[0])
+        S.set_bsdf_reflectance(bsdf, vm); lm = loss(S.render_image(desc)[0])
+        S.set_bsdf_reflectance(bsdf, base)
+        fd = (lp - lm) / (2 * eps)
+        g = gs[shapes, c].sum()
+        assert abs(fd - g) <= 5e-3 * max(abs(fd), 1e-3) + 1e-5, (bsdf, c, fd, g)
+    # the same box with one-sided BSDFs: the wall seen from behind neither scatters nor receives a gradient
+    one = scenes.cornell_box()
+    one["meshes"][wall] = sd["meshes"][wall]
+    S1 = oracle.OracleScene(one, naive=True)
+    image1, film1 = S1.render_image(desc)
+    gs1, _ = S1.render_adjoint(desc, dimage, film1, len(one["meshes"]), 0)
+    assert np.all(gs1[wall] == 0.0) and not np.allclose(image1, image)
+    # a scene with any other BSDF is refused
+    gl = scenes.cornell_box(); gl["bsdfs"] = list(gl["bsdfs"]); gl["bsdfs"][1] = {"type": "conductor"}
+    with pytest.raises(RuntimeError, match="adjoint failed"):
+        oracle.OracleScene(gl, naive=True).render_adjoint(desc, dimage, film, len(gl["meshes"]), 0)
