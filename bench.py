@@ -21,6 +21,7 @@ N = 1, cbox4k at every N), each with its own small fixed step count, so that eve
 A step is one complete render (every sample traced to termination, film splatted, N > 1: films reduced).
 """
 import argparse
+import glob
 import json
 import os
 import socket
@@ -337,6 +338,16 @@ def run_mesh(args, R, matpreview=False):
     achieved = alg_bytes / max(trace_s, 1e-12) / 1e9
     any_launches = max(acc["trace_any_launches"], 1)
     any_bytes = 36 * acc["any_hit_rays"] + geometry * any_launches
+    # HBM traffic of the closest-hit walk: PMC counters cannot be read inside this process; the ratio counted / algorithmic bytes of the
+    # kernel comes from the committed rocprofv3 --pmc summary of the same scene (RGB, 64 spp: the walk is the same) -- an OFFLINE figure
+    traffic, traffic_src = None, None
+    pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mesh_pmc.json")))
+    if pmc and not matpreview:
+        try:
+            traffic = json.load(open(pmc[-1]))["k_trace_closest"]["traffic_over_algorithmic"] * (alg_bytes / launches)
+            traffic_src = "offline profile " + os.path.relpath(pmc[-1], ROOT) + " (counted / algorithmic bytes of this kernel on the RGB 64-spp render), scaled to this run"
+        except (KeyError, ValueError, OSError):
+            traffic, traffic_src = None, None
     out = {
         "metric": "Msample/s, %d k-triangle mesh, %s variant, %dx%d@%dspp, path integrator (max_depth=-1, rr_depth=5)" % (info["primitives"] // 1000, variant, w, h, spp),
         "value": acc["samples"] / dt / 1e6, "unit": "Msample/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
@@ -354,7 +365,7 @@ def run_mesh(args, R, matpreview=False):
                       "k_shade_sum_per_step": acc["shade_ns"] / steps * 1e-6, "k_trace_closest_launches_per_step": launches / steps,
                       "k_trace_closest_avg_launch_us": trace_s / launches * 1e6, "passes_per_step": acc["passes"] / steps},
         "roofline": {"bound": "hbm", "kernel": "k_trace<false, false>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_launch": alg_bytes / launches,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "alg_bytes_per_launch": alg_bytes / launches,
                      "gray_per_s_in_kernel": acc["closest_hit_rays"] / max(trace_s, 1e-12) / 1e9,
                      "k_trace_any": {"achieved": any_bytes / max(acc["trace_any_ns"] * 1e-9, 1e-12) / 1e9,
                                      "gray_per_s_in_kernel": acc["any_hit_rays"] / max(acc["trace_any_ns"] * 1e-9, 1e-12) / 1e9}},

@@ -73,7 +73,7 @@ typedef enum { MTSAMD_BSDF_DIFFUSE = 0, MTSAMD_BSDF_CONDUCTOR = 1, MTSAMD_BSDF_R
                MTSAMD_BSDF_ROUGHDIELECTRIC = 6,
                MTSAMD_BSDF_THINDIELECTRIC = 7 /* src/bsdfs/thindielectric.cpp: delta reflection + null transmission of a thin slab */,
                /* src/bsdfs/blendbsdf.cpp (weight * nested[1] + (1 - weight) * nested[0]) and src/bsdfs/mask.cpp (opacity * nested[0] +
-                * a null lobe): `nested` index plain records of the same table whose parameters are constants; the weight / opacity
+                * a null lobe): `nested` index plain records of the same table (constant parameters; RGB variant: also a textured reflectance); the weight / opacity
                 * is reflectance[0], or Texture::eval_1 of `texture` (luminance of a bitmap texel, bitmap.cpp:215-231; first colour
                 * channel of a checkerboard cell).  `twosided` wraps a whole blend (mask transmits: twosided.cpp:78-80 refuses it). */
                MTSAMD_BSDF_BLEND = 8, MTSAMD_BSDF_MASK = 9 } mtsamd_bsdf_type;

@@ -72,7 +72,8 @@ def is_smooth(n):
 
 def _normalize_nesting(b, t):
     """blendbsdf.cpp:57-79 / mask.cpp:67-91: child BSDFs in the order they are given, `weight` (required) / `opacity` (default 0.5) as
-    a constant or a texture.  This backend nests one level: the children are plain BSDFs with constant parameters."""
+    a constant or a texture.  This backend nests one level: the children are plain BSDFs (their reflectance may be a `bitmap` /
+    `checkerboard` texture in the RGB variant)."""
     pname = "weight" if t == "blendbsdf" else "opacity"
     bsdf_types = set(TYPE_IDS) | set(NESTING) | {"twosided"}
     children = [v for k, v in b.items() if k not in ("type", "id", pname) and isinstance(v, dict) and v.get("type", "diffuse") in bsdf_types]
@@ -95,8 +96,6 @@ def _normalize_nesting(b, t):
     for k in kids:
         if k["type"] in (BLEND, MASK):
             raise RuntimeError("%s: nested blendbsdf / mask children are not supported by this backend (one level of nesting)" % t)
-        if isinstance(k["reflectance"], dict):
-            raise RuntimeError("%s: textured parameters of a child BSDF are not supported by this backend (constants only)" % t)
     w = b.get(pname, 0.5)
     if isinstance(w, dict):
         if w.get("type") not in ("bitmap", "checkerboard"):

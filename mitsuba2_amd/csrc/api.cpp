@@ -571,10 +571,13 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
             bool smooth = false;
             for (int k = 0; k < n_child; ++k) {
                 const int32_t c = bd.nested[k];
-                if (c < 0 || (uint32_t) c >= desc->bsdf_count || desc->bsdfs[c].type < MTSAMD_BSDF_DIFFUSE || desc->bsdfs[c].type > MTSAMD_BSDF_THINDIELECTRIC ||
-                    desc->bsdfs[c].texture >= 0) {
+                if (c < 0 || (uint32_t) c >= desc->bsdf_count || desc->bsdfs[c].type < MTSAMD_BSDF_DIFFUSE || desc->bsdfs[c].type > MTSAMD_BSDF_THINDIELECTRIC) {
                     delete s;
-                    return fail(MTSAMD_ERR_INVALID, "bsdf %u: nested[%d] must index a plain BSDF record with constant parameters", b, k);
+                    return fail(MTSAMD_ERR_INVALID, "bsdf %u: nested[%d] must index a plain BSDF record", b, k);
+                }
+                if (desc->spectral && desc->bsdfs[c].texture >= 0) {
+                    delete s;
+                    return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u: textured children of a blendbsdf / mask are implemented for the RGB variant only", b);
                 }
                 const int ct = desc->bsdfs[c].type;
                 smooth = smooth || ct == kBsdfDiffuse || ct == kBsdfRoughConductor || ct == kBsdfPlastic || ct == kBsdfRoughPlastic || ct == kBsdfRoughDielectric;

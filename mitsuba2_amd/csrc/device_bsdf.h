@@ -650,18 +650,20 @@ MTS_DEV void surface_bsdf_eval_pdf(DevBsdf &cur, const NestInfo &ni, const Table
 }
 
 // RGB variant
-template <bool NEST, typename Table>
-MTS_DEV bool surface_bsdf_sample(DevBsdf &cur, const NestInfo &ni, f3 refl, const Table &table, f3 wi, float sample1, f2 sample2, BsdfSample &bs, f3 &weight) {
+// `refl_of(rec)`: reflectance of a child record at the surface point (its constant, or its texture: RGB variant)
+template <bool NEST, typename Table, typename ReflOf>
+MTS_DEV bool surface_bsdf_sample(DevBsdf &cur, const NestInfo &ni, f3 refl, const Table &table, const ReflOf &refl_of, f3 wi, float sample1, f2 sample2,
+                                 BsdfSample &bs, f3 &weight) {
     float w[3];
-    auto chan_of = [&](const DevBsdf &rec, bool child) { return rgb_channels(rec, child ? mk3(rec.r, rec.g, rec.b) : refl); };
+    auto chan_of = [&](const DevBsdf &rec, bool child) { return rgb_channels(rec, child ? refl_of(rec) : refl); };
     const bool ok = surface_bsdf_sample<NEST, 3>(cur, ni, table, chan_of, wi, sample1, sample2, bs, w);
     weight = mk3(w[0], w[1], w[2]);
     return ok;
 }
-template <bool NEST, typename Table>
-MTS_DEV void surface_bsdf_eval_pdf(DevBsdf &cur, const NestInfo &ni, f3 refl, const Table &table, f3 wi, f3 wo, f3 &value, float &pdf) {
+template <bool NEST, typename Table, typename ReflOf>
+MTS_DEV void surface_bsdf_eval_pdf(DevBsdf &cur, const NestInfo &ni, f3 refl, const Table &table, const ReflOf &refl_of, f3 wi, f3 wo, f3 &value, float &pdf) {
     float v[3];
-    auto chan_of = [&](const DevBsdf &rec, bool child) { return rgb_channels(rec, child ? mk3(rec.r, rec.g, rec.b) : refl); };
+    auto chan_of = [&](const DevBsdf &rec, bool child) { return rgb_channels(rec, child ? refl_of(rec) : refl); };
     surface_bsdf_eval_pdf<NEST, 3>(cur, ni, table, chan_of, wi, wo, v, pdf);
     value = mk3(v[0], v[1], v[2]);
 }

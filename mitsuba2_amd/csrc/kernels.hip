@@ -171,6 +171,7 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
     uint32_t texel; f2 tw1;
     const f3 refl = eval_reflectance(sv, bsdf, si.uv, texel, tw1);
     const NestInfo ni = nest_info<NEST>(bsdf, refl.x, refl.y, refl.z);
+    auto child_refl = [&](const DevBsdf &rec) { uint32_t t; f2 w; return eval_reflectance(sv, rec, si.uv, t, w); };      // blend / mask children
     const bool smooth = !GENERAL || bsdf_is_smooth(bsdf);
     if (REC) { rec->Tp = s.thr; rec->rho = refl; rec->texel = texel; rec->w1 = tw1; rec->bsdf = si.shape_rec.bsdf; rec->has_bsdf = 1u; }
     // adjoint replay of a `twosided` diffuse BSDF (twosided.cpp:94-175; the primal render of such a scene runs the GENERAL kernels, whose
@@ -210,7 +211,7 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
         if (ds.pdf != 0.0f) {
             f3 wo = to_local(si.sh, ds.d);
             f3 bv; float bp;
-            if (GENERAL) surface_bsdf_eval_pdf<NEST>(bsdf, ni, refl, [&](uint32_t i) { return geo.bsdf(i); }, si.wi, wo, bv, bp);
+            if (GENERAL) surface_bsdf_eval_pdf<NEST>(bsdf, ni, refl, [&](uint32_t i) { return geo.bsdf(i); }, child_refl, si.wi, wo, bv, bp);
             else diffuse_eval_pdf(refl, wi_b, flip ? mk3(wo.x, wo.y, -wo.z) : wo, bv, bp);
             float mis = (GENERAL && ds.delta) ? 1.0f : mis_weight(ds.pdf, bp);      // path.cpp:170
             f3 contrib = mk3(((mis * s.thr.x) * bv.x) * spec.x, ((mis * s.thr.y) * bv.y) * spec.y,
@@ -255,7 +256,7 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
     f3 wo, weight; float pdf;
     if (GENERAL) {
         BsdfSample bs;
-        surface_bsdf_sample<NEST>(bsdf, ni, refl, [&](uint32_t i) { return geo.bsdf(i); }, si.wi, s1, s2, bs, weight);
+        surface_bsdf_sample<NEST>(bsdf, ni, refl, [&](uint32_t i) { return geo.bsdf(i); }, child_refl, si.wi, s1, s2, bs, weight);
         wo = bs.wo; pdf = bs.pdf;
         s.eta *= bs.eta;                                     // harmless for a failed sample: the path ends below
         s.flags = bs.delta ? (s.flags | kFlagDelta) : (s.flags & ~kFlagDelta);
@@ -799,6 +800,7 @@ __global__ __launch_bounds__(kBlock) void k_direct(const RenderParams P, uint64_
             uint32_t texel; f2 tw1;
             const f3 refl = eval_reflectance(sv, bsdf, si.uv, texel, tw1);
             const NestInfo ni = nest_info<NEST>(bsdf, refl.x, refl.y, refl.z);
+            auto child_refl = [&](const DevBsdf &rec) { uint32_t t; f2 w; return eval_reflectance(sv, rec, si.uv, t, w); };
             if (!GENERAL || bsdf_is_smooth(bsdf)) {
                 for (int32_t i = 0; i < ne; ++i) {
                     f2 s2; s2.x = pcg_next_f32(s.rng); s2.y = pcg_next_f32(s.rng);
@@ -807,7 +809,7 @@ __global__ __launch_bounds__(kBlock) void k_direct(const RenderParams P, uint64_
                     if (ds.pdf == 0.0f) continue;
                     const f3 wo = to_local(si.sh, ds.d);
                     f3 bv; float bp;
-                    if (GENERAL) surface_bsdf_eval_pdf<NEST>(bsdf, ni, refl, [&](uint32_t i) { return geo.bsdf(i); }, si.wi, wo, bv, bp);
+                    if (GENERAL) surface_bsdf_eval_pdf<NEST>(bsdf, ni, refl, [&](uint32_t i) { return geo.bsdf(i); }, child_refl, si.wi, wo, bv, bp);
                     else diffuse_eval_pdf(refl, si.wi, wo, bv, bp);
                     const float mis = (GENERAL && ds.delta) ? 1.0f : mis_weight(ds.pdf * frac_lum, bp * frac_bsdf) * weight_lum;      // direct.cpp:155-156
                     const f3 contrib = mk3((mis * bv.x) * spec.x, (mis * bv.y) * spec.y, (mis * bv.z) * spec.z);
@@ -826,7 +828,7 @@ __global__ __launch_bounds__(kBlock) void k_direct(const RenderParams P, uint64_
                 f3 wo, weight; float pdf; bool delta = false;
                 if (GENERAL) {
                     BsdfSample bs;
-                    surface_bsdf_sample<NEST>(bsdf, ni, refl, [&](uint32_t i) { return geo.bsdf(i); }, si.wi, s1, s2, bs, weight);
+                    surface_bsdf_sample<NEST>(bsdf, ni, refl, [&](uint32_t i) { return geo.bsdf(i); }, child_refl, si.wi, s1, s2, bs, weight);
                     wo = bs.wo; pdf = bs.pdf; delta = bs.delta;
                 } else {
                     diffuse_sample(refl, si.wi, s2, wo, pdf, weight);

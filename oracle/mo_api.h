@@ -76,7 +76,8 @@ int mo_scene_set_bsdf(mo_scene *s, uint32_t shape, const mo_bsdf_desc *desc);
  * the interpolated bitmap texel (bitmap.cpp:215-231) or the (constant, first-channel) colour of the checkerboard cell
  * (checkerboard.cpp:67-86).  `twosided` wraps the whole nest in the TwoSidedBRDF adapter (blend only: mask transmits). */
 enum { MO_NEST_BLEND = 1, MO_NEST_MASK = 2 };
-int mo_scene_set_nested_bsdf(mo_scene *s, uint32_t shape, int kind, float weight, int twosided, const mo_bsdf_desc *child0, const mo_bsdf_desc *child1);
+int mo_scene_set_nested_bsdf(mo_scene *s, uint32_t shape, int kind, float weight, int twosided, const mo_bsdf_desc *child0, const mo_bsdf_desc *child1,
+                             int child_tex0, int child_tex1);      /* child_tex: reflectance texture of a child (RGB variant) or -1 */
 /* one BSDF query per row as mo_kat_bsdf, on a blend / mask with constant weight */
 void mo_kat_nested_bsdf(int kind, float weight, int twosided, const mo_bsdf_desc *child0, const mo_bsdf_desc *child1, uint64_t n,
                         const float *wi3, const float *wo3, const float *sample3, float *out14);

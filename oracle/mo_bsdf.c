@@ -620,13 +620,13 @@ static float nest_weight(const mo_bsdf *b, const float *value) {
     if (b->weight_lum) w = fmaf(0.072169f, value[2], fmaf(0.715160f, value[1], 0.212671f * value[0]));      /* luminance (spectrum.h:239-241) */
     return fminf(fmaxf(w, 0.0f), 1.0f);
 }
-/* per-channel inputs of child k: its own constant parameters */
-static void child_channels(const mo_bsdf *c, int n, const float *wav, mo_bsdf_chan *out) {
-    if (n == 3) rgb_channels(c, c->d.reflectance, out);
+/* per-channel inputs of child k: its own parameters; `refl` = its reflectance at the surface point (RGB variant: constant or textured) */
+static void child_channels(const mo_bsdf *c, int n, const float *wav, const float *refl, mo_bsdf_chan *out) {
+    if (n == 3) rgb_channels(c, refl, out);
     else mo_bsdf_spectral_channels(c, wav, out);
 }
 /* blendbsdf.cpp:82-123 (ctx.component == -1) and mask.cpp:92-131 (both the null and the nested components enabled) */
-static int nest_sample(const mo_bsdf *b, int n, const float *wav, float w, mo_v3 wi, float sample1, mo_v2 sample2, mo_bsample *bs, float *weight) {
+static int nest_sample(const mo_bsdf *b, int n, const float *wav, const float *refl9, float w, mo_v3 wi, float sample1, mo_v2 sample2, mo_bsample *bs, float *weight) {
     bs->wo = mo_v3_make(0.0f, 0.0f, 0.0f); bs->pdf = 0.0f; bs->eta = 0.0f; bs->delta = 0;
     for (int k = 0; k < n; ++k) weight[k] = 0.0f;
     int flip = 0;
@@ -638,10 +638,10 @@ static int nest_sample(const mo_bsdf *b, int n, const float *wav, float w, mo_v3
     mo_bsdf_chan c; int ok = 0;
     if (b->nest == MO_NEST_BLEND) {
         if (sample1 > w) {
-            child_channels(b->child[0], n, wav, &c);
+            child_channels(b->child[0], n, wav, refl9 + 3, &c);
             ok = mo_bsdf_sample_n(b->child[0], n, &c, wi, (sample1 - w) / (1.0f - w), sample2, bs, weight);
         } else if (sample1 <= w) {
-            child_channels(b->child[1], n, wav, &c);
+            child_channels(b->child[1], n, wav, refl9 + 6, &c);
             ok = mo_bsdf_sample_n(b->child[1], n, &c, wi, sample1 / w, sample2, bs, weight);
         }
     } else {
@@ -649,7 +649,7 @@ static int nest_sample(const mo_bsdf *b, int n, const float *wav, float w, mo_v3
         for (int k = 0; k < n; ++k) weight[k] = 1.0f;
         ok = 1;
         if (sample1 < w) {                                  /* the nested sample replaces the record as it is (mask.cpp:123-128) */
-            child_channels(b->child[0], n, wav, &c);
+            child_channels(b->child[0], n, wav, refl9 + 3, &c);
             ok = mo_bsdf_sample_n(b->child[0], n, &c, wi, sample1 / w, sample2, bs, weight);
         }
     }
@@ -657,7 +657,7 @@ static int nest_sample(const mo_bsdf *b, int n, const float *wav, float w, mo_v3
     return ok;
 }
 /* blendbsdf.cpp:125-158, mask.cpp:133-159 */
-static void nest_eval_pdf(const mo_bsdf *b, int n, const float *wav, float w, mo_v3 wi, mo_v3 wo, float *value, float *pdf) {
+static void nest_eval_pdf(const mo_bsdf *b, int n, const float *wav, const float *refl9, float w, mo_v3 wi, mo_v3 wo, float *value, float *pdf) {
     for (int k = 0; k < n; ++k) value[k] = 0.0f;
     *pdf = 0.0f;
     if (b->d.twosided) {
@@ -665,7 +665,7 @@ static void nest_eval_pdf(const mo_bsdf *b, int n, const float *wav, float w, mo
         if (wi.z < 0.0f) { wi.z = -wi.z; wo.z = -wo.z; }
     }
     mo_bsdf_chan c; float v0[4], p0;
-    child_channels(b->child[0], n, wav, &c);
+    child_channels(b->child[0], n, wav, refl9 + 3, &c);
     mo_bsdf_eval_pdf_n(b->child[0], n, &c, wi, wo, v0, &p0);
     if (b->nest == MO_NEST_MASK) {
         for (int k = 0; k < n; ++k) value[k] = v0[k] * w;
@@ -673,7 +673,7 @@ static void nest_eval_pdf(const mo_bsdf *b, int n, const float *wav, float w, mo
         return;
     }
     float v1[4], p1;
-    child_channels(b->child[1], n, wav, &c);
+    child_channels(b->child[1], n, wav, refl9 + 6, &c);
     mo_bsdf_eval_pdf_n(b->child[1], n, &c, wi, wo, v1, &p1);
     for (int k = 0; k < n; ++k) value[k] = fmaf(v1[k], w, v0[k] * (1.0f - w));
     *pdf = fmaf(p1, w, p0 * (1.0f - w));
@@ -681,22 +681,22 @@ static void nest_eval_pdf(const mo_bsdf *b, int n, const float *wav, float w, mo
 
 /* RGB variant */
 int mo_bsdf_sample(const mo_bsdf *b, const float refl[3], mo_v3 wi, float sample1, mo_v2 sample2, mo_bsample *bs, float weight[3]) {
-    if (b->nest) return nest_sample(b, 3, NULL, nest_weight(b, refl), wi, sample1, sample2, bs, weight);
+    if (b->nest) return nest_sample(b, 3, NULL, refl, nest_weight(b, refl), wi, sample1, sample2, bs, weight);      /* refl: 9 values (mo_surface_reflectance) */
     mo_bsdf_chan c; rgb_channels(b, refl, &c);
     return mo_bsdf_sample_n(b, 3, &c, wi, sample1, sample2, bs, weight);
 }
 void mo_bsdf_eval_pdf(const mo_bsdf *b, const float refl[3], mo_v3 wi, mo_v3 wo, float value[3], float *pdf) {
-    if (b->nest) { nest_eval_pdf(b, 3, NULL, nest_weight(b, refl), wi, wo, value, pdf); return; }
+    if (b->nest) { nest_eval_pdf(b, 3, NULL, refl, nest_weight(b, refl), wi, wo, value, pdf); return; }
     mo_bsdf_chan c; rgb_channels(b, refl, &c);
     mo_bsdf_eval_pdf_n(b, 3, &c, wi, wo, value, pdf);
 }
 /* spectral variant */
 int mo_bsdf_sample_spec(const mo_bsdf *b, const float *wav, const mo_bsdf_chan *c, mo_v3 wi, float sample1, mo_v2 sample2, mo_bsample *bs, float *weight) {
-    if (b->nest) return nest_sample(b, MO_WAV, wav, nest_weight(b, c->refl), wi, sample1, sample2, bs, weight);
+    if (b->nest) return nest_sample(b, MO_WAV, wav, NULL, nest_weight(b, c->refl), wi, sample1, sample2, bs, weight);
     return mo_bsdf_sample_n(b, MO_WAV, c, wi, sample1, sample2, bs, weight);
 }
 void mo_bsdf_eval_pdf_spec(const mo_bsdf *b, const float *wav, const mo_bsdf_chan *c, mo_v3 wi, mo_v3 wo, float *value, float *pdf) {
-    if (b->nest) { nest_eval_pdf(b, MO_WAV, wav, nest_weight(b, c->refl), wi, wo, value, pdf); return; }
+    if (b->nest) { nest_eval_pdf(b, MO_WAV, wav, NULL, nest_weight(b, c->refl), wi, wo, value, pdf); return; }
     mo_bsdf_eval_pdf_n(b, MO_WAV, c, wi, wo, value, pdf);
 }
 
@@ -745,7 +745,9 @@ void mo_kat_nested_bsdf(int kind, float weight, int twosided, const mo_bsdf_desc
     c0.d = *child0; mo_bsdf_prepare(&c0);
     if (child1) { c1.d = *child1; mo_bsdf_prepare(&c1); }
     top.nest = kind; top.d.twosided = twosided; top.child[0] = &c0; top.child[1] = child1 ? &c1 : NULL;
-    const float wv[3] = { weight, weight, weight };
+    float wv[9] = { weight, weight, weight, 0, 0, 0, 0, 0, 0 };
+    for (int k = 0; k < 3; ++k) { wv[3 + k] = child0->reflectance[k]; if (child1) wv[6 + k] = child1->reflectance[k]; }
+    top.child_tex[0] = top.child_tex[1] = -1;
     for (uint64_t i = 0; i < n; ++i) {
         mo_v3 wi = mo_v3_make(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]), wo = mo_v3_make(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]);
         float *o = out14 + 14 * i;

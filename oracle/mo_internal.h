@@ -24,7 +24,7 @@ typedef struct mo_bsdf {
     /* nest = MO_NEST_BLEND / MO_NEST_MASK: blendbsdf.cpp / mask.cpp over child[0..1] (mask: child[0]); the weight / opacity
      * arrives where a plain BSDF receives its reflectance (the shape's constant or texture); weight_lum: it is a bitmap
      * texel whose eval_1 is the luminance (bitmap.cpp:215-231) */
-    int nest, weight_lum; struct mo_bsdf *child[2];
+    int nest, weight_lum; struct mo_bsdf *child[2]; int child_tex[2];      /* child_tex: reflectance texture of a child or -1 */
 } mo_bsdf;
 /* per-channel inputs of a BSDF evaluation: 3 colour channels or MO_WAV wavelengths */
 typedef struct { float refl[4], spec[4], trans[4], eta[4], k[4]; } mo_bsdf_chan;
@@ -98,6 +98,9 @@ void mo_scene_set_naive(mo_scene *s, int naive);
 /* reflectance at a surface interaction: constant colour or BitmapTexture::interpolate (bitmap.cpp:250-293);
  * footprint (may be NULL): texel index of v00 and the bilinear weights w1.x, w1.y */
 void mo_reflectance(const mo_scene *s, const mo_mesh *m, mo_v2 uv, float out[3], uint32_t *texel, float w1[2]);
+/* out9 = (reflectance or blend weight lookup, reflectance of child 0, of child 1): what mo_bsdf_sample / mo_bsdf_eval_pdf take as `refl`
+ * (plain BSDFs read the first three values only) */
+void mo_surface_reflectance(const mo_scene *s, const mo_mesh *m, mo_v2 uv, float out9[9]);
 
 
 /* 8-wide ray queries of the packet_rgb-equivalent CPU baseline (mo_packet.c) */

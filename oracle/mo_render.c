@@ -461,8 +461,8 @@ static void path_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, 
         /* --------------------- Emitter sampling --------------------- */
         const mo_mesh *mesh = &s->meshes[si.shape];
         const mo_bsdf *bsdf = &mesh->bsdf;
-        float refl[3];
-        mo_reflectance(s, mesh, si.uv, refl, NULL, NULL);
+        float refl[9];
+        mo_surface_reflectance(s, mesh, si.uv, refl);
         if (mo_bsdf_is_smooth(bsdf)) {   /* active_e = active && has_flag(bsdf->flags(), BSDFFlags::Smooth) (path.cpp:154) */
             mo_v2 s2; s2.x = mo_pcg32_next_f32(rng); s2.y = mo_pcg32_next_f32(rng);
             mo_dsample ds; float emitter_val[3];
@@ -545,7 +545,7 @@ static void path_sample_packet(const mo_scene *s, const mo_packet_accel *acc, mo
     mo_ray ray[8]; mo_si si[8], si_bsdf[8]; int si_valid[8], v2[8], emitter[8], active[8];
     float eta[8], emission_weight[8], throughput[8][3];
     /* per-lane values that live from the emitter-sampling stage to the BSDF stage of one iteration */
-    float refl[8][3], emitter_val[8][3]; mo_dsample ds[8]; int active_e[8], smooth[8]; mo_bsample bs[8];
+    float refl[8][9], emitter_val[8][3]; mo_dsample ds[8]; int active_e[8], smooth[8]; mo_bsample bs[8];
     for (int l = 0; l < 8; ++l) {
         ray[l] = rays_in[l]; eta[l] = 1.0f; emission_weight[l] = 1.0f; active[l] = 1; active_e[l] = 0; smooth[l] = 0;
         for (int k = 0; k < 3; ++k) { throughput[l][k] = 1.0f; result[l][k] = 0.0f; }
@@ -579,7 +579,7 @@ static void path_sample_packet(const mo_scene *s, const mo_packet_accel *acc, mo
             }
             if ((uint32_t) depth >= (uint32_t) max_depth || !active[l]) { alive &= ~(1u << l); continue; }
             const mo_mesh *mesh = &s->meshes[si[l].shape];
-            mo_reflectance(s, mesh, si[l].uv, refl[l], NULL, NULL);
+            mo_surface_reflectance(s, mesh, si[l].uv, refl[l]);
             smooth[l] = mo_bsdf_is_smooth(&mesh->bsdf);
             active_e[l] = 0;
             if (smooth[l]) {
@@ -667,8 +667,8 @@ static void direct_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray, i
     if (!hide_emitters && mesh->emitter >= 0 && si.wi.z > 0.0f)                                /* visible emitters (direct.cpp:117-121) */
         for (int k = 0; k < 3; ++k) result[k] += s->emitters[mesh->emitter].radiance[k];
     const mo_bsdf *bsdf = &mesh->bsdf;
-    float refl[3];
-    mo_reflectance(s, mesh, si.uv, refl, NULL, NULL);
+    float refl[9];
+    mo_surface_reflectance(s, mesh, si.uv, refl);
     if (mo_bsdf_is_smooth(bsdf)) {
         for (int i = 0; i < emitter_samples; ++i) {
             mo_v2 s2; s2.x = mo_pcg32_next_f32(rng); s2.y = mo_pcg32_next_f32(rng);

@@ -245,7 +245,8 @@ int mo_scene_set_bsdf(mo_scene *s, uint32_t shape, const mo_bsdf_desc *desc) {
 
 /* blendbsdf / mask over plain children (see mo_api.h).  The weight takes the place of the shape's reflectance: constant, or the
  * texture attached with mo_scene_set_texture afterwards. */
-int mo_scene_set_nested_bsdf(mo_scene *s, uint32_t shape, int kind, float weight, int twosided, const mo_bsdf_desc *child0, const mo_bsdf_desc *child1) {
+int mo_scene_set_nested_bsdf(mo_scene *s, uint32_t shape, int kind, float weight, int twosided, const mo_bsdf_desc *child0, const mo_bsdf_desc *child1,
+                             int child_tex0, int child_tex1) {
     if (!s || shape >= s->n_meshes || !child0 || (kind != MO_NEST_BLEND && kind != MO_NEST_MASK)) return -1;
     if ((kind == MO_NEST_BLEND) != (child1 != NULL) || (kind == MO_NEST_MASK && twosided)) return -1;
     if (s->spectral) return -2;
@@ -255,12 +256,20 @@ int mo_scene_set_nested_bsdf(mo_scene *s, uint32_t shape, int kind, float weight
     mo_mesh *m = &s->meshes[shape];
     free(m->bsdf.child[0]); free(m->bsdf.child[1]);
     memset(&m->bsdf, 0, sizeof(m->bsdf));
+    if (child_tex0 >= (int) s->n_textures || child_tex1 >= (int) s->n_textures) return -1;
     m->bsdf.nest = kind; m->bsdf.d.twosided = twosided; m->bsdf.d.type = -kind; m->bsdf.d.uniform_mask = 1;
+    m->bsdf.child_tex[0] = child_tex0 < 0 ? -1 : child_tex0; m->bsdf.child_tex[1] = child_tex1 < 0 ? -1 : child_tex1;
     for (int k = 0; k < 2; ++k) {
         if (!cd[k]) continue;
         mo_bsdf *c = (mo_bsdf *) calloc(1, sizeof(mo_bsdf));
         if (!c) return -1;
         c->d = *cd[k]; mo_bsdf_prepare(c);
+        const int ct = k ? child_tex1 : child_tex0;
+        if (ct >= 0 && (c->d.type == MO_BSDF_PLASTIC || c->d.type == MO_BSDF_ROUGHPLASTIC)) {      /* plastic.cpp:170-175 with Texture::mean() */
+            const float *sr = c->d.specular_reflectance;
+            float d_mean = s->textures[ct].mean, s_mean = (sr[0] + sr[1] + sr[2]) * (1.0f / 3.0f);
+            c->spec_weight = s_mean / (d_mean + s_mean);
+        }
         m->bsdf.child[k] = c;
     }
     m->bsdf_kind = 100 + kind;                          /* not `diffuse`: the adjoint pass rejects the scene */
@@ -270,13 +279,27 @@ int mo_scene_set_nested_bsdf(mo_scene *s, uint32_t shape, int kind, float weight
 }
 
 /* BitmapTextureImpl::interpolate (bitmap.cpp:250-293), identity to_uv */
+static void texture_lookup(const mo_scene *s, int texture, const float *constant, mo_v2 uv, float out[3], uint32_t *texel, float w1o[2]);
 void mo_reflectance(const mo_scene *s, const mo_mesh *m, mo_v2 uv, float out[3], uint32_t *texel, float w1o[2]) {
-    if (m->texture < 0) {
-        for (int k = 0; k < 3; ++k) out[k] = m->refl[k];
+    texture_lookup(s, m->texture, m->refl, uv, out, texel, w1o);
+}
+/* everything BSDF::sample / eval read from textures at a surface point: out9[0..2] = the shape's reflectance (or, for a blendbsdf /
+ * mask, what Texture::eval_1 of the weight reads), out9[3..5] / [6..8] = the reflectances of the children of a blendbsdf / mask */
+void mo_surface_reflectance(const mo_scene *s, const mo_mesh *m, mo_v2 uv, float out9[9]) {
+    texture_lookup(s, m->texture, m->refl, uv, out9, NULL, NULL);
+    for (int k = 0; k < 2; ++k) {
+        const mo_bsdf *c = m->bsdf.nest ? m->bsdf.child[k] : NULL;
+        if (c) texture_lookup(s, m->bsdf.child_tex[k], c->d.reflectance, uv, out9 + 3 + 3 * k, NULL, NULL);
+        else out9[3 + 3 * k] = out9[4 + 3 * k] = out9[5 + 3 * k] = 0.0f;
+    }
+}
+static void texture_lookup(const mo_scene *s, int texture, const float *constant, mo_v2 uv, float out[3], uint32_t *texel, float w1o[2]) {
+    if (texture < 0) {
+        for (int k = 0; k < 3; ++k) out[k] = constant[k];
         if (texel) *texel = 0xffffffffu;
         return;
     }
-    const mo_texture *t = &s->textures[m->texture];
+    const mo_texture *t = &s->textures[texture];
     {   /* m_transform.transform_affine(si.uv) (bitmap.cpp:254, checkerboard.cpp:49) */
         float u2 = fmaf(t->uvm[0], uv.x, fmaf(t->uvm[1], uv.y, t->uvm[2])), v2 = fmaf(t->uvm[3], uv.x, fmaf(t->uvm[4], uv.y, t->uvm[5]));
         uv.x = u2; uv.y = v2;

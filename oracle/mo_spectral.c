@@ -147,7 +147,7 @@ int mo_scene_set_spectral(mo_scene *s, const char *coeff_path) {
         if (b->nest) {
             /* blendbsdf / mask: the weight is a scalar (a bitmap without raw = true throws in eval_1, bitmap.cpp:218-222);
              * the children upsample their own constant colours */
-            if (m->texture >= 0) { free(t.scale); free(t.data); return -5; }
+            if (m->texture >= 0 || b->child_tex[0] >= 0 || b->child_tex[1] >= 0) { free(t.scale); free(t.data); return -5; }      /* textured children: RGB variant only */
             b = b->child[nest_k];
             if (!b) continue;
         } else if (nest_k) continue;

@@ -49,6 +49,19 @@ for k in sorted(sq, key=lambda k: -sq[k].get("SQ_WAVE_CYCLES", 0.0)):
     if s.get("SQ_WAVES"):
         e["valu_instructions_per_wave"] = s.get("SQ_INSTS_VALU", 0.0) / s["SQ_WAVES"]
     out["kernels"][k] = e
+# HBM traffic of the closest-hit walk against its algorithmic bytes (48 B per ray + the geometry once per launch): the
+# script renders the 1920x1080@64 film twice (warm-up + timed); one closest-hit ray per path segment
+for line in open(os.path.join(src, "fetch.log")):
+    m = re.search(r"(\d+)x(\d+)@(\d+)spp:.* ([0-9.]+) segments/sample", line)
+    if m:
+        bench = [x for x in out["kernels"] if x.startswith("k_trace<false")][0]
+        rays = 2.0 * int(m.group(1)) * int(m.group(2)) * int(m.group(3)) * float(m.group(4))
+        geometry = 32.0 * 160979 + 48.0 * 261124         # as bench.py prices it: nodes + triangle slots of the 261 k-triangle scene (scene.info())
+        e = out["kernels"][bench]
+        alg = 48.0 * rays + geometry * e["launches"]
+        out["k_trace_closest"] = {"rays": rays, "algorithmic_bytes": alg, "counted_bytes": e["hbm_read_bytes_corrected"] + e["hbm_write_bytes"],
+                                  "traffic_over_algorithmic": (e["hbm_read_bytes_corrected"] + e["hbm_write_bytes"]) / alg}
+        out["bench_line"] = line.strip()
 json.dump(out, open(os.path.join(root, "profiles", tag + "_mesh_pmc.json"), "w"), indent=1)
 for k, e in out["kernels"].items():
     print("%-60s launches %5d  read %.2f GB  write %.2f GB  lanes %.2f" % (k, e["launches"], e["hbm_read_bytes_corrected"] / 1e9, e["hbm_write_bytes"] / 1e9, e.get("valu_lane_utilisation", 0.0)))

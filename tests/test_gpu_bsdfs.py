@@ -47,6 +47,15 @@ MATERIALS = {
     "mask_checker_glass": {"type": "mask", "opacity": {"type": "checkerboard", "color0": 1.0, "color1": 0.0, "to_uv": [[5.0, 0, 0, 0], [0, 5.0, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]]},
                            "nested": {"type": "roughdielectric", "alpha": 0.2}},
     "mask_default_opacity": {"type": "mask", "nested": {"type": "roughconductor", "alpha": 0.3, "eta": 0.0, "k": 1.0}},
+    # textured children (RGB variant): a leaf-style cutout -- checkerboard opacity over a bitmap-textured two-sided diffuse child -- and a
+    # blend of a checkerboard diffuse with a bitmap-textured roughplastic (Texture::mean() feeds the child's lobe weights)
+    "mask_textured_child": {"type": "mask", "opacity": {"type": "checkerboard", "color0": 1.0, "color1": 0.0, "to_uv": [[6.0, 0, 0, 0], [0, 6.0, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]]},
+                            "nested": {"type": "twosided", "bsdf": {"type": "diffuse", "reflectance": {"type": "bitmap",
+                                       "data": np.random.default_rng(6).uniform(0.1, 0.9, size=(7, 5, 3)).astype(np.float32)}}}},
+    "blend_textured_children": {"type": "blendbsdf", "weight": 0.45,
+                                "bsdf_0": {"type": "diffuse", "reflectance": {"type": "checkerboard", "color0": [0.8, 0.2, 0.1], "color1": [0.1, 0.3, 0.7]}},
+                                "bsdf_1": {"type": "roughplastic", "alpha": 0.2, "diffuse_reflectance": {"type": "bitmap",
+                                           "data": np.random.default_rng(7).uniform(0.1, 0.9, size=(4, 6, 3)).astype(np.float32)}}},
 }
 
 
@@ -109,6 +118,8 @@ def test_unsupported_combinations():
                      ({"type": "mask", "a": {"type": "mask", "a": d}}, "one level")):
         with pytest.raises(RuntimeError, match=msg):
             R.Scene(dict(cb, bsdfs=[bad] * len(cb["bsdfs"])))
+    with pytest.raises(RuntimeError, match="RGB variant only"):      # textured children of a nest: RGB variant
+        R.Scene(dict(cb, bsdfs=[{"type": "mask", "a": {"type": "diffuse", "reflectance": {"type": "checkerboard"}}}] * len(cb["bsdfs"])), variant="spectral")
     with pytest.raises(RuntimeError, match="eval_1"):      # a textured weight is converted into spectra in the spectral variant
         R.Scene(dict(cb, bsdfs=[{"type": "blendbsdf", "weight": {"type": "checkerboard"}, "a": d, "b": d}] * len(cb["bsdfs"])), variant="spectral")
     with pytest.raises(RuntimeError, match="positive and differ"):
