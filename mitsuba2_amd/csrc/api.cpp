@@ -755,6 +755,28 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         pair_recs[5 * k + 3] = make_float4(a[6], b[6], a[7], b[7]);
         pair_recs[5 * k + 4] = make_float4(a[8], b[8], 0.0f, 0.0f);
     }
+    // clusters of consecutive pairs that belong to one shape, with their bounding box padded by 1e-4 of the scene's extent (the box
+    // test of coherent waves only culls; device_scene.h, traverse_flat_clustered).  Appended to the pair records.
+    uint32_t n_clusters = 0;
+    if (flat && n_pairs > 0) {
+        float ext = 0.0f;
+        for (uint32_t gp = 0; gp < s->n_prims; ++gp) for (int q = 0; q < 9; ++q) ext = std::max(ext, std::fabs(tri_pos[9 * (size_t) gp + q]));
+        const float pad = 1e-4f * std::max(ext, 1e-3f);
+        uint32_t k0 = 0;
+        while (k0 < n_pairs) {
+            uint32_t k1 = k0 + 1;
+            while (k1 < n_pairs && prim_shape[2 * k1] == prim_shape[2 * k0]) ++k1;
+            float lo[3] = { 3e38f, 3e38f, 3e38f }, hi[3] = { -3e38f, -3e38f, -3e38f };
+            for (uint32_t gp = 2 * k0; gp < std::min(2 * k1, s->n_prims); ++gp)
+                for (int vtx = 0; vtx < 3; ++vtx) for (int a = 0; a < 3; ++a) {
+                    lo[a] = std::min(lo[a], tri_pos[9 * (size_t) gp + 3 * vtx + a]); hi[a] = std::max(hi[a], tri_pos[9 * (size_t) gp + 3 * vtx + a]);
+                }
+            const uint32_t cnt = k1 - k0; float cntf; std::memcpy(&cntf, &cnt, 4);
+            pair_recs.push_back(make_float4(lo[0] - pad, lo[1] - pad, lo[2] - pad, cntf));
+            pair_recs.push_back(make_float4(hi[0] + pad, hi[1] + pad, hi[2] + pad, 0.0f));
+            ++n_clusters; k0 = k1;
+        }
+    }
     int rc = 0;
     if ((rc = upload(&s->d_textures, s->textures)) || (rc = upload(&s->d_flat, flat_recs)) || (rc = upload(&s->d_pairs, pair_recs)) || (rc = upload(&s->d_nodes, nodes)) || (rc = upload(&s->d_qnodes, qnodes)) || (rc = upload(&s->d_wnodes, wnodes)) || (rc = upload(&s->d_tris, tris)) || (rc = upload(&s->d_tri_pos, tri_pos)) ||
         (rc = upload(&s->d_tri_nrm, tri_nrm)) || (rc = upload(&s->d_tri_uv, tri_uv)) || (rc = upload(&s->d_prim_shape, prim_shape)) ||
@@ -857,7 +879,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     v.textures = s->d_textures; v.n_textures = desc->texture_count;
     v.flat_recs = s->d_flat; v.flat = flat ? 1u : 0u;
     v.general = s->nested_bsdfs ? 2u : (s->general_bsdfs || s->delta_emitters || s->environment >= 0) ? 1u : 0u;       // the diffuse / area-light fast path (kernels.hip) handles none of these
-    v.flat_pairs = s->d_pairs; v.n_pairs = n_pairs;
+    v.flat_pairs = s->d_pairs; v.n_pairs = n_pairs; v.n_clusters = n_clusters;
     if (bounce_lds_bytes(v) > 150 * 1024) {
         mtsamd_scene_destroy(s);
         return fail(MTSAMD_ERR_UNSUPPORTED, "BVH too deep for the LDS traversal stack (depth %u)", v.stack_depth);

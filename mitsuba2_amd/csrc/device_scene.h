@@ -99,8 +99,8 @@ struct SceneView {
     // plus 80-byte intersection records for primitive pairs (A = 2k, B = 2k+1), laid out for packed fp32 math:
     //   (p0x.ab, p0y.ab) (p0z.ab, e1x.ab) (e1y.ab, e1z.ab) (e2x.ab, e2y.ab) (e2z.ab, -, -)
     const float4 *flat_recs;
-    const float4 *flat_pairs;
-    uint32_t flat, n_pairs;
+    const float4 *flat_pairs;  // 5 float4 per primitive pair, followed by 2 float4 per pair cluster (padded box; .w of the first = pair count)
+    uint32_t flat, n_pairs, n_clusters;
     int32_t env_emitter;       // index of the environment emitter or -1 (scene.cpp:44-48)
     const DevEnvmap *envmap;   // its image + sampling hierarchy if it is an `envmap`
     uint32_t general;          // some BSDF is not a one-sided `diffuse`: kernels instantiated with the BSDF switch are used
@@ -119,6 +119,7 @@ struct LdsView {
     uint32_t spill_stride, stack_lds_depth;      // ... that takes the entries beyond the first stack_lds_depth
     const float4 *flat;        // 4 per prim (shading records)
     const float4 *pairs;       // 5 per primitive pair (intersection records), + 1 all-zero pair
+    const float4 *clusters;    // 2 per cluster of consecutive pairs (one shape): (lo.xyz, pair count), (hi.xyz, -)
     const DevShape *shapes;
     const DevBsdf *bsdfs;
     const DevEmitter *emitters;
@@ -139,7 +140,10 @@ MTS_DEV LdsView lds_stage(const SceneView &sv, float4 *smem) {
         for (uint32_t i = threadIdx.x; i < 5u * sv.n_pairs; i += blockDim.x) pr[i] = sv.flat_pairs[i];
         if (threadIdx.x < 5u) pr[5u * sv.n_pairs + threadIdx.x] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         l.pairs = pr;
-        uint32_t *w = reinterpret_cast<uint32_t *>(pr + 5u * sv.n_pairs + 5u);
+        float4 *cl = pr + 5u * sv.n_pairs + 5u;
+        for (uint32_t i = threadIdx.x; i < 2u * sv.n_clusters; i += blockDim.x) cl[i] = sv.flat_pairs[5u * sv.n_pairs + i];
+        l.clusters = cl;
+        uint32_t *w = reinterpret_cast<uint32_t *>(cl + 2u * sv.n_clusters);
         const uint32_t n_sh = (sizeof(DevShape) / 4u) * sv.n_shapes, n_bs = (sizeof(DevBsdf) / 4u) * sv.n_bsdfs,
                        n_em = (sizeof(DevEmitter) / 4u) * sv.n_emitters;
         const uint32_t *g_sh = reinterpret_cast<const uint32_t *>(sv.shapes), *g_bs = reinterpret_cast<const uint32_t *>(sv.bsdfs),
@@ -166,7 +170,7 @@ MTS_DEV LdsView lds_stage(const SceneView &sv, float4 *smem) {
 }
 inline size_t lds_bytes(const SceneView &sv, uint32_t block) {
     if (sv.flat)
-        return (size_t) 64 * sv.n_prims + (size_t) 80 * (sv.n_pairs + 1) + sizeof(DevShape) * sv.n_shapes + sizeof(DevBsdf) * sv.n_bsdfs +
+        return (size_t) 64 * sv.n_prims + (size_t) 80 * (sv.n_pairs + 1) + (size_t) 32 * sv.n_clusters + sizeof(DevShape) * sv.n_shapes + sizeof(DevBsdf) * sv.n_bsdfs +
                sizeof(DevEmitter) * sv.n_emitters + (size_t) 8 * sv.n_prims;
     return (size_t) 64 * sv.lds_nodes + (size_t) 48 * sv.lds_slots + sizeof(StackEntry) * sv.stack_depth * block;
 }
@@ -586,8 +590,63 @@ MTS_DEV bool traverse_flat(const SceneView &sv, const LdsView &lds, f3 o, f3 d, 
     return best_prim != kNoPrim;
 }
 
+// Closest hit of a COHERENT wave on a flat scene (the camera rays of one or two pixels: all lanes at depth 1): the pairs are walked
+// cluster by cluster -- a cluster = the consecutive pairs of one shape with their padded bounding box -- and a cluster that no lane's
+// ray reaches before its closest hit so far is skipped by the whole wave (a wave-uniform branch: no divergence, nothing to compact).
+// The boxes only cull: primitive order, arithmetic and tie rule of the triangle tests are those of traverse_flat, so the hit is
+// bit-identical.  A wall pixel of the Cornell box tests 1 pair instead of 18.  Incoherent waves (any lane at depth > 1) keep the plain
+// loop: there some lane reaches nearly every box and the 8 box tests (~20 VALU each) would only be added work.
+#ifndef MTS_FLAT_CULL
+#define MTS_FLAT_CULL 1
+#endif
+MTS_DEV bool traverse_flat_clustered(const SceneView &sv, const LdsView &lds, f3 o, f3 d, float mint, float maxt, Hit &hit, uint32_t &tri_tests) {
+    float best = maxt, bu = 0.0f, bv = 0.0f;
+    uint32_t best_prim = kNoPrim;
+    tri_tests += sv.n_prims;                                 // nominal count, as the plain loop (the statistics do not depend on the schedule)
+    const v2f ox = splat(o.x), oy = splat(o.y), oz = splat(o.z), dx = splat(d.x), dy = splat(d.y), dz = splat(d.z);
+    const f3 inv = mk3(clamp_inv(d.x), clamp_inv(d.y), clamp_inv(d.z));
+    const float4 *rec = lds.pairs;
+    uint32_t k = 0u;
+    for (uint32_t c = 0; c < sv.n_clusters; ++c) {
+        const float4 lo = lds.clusters[2u * c], hi = lds.clusters[2u * c + 1u];
+        const uint32_t n = __float_as_uint(lo.w);
+        // slab test against the padded box; the interval is [mint, best]
+        const float ax = (lo.x - o.x) * inv.x, bx = (hi.x - o.x) * inv.x;
+        const float ay = (lo.y - o.y) * inv.y, by = (hi.y - o.y) * inv.y;
+        const float az = (lo.z - o.z) * inv.z, bz = (hi.z - o.z) * inv.z;
+        const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), mint));
+        const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best));
+        if (__ballot(tn <= tf) == 0ull) { rec += 5u * n; k += n; continue; }
+        for (uint32_t i = 0; i < n; ++i, ++k) {
+            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4];
+            rec += 5;
+            const v2f p0x = { q0.x, q0.y }, p0y = { q0.z, q0.w }, p0z = { q1.x, q1.y };
+            const v2f e1x = { q1.z, q1.w }, e1y = { q2.x, q2.y }, e1z = { q2.z, q2.w };
+            const v2f e2x = { q3.x, q3.y }, e2y = { q3.z, q3.w }, e2z = { q4.x, q4.y };
+            const v2f pvx = vfma(dy, e2z, -(dz * e2y)), pvy = vfma(dz, e2x, -(dx * e2z)), pvz = vfma(dx, e2y, -(dy * e2x));
+            const v2f det = vfma(e1z, pvz, vfma(e1y, pvy, e1x * pvx));
+            const v2f ivd = rcp_nr2(det);
+            const v2f tx = ox - p0x, ty = oy - p0y, tz = oz - p0z;
+            const v2f u = vfma(tz, pvz, vfma(ty, pvy, tx * pvx)) * ivd;
+            const v2f qx = vfma(ty, e1z, -(tz * e1y)), qy = vfma(tz, e1x, -(tx * e1z)), qz = vfma(tx, e1y, -(ty * e1x));
+            const v2f v = vfma(dz, qz, vfma(dy, qy, dx * qx)) * ivd;
+            const v2f t = vfma(e2z, qz, vfma(e2y, qy, e2x * qx)) * ivd;
+            const v2f uv = u + v;
+            bool ok_a = (u.x >= 0.0f) && (v.x >= 0.0f) && (uv.x <= 1.0f) && (t.x >= mint) && (t.x <= best);
+            best = ok_a ? t.x : best; best_prim = ok_a ? 2u * k : best_prim; bu = ok_a ? u.x : bu; bv = ok_a ? v.x : bv;
+            bool ok_b = (u.y >= 0.0f) && (v.y >= 0.0f) && (uv.y <= 1.0f) && (t.y >= mint) && (t.y <= best);
+            best = ok_b ? t.y : best; best_prim = ok_b ? 2u * k + 1u : best_prim; bu = ok_b ? u.y : bu; bv = ok_b ? v.y : bv;
+        }
+    }
+    hit.t = best; hit.prim = best_prim; hit.u = bu; hit.v = bv;
+    return best_prim != kNoPrim;
+}
+
+// `coherent` (wave-uniform): the active lanes carry the camera rays of one or two pixels -> cluster culling (flat scenes, closest hit)
 template <bool FLAT, bool ANY>
-MTS_DEV bool traverse(const SceneView &sv, const LdsView &lds, f3 o, f3 d, float mint, float maxt, Hit &hit, uint32_t &tri_tests) {
+MTS_DEV bool traverse(const SceneView &sv, const LdsView &lds, f3 o, f3 d, float mint, float maxt, Hit &hit, uint32_t &tri_tests,
+                      bool coherent = false) {
+    if (FLAT && !ANY && MTS_FLAT_CULL && coherent && sv.n_clusters > 1u) return traverse_flat_clustered(sv, lds, o, d, mint, maxt, hit, tri_tests);
     if (FLAT) return traverse_flat<ANY>(sv, lds, o, d, mint, maxt, hit, tri_tests);
     return traverse_bvh<ANY>(sv, lds, o, d, mint, maxt, hit, tri_tests);
 }

@@ -115,7 +115,8 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
     bool found;
     if (DEFER) df->pending = false;
     if (DEFER == 1) { hit = df->hit; found = df->found; }
-    else found = traverse<FLAT, false>(sv, lds, s.o, s.d, s.mint, s.maxt, hit, c.tri_tests);
+    else found = traverse<FLAT, false>(sv, lds, s.o, s.d, s.mint, s.maxt, hit, c.tri_tests,
+                                       FLAT && __ballot(s.depth != 1u) == 0ull);      // all active lanes carry camera rays: cluster culling
     if (s.depth == 1u) s.flags = found ? 1u : 0u;          // valid_ray (path.cpp:121)
 
     SurfaceInteraction si;
