@@ -1038,7 +1038,7 @@ static int ensure_workspace(mtsamd_scene *s, uint32_t n_waves, uint32_t seg_cap,
         HIP_TRY(hipMalloc((void **) &w.pool[k].res, slots * sizeof(float4)));
         HIP_TRY(hipMalloc((void **) &w.pool[k].rng, slots * sizeof(uint4)));
         HIP_TRY(hipMalloc((void **) &w.pool[k].misc, slots * sizeof(uint2)));
-        HIP_TRY(hipMalloc((void **) &w.count[k], n_waves * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **) &w.count[k], 2 * (size_t) n_waves * sizeof(uint32_t)));      // counts + survivor borders (k_shade, flat scenes)
         if (s->spectral) {
             HIP_TRY(hipMalloc((void **) &w.pool[k].wav, slots * sizeof(float4)));
             HIP_TRY(hipMalloc((void **) &w.pool[k].aux, slots * sizeof(float2)));
@@ -1119,8 +1119,8 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     if (n >= (1ull << 31)) return fail(MTSAMD_ERR_INVALID, "a pass holds fewer than 2^31 samples");
     HIP_TRY(hipMemcpyAsync(w.cursor, w.h_cursor, nw * sizeof(uint64_t), hipMemcpyHostToDevice, j.stream));
     HIP_TRY(hipMemcpyAsync(w.cursor_end, w.h_cursor + nw, nw * sizeof(uint64_t), hipMemcpyHostToDevice, j.stream));
-    HIP_TRY(hipMemsetAsync(w.count[0], 0, nw * sizeof(uint32_t), j.stream));
-    HIP_TRY(hipMemsetAsync(w.count[1], 0, nw * sizeof(uint32_t), j.stream));
+    HIP_TRY(hipMemsetAsync(w.count[0], 0, 2 * (size_t) nw * sizeof(uint32_t), j.stream));
+    HIP_TRY(hipMemsetAsync(w.count[1], 0, 2 * (size_t) nw * sizeof(uint32_t), j.stream));
 
     RenderParams p{};
     p.sv = j.s->view; p.cam = j.cam;

@@ -602,7 +602,10 @@ MTS_DEV bool traverse_flat(const SceneView &sv, const LdsView &lds, f3 o, f3 d, 
 MTS_DEV bool traverse_flat_clustered(const SceneView &sv, const LdsView &lds, f3 o, f3 d, float mint, float maxt, Hit &hit, uint32_t &tri_tests) {
     float best = maxt, bu = 0.0f, bv = 0.0f;
     uint32_t best_prim = kNoPrim;
-    tri_tests += sv.n_prims;                                 // nominal count, as the plain loop (the statistics do not depend on the schedule)
+#ifndef MTS_CULL_STATS
+#define MTS_CULL_STATS 0                                     // 1 (diagnostic builds): count the triangles really tested
+#endif
+    if (!MTS_CULL_STATS) tri_tests += sv.n_prims;            // nominal count, as the plain loop (the statistics do not depend on the schedule)
     const v2f ox = splat(o.x), oy = splat(o.y), oz = splat(o.z), dx = splat(d.x), dy = splat(d.y), dz = splat(d.z);
     const f3 inv = mk3(clamp_inv(d.x), clamp_inv(d.y), clamp_inv(d.z));
     const float4 *rec = lds.pairs;
@@ -617,6 +620,7 @@ MTS_DEV bool traverse_flat_clustered(const SceneView &sv, const LdsView &lds, f3
         const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), mint));
         const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best));
         if (__ballot(tn <= tf) == 0ull) { rec += 5u * n; k += n; continue; }
+        if (MTS_CULL_STATS) tri_tests += 2u * n;
         for (uint32_t i = 0; i < n; ++i, ++k) {
             const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4];
             rec += 5;

@@ -533,7 +533,8 @@ MTS_DEV bool bounce_step_spectral(const RenderParams &P, const LdsView &lds, Pat
     bool found;
     if (DEFER) df->pending = false;
     if (DEFER == 1) { hit = df->hit; found = df->found; }
-    else found = traverse<FLAT, false>(sv, lds, s.o, s.d, s.mint, s.maxt, hit, c.tri_tests);
+    else found = traverse<FLAT, false>(sv, lds, s.o, s.d, s.mint, s.maxt, hit, c.tri_tests,
+                                       FLAT && __ballot(s.depth != 1u) == 0ull);      // camera rays only: cluster culling (as bounce_step)
     if (s.depth == 1u) s.flags = found ? 1u : 0u;
 
     SurfaceInteraction si;
@@ -774,7 +775,7 @@ __global__ __launch_bounds__(kBlock) void k_direct(const RenderParams P, uint64_
         generate_path(P, ordinal, lp, j, s);
         Hit hit;
         ++c.closest; ++c.segments;
-        const bool found = traverse<FLAT, false>(sv, lds, s.o, s.d, s.mint, s.maxt, hit, c.tri_tests);
+        const bool found = traverse<FLAT, false>(sv, lds, s.o, s.d, s.mint, s.maxt, hit, c.tri_tests, FLAT);      // camera rays of consecutive samples: cluster culling
         s.flags = found ? 1u : 0u;
         if (P.integrator == 2) {
             const float t = found ? hit.t : 0.0f;
@@ -949,6 +950,9 @@ MTS_DEV void drain_shadow_ring(const RenderParams &P, const LdsView &lds, const 
     }
 }
 
+#ifndef MTS_SURV_ORDER
+#define MTS_SURV_ORDER 1      // 0 (experiment): the pooled list of a workgroup in segment order, survivors and camera paths interleaved
+#endif
 template <typename State, bool GENERAL, bool FLAT, bool INLINE = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FLAT ? MTS_BOUNCE_WAVES : ShadeWaves<State, GENERAL>::kMin, FLAT ? MTS_BOUNCE_WAVES : 8)))
 void k_shade(const RenderParams P) {
@@ -964,7 +968,7 @@ void k_shade(const RenderParams P) {
     const uint32_t hw = threadIdx.x >> 6;
     const uint32_t wave = gw > 4u ? P.wave_first + blockIdx.x * gw + hw : P.wave_first + ((blockIdx.x * kBlock + threadIdx.x) >> 6);
     const uint32_t wave_last = P.wave_last ? P.wave_last : P.n_waves;
-    __shared__ uint32_t s_cnt[kBlock / 64u];
+    __shared__ uint32_t s_cnt[kBlock / 64u], s_surv[kBlock / 64u];
     __shared__ uint32_t s_pre[FLAT ? 1025 : 1];      // gather: s_pre[k] = paths in the group's waves before the k-th
     if (FLAT && gw > 4u) {
         const uint32_t g0 = wave - hw;
@@ -990,7 +994,9 @@ void k_shade(const RenderParams P) {
         // While the pool drains at the end of a pass most scheduling waves have nothing left to do: a workgroup whose four
         // waves are all idle leaves before staging the scene into LDS (its output counts still have to be reset).
         const uint32_t n_own = wave < wave_last ? P.count_in[wave] : 0u;
-        if (lane_id() == 0u) s_cnt[threadIdx.x >> 6] = n_own;
+        // the segment of a wave is [survivors of the last launch | camera paths generated by it]; the second half of the count array says
+        // where the border is (a hint: any value <= the count gives a valid order, so stale entries of other schedules are harmless)
+        if (lane_id() == 0u) { s_cnt[threadIdx.x >> 6] = n_own; s_surv[threadIdx.x >> 6] = (wave < wave_last && MTS_SURV_ORDER) ? min(P.count_in[P.n_waves + wave], n_own) : 0u; }
         const bool work = wave < wave_last && (n_own > 0u || P.cursor[wave] < P.cursor_end[wave]);
         if (!__syncthreads_or(work ? 1 : 0)) {
             if (wave < wave_last && lane_id() == 0u) {
@@ -1019,12 +1025,19 @@ void k_shade(const RenderParams P) {
     // output segment of the wave that processed them (seg_cap is a multiple of 64, so a wave never gets more than it can hold).
     const uint32_t wg_wave0 = wave - (threadIdx.x >> 6);
     const uint32_t n_valid = FLAT ? min((uint32_t) (kBlock / 64u), wave_last - wg_wave0) : 1u;
-    uint32_t cnt4[kBlock / 64u], n_in = 0;
+    // FLAT: the pooled list is ordered [survivors of wave 0 .. 3 | new camera paths of wave 0 .. 3] (reg[0 .. 7]): the chunks of the second
+    // part hold camera rays only -- the samples of one or two pixels -- and take the cluster-culling closest-hit loop (traverse())
+    uint32_t reg[2u * (kBlock / 64u)], surv4[kBlock / 64u], n_in = 0;
     if (FLAT && gw > 4u) {
         n_in = s_pre[gw];
     } else if (FLAT) {
 #pragma unroll
-        for (uint32_t g = 0; g < kBlock / 64u; ++g) { cnt4[g] = g < n_valid ? s_cnt[g] : 0u; n_in += cnt4[g]; }
+        for (uint32_t g = 0; g < kBlock / 64u; ++g) {
+            const uint32_t cg = g < n_valid ? s_cnt[g] : 0u;
+            surv4[g] = g < n_valid ? s_surv[g] : 0u;
+            reg[g] = surv4[g]; reg[kBlock / 64u + g] = cg - surv4[g];
+            n_in += cg;
+        }
     } else {
         n_in = __builtin_amdgcn_readfirstlane(P.count_in[wave]);
     }
@@ -1042,11 +1055,16 @@ void k_shade(const RenderParams P) {
                 for (uint32_t step = gw >> 1; step; step >>= 1) if (s_pre[k + step] <= idx) k += step;
                 i = (size_t) (wg_wave0 + k) * P.seg_cap + (idx - s_pre[k]);
             } else if (FLAT) {
-                uint32_t src = wg_wave0, j = i0 + lane;
+                uint32_t r = 0u, j = i0 + lane;
 #pragma unroll
-                for (uint32_t g = 0; g + 1 < kBlock / 64u; ++g)
-                    if (src == wg_wave0 + g && j >= cnt4[g]) { j -= cnt4[g]; ++src; }
-                i = (size_t) src * P.seg_cap + j;
+                for (uint32_t g = 0; g + 1 < 2u * (kBlock / 64u); ++g)
+                    if (r == g && j >= reg[g]) { j -= reg[g]; ++r; }
+                constexpr uint32_t kW = kBlock / 64u;
+                const uint32_t g = r >= kW ? r - kW : r;
+                uint32_t off = 0u;
+#pragma unroll
+                for (uint32_t q = 0; q < kW; ++q) off = (r >= kW && g == q) ? surv4[q] : off;
+                i = (size_t) (wg_wave0 + g) * P.seg_cap + off + j;
             }
             load_state(P.in, i, s);
             if (s.flags & kFlagZombie) {
@@ -1099,6 +1117,7 @@ void k_shade(const RenderParams P) {
     }
     if (INLINE && q_count > 0u) drain_shadow_ring<State, GENERAL>(P, lds, ring, q_head, q_count, base, c);
 
+    const uint32_t n_surv = n_out;                           // border between the survivors and the camera paths generated below
     uint64_t cursor = P.cursor[wave];
     const uint64_t end = P.cursor_end[wave];
     while (n_out < P.target && cursor < end) {
@@ -1127,6 +1146,7 @@ void k_shade(const RenderParams P) {
     }
     if (lane == 0) {
         if (!(FLAT && gw > 4u)) P.count_out[wave] = n_out;
+        if (FLAT && !(gw > 4u)) P.count_out[P.n_waves + wave] = n_surv;
         if (!INLINE) P.count_shadow[wave] = n_sh;
         P.cursor[wave] = cursor;
         uint64_t *ws = P.wave_stats + 4u * (size_t) wave;
