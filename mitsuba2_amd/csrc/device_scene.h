@@ -646,6 +646,46 @@ MTS_DEV bool traverse_flat_clustered(const SceneView &sv, const LdsView &lds, f3
     return best_prim != kNoPrim;
 }
 
+// Any-hit counterpart for the shadow rays of such a wave (they leave a pixel-sized patch of a surface towards one emitter): clusters no
+// active lane's segment reaches are skipped; a lane that has found an occluder no longer votes.
+MTS_DEV bool traverse_flat_clustered_any(const SceneView &sv, const LdsView &lds, f3 o, f3 d, float mint, float maxt, uint32_t &tri_tests) {
+    bool any = false;
+    tri_tests += sv.n_prims;                                 // nominal count, as the plain loop
+    const v2f ox = splat(o.x), oy = splat(o.y), oz = splat(o.z), dx = splat(d.x), dy = splat(d.y), dz = splat(d.z);
+    const f3 inv = mk3(clamp_inv(d.x), clamp_inv(d.y), clamp_inv(d.z));
+    const float4 *rec = lds.pairs;
+    for (uint32_t c = 0; c < sv.n_clusters; ++c) {
+        const float4 lo = lds.clusters[2u * c], hi = lds.clusters[2u * c + 1u];
+        const uint32_t n = __float_as_uint(lo.w);
+        const float ax = (lo.x - o.x) * inv.x, bx = (hi.x - o.x) * inv.x;
+        const float ay = (lo.y - o.y) * inv.y, by = (hi.y - o.y) * inv.y;
+        const float az = (lo.z - o.z) * inv.z, bz = (hi.z - o.z) * inv.z;
+        const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), mint));
+        const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), maxt));
+        if (__ballot(!any && tn <= tf) == 0ull) { rec += 5u * n; continue; }
+        for (uint32_t i = 0; i < n; ++i) {
+            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4];
+            rec += 5;
+            const v2f p0x = { q0.x, q0.y }, p0y = { q0.z, q0.w }, p0z = { q1.x, q1.y };
+            const v2f e1x = { q1.z, q1.w }, e1y = { q2.x, q2.y }, e1z = { q2.z, q2.w };
+            const v2f e2x = { q3.x, q3.y }, e2y = { q3.z, q3.w }, e2z = { q4.x, q4.y };
+            const v2f pvx = vfma(dy, e2z, -(dz * e2y)), pvy = vfma(dz, e2x, -(dx * e2z)), pvz = vfma(dx, e2y, -(dy * e2x));
+            const v2f det = vfma(e1z, pvz, vfma(e1y, pvy, e1x * pvx));
+            const v2f ivd = rcp_nr2(det);
+            const v2f tx = ox - p0x, ty = oy - p0y, tz = oz - p0z;
+            const v2f u = vfma(tz, pvz, vfma(ty, pvy, tx * pvx)) * ivd;
+            const v2f qx = vfma(ty, e1z, -(tz * e1y)), qy = vfma(tz, e1x, -(tx * e1z)), qz = vfma(tx, e1y, -(ty * e1x));
+            const v2f v = vfma(dz, qz, vfma(dy, qy, dx * qx)) * ivd;
+            const v2f t = vfma(e2z, qz, vfma(e2y, qy, e2x * qx)) * ivd;
+            const v2f uv = u + v;
+            const bool ok_a = (u.x >= 0.0f) && (v.x >= 0.0f) && (uv.x <= 1.0f) && (t.x >= mint) && (t.x <= maxt);
+            const bool ok_b = (u.y >= 0.0f) && (v.y >= 0.0f) && (uv.y <= 1.0f) && (t.y >= mint) && (t.y <= maxt);
+            any = any || ok_a || ok_b;
+        }
+    }
+    return any;
+}
+
 // `coherent` (wave-uniform): the active lanes carry the camera rays of one or two pixels -> cluster culling (flat scenes, closest hit)
 template <bool FLAT, bool ANY>
 MTS_DEV bool traverse(const SceneView &sv, const LdsView &lds, f3 o, f3 d, float mint, float maxt, Hit &hit, uint32_t &tri_tests,

@@ -905,6 +905,12 @@ template <bool GENERAL, bool FLAT>
 MTS_DEV bool step_deferred(const RenderParams &P, const LdsView &lds, PathStateS &s, Counters &c, Deferred &df) {
     return bounce_step_spectral<FLAT, FLAT ? 2 : 1, GENERAL>(P, lds, s, c, &df);
 }
+// radiance += nee of an unoccluded shadow ray: the additions drain_shadow_ring / k_trace<any> make on the stored record
+MTS_DEV void add_nee(PathState &s, const float (&nee)[4]) { s.res = mk3(s.res.x + nee[0], s.res.y + nee[1], s.res.z + nee[2]); }
+MTS_DEV void add_nee(PathStateS &s, const float (&nee)[4]) {
+#pragma unroll
+    for (int k = 0; k < kWav; ++k) s.res.v[k] += nee[k];
+}
 MTS_DEV void finish_path(const RenderParams &P, const PathState &s) { store_result(P, s); }
 MTS_DEV void finish_path(const RenderParams &P, const PathStateS &s) { store_result_spectral(P, s); }
 MTS_DEV void start_path(const RenderParams &P, uint64_t ordinal, uint32_t lp, uint32_t j, PathState &s) { generate_path(P, ordinal, lp, j, s); }
@@ -950,6 +956,9 @@ MTS_DEV void drain_shadow_ring(const RenderParams &P, const LdsView &lds, const 
     }
 }
 
+#ifndef MTS_PRIMARY_SHADOW
+#define MTS_PRIMARY_SHADOW 1  // 0 (experiment): the shadow rays of camera-path chunks go through the ring like all others
+#endif
 #ifndef MTS_SURV_ORDER
 #define MTS_SURV_ORDER 1      // 0 (experiment): the pooled list of a workgroup in segment order, survivors and camera paths interleaved
 #endif
@@ -1046,7 +1055,8 @@ void k_shade(const RenderParams P) {
         State s;
         Deferred df;
         df.pending = false;
-        bool alive = false;
+        bool alive = false, zombie_now = false;
+        uint32_t depth0 = 0u;                                // depth of the path before this step (0: no path, or a zombie)
         if (i0 + lane < n_in) {
             size_t i = base + i0 + lane;
             if (FLAT && gw > 4u) {          // s_pre[k] <= index < s_pre[k + 1]: the k-th wave of the group holds the path
@@ -1070,6 +1080,7 @@ void k_shade(const RenderParams P) {
             if (s.flags & kFlagZombie) {
                 finish_path(P, s);
             } else {
+                depth0 = s.depth;
                 if (!FLAT) {
                     const float4 h = P.in.hit[i];
                     df.hit.t = h.x; df.hit.prim = __float_as_uint(h.y); df.hit.u = h.z; df.hit.v = h.w;
@@ -1077,9 +1088,20 @@ void k_shade(const RenderParams P) {
                 }
                 alive = step_deferred<GENERAL, FLAT>(P, lds, s, c, df);
                 if (!alive) {
-                    if (df.pending) { s.flags |= kFlagZombie; alive = true; }
+                    if (df.pending) { s.flags |= kFlagZombie; alive = true; zombie_now = true; }
                     else finish_path(P, s);
                 }
+            }
+        }
+        // A chunk of camera paths only (the samples of one or two pixels): nearly every lane casts a shadow ray and the rays leave a
+        // pixel-sized patch towards one emitter, so they are resolved here, on the spot, by the cluster-culling any-hit loop instead of
+        // going through the ring (same additions to the radiance in the same order: res + nee; a path that died after casting its ray
+        // is finished at once instead of waiting one launch as a zombie)
+        if (INLINE && MTS_FLAT_CULL && MTS_PRIMARY_SHADOW && P.sv.n_clusters > 1u && __ballot(depth0 != 1u && (i0 + lane < n_in)) == 0ull) {
+            if (df.pending) {
+                if (!traverse_flat_clustered_any(P.sv, lds, df.so, df.sd, df.smint, df.smaxt, c.tri_tests)) add_nee(s, df.nee);
+                df.pending = false;
+                if (zombie_now) { s.flags &= ~kFlagZombie; finish_path(P, s); alive = false; }
             }
         }
         // survivors are compacted to the front of the output segment, their shadow rays into a dense queue of their own
