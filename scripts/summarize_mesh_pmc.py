@@ -24,7 +24,7 @@ def short(name):
 
 
 def counters(sub):
-    f = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")), key=os.path.getmtime)
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     launches = collections.defaultdict(set)
     for r in csv.DictReader(open(f)):

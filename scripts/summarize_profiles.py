@@ -19,7 +19,7 @@ src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+stats = max(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
 shutil.copy(stats, os.path.join(dst, tag + "_kernel_stats.csv"))
 
 
@@ -38,7 +38,7 @@ KEY = KERNEL.split("<")[0]                      # k_shade / k_bounce: the only i
 
 
 def counters(sub):
-    f = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")), key=os.path.getmtime)
     agg = collections.defaultdict(float)
     launches = set()
     for r in csv.DictReader(open(f)):
