@@ -243,3 +243,46 @@ def test_delta_emitters_match_oracle(lights, integrator):
         swant, _ = ob.OracleScene(cb, spectral_path=R.srgb_coeff_path()).sample_radiance(ob.make_desc(sp), 0, n)
         sclose = np.isclose(xyz.cpu().numpy(), swant[:, :3], rtol=5e-3, atol=1e-4 * max(1.0, swant[:, :3].mean())).all(1)
         assert sclose.mean() > 0.99, sclose.mean()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_cluster_culling_on_random_flat_scenes(seed):
+    """LDS-resident scenes: the camera-path chunks take the cluster-culling loops (device_scene.h, traverse_flat_clustered*): boxes of the
+    consecutive pairs of one shape, skipped by the whole wave.  The boxes must only ever cull: random triangle soups with odd triangle
+    counts per shape (pairs straddle shapes), slivers, a camera inside the geometry and an axis-parallel view -- the depth integrator
+    (hit distance per sample) is bit-exact against the oracle's brute force, path samples agree as for every other scene."""
+    from mitsuba2_amd import render as R, scenes
+    rng = np.random.default_rng(100 + seed)
+    meshes, counts = [], [1, 3, 7, 2, 5, 9, 4][: 4 + seed % 3]
+    for si, nt in enumerate(counts):
+        centre = rng.uniform(-2.0, 2.0, 3)
+        tris = centre + rng.normal(size=(nt, 3, 3)) * rng.uniform(0.05, 1.5)
+        if si == 1:
+            tris[0, 2] = tris[0, 0] + (tris[0, 1] - tris[0, 0]) * 0.5 + 1e-4       # a sliver
+        meshes.append(dict(positions=tris.reshape(-1, 3).astype(np.float32), faces=np.arange(3 * nt, dtype=np.uint32).reshape(-1, 3),
+                           bsdf=si % 2, emitter=0 if si == 0 else -1))
+    sd = dict(meshes=meshes, bsdfs=[{"type": "diffuse", "reflectance": [0.6, 0.5, 0.4]}, {"type": "diffuse", "reflectance": [0.2, 0.7, 0.3]}],
+              emitters=[dict(type="area", radiance=np.array([9.0, 8.0, 7.0], np.float32))])
+    allp = np.concatenate([m["positions"] for m in meshes])
+    mid = allp.mean(0)
+    c0, c1 = meshes[2]["positions"].mean(0), meshes[3]["positions"].mean(0)
+    # from outside; from inside one shape's cloud towards another; exactly along -x (zero direction components in the box tests)
+    views = [(mid + [0.3, 0.2, -8.0], mid), (c0, c1), (mid + [7.0, 0.0, 0.0], mid)]
+    origin, target = [[float(x) for x in v] for v in views[seed % 3]]
+    sp = dict(scenes.cornell_box_sensor(48, 32, spp=64, seed=seed), to_world=scenes.look_at(origin, target, [0, 1, 0]), fov=50.0,
+              near_clip=1e-2, far_clip=100.0, max_depth=4)
+    scene, sensor = R.Scene(sd), R.make_sensor(sp)
+    assert scene.info()["primitives"] == sum(counts) and scene.info()["primitives"] <= 64
+    n = 48 * 32 * 64
+    oracle = ob.OracleScene(sd, naive=True)
+    rgb, mask, pos = R.DepthIntegrator().sample(scene, sensor, 0, n)
+    want, wpos = oracle.sample_radiance(ob.make_desc(dict(sp, integrator="depth")), 0, n)
+    assert np.array_equal(pos.cpu().numpy(), wpos)
+    assert np.array_equal(mask.cpu().numpy(), want[:, 3] > 0.5) and np.array_equal(rgb.cpu().numpy(), want[:, :3])
+    assert mask.float().mean().item() > 0.01                 # the view sees some geometry
+    for pipeline in (0, 1):                                  # default schedule (culling + on-the-spot shadow rays) and the fused kernel
+        rgb, mask, pos = R.PathIntegrator(max_depth=4, pipeline=pipeline).sample(scene, sensor, 0, n)
+        want, wpos = oracle.sample_radiance(ob.make_desc(sp), 0, n)
+        assert np.array_equal(pos.cpu().numpy(), wpos) and np.array_equal(mask.cpu().numpy(), want[:, 3] > 0.5)
+        close = np.isclose(rgb.cpu().numpy(), want[:, :3], rtol=2e-3, atol=1e-4).all(1)
+        assert close.mean() > 0.999, (pipeline, close.mean())
