@@ -364,3 +364,38 @@ def test_xml_delta_emitters():
         mxml.parse_string(x.replace('<point name="position" x="1" y="2" z="3"/>', '<point name="position" x="1" y="2" z="3"/><transform name="to_world"><translate x="1"/></transform>'))
     with pytest.raises(mxml.XMLError, match="unreferenced"):
         mxml.parse_string(x.replace('<float name="cutoff_angle" value="30"/>', '<float name="cutoff" value="30"/>'))
+
+
+def test_xml_nesting_bsdfs():
+    """blendbsdf / mask in a scene file (the layouts of blendbsdf.cpp:36-49 and mask.cpp:44-60): children in document order, the weight as
+    <spectrum> / <float> or a <texture>; the host module flattens the children behind the top-level records"""
+    from mitsuba2_amd import bsdfs as B
+    xml = """<scene version="2.0.0">
+    <shape type="rectangle">
+        <bsdf type="blendbsdf" id="mix">
+            <texture name="weight" type="checkerboard"><float name="color0" value="0.9"/><float name="color1" value="0.1"/></texture>
+            <bsdf type="conductor"/>
+            <bsdf type="roughplastic"><spectrum name="diffuse_reflectance" value="0.1"/></bsdf>
+        </bsdf>
+    </shape>
+    <shape type="rectangle">
+        <bsdf type="mask" id="cutout">
+            <float name="opacity" value="0.25"/>
+            <bsdf type="twosided"><bsdf type="diffuse"><rgb name="reflectance" value="0.2, 0.6, 0.3"/></bsdf></bsdf>
+        </bsdf>
+    </shape>
+    <shape type="rectangle"><bsdf type="diffuse"/></shape>
+</scene>"""
+    sd = mxml.parse_string(xml).scene_dict
+    assert [b["type"] for b in sd["bsdfs"]] == ["blendbsdf", "mask", "diffuse"]
+    recs = [B.normalize(b) for b in sd["bsdfs"]]
+    mix, cut, plain = recs
+    assert mix["type"] == B.BLEND and [c["type"] for c in mix["children"]] == [B.CONDUCTOR, B.ROUGHPLASTIC] and mix["reflectance"]["type"] == "checkerboard"
+    assert np.allclose(mix["children"][1]["reflectance"], 0.1) and B.is_smooth(mix) and not B.is_transmissive(mix)
+    assert cut["type"] == B.MASK and cut["reflectance"] == [0.25] * 3 and cut["children"][0]["twosided"] and cut["children"][0]["type"] == B.DIFFUSE
+    assert B.is_transmissive(cut) and B.is_smooth(cut) and cut["id"] == "cutout"
+    flat = B.flatten(recs)
+    assert len(flat) == 6 and mix["nested"] == [3, 4] and cut["nested"] == [5, -1] and "nested" not in plain
+    assert flat[3] is mix["children"][0] and flat[5] is cut["children"][0]
+    with pytest.raises(RuntimeError, match="scalar"):
+        B.normalize({"type": "mask", "opacity": [0.1, 0.2, 0.3], "a": {"type": "diffuse"}})
