@@ -302,12 +302,14 @@ MTS_DEV void walk_leaf(BvhWalk &w, const SceneView &sv, uint32_t &cur, uint32_t 
         const float4 t0 = p[0], t1 = p[1], t2 = p[2];
         float u, v, t;
         ++tri_tests;
-        if (tri_test(mk3(t0.x, t0.y, t0.z), mk3(t0.w, t1.x, t1.y), mk3(t1.z, t1.w, t2.x), w.o, w.d, w.mint, w.maxt, u, v, t)) {
+        // closest hit: the interval ends at the closest hit so far (w.best <= maxt, equal until something is found), which is what the
+        // update rule below would enforce anyway; the hit lives in (best, best_prim, hit.u, hit.v) -- no second copy of t and prim
+        if (tri_test(mk3(t0.x, t0.y, t0.z), mk3(t0.w, t1.x, t1.y), mk3(t1.z, t1.w, t2.x), w.o, w.d, w.mint, ANY ? w.maxt : w.best, u, v, t)) {
             if (ANY) { w.found = true; return true; }
             const uint32_t prim = __float_as_uint(t2.y);
             if (!w.found || t < w.best || (t == w.best && prim > w.best_prim)) {
                 w.found = true; w.best = t; w.best_prim = prim;
-                w.hit.t = t; w.hit.prim = prim; w.hit.u = u; w.hit.v = v;
+                w.hit.u = u; w.hit.v = v;
             }
         }
         return false;
@@ -507,7 +509,7 @@ MTS_DEV bool traverse_bvh(const SceneView &sv, const LdsView &lds, f3 o, f3 d, f
         if (w.far) walk_round<ANY, true>(w, sv, st, tri_tests);
         else walk_round<ANY, false>(w, sv, st, tri_tests);
     }
-    if (!ANY && w.found) hit = w.hit;
+    if (!ANY && w.found) { hit.t = w.best; hit.prim = w.best_prim; hit.u = w.hit.u; hit.v = w.hit.v; }
     return w.found;
 }
 

@@ -1426,7 +1426,7 @@ void k_trace(const RenderParams P) {
             const bool need = w.cur == kNoNode;
             if (need && busy) {                              // retire the finished item
                 if (ANY) { if (!w.found) retire_any(k); }
-                else pool.hit[k] = w.found ? make_float4(w.hit.t, __uint_as_float(w.hit.prim), w.hit.u, w.hit.v)
+                else pool.hit[k] = w.found ? make_float4(w.best, __uint_as_float(w.best_prim), w.hit.u, w.hit.v)
                                            : make_float4(__builtin_inff(), __uint_as_float(kNoPrim), 0.0f, 0.0f);
                 busy = false;
             }
@@ -2127,9 +2127,9 @@ void k_ray_walk(const SceneView sv, uint64_t n, const RayStreams r, float *t, ui
     uint64_t i = 0;
     auto retire = [&](uint64_t k, bool found) {
         if (ANY) { hit[k] = found ? 1 : 0; return; }
-        t[k] = found ? w.hit.t : __builtin_inff();
-        prim[k] = found ? w.hit.prim : kNoPrim;
-        if (shape) shape[k] = found ? geo.prim_shape(w.hit.prim) : kNoPrim;
+        t[k] = found ? w.best : __builtin_inff();
+        prim[k] = found ? w.best_prim : kNoPrim;
+        if (shape) shape[k] = found ? geo.prim_shape(w.best_prim) : kNoPrim;
         if (u) u[k] = found ? w.hit.u : 0.0f;
         if (v) v[k] = found ? w.hit.v : 0.0f;
     };
