@@ -98,6 +98,7 @@ SYMBOLS = {
     "mtsamd_imageblock_put_block": (C.c_int, [vp] + [C.c_int32] * 5 + [vp] + [C.c_int32] * 6 + [vp]),
     "mtsamd_rfilter_info": (C.c_int, [C.c_int32, C.c_float, C.c_float, f32p, f32p, C.POINTER(C.c_int32)]),
     "mtsamd_film_develop": (C.c_int, [vp, C.c_uint64, vp, vp]),
+    "mtsamd_libm_eval": (C.c_int, [C.c_int32, C.c_uint64, vp, vp, vp, vp]),
 }
 
 _lib = None

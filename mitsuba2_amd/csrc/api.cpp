@@ -128,7 +128,7 @@ int make_filter(int32_t kind, float param, float param2, int32_t analytic, Filte
         if (!(param > 0.0f)) return fail(MTSAMD_ERR_INVALID, "gaussian rfilter: stddev must be positive");
         f.radius = 4 * param;
         f.alpha = -1.0f / (2.0f * param * param);
-        f.bias = std::exp(f.alpha * (f.radius * f.radius));
+        f.bias = lm_exp(f.alpha * (f.radius * f.radius));
     } else if (kind == MTSAMD_RFILTER_BOX) {
         if (!(param > 0.0f)) return fail(MTSAMD_ERR_INVALID, "box rfilter: radius must be positive");
         f.radius = param + kRayEpsilon;
@@ -146,13 +146,13 @@ int make_filter(int32_t kind, float param, float param2, int32_t analytic, Filte
     }
     auto eval = [&](float x) -> float {
         switch (kind) {
-        case MTSAMD_RFILTER_GAUSSIAN: return std::max(0.0f, std::exp(f.alpha * (x * x)) - f.bias);
+        case MTSAMD_RFILTER_GAUSSIAN: return std::max(0.0f, lm_exp(f.alpha * (x * x)) - f.bias);
         case MTSAMD_RFILTER_TENT: return std::max(0.0f, 1.0f - std::fabs(x * f.alpha));
         case MTSAMD_RFILTER_CATMULLROM: return cubic_filter(x, 0.0f, 0.5f);
         case MTSAMD_RFILTER_MITCHELL: return cubic_filter(x, f.alpha, f.bias);
         case MTSAMD_RFILTER_LANCZOS: {
             x = std::fabs(x);
-            const float x1 = kPi * x, x2 = x1 / f.radius, result = (std::sin(x1) * std::sin(x2)) / (x1 * x2);
+            const float x1 = kPi * x, x2 = x1 / f.radius, result = (lm_sin(x1) * lm_sin(x2)) / (x1 * x2);
             return x < kEpsilon ? 1.0f : (x > f.radius ? 0.0f : result);
         }
         default: return std::fabs(x) <= f.radius ? 1.0f : 0.0f;
@@ -852,7 +852,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         }
     }
     SceneView &v = s->view;
-    v.nodes = s->d_nodes; v.qnodes = s->d_qnodes; v.wnodes = s->d_wnodes; v.wroot = s->bvh.wroot; v.tris = s->d_tris; v.root = s->bvh.root;
+    v.nodes = s->d_nodes; v.qnodes = s->d_qnodes; v.wnodes = s->d_wnodes; v.wroot = s->bvh.wroot; v.n_wnodes = s->bvh.n_wnodes; v.tris = s->d_tris; v.root = s->bvh.root;
     for (int k = 0; k < 3; ++k) { v.q_lo[k] = s->bvh.q_lo[k]; v.q_step[k] = s->bvh.q_step[k]; }
     v.n_nodes = s->bvh.n_nodes; v.n_slots = s->bvh.n_slots; v.n_prims = s->n_prims;
     // LDS residency: flat scenes keep everything in LDS (see flat_recs below).  For hierarchy scenes staging the
@@ -1108,7 +1108,7 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     const uint64_t n_chunks = (n + chunk - 1u) / chunk, last_size = n - (n_chunks - 1u) * chunk;
     // hierarchy scenes run two launch chains over the halves of the scheduling waves: their chunks alternate (kernels.h, chunk_owner)
     uint32_t chain_split = 0;
-    if (!j.s->view.flat && j.split && nw >= 256u && !getenv("MTSAMD_ONE_CHAIN") && !getenv("MTSAMD_NO_CHAIN_INTERLEAVE")) chain_split = (nw / 2u + 7u) & ~7u;
+    if (!j.s->view.flat && j.split && nw >= 256u && !getenv("MTSAMD_ONE_CHAIN") && !getenv("MTSAMD_NO_CHAIN_INTERLEAVE")) chain_split = (nw / 2u + trace_group() - 1u) & ~(trace_group() - 1u);
     for (uint32_t k = 0; k < nw; ++k) {
         const uint64_t c0 = chunk_owner(k, nw, chain_split);      // this wave owns the chunks c0, c0 + nw, ...
         const uint64_t mine = c0 < n_chunks ? (n_chunks - 1u - c0) / nw + 1u : 0u;
@@ -1145,7 +1145,7 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
             HIP_TRY(hipMalloc((void **) &w.trace_spill, std::max<size_t>(words, 1) * sizeof(uint32_t)));
             w.trace_spill_words = words;
         }
-        p.trace_lds_depth = trace_lds_depth(p.sv); p.trace_spill = w.trace_spill;
+        p.trace_lds_depth = trace_lds_depth(p.sv); p.trace_top_nodes = trace_top_nodes(p.sv); p.trace_spill = w.trace_spill;
     }
     p.integrator = j.d->integrator; p.emitter_samples = j.d->emitter_samples; p.bsdf_samples = j.d->bsdf_samples;
     p.hide_emitters = j.d->hide_emitters;
@@ -1206,7 +1206,7 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     uint32_t split_parts = p.split == 1 && nw >= 256u ? 2u : 1u;
     if (getenv("MTSAMD_ONE_CHAIN")) split_parts = 1;      // experiment switch
     uint32_t split_lo[3] = { 0, nw, nw };
-    if (split_parts == 2) split_lo[1] = (nw / 2u + 7u) & ~7u;      // multiple of the k_trace group size
+    if (split_parts == 2) split_lo[1] = (nw / 2u + trace_group() - 1u) & ~(trace_group() - 1u);      // multiple of the k_trace group size
     if (split_parts == 2) {      // the second chain starts after the cursors and counts are in place
         HIP_TRY(hipEventRecord(w.part_ev[2], j.stream));
         HIP_TRY(hipStreamWaitEvent(w.part_stream[0], w.part_ev[2], 0));
@@ -1772,6 +1772,14 @@ int mtsamd_rfilter_info(int32_t rfilter, float param, float param2, float *table
 int mtsamd_film_develop(const float *xyzaw, uint64_t n, float *rgba, void *stream) {
     if (!xyzaw || !rgba) return fail(MTSAMD_ERR_INVALID, "null argument");
     HIP_TRY(launch_film_develop(xyzaw, n, rgba, (hipStream_t) stream));
+    return MTSAMD_OK;
+}
+
+int mtsamd_libm_eval(int32_t fn, uint64_t n, const float *x, const float *y, float *out, void *stream) {
+    if (fn < 0 || fn > 7) return fail(MTSAMD_ERR_INVALID, "libm_eval: unknown function %d", fn);
+    if (n && (!x || !out || (fn == 7 && !y))) return fail(MTSAMD_ERR_INVALID, "libm_eval: null buffer");
+    if (n >> 40) return fail(MTSAMD_ERR_INVALID, "libm_eval: too many arguments");
+    HIP_TRY(launch_libm_eval(fn, n, x, y, out, (hipStream_t) stream));
     return MTSAMD_OK;
 }
 

@@ -73,7 +73,7 @@ MTS_DEV Mdf mdf_make(bool ggx, float au, float av, bool visible) {
 MTS_DEV float mdf_eval(const Mdf &d, f3 m) {
     const float alpha_uv = d.au * d.av, cos_theta = m.z, cos_theta_2 = sqr(cos_theta);
     float result;
-    if (!d.ggx) result = expf(-(sqr(m.x / d.au) + sqr(m.y / d.av)) / cos_theta_2) / (kPi * alpha_uv * sqr(cos_theta_2));
+    if (!d.ggx) result = lm_exp(-(sqr(m.x / d.au) + sqr(m.y / d.av)) / cos_theta_2) / (kPi * alpha_uv * sqr(cos_theta_2));
     else result = rcp(kPi * alpha_uv * sqr(sqr(m.x / d.au) + sqr(m.y / d.av) + sqr(m.z)));
     return result * cos_theta > 1e-20f ? result : 0.0f;
 }
@@ -100,7 +100,7 @@ MTS_DEV float mdf_pdf(const Mdf &d, f3 wi, f3 m) {
 
 // Giles, "Approximating the erfinv function" (single precision)
 MTS_DEV float erfinv_f(float x) {
-    float w = -logf((1.0f - x) * (1.0f + x)), p;
+    float w = -lm_log((1.0f - x) * (1.0f + x)), p;
     if (w < 5.0f) {
         w = w - 2.5f;
         p = 2.81022636e-08f; p = fmaf(p, w, 3.43273939e-07f); p = fmaf(p, w, -3.5233877e-06f);
@@ -120,14 +120,14 @@ MTS_DEV f2 mdf_sample_visible_11(const Mdf &d, float cos_theta_i, f2 sample) {
     if (!d.ggx) {
         const float tan_theta_i = safe_sqrt(fmaf(-cos_theta_i, cos_theta_i, 1.0f)) / cos_theta_i;
         const float cot_theta_i = rcp(tan_theta_i);
-        const float maxval = erff(cot_theta_i);
+        const float maxval = lm_erf(cot_theta_i);
         sample.x = fmaxf(fminf(sample.x, 1.0f - 1e-6f), 1e-6f);
         sample.y = fmaxf(fminf(sample.y, 1.0f - 1e-6f), 1e-6f);
-        float x = maxval - (maxval + 1.0f) * erff(sqrtf(-logf(sample.x)));
-        sample.x *= 1.0f + maxval + kInvSqrtPi * tan_theta_i * expf(-sqr(cot_theta_i));
+        float x = maxval - (maxval + 1.0f) * lm_erf(sqrtf(-lm_log(sample.x)));
+        sample.x *= 1.0f + maxval + kInvSqrtPi * tan_theta_i * lm_exp(-sqr(cot_theta_i));
         for (int i = 0; i < 3; ++i) {
             const float slope = erfinv_f(x);
-            const float value = 1.0f + x + kInvSqrtPi * tan_theta_i * expf(-sqr(slope)) - sample.x;
+            const float value = 1.0f + x + kInvSqrtPi * tan_theta_i * lm_exp(-sqr(slope)) - sample.x;
             const float derivative = 1.0f - slope * tan_theta_i;
             x -= value / derivative;
         }
@@ -150,17 +150,17 @@ MTS_DEV f3 mdf_sample(const Mdf &d, f3 wi, f2 sample, float &pdf) {
         float sin_phi, cos_phi, cos_theta, cos_theta_2, alpha_2;
         if (d.au == d.av) {
             const float ang = (2.0f * kPi) * sample.y;
-            sin_phi = sinf(ang); cos_phi = cosf(ang);
+            sin_phi = lm_sin(ang); cos_phi = lm_cos(ang);
             alpha_2 = d.au * d.au;
         } else {
-            const float ratio = d.av / d.au, tmp = ratio * tanf((2.0f * kPi) * sample.y);
+            const float ratio = d.av / d.au, tmp = ratio * lm_tan((2.0f * kPi) * sample.y);
             cos_phi = 1.0f / sqrtf(fmaf(tmp, tmp, 1.0f));
             cos_phi = mulsign(cos_phi, fabsf(sample.y - 0.5f) - 0.25f);
             sin_phi = cos_phi * tmp;
             alpha_2 = rcp(sqr(cos_phi / d.au) + sqr(sin_phi / d.av));
         }
         if (!d.ggx) {
-            cos_theta = 1.0f / sqrtf(fmaf(-alpha_2, logf(1.0f - sample.x), 1.0f));
+            cos_theta = 1.0f / sqrtf(fmaf(-alpha_2, lm_log(1.0f - sample.x), 1.0f));
             cos_theta_2 = sqr(cos_theta);
             const float cos_theta_3 = fmaxf(cos_theta_2 * cos_theta, 1e-20f);
             pdf = (1.0f - sample.x) / (kPi * d.au * d.av * cos_theta_3);

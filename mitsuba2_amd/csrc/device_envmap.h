@@ -92,8 +92,8 @@ MTS_DEV f3 envmap_lookup(const DevEnvmap &e, float u, float v) {
     return r;
 }
 MTS_DEV void env_dir_to_uv(f3 v, float &u, float &vv) {            // envmap.cpp:139-142
-    const float a = atan2f(v.x, -v.z) * (0.5f * kInvPi);
-    const float b = acosf(fminf(fmaxf(v.y, -1.0f), 1.0f)) * kInvPi;
+    const float a = lm_atan2(v.x, -v.z) * (0.5f * kInvPi);
+    const float b = lm_acos(fminf(fmaxf(v.y, -1.0f), 1.0f)) * kInvPi;
     u = a - floorf(a); vv = b - floorf(b);
 }
 // EnvironmentMapEmitter::eval for the world-space direction the ray travels in (si.wi = -d)
@@ -107,7 +107,7 @@ MTS_DEV void envmap_sample(const DevEnvmap &e, f2 sample, f3 &d_out, float &pdf_
     float u, v, pdf;
     hier2d_sample(e, sample.x, sample.y, u, v, pdf);
     const float theta = v * kPi, phi = u * (2.0f * kPi);
-    const float st = sinf(theta), ct = cosf(theta), sp = sinf(phi), cp = cosf(phi);
+    const float st = lm_sin(theta), ct = lm_cos(theta), sp = lm_sin(phi), cp = lm_cos(phi);
     const f3 sd = mk3(cp * st, sp * st, ct);
     f3 d = mk3(sd.y, sd.z, -sd.x);
     const float inv_sin_theta = 1.0f / sqrtf(fmaxf(d.x * d.x + d.z * d.z, kEpsilon * kEpsilon));

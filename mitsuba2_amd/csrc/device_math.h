@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "device_libm.h"
 
 namespace mtsamd {
 
@@ -99,7 +100,7 @@ MTS_DEV f2 square_to_uniform_disk_concentric(f2 s) {
     if (q13) phi = 0.5f * kPi - phi;
     if (is_zero) phi = 0.0f;
     float sn, cs;
-    sincosf(phi, &sn, &cs);
+    lm_sincos(phi, &sn, &cs);
     f2 o; o.x = r * cs; o.y = r * sn;
     return o;
 }
@@ -136,5 +137,55 @@ MTS_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amd
 MTS_DEV uint32_t mask_rank(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
 }
+
+// ---- once-read / once-written streams (path pool, ray / hit / shadow-ray records, sample stream): marked non-temporal on hierarchy
+// scenes so that they do not push the BVH nodes and triangle slots -- the only data with reuse -- out of L2 and the Infinity Cache.
+// The wave-contiguous 16-byte SoA vectors are full-line accesses, the shape the hint is meant for.
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+typedef float nt_f2 __attribute__((ext_vector_type(2)));
+typedef uint32_t nt_u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t nt_u2 __attribute__((ext_vector_type(2)));
+template <bool NT> MTS_DEV float4 ld_stream(const float4 *p) {
+    if (!NT) return *p;
+    const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+template <bool NT> MTS_DEV float2 ld_stream(const float2 *p) {
+    if (!NT) return *p;
+    const nt_f2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f2 *>(p));
+    return make_float2(v.x, v.y);
+}
+template <bool NT> MTS_DEV uint4 ld_stream(const uint4 *p) {
+    if (!NT) return *p;
+    const nt_u4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+template <bool NT> MTS_DEV uint2 ld_stream(const uint2 *p) {
+    if (!NT) return *p;
+    const nt_u2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u2 *>(p));
+    return make_uint2(v.x, v.y);
+}
+template <bool NT> MTS_DEV uint32_t ld_stream(const uint32_t *p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT> MTS_DEV void st_stream(float4 *p, float4 v) {
+    if (!NT) { *p = v; return; }
+    const nt_f4 w = { v.x, v.y, v.z, v.w };
+    __builtin_nontemporal_store(w, reinterpret_cast<nt_f4 *>(p));
+}
+template <bool NT> MTS_DEV void st_stream(float2 *p, float2 v) {
+    if (!NT) { *p = v; return; }
+    const nt_f2 w = { v.x, v.y };
+    __builtin_nontemporal_store(w, reinterpret_cast<nt_f2 *>(p));
+}
+template <bool NT> MTS_DEV void st_stream(uint4 *p, uint4 v) {
+    if (!NT) { *p = v; return; }
+    const nt_u4 w = { v.x, v.y, v.z, v.w };
+    __builtin_nontemporal_store(w, reinterpret_cast<nt_u4 *>(p));
+}
+template <bool NT> MTS_DEV void st_stream(uint2 *p, uint2 v) {
+    if (!NT) { *p = v; return; }
+    const nt_u2 w = { v.x, v.y };
+    __builtin_nontemporal_store(w, reinterpret_cast<nt_u2 *>(p));
+}
+template <bool NT> MTS_DEV void st_stream(uint32_t *p, uint32_t v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
 
 } // namespace mtsamd

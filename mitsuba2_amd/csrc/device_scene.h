@@ -71,7 +71,7 @@ struct SceneView {
     const uint4 *qnodes;       // 2 per node: child boxes on a 16-bit grid (origin q_lo, cell q_step), child references
     const uint4 *wnodes;       // BVH4 collapsed from the BVH2, 4 per node: per child (x, y, z) = lo | hi << 16 on the same grid, w = child
                                // reference (kNoNode: no child, its box is inverted); wroot = reference of the root
-    uint32_t wroot;
+    uint32_t wroot, n_wnodes;
     float q_lo[3], q_step[3];
     const float4 *tris;        // 3 per slot (leaf order)
     uint32_t root;             // child ref of the root
@@ -255,7 +255,10 @@ MTS_DEV void walk_begin(BvhWalk &w, const SceneView &sv, f3 o, f3 d, float mint,
 // ends (cur = kNoNode, found = true) at the first hit.
 // Traversal stack of one lane: the first `lds_depth` entries live in LDS ([depth][lane], conflict-free), deeper ones -- rare:
 // a walk seldom defers more than a dozen subtrees -- in a global spill area, so that the LDS footprint does not cap occupancy.
-struct WalkStack { StackEntry *lds; uint32_t shift, lds_depth; StackEntry *spill; uint32_t spill_stride; };      // shift: log2 of the row stride (threads per workgroup, a power of two)
+// top_nodes / n_top (k_trace): the first n_top BVH4 nodes -- the top of the tree, BFS order -- staged in LDS by the workgroup (0: none)
+struct WalkStack { StackEntry *lds; uint32_t shift, lds_depth; StackEntry *spill; uint32_t spill_stride; const uint4 *top_nodes; uint32_t n_top; };      // shift: log2 of the row stride (threads per workgroup, a power of two)
+typedef uint32_t node_u4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const node_u4 LdsNodeWord;
 // The LDS part is addressed through an explicit LDS pointer (ds_read / ds_write of a whole entry; a pointer select between LDS and
 // the spill area compiles to flat accesses of half entries).  Row min(sp, lds_depth) is touched unconditionally: with a spill area
 // the row after the lds_depth real ones is a scratch row, so the deep (rare) case only adds the spill access behind a branch that
@@ -330,7 +333,10 @@ MTS_DEV void walk_leaf(BvhWalk &w, const SceneView &sv, uint32_t &cur, uint32_t 
 // leaves together.  A step loads one 64-byte node, tests the four child boxes (per child: 3 v_perm_b32, 6 cvt, 6 fma, min3 / max3),
 // sorts the hit children by entry distance (5 compare-exchanges), continues with the nearest and pushes the others, farthest first,
 // together with their entry distances.
-template <bool ANY, bool FAR = true>
+// TOP: nodes below st.n_top are read from the workgroup's LDS copy (ds_read_b128 through an explicit LDS pointer, as the stack): the
+// per-lane 16-byte loads of a divergent walk cost the vector-memory pipe ~39 CU-cycles per wave-instruction even when every line hits
+// L1, a random ds_read_b128 ~7 (scripts/ubench/gather_rate.hip); the upper levels are where every ray passes.
+template <bool ANY, bool FAR = true, bool TOP = false>
 MTS_DEV void walk_round(BvhWalk &w, const SceneView &sv, const WalkStack &st, uint32_t &tri_tests) {
     uint32_t cur = w.cur, sp = w.sp;
     const f3 inv = w.inv;
@@ -354,8 +360,16 @@ MTS_DEV void walk_round(BvhWalk &w, const SceneView &sv, const WalkStack &st, ui
         const f3 oq = w.o_q;
         const f3 noi = FAR ? mk3(fminf(2.4e-7f * fabsf(oq.x * inv.x), 1.0e30f), fminf(2.4e-7f * fabsf(oq.y * inv.y), 1.0e30f),
                                  fminf(2.4e-7f * fabsf(oq.z * inv.z), 1.0e30f)) : w.noi;
-        const uint4 *node = sv.wnodes + 4u * cur;
-        const uint4 c0 = node[0], c1 = node[1], c2 = node[2], c3 = node[3];
+        uint4 c0, c1, c2, c3;
+        if (TOP && cur < st.n_top) {
+            const LdsNodeWord *node = reinterpret_cast<LdsNodeWord *>((uint32_t) reinterpret_cast<uintptr_t>(st.top_nodes)) + 4u * cur;
+            const node_u4 n0 = node[0], n1 = node[1], n2 = node[2], n3 = node[3];
+            c0 = make_uint4(n0.x, n0.y, n0.z, n0.w); c1 = make_uint4(n1.x, n1.y, n1.z, n1.w);
+            c2 = make_uint4(n2.x, n2.y, n2.z, n2.w); c3 = make_uint4(n3.x, n3.y, n3.z, n3.w);
+        } else {
+            const uint4 *node = sv.wnodes + 4u * cur;
+            c0 = node[0]; c1 = node[1]; c2 = node[2]; c3 = node[3];
+        }
         auto slab_n = [&](uint32_t q, float o1, float i1, float n1) -> float {
             return FAR ? fmaf((float) q - o1, i1, -n1) : fmaf((float) q, i1, n1);
         };
@@ -504,7 +518,7 @@ MTS_DEV bool traverse_bvh(const SceneView &sv, const LdsView &lds, f3 o, f3 d, f
     BvhWalk w;
     walk_begin(w, sv, o, d, mint, maxt);
     const WalkStack st = { reinterpret_cast<StackEntry *>(lds.stack) + threadIdx.x, log2_stride(lds.stride), lds.spill ? lds.stack_lds_depth : 0xffffffffu,
-                           lds.spill, lds.spill_stride };      // k_bounce: whole stack in LDS; k_finish: short LDS part + spill
+                           lds.spill, lds.spill_stride, nullptr, 0u };      // k_bounce: whole stack in LDS; k_finish: short LDS part + spill
     while (w.cur != kNoNode) {
         if (w.far) walk_round<ANY, true>(w, sv, st, tri_tests);
         else walk_round<ANY, false>(w, sv, st, tri_tests);
@@ -843,7 +857,7 @@ MTS_DEV void sample_emitter_direction(const Geo<FLAT> &g, f3 ref_p, f2 sample, D
             ds.d = ds.d * inv_dist;
             if (e.pad0 == kEmitterSpot) {                      // falloff_curve (spot.cpp:95-113)
                 const float cos_theta = normalize(mat3_apply(e.aux, -ds.d)).z;
-                if (!(cos_theta >= e.aux[11])) ds.falloff = (e.aux[9] - acosf(cos_theta)) * e.aux[12];
+                if (!(cos_theta >= e.aux[11])) ds.falloff = (e.aux[9] - lm_acos(cos_theta)) * e.aux[12];
                 if (cos_theta <= e.aux[10]) ds.falloff = 0.0f;
             }
             r1 = inv_dist * inv_dist;
@@ -855,7 +869,7 @@ MTS_DEV void sample_emitter_direction(const Geo<FLAT> &g, f3 ref_p, f2 sample, D
         // ConstantBackgroundEmitter::sample_direction (constant.cpp:82-107), square_to_uniform_sphere (warp.h:262-267)
         const float z = fmaf(-2.0f, sample.y, 1.0f), r = safe_sqrt(fmaf(-z, z, 1.0f));
         const float ang = 2.0f * kPi * sample.x;
-        const f3 d = mk3(r * cosf(ang), r * sinf(ang), z);
+        const f3 d = mk3(r * lm_cos(ang), r * lm_sin(ang), z);
         ds.dist = 2.0f * e.radius;
         ds.p = ref_p + d * ds.dist;
         ds.n = -d; ds.d = d;

@@ -79,6 +79,7 @@ struct RenderParams {
     uint32_t gather_w;          // k_shade on LDS-resident scenes: a workgroup gathers the paths of gather_w (4, 16, ... 1024) consecutive scheduling
                                 // waves into the first four (pool drain: the sample cursors of the launch are dry); 0 / 4: no gathering
     uint32_t trace_lds_depth;   // k_trace: stack entries per lane kept in LDS; deeper ones go to trace_spill
+    uint32_t trace_top_nodes;   // k_trace: BVH4 nodes [0, trace_top_nodes) are staged in LDS by every workgroup
     uint32_t *trace_spill;      // k_trace: [workgroup][entry][thread]
 };
 
@@ -130,6 +131,8 @@ size_t bounce_lds_bytes(const SceneView &sv);
 hipError_t launch_bounce(const RenderParams &p, hipStream_t s);
 hipError_t launch_split_stage(const RenderParams &p, int stage, hipStream_t s);
 uint32_t trace_lds_depth(const SceneView &sv);
+uint32_t trace_top_nodes(const SceneView &sv);
+uint32_t trace_group();          // scheduling waves per k_trace workgroup (a power of two): launch ranges start on multiples of it
 size_t trace_spill_words(const SceneView &sv, uint32_t n_waves);
 // `direct` / `depth` integrators: every sample of [first_ordinal, first_ordinal + n) is finished by one thread
 hipError_t launch_direct(const RenderParams &p, uint64_t n, hipStream_t s);
@@ -168,5 +171,6 @@ hipError_t launch_moment_pack(const float *values5, const float *squares5, float
 // (DevBsdf::eb).  gl = Gauss-Legendre nodes / weights: [nodes_t(128) | weights_t(128) | nodes_r(128) | weights_r(128)]
 hipError_t launch_roughplastic_tables(DevBsdf *bsdfs, uint32_t index, float *table, const float *gl, int res_t, int res_r, hipStream_t s);
 hipError_t launch_film_develop(const float *xyzaw, uint64_t n, float *rgba, hipStream_t s);
+hipError_t launch_libm_eval(int fn, uint64_t n, const float *x, const float *y, float *out, hipStream_t s);
 
 } // namespace mtsamd

@@ -29,9 +29,11 @@ struct PathState {
     uint32_t ordinal, depth, flags;
 };
 
+// NT: the pool is a once-read / once-written stream (hierarchy scenes: keep it out of the caches the BVH lives in)
+template <bool NT = false>
 MTS_DEV void load_state(const PoolView &p, size_t i, PathState &s) {
-    float4 a = p.ray_o[i], b = p.ray_d[i], c = p.thr[i], e = p.res[i];
-    uint4 r = p.rng[i]; uint2 m = p.misc[i];
+    float4 a = ld_stream<NT>(p.ray_o + i), b = ld_stream<NT>(p.ray_d + i), c = ld_stream<NT>(p.thr + i), e = ld_stream<NT>(p.res + i);
+    uint4 r = ld_stream<NT>(p.rng + i); uint2 m = ld_stream<NT>(p.misc + i);
     s.o = mk3(a.x, a.y, a.z); s.mint = a.w;
     s.d = mk3(b.x, b.y, b.z); s.maxt = b.w;
     s.thr = mk3(c.x, c.y, c.z); s.bs_pdf = c.w;
@@ -40,14 +42,15 @@ MTS_DEV void load_state(const PoolView &p, size_t i, PathState &s) {
     s.rng.inc = (uint64_t) r.z | ((uint64_t) r.w << 32);
     s.ordinal = m.x; s.depth = m.y & 0xffffu; s.flags = m.y >> 16;
 }
+template <bool NT = false>
 MTS_DEV void store_state(const PoolView &p, size_t i, const PathState &s) {
-    p.ray_o[i] = make_float4(s.o.x, s.o.y, s.o.z, s.mint);
-    p.ray_d[i] = make_float4(s.d.x, s.d.y, s.d.z, s.maxt);
-    p.thr[i] = make_float4(s.thr.x, s.thr.y, s.thr.z, s.bs_pdf);
-    p.res[i] = make_float4(s.res.x, s.res.y, s.res.z, s.eta);
-    p.rng[i] = make_uint4((uint32_t) s.rng.state, (uint32_t) (s.rng.state >> 32), (uint32_t) s.rng.inc,
-                          (uint32_t) (s.rng.inc >> 32));
-    p.misc[i] = make_uint2(s.ordinal, (s.depth & 0xffffu) | (s.flags << 16));
+    st_stream<NT>(p.ray_o + i, make_float4(s.o.x, s.o.y, s.o.z, s.mint));
+    st_stream<NT>(p.ray_d + i, make_float4(s.d.x, s.d.y, s.d.z, s.maxt));
+    st_stream<NT>(p.thr + i, make_float4(s.thr.x, s.thr.y, s.thr.z, s.bs_pdf));
+    p.res[i] = make_float4(s.res.x, s.res.y, s.res.z, s.eta);      // read-modify-written by the shadow-ray stage: default policy
+    st_stream<NT>(p.rng + i, make_uint4((uint32_t) s.rng.state, (uint32_t) (s.rng.state >> 32), (uint32_t) s.rng.inc,
+                                        (uint32_t) (s.rng.inc >> 32)));
+    st_stream<NT>(p.misc + i, make_uint2(s.ordinal, (s.depth & 0xffffu) | (s.flags << 16)));
 }
 
 struct Counters { uint32_t closest, any, segments, tri_tests; };
@@ -421,9 +424,10 @@ struct PathStateS {
     uint32_t ordinal, depth, flags;
 };
 
+template <bool NT = false>
 MTS_DEV void load_state(const PoolView &p, size_t i, PathStateS &s) {
-    float4 a = p.ray_o[i], b = p.ray_d[i], c = p.thr[i], e = p.res[i], w = p.wav[i];
-    float2 x = p.aux[i]; uint4 r = p.rng[i]; uint2 m = p.misc[i];
+    float4 a = ld_stream<NT>(p.ray_o + i), b = ld_stream<NT>(p.ray_d + i), c = ld_stream<NT>(p.thr + i), e = ld_stream<NT>(p.res + i), w = ld_stream<NT>(p.wav + i);
+    float2 x = ld_stream<NT>(p.aux + i); uint4 r = ld_stream<NT>(p.rng + i); uint2 m = ld_stream<NT>(p.misc + i);
     s.o = mk3(a.x, a.y, a.z); s.mint = a.w;
     s.d = mk3(b.x, b.y, b.z); s.maxt = b.w;
     s.thr.v[0] = c.x; s.thr.v[1] = c.y; s.thr.v[2] = c.z; s.thr.v[3] = c.w;
@@ -434,16 +438,17 @@ MTS_DEV void load_state(const PoolView &p, size_t i, PathStateS &s) {
     s.rng.inc = (uint64_t) r.z | ((uint64_t) r.w << 32);
     s.ordinal = m.x; s.depth = m.y & 0xffffu; s.flags = m.y >> 16;
 }
+template <bool NT = false>
 MTS_DEV void store_state(const PoolView &p, size_t i, const PathStateS &s) {
-    p.ray_o[i] = make_float4(s.o.x, s.o.y, s.o.z, s.mint);
-    p.ray_d[i] = make_float4(s.d.x, s.d.y, s.d.z, s.maxt);
-    p.thr[i] = make_float4(s.thr.v[0], s.thr.v[1], s.thr.v[2], s.thr.v[3]);
-    p.res[i] = make_float4(s.res.v[0], s.res.v[1], s.res.v[2], s.res.v[3]);
-    p.wav[i] = make_float4(s.wav.v[0], s.wav.v[1], s.wav.v[2], s.wav.v[3]);
-    p.aux[i] = make_float2(s.bs_pdf, s.eta);
-    p.rng[i] = make_uint4((uint32_t) s.rng.state, (uint32_t) (s.rng.state >> 32), (uint32_t) s.rng.inc,
-                          (uint32_t) (s.rng.inc >> 32));
-    p.misc[i] = make_uint2(s.ordinal, (s.depth & 0xffffu) | (s.flags << 16));
+    st_stream<NT>(p.ray_o + i, make_float4(s.o.x, s.o.y, s.o.z, s.mint));
+    st_stream<NT>(p.ray_d + i, make_float4(s.d.x, s.d.y, s.d.z, s.maxt));
+    st_stream<NT>(p.thr + i, make_float4(s.thr.v[0], s.thr.v[1], s.thr.v[2], s.thr.v[3]));
+    p.res[i] = make_float4(s.res.v[0], s.res.v[1], s.res.v[2], s.res.v[3]);      // read-modify-written by the shadow-ray stage
+    st_stream<NT>(p.wav + i, make_float4(s.wav.v[0], s.wav.v[1], s.wav.v[2], s.wav.v[3]));
+    st_stream<NT>(p.aux + i, make_float2(s.bs_pdf, s.eta));
+    st_stream<NT>(p.rng + i, make_uint4((uint32_t) s.rng.state, (uint32_t) (s.rng.state >> 32), (uint32_t) s.rng.inc,
+                                        (uint32_t) (s.rng.inc >> 32)));
+    st_stream<NT>(p.misc + i, make_uint2(s.ordinal, (s.depth & 0xffffu) | (s.flags << 16)));
 }
 
 // spectral variant: `srgb` parameters evaluate the upsampled colour at each wavelength (srgb.cpp:45-52), `uniform` ones are
@@ -956,6 +961,10 @@ MTS_DEV void drain_shadow_ring(const RenderParams &P, const LdsView &lds, const 
     }
 }
 
+// Non-temporal pool / ray / hit / shadow-queue streams on hierarchy scenes: bit 0 = k_trace, bit 1 = k_shade
+#ifndef MTS_NT_STREAMS
+#define MTS_NT_STREAMS 3
+#endif
 #ifndef MTS_PRIMARY_SHADOW
 #define MTS_PRIMARY_SHADOW 1  // 0 (experiment): the shadow rays of camera-path chunks go through the ring like all others
 #endif
@@ -966,6 +975,7 @@ template <typename State, bool GENERAL, bool FLAT, bool INLINE = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FLAT ? MTS_BOUNCE_WAVES : ShadeWaves<State, GENERAL>::kMin, FLAT ? MTS_BOUNCE_WAVES : 8)))
 void k_shade(const RenderParams P) {
     static_assert(FLAT || !INLINE, "the in-kernel shadow queue is for LDS-resident scenes");
+    constexpr bool kNT = !FLAT && (MTS_NT_STREAMS & 2) != 0;      // hierarchy scenes: the pool streams bypass the caches the BVH lives in
     extern __shared__ float4 smem[];
     LdsView lds = {};                      // Geo<false> reads the scene tables from global memory
     // a launch covers the scheduling waves [wave_first, wave_last) (all of them, or one half when two launches share the GPU).
@@ -1076,13 +1086,13 @@ void k_shade(const RenderParams P) {
                 for (uint32_t q = 0; q < kW; ++q) off = (r >= kW && g == q) ? surv4[q] : off;
                 i = (size_t) (wg_wave0 + g) * P.seg_cap + off + j;
             }
-            load_state(P.in, i, s);
+            load_state<kNT>(P.in, i, s);
             if (s.flags & kFlagZombie) {
                 finish_path(P, s);
             } else {
                 depth0 = s.depth;
                 if (!FLAT) {
-                    const float4 h = P.in.hit[i];
+                    const float4 h = ld_stream<kNT>(P.in.hit + i);
                     df.hit.t = h.x; df.hit.prim = __float_as_uint(h.y); df.hit.u = h.z; df.hit.v = h.w;
                     df.found = df.hit.prim != kNoPrim;
                 }
@@ -1110,7 +1120,7 @@ void k_shade(const RenderParams P) {
             const uint32_t slot = n_out + mask_rank(m);
             // gathering: the segment of wave + 4 q takes the slots [q seg_cap, (q + 1) seg_cap) of this hardware wave
             const size_t oidx = (FLAT && gw > 4u) ? ((size_t) wave + 4u * (slot / P.seg_cap)) * P.seg_cap + slot % P.seg_cap : base + slot;
-            store_state(P.out, oidx, s);
+            store_state<kNT>(P.out, oidx, s);
             if (df.pending) {
                 if (INLINE) {
                     const uint32_t k = (q_head + q_count + mask_rank(ms)) & (kShadowRing - 1u);
@@ -1120,10 +1130,10 @@ void k_shade(const RenderParams P) {
                     ring.slot[k] = (uint32_t) (oidx - base);      // may exceed the segment (gathering): an offset from `base` all the same
                 } else {
                     const size_t q = base + n_sh + mask_rank(ms);
-                    P.out.sh_o[q] = make_float4(df.so.x, df.so.y, df.so.z, df.smint);
-                    P.out.sh_d[q] = make_float4(df.sd.x, df.sd.y, df.sd.z, df.smaxt);
-                    P.out.nee[q] = make_float4(df.nee[0], df.nee[1], df.nee[2], df.nee[3]);
-                    P.out.sh_slot[q] = slot;
+                    st_stream<kNT>(P.out.sh_o + q, make_float4(df.so.x, df.so.y, df.so.z, df.smint));
+                    st_stream<kNT>(P.out.sh_d + q, make_float4(df.sd.x, df.sd.y, df.sd.z, df.smaxt));
+                    st_stream<kNT>(P.out.nee + q, make_float4(df.nee[0], df.nee[1], df.nee[2], df.nee[3]));
+                    st_stream<kNT>(P.out.sh_slot + q, slot);
                 }
             }
         }
@@ -1151,7 +1161,7 @@ void k_shade(const RenderParams P) {
             uint64_t ordinal; uint32_t lp, sj;
             cursor_sample(P, wave, cursor + lane, ordinal, lp, sj);
             start_path(P, ordinal, lp, sj, s);
-            store_state(P.out, base + n_out + lane, s);
+            store_state<kNT>(P.out, base + n_out + lane, s);
         }
         n_out += n_new; cursor += n_new;
     }
@@ -1341,36 +1351,54 @@ hipError_t launch_finish(const RenderParams &p, uint64_t alive, hipStream_t s) {
 // k_trace<true>: visibility of the queued shadow rays (output pool of k_shade), radiance[slot] += nee if unoccluded.
 // Only about a third of the paths queue a shadow ray, so one workgroup drains the queues of kShadowGroup scheduling
 // waves back to back to keep its lanes filled.  (64-thread workgroups sized to the queues were measured slower.)
-#ifndef MTS_TRACE_GROUP
-#define MTS_TRACE_GROUP 8
+// Workgroup shape of k_trace on hierarchy scenes.  kTraceBlock threads drain the rays of kShadowGroup scheduling waves (16 rays per
+// lane).  1024 threads = two workgroups per CU: each has 80 KB of LDS, enough for the first kTraceLdsDepth stack entries of every lane
+// AND a copy of the top of the BVH (round 3; with 256-thread workgroups eight copies would have to share the same 160 KB).
+#ifndef MTS_TRACE_BLOCK
+#define MTS_TRACE_BLOCK 1024
 #endif
-constexpr uint32_t kShadowGroup = MTS_TRACE_GROUP;
-// LDS part of k_trace's per-lane stack: 8 entries of 8 bytes (BVH4: reference + entry distance) = 16 KB per workgroup, 8 workgroups
-// (32 waves) per CU; the full 41-entry stack of the 261 k-triangle mesh would cap the CU at one workgroup
+#ifndef MTS_TRACE_GROUP
+#define MTS_TRACE_GROUP (MTS_TRACE_BLOCK / 32)
+#endif
+constexpr uint32_t kTraceBlock = MTS_TRACE_BLOCK;      // threads per k_trace workgroup (hierarchy scenes)
+constexpr uint32_t kShadowGroup = MTS_TRACE_GROUP;     // scheduling waves per workgroup (a power of two)
+static_assert((kShadowGroup & (kShadowGroup - 1u)) == 0u, "locate() searches a power-of-two table");
+// LDS part of k_trace's per-lane stack: entries of 8 bytes (BVH4: reference + entry distance); the full 41-entry stack of the
+// 261 k-triangle mesh would cap the CU at a fraction of a workgroup.  Deeper entries go to a global spill area (rare).
 #ifndef MTS_TRACE_LDS_DEPTH
-#define MTS_TRACE_LDS_DEPTH (MTS_BVH4 ? 8 : 16)
+#define MTS_TRACE_LDS_DEPTH (MTS_BVH4 ? (MTS_TRACE_BLOCK >= 1024 ? 6 : 8) : 16)
 #endif
 constexpr uint32_t kTraceLdsDepth = MTS_TRACE_LDS_DEPTH;
+// Top of the BVH4 staged in LDS by every k_trace workgroup: the first kTraceTopNodes nodes in BFS order (64 B each).
+#ifndef MTS_TRACE_TOP_NODES
+#define MTS_TRACE_TOP_NODES (MTS_BVH4 && MTS_TRACE_BLOCK >= 1024 ? 360 : 0)
+#endif
+constexpr uint32_t kTraceTopNodes = MTS_TRACE_TOP_NODES;
 
 // Register budget of k_trace: 64 VGPRs = 8 waves per SIMD.  The walks are bound by the latency of their node / triangle fetches
 // (L2 and beyond for a 261 k-triangle scene), which only more waves in flight hide: 5 waves (84 VGPRs, the compiler's own choice)
-// -> 8 waves: +7.5 % on the whole render (RGB and spectral); the closest-hit kernel then spills 20 bytes per lane.
+// -> 8 waves: +7.5 % on the whole render (RGB and spectral).
 #ifndef MTS_TRACE_WAVES
 #define MTS_TRACE_WAVES 8
 #endif
 template <bool ANY, bool FLAT = false>
-__global__ __launch_bounds__(kBlock)
+__global__ __launch_bounds__(FLAT ? kBlock : kTraceBlock)
 #if MTS_TRACE_WAVES > 0
 __attribute__((amdgpu_waves_per_eu(MTS_TRACE_WAVES, MTS_TRACE_WAVES)))
 #endif
 void k_trace(const RenderParams P) {
     extern __shared__ float4 smem[];
+    __shared__ uint32_t s_pre[kShadowGroup + 1u];            // s_pre[g] = work items of the group's scheduling waves before the g-th
     LdsView lds = {};
+    const uint32_t n_top = FLAT ? 0u : P.trace_top_nodes;
     if (FLAT) {
         lds = lds_stage<true>(P.sv, smem);
     } else {
+        // LDS: [top of the BVH4: n_top nodes of 4 x 16 B][traversal stack rows]
+        uint4 *top = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = threadIdx.x; i < 4u * n_top; i += blockDim.x) top[i] = P.sv.wnodes[i];
         lds.stride = blockDim.x;
-        lds.stack = reinterpret_cast<uint32_t *>(smem);
+        lds.stack = reinterpret_cast<uint32_t *>(smem + 4u * n_top);
     }
     uint32_t tri_tests = 0;
     // work list of this workgroup: the shadow queues (ANY) or the path slots (closest hit) of kShadowGroup scheduling waves
@@ -1379,21 +1407,29 @@ void k_trace(const RenderParams P) {
     const uint32_t wave_last = P.wave_last ? P.wave_last : P.n_waves;
     const uint32_t group = P.wave_first / kShadowGroup + blockIdx.x;      // global group index
     const uint32_t w0 = group * kShadowGroup;
-    uint32_t cnt[kShadowGroup], total = 0;
     const uint32_t *counts = ANY ? P.count_shadow : P.count_in;
+    if (threadIdx.x < 64u) {                                 // prefix sums of the group's counts by the first wave
+        const uint32_t ln = threadIdx.x;
+        uint32_t incl = (ln < kShadowGroup && w0 + ln < wave_last) ? counts[w0 + ln] : 0u;
+        for (uint32_t off = 1u; off < kShadowGroup; off <<= 1) { const uint32_t v = __shfl_up(incl, off); if (ln >= off) incl += v; }
+        if (ln < kShadowGroup) s_pre[ln + 1u] = incl;
+        if (ln == 0u) s_pre[0] = 0u;
+    }
+    __shared__ uint32_t s_next;
+    if (threadIdx.x == 0) s_next = 0u;
+    __syncthreads();
+    const uint32_t total = s_pre[kShadowGroup];
+    auto locate = [&](uint32_t idx) -> size_t {              // work item -> pool index: s_pre[g] <= idx < s_pre[g + 1]
+        uint32_t g = 0u;
 #pragma unroll
-    for (uint32_t g = 0; g < kShadowGroup; ++g) { cnt[g] = (w0 + g < wave_last) ? counts[w0 + g] : 0u; total += cnt[g]; }
-    auto locate = [&](uint32_t idx) -> size_t {              // work item -> pool index
-        uint32_t wave = w0, i = idx;
-#pragma unroll
-        for (uint32_t g = 0; g + 1 < kShadowGroup; ++g)
-            if (wave == w0 + g && i >= cnt[g]) { i -= cnt[g]; ++wave; }
-        return (size_t) wave * P.seg_cap + i;
+        for (uint32_t step = kShadowGroup >> 1; step; step >>= 1) if (s_pre[g + step] <= idx) g += step;
+        return (size_t) (w0 + g) * P.seg_cap + (idx - s_pre[g]);
     };
+    constexpr bool kNT = !FLAT && (MTS_NT_STREAMS & 1) != 0;
     auto retire_any = [&](size_t k) {                        // unoccluded shadow ray: radiance[slot] += nee
-        const size_t slot = (k / P.seg_cap) * P.seg_cap + pool.sh_slot[k];
+        const size_t slot = (k / P.seg_cap) * P.seg_cap + ld_stream<kNT>(pool.sh_slot + k);
         float4 r = pool.res[slot];
-        const float4 e = pool.nee[k];
+        const float4 e = ld_stream<kNT>(pool.nee + k);
         r.x += e.x; r.y += e.y; r.z += e.z; r.w += e.w;      // RGB: w = eta + 0
         pool.res[slot] = r;
     };
@@ -1408,15 +1444,13 @@ void k_trace(const RenderParams P) {
         // Dynamic ray fetch: a lane that has finished its walk takes the next item of the workgroup's list at once instead of
         // idling until the slowest lane of its wave is done (the walks of incoherent rays differ several-fold in length: with
         // one ray per lane and loop trip only 22-29 % of the VALU lane-cycles were useful).
-        __shared__ uint32_t s_next;
-        if (threadIdx.x == 0) s_next = 0u;
-        __syncthreads();
         const uint32_t lane = lane_id();
         // LDS holds the first P.trace_lds_depth stack entries of every lane; deeper entries spill to this workgroup's slice of
         // P.trace_spill ([entry][thread])
         const uint32_t spill_depth = P.sv.stack_depth > P.trace_lds_depth ? P.sv.stack_depth - P.trace_lds_depth : 0u;
         const WalkStack st = { reinterpret_cast<StackEntry *>(lds.stack) + threadIdx.x, log2_stride(lds.stride), P.trace_lds_depth,
-                               reinterpret_cast<StackEntry *>(P.trace_spill) + ((size_t) (ANY ? (P.n_waves + kShadowGroup - 1u) / kShadowGroup : 0u) + group) * spill_depth * kBlock + threadIdx.x, blockDim.x };
+                               reinterpret_cast<StackEntry *>(P.trace_spill) + ((size_t) (ANY ? (P.n_waves + kShadowGroup - 1u) / kShadowGroup : 0u) + group) * spill_depth * kTraceBlock + threadIdx.x, blockDim.x,
+                               reinterpret_cast<const uint4 *>(smem), n_top };
         BvhWalk w;
         w.cur = kNoNode; w.sp = 0u; w.found = false;
         bool busy = false;                                   // the lane holds a work item
@@ -1426,8 +1460,8 @@ void k_trace(const RenderParams P) {
             const bool need = w.cur == kNoNode;
             if (need && busy) {                              // retire the finished item
                 if (ANY) { if (!w.found) retire_any(k); }
-                else pool.hit[k] = w.found ? make_float4(w.best, __uint_as_float(w.best_prim), w.hit.u, w.hit.v)
-                                           : make_float4(__builtin_inff(), __uint_as_float(kNoPrim), 0.0f, 0.0f);
+                else st_stream<kNT>(pool.hit + k, w.found ? make_float4(w.best, __uint_as_float(w.best_prim), w.hit.u, w.hit.v)
+                                                          : make_float4(__builtin_inff(), __uint_as_float(kNoPrim), 0.0f, 0.0f));
                 busy = false;
             }
             const uint64_t m = __ballot(need);
@@ -1442,11 +1476,11 @@ void k_trace(const RenderParams P) {
                     if (idx < total) {
                         k = locate(idx);
                         if (ANY) {
-                            const float4 o = pool.sh_o[k], d = pool.sh_d[k];
+                            const float4 o = ld_stream<kNT>(pool.sh_o + k), d = ld_stream<kNT>(pool.sh_d + k);
                             walk_begin(w, P.sv, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), o.w, d.w);
                             busy = true;
                         } else if (!((pool.misc[k].y >> 16) & kFlagZombie)) {      // zombies only wait for their shadow ray
-                            const float4 o = pool.ray_o[k], d = pool.ray_d[k];
+                            const float4 o = ld_stream<kNT>(pool.ray_o + k), d = ld_stream<kNT>(pool.ray_d + k);
                             walk_begin(w, P.sv, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), o.w, d.w);
                             busy = true;
                         }
@@ -1458,9 +1492,9 @@ void k_trace(const RenderParams P) {
                 continue;                                    // only zombies were fetched: try again
             }
             if (__ballot(w.cur != kNoNode && w.far) != 0ull) {      // wave-uniform choice of the slab-test form
-                if (w.cur != kNoNode) walk_round<ANY, true>(w, P.sv, st, tri_tests);
+                if (w.cur != kNoNode) walk_round<ANY, true, kTraceTopNodes != 0u>(w, P.sv, st, tri_tests);
             } else {
-                if (w.cur != kNoNode) walk_round<ANY, false>(w, P.sv, st, tri_tests);
+                if (w.cur != kNoNode) walk_round<ANY, false, kTraceTopNodes != 0u>(w, P.sv, st, tri_tests);
             }
         }
     }
@@ -1470,15 +1504,23 @@ void k_trace(const RenderParams P) {
                   (unsigned long long) tri_tests);
 }
 
-#ifndef MTS_TRACE_BLOCK
-#define MTS_TRACE_BLOCK 256
-#endif
-constexpr uint32_t kTraceBlock = MTS_TRACE_BLOCK;      // threads per k_trace workgroup (hierarchy scenes)
-size_t trace_lds_bytes(const SceneView &sv) { return sizeof(StackEntry) * (std::min(sv.stack_depth, kTraceLdsDepth) + 1u) * kTraceBlock; }      // + the scratch row of stack_row()
+uint32_t trace_top_nodes(const SceneView &sv) { return std::min(sv.n_wnodes, kTraceTopNodes); }
+uint32_t trace_group() { return kShadowGroup; }
+size_t trace_lds_bytes(const SceneView &sv) {      // top of the tree + the stack rows (+ the scratch row of stack_row())
+    return (size_t) 64 * trace_top_nodes(sv) + sizeof(StackEntry) * (std::min(sv.stack_depth, kTraceLdsDepth) + 1u) * kTraceBlock;
+}
 uint32_t trace_lds_depth(const SceneView &sv) { return std::min(sv.stack_depth, kTraceLdsDepth); }
+// spill area shared by k_trace (closest-hit and any-hit launches may overlap: two slices per group) and k_finish (its workgroups are
+// single waves that keep kFinishLdsDepth entries in LDS)
 size_t trace_spill_words(const SceneView &sv, uint32_t n_waves) {
     const uint32_t spill = sv.stack_depth > kTraceLdsDepth ? sv.stack_depth - kTraceLdsDepth : 0u;
-    return (sizeof(StackEntry) / 4) * (size_t) 2 * ((n_waves + kShadowGroup - 1) / kShadowGroup) * spill * kBlock;      // closest-hit and any-hit launches may overlap
+    const uint32_t spill_f = sv.stack_depth > kFinishLdsDepth ? sv.stack_depth - kFinishLdsDepth : 0u;
+    const size_t trace = (size_t) 2 * ((n_waves + kShadowGroup - 1) / kShadowGroup) * spill * kTraceBlock;
+    const size_t finish = (size_t) n_waves * spill_f * 64u;      // at most one k_finish workgroup per scheduling wave
+    return (sizeof(StackEntry) / 4) * std::max(trace, finish);
+}
+static hipError_t allow_lds(const void *fn, size_t bytes) {
+    return bytes > 48u * 1024u ? hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes) : hipSuccess;
 }
 
 // split pipeline of hierarchy scenes, one stage at a time: 0 = k_trace<closest>, 1 = k_shade, 2 = k_trace<any>.  Stage 2 of one
@@ -1487,6 +1529,7 @@ hipError_t launch_split_stage(const RenderParams &p, int stage, hipStream_t s) {
     const uint32_t n_launch = (p.wave_last ? p.wave_last : p.n_waves) - p.wave_first;
     const uint32_t shade_blocks = (n_launch * 64u + kBlock - 1) / kBlock, trace_blocks = (n_launch + kShadowGroup - 1) / kShadowGroup;
     if (stage == 0) {
+        if (hipError_t e = allow_lds(reinterpret_cast<const void *>(&k_trace<false, false>), trace_lds_bytes(p.sv))) return e;
         hipLaunchKernelGGL((k_trace<false, false>), dim3(trace_blocks), dim3(kTraceBlock), trace_lds_bytes(p.sv), s, p);
     } else if (stage == 1) {
         if (p.spectral && p.sv.general) hipLaunchKernelGGL((k_shade<PathStateS, true, false>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
@@ -1494,6 +1537,7 @@ hipError_t launch_split_stage(const RenderParams &p, int stage, hipStream_t s) {
         else if (p.sv.general) hipLaunchKernelGGL((k_shade<PathState, true, false>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
         else hipLaunchKernelGGL((k_shade<PathState, false, false>), dim3(shade_blocks), dim3(kBlock), 0, s, p);
     } else {
+        if (hipError_t e = allow_lds(reinterpret_cast<const void *>(&k_trace<true, false>), trace_lds_bytes(p.sv))) return e;
         hipLaunchKernelGGL((k_trace<true, false>), dim3(trace_blocks), dim3(kTraceBlock), trace_lds_bytes(p.sv), s, p);
     }
     return hipGetLastError();
@@ -1568,13 +1612,13 @@ MTS_DEV float cubic_filter(float x, float B, float C) {
 }
 MTS_DEV float filter_eval(const FilterView &f, float x) {
     switch (f.kind) {
-    case 0: return fmaxf(0.0f, expf(f.alpha * (x * x)) - f.bias);
+    case 0: return fmaxf(0.0f, lm_exp(f.alpha * (x * x)) - f.bias);
     case 2: return fmaxf(0.0f, 1.0f - fabsf(x * f.alpha));
     case 3: return cubic_filter(x, 0.0f, 0.5f);
     case 4: return cubic_filter(x, f.alpha, f.bias);
     case 5: {
         x = fabsf(x);
-        const float x1 = kPi * x, x2 = x1 / f.radius, result = (sinf(x1) * sinf(x2)) / (x1 * x2);
+        const float x1 = kPi * x, x2 = x1 / f.radius, result = (lm_sin(x1) * lm_sin(x2)) / (x1 * x2);
         return x < kEpsilon ? 1.0f : (x > f.radius ? 0.0f : result);
     }
     default: return fabsf(x) <= f.radius ? 1.0f : 0.0f;
@@ -2353,6 +2397,30 @@ __global__ __launch_bounds__(kBlock) void k_film_develop(const float *xyzaw, uin
 hipError_t launch_film_develop(const float *xyzaw, uint64_t n, float *rgba, hipStream_t s) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_film_develop, dim3(stream_grid(n)), dim3(kBlock), 0, s, xyzaw, n, rgba);
+    return hipGetLastError();
+}
+
+// device_libm.h on argument streams (mtsamd_libm_eval: host / device bit-equality tests)
+__global__ __launch_bounds__(kBlock) void k_libm_eval(int fn, uint64_t n, const float *x, const float *y, float *out) {
+    const uint64_t i = (uint64_t) blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float a = x[i];
+    float r;
+    switch (fn) {
+    case 0: r = lm_sin(a); break;
+    case 1: r = lm_cos(a); break;
+    case 2: r = lm_tan(a); break;
+    case 3: r = lm_exp(a); break;
+    case 4: r = lm_log(a); break;
+    case 5: r = lm_erf(a); break;
+    case 6: r = lm_acos(a); break;
+    default: r = lm_atan2(a, y[i]); break;
+    }
+    out[i] = r;
+}
+hipError_t launch_libm_eval(int fn, uint64_t n, const float *x, const float *y, float *out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_libm_eval, dim3((uint32_t) ((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, fn, n, x, y, out);
     return hipGetLastError();
 }
 

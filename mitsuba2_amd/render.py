@@ -313,6 +313,23 @@ class HDRFilm:
         return out
 
 
+LIBM_FUNCTIONS = ("sin", "cos", "tan", "exp", "log", "erf", "acos", "atan2")
+
+
+def libm_eval(name, x, y=None):
+    """The kernels' own elementary functions (csrc/device_libm.h) on a CUDA tensor of float32 arguments -- the role enoki::sin / exp /
+    erf ... play in the reference (include/mitsuba/core/warp.h:54-90, render/microfacet.h:187-493).  `atan2` takes (y, x)."""
+    fn = LIBM_FUNCTIONS.index(name)
+    x = x.contiguous().float()
+    if fn == 7:
+        if y is None:
+            raise RuntimeError("atan2 takes two arguments")
+        y = y.contiguous().float()
+    out = torch.empty_like(x)
+    L.check(L.lib().mtsamd_libm_eval(fn, x.numel(), _ptr(x), _ptr(y) if fn == 7 else None, _ptr(out), _stream()))
+    return out
+
+
 def parse_fov(fov=None, focal_length=None, fov_axis="x", aspect=1.0):
     """src/librender/sensor.cpp:119-169"""
     if fov is not None and focal_length is not None:

@@ -228,4 +228,8 @@ void mo_kat_sample_emitter(const mo_scene *s, const float *ref_p3, const float *
 #ifdef __cplusplus
 }
 #endif
+/* mo_libm.h on argument arrays (fn: 0 sin, 1 cos, 2 tan, 3 exp, 4 log, 5 erf, 6 acos, 7 atan2(x[i], y[i])); the counterpart of
+ * mtsamd_libm_eval, so that a test can compare host and device bit for bit */
+void mo_libm_eval(int fn, uint64_t n, const float *x, const float *y, float *out);
+
 #endif

@@ -81,7 +81,7 @@ static mdf mdf_make(int ggx, float au, float av, int visible) {
 static float mdf_eval(const mdf *d, mo_v3 m) {
     float alpha_uv = d->au * d->av, cos_theta = m.z, cos_theta_2 = sqr(cos_theta), result;
     if (!d->ggx)
-        result = expf(-(sqr(m.x / d->au) + sqr(m.y / d->av)) / cos_theta_2) / (MO_PI * alpha_uv * sqr(cos_theta_2));
+        result = mo_lm_exp(-(sqr(m.x / d->au) + sqr(m.y / d->av)) / cos_theta_2) / (MO_PI * alpha_uv * sqr(cos_theta_2));
     else
         result = mo_rcp(MO_PI * alpha_uv * sqr(sqr(m.x / d->au) + sqr(m.y / d->av) + sqr(m.z)));
     return result * cos_theta > 1e-20f ? result : 0.0f;
@@ -112,7 +112,7 @@ static float mdf_pdf(const mdf *d, mo_v3 wi, mo_v3 m) {
 
 /* Giles, "Approximating the erfinv function" (single precision branch) */
 static float erfinv_f(float x) {
-    float w = -logf((1.0f - x) * (1.0f + x)), p;
+    float w = -mo_lm_log((1.0f - x) * (1.0f + x)), p;
     if (w < 5.0f) {
         w = w - 2.5f;
         p = 2.81022636e-08f; p = fmaf(p, w, 3.43273939e-07f); p = fmaf(p, w, -3.5233877e-06f);
@@ -133,14 +133,14 @@ static mo_v2 mdf_sample_visible_11(const mdf *d, float cos_theta_i, mo_v2 sample
     if (!d->ggx) {
         float tan_theta_i = mo_safe_sqrt(fnmadd(cos_theta_i, cos_theta_i, 1.0f)) / cos_theta_i;
         float cot_theta_i = mo_rcp(tan_theta_i);
-        float maxval = erff(cot_theta_i);
+        float maxval = mo_lm_erf(cot_theta_i);
         sample.x = fmaxf(fminf(sample.x, 1.0f - 1e-6f), 1e-6f);
         sample.y = fmaxf(fminf(sample.y, 1.0f - 1e-6f), 1e-6f);
-        float x = maxval - (maxval + 1.0f) * erff(sqrtf(-logf(sample.x)));
-        sample.x *= 1.0f + maxval + MO_INV_SQRT_PI * tan_theta_i * expf(-sqr(cot_theta_i));
+        float x = maxval - (maxval + 1.0f) * mo_lm_erf(sqrtf(-mo_lm_log(sample.x)));
+        sample.x *= 1.0f + maxval + MO_INV_SQRT_PI * tan_theta_i * mo_lm_exp(-sqr(cot_theta_i));
         for (int i = 0; i < 3; ++i) {
             float slope = erfinv_f(x);
-            float value = 1.0f + x + MO_INV_SQRT_PI * tan_theta_i * expf(-sqr(slope)) - sample.x;
+            float value = 1.0f + x + MO_INV_SQRT_PI * tan_theta_i * mo_lm_exp(-sqr(slope)) - sample.x;
             float derivative = 1.0f - slope * tan_theta_i;
             x -= value / derivative;
         }
@@ -164,17 +164,17 @@ static mo_v3 mdf_sample(const mdf *d, mo_v3 wi, mo_v2 sample, float *pdf) {
         float sin_phi, cos_phi, cos_theta, cos_theta_2, alpha_2;
         if (d->au == d->av) {
             float ang = (2.0f * MO_PI) * sample.y;
-            sin_phi = sinf(ang); cos_phi = cosf(ang);
+            sin_phi = mo_lm_sin(ang); cos_phi = mo_lm_cos(ang);
             alpha_2 = d->au * d->au;
         } else {
-            float ratio = d->av / d->au, tmp = ratio * tanf((2.0f * MO_PI) * sample.y);
+            float ratio = d->av / d->au, tmp = ratio * mo_lm_tan((2.0f * MO_PI) * sample.y);
             cos_phi = 1.0f / sqrtf(fmaf(tmp, tmp, 1.0f));
             cos_phi = mo_mulsign(cos_phi, fabsf(sample.y - 0.5f) - 0.25f);
             sin_phi = cos_phi * tmp;
             alpha_2 = mo_rcp(sqr(cos_phi / d->au) + sqr(sin_phi / d->av));
         }
         if (!d->ggx) {
-            cos_theta = 1.0f / sqrtf(fnmadd(alpha_2, logf(1.0f - sample.x), 1.0f));
+            cos_theta = 1.0f / sqrtf(fnmadd(alpha_2, mo_lm_log(1.0f - sample.x), 1.0f));
             cos_theta_2 = sqr(cos_theta);
             float cos_theta_3 = fmaxf(cos_theta_2 * cos_theta, 1e-20f);
             *pdf = (1.0f - sample.x) / (MO_PI * d->au * d->av * cos_theta_3);

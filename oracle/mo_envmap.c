@@ -224,8 +224,8 @@ static void envmap_lookup(const mo_envmap *e, float u, float v, float out[3]) {
     }
 }
 static void dir_to_uv(mo_v3 v, float *u, float *vv) {                    /* envmap.cpp:139-142 */
-    float a = atan2f(v.x, -v.z) * (0.5f * MO_INV_PI);
-    float b = acosf(fminf(fmaxf(v.y, -1.0f), 1.0f)) * MO_INV_PI;
+    float a = mo_lm_atan2(v.x, -v.z) * (0.5f * MO_INV_PI);
+    float b = mo_lm_acos(fminf(fmaxf(v.y, -1.0f), 1.0f)) * MO_INV_PI;
     *u = a - floorf(a); *vv = b - floorf(b);
 }
 
@@ -276,7 +276,7 @@ void mo_envmap_sample(const mo_envmap *e, mo_v2 sample, mo_v3 *d_out, float *pdf
     float u, v, pdf;
     mo_hier2d_sample(&e->warp, sample.x, sample.y, &u, &v, &pdf);
     float theta = v * MO_PI_F, phi = u * (2.0f * MO_PI_F);
-    float st = sinf(theta), ct = cosf(theta), sp = sinf(phi), cp = cosf(phi);
+    float st = mo_lm_sin(theta), ct = mo_lm_cos(theta), sp = mo_lm_sin(phi), cp = mo_lm_cos(phi);
     mo_v3 sd = mo_v3_make(cp * st, sp * st, ct);                         /* math::sphdir */
     mo_v3 d = mo_v3_make(sd.y, sd.z, -sd.x);
     float inv_sin_theta = 1.0f / sqrtf(fmaxf(d.x * d.x + d.z * d.z, MO_EPSILON * MO_EPSILON));

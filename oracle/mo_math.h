@@ -34,6 +34,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
+#include "mo_libm.h"
 
 typedef struct { float x, y, z; } mo_v3;
 typedef struct { float x, y; } mo_v2;
@@ -153,7 +154,9 @@ static inline mo_v2 mo_square_to_uniform_disk_concentric(mo_v2 s) {
     float phi = 0.25f * MO_PI * rp / r;
     if (q13) phi = 0.5f * MO_PI - phi;
     if (is_zero) phi = 0.0f;
-    mo_v2 o = { r * cosf(phi), r * sinf(phi) };
+    float sn, cs;
+    mo_lm_sincos(phi, &sn, &cs);
+    mo_v2 o = { r * cs, r * sn };
     return o;
 }
 /* warp.h:332-341 */

@@ -185,13 +185,13 @@ static float cubic_filter(float x, float B, float C) {
 }
 static float rfilter_eval(const rfilter *f, float x) {
     switch (f->kind) {
-    case 0: return fmaxf(0.0f, expf(f->alpha * (x * x)) - f->bias);
+    case 0: return fmaxf(0.0f, mo_lm_exp(f->alpha * (x * x)) - f->bias);
     case 2: return fmaxf(0.0f, 1.0f - fabsf(x * f->alpha));                    /* tent.cpp:33-35, alpha = 1 / radius */
     case 3: return cubic_filter(x, 0.0f, 0.5f);
     case 4: return cubic_filter(x, f->alpha, f->bias);                         /* alpha = B, bias = C */
     case 5: {                                                                  /* lanczos.cpp:38-48 */
         x = fabsf(x);
-        float x1 = MO_PI_F * x, x2 = x1 / f->radius, result = (sinf(x1) * sinf(x2)) / (x1 * x2);
+        float x1 = MO_PI_F * x, x2 = x1 / f->radius, result = (mo_lm_sin(x1) * mo_lm_sin(x2)) / (x1 * x2);
         return x < MO_EPSILON ? 1.0f : (x > f->radius ? 0.0f : result);
     }
     default: return fabsf(x) <= f->radius ? 1.0f : 0.0f;
@@ -205,7 +205,7 @@ static void rfilter_init(rfilter *f, int kind, float param, float param2) {
         float stddev = param;
         f->radius = 4 * stddev;
         f->alpha = -1.0f / (2.0f * stddev * stddev);
-        f->bias = expf(f->alpha * (f->radius * f->radius));
+        f->bias = mo_lm_exp(f->alpha * (f->radius * f->radius));
     } else if (kind == 2) {
         f->radius = 1.0f; f->alpha = 1.0f / f->radius;
     } else if (kind == 3) {
@@ -1380,4 +1380,20 @@ int mo_render_adjoint_envmap(const mo_scene *s, const mo_render_desc *d, const f
         path_sample(s, &rng, &ray, d->max_depth, d->rr_depth, L, &valid, &st, &eg);
     }
     return 0;
+}
+
+void mo_libm_eval(int fn, uint64_t n, const float *x, const float *y, float *out) {
+    for (uint64_t i = 0; i < n; ++i) {
+        const float a = x[i];
+        switch (fn) {
+        case 0: out[i] = mo_lm_sin(a); break;
+        case 1: out[i] = mo_lm_cos(a); break;
+        case 2: out[i] = mo_lm_tan(a); break;
+        case 3: out[i] = mo_lm_exp(a); break;
+        case 4: out[i] = mo_lm_log(a); break;
+        case 5: out[i] = mo_lm_erf(a); break;
+        case 6: out[i] = mo_lm_acos(a); break;
+        default: out[i] = mo_lm_atan2(a, y[i]); break;
+        }
+    }
 }

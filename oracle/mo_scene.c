@@ -738,7 +738,7 @@ void mo_sample_emitter_direction(const mo_scene *s, mo_v3 ref_p, mo_v2 sample, m
                 mo_v3 ld = mo_v3_make(fmaf(m[2], nd.z, fmaf(m[1], nd.y, m[0] * nd.x)), fmaf(m[5], nd.z, fmaf(m[4], nd.y, m[3] * nd.x)),
                                       fmaf(m[8], nd.z, fmaf(m[7], nd.y, m[6] * nd.x)));
                 float cos_theta = mo_normalize(ld).z;
-                if (!(cos_theta >= e->cos_beam)) falloff = (e->cutoff_angle - acosf(cos_theta)) * e->inv_transition;
+                if (!(cos_theta >= e->cos_beam)) falloff = (e->cutoff_angle - mo_lm_acos(cos_theta)) * e->inv_transition;
                 if (cos_theta <= e->cos_cutoff) falloff = 0.0f;
             }
             ds->falloff = falloff; ds->scale = inv_dist * inv_dist;
@@ -755,7 +755,7 @@ void mo_sample_emitter_direction(const mo_scene *s, mo_v3 ref_p, mo_v2 sample, m
         /* ConstantBackgroundEmitter::sample_direction (constant.cpp:82-107); square_to_uniform_sphere (warp.h:262-267) */
         float z = fmaf(-2.0f, sample.y, 1.0f), r = mo_safe_sqrt(fmaf(-z, z, 1.0f));
         float ang = 2.0f * MO_PI_F * sample.x;
-        mo_v3 d = mo_v3_make(r * cosf(ang), r * sinf(ang), z);
+        mo_v3 d = mo_v3_make(r * mo_lm_cos(ang), r * mo_lm_sin(ang), z);
         ds->dist = 2.0f * e->radius;
         ds->p = mo_add(ref_p, mo_scale(d, ds->dist));
         ds->n = mo_neg(d);

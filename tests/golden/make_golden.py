@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/oracle_v1.npz with the CPU oracle (the reference itself cannot be built or imported in
+"""Generates tests/golden/oracle_v2.npz with the CPU oracle (the reference itself cannot be built or imported in
 the build container; its own known-answer values are asserted in tests/test_oracle_kat.py).
 The file freezes the oracle's outputs on small seeded inputs so that (a) the oracle cannot drift silently and
 (b) the GPU box can check the HIP path against committed data.  Inputs are regenerated from fixed seeds by
@@ -49,8 +49,8 @@ def main():
     ob.lib().mo_kat_pcg32(7, 11, 16, u32.ctypes.data, f32.ctypes.data)
     out.update(pcg_u32=u32, pcg_f32=f32)
     out["tea64"] = np.array([ob.lib().mo_kat_tea64_u64(a, b, 4) for a, b in ((0, 0), (1, 1), (12345678901234, 5), (5, 12345678901234))], np.uint64)
-    np.savez_compressed(os.path.join(HERE, "oracle_v1.npz"), **out)
-    print("wrote", os.path.join(HERE, "oracle_v1.npz"), {k: v.shape for k, v in out.items()})
+    np.savez_compressed(os.path.join(HERE, "oracle_v2.npz"), **out)
+    print("wrote", os.path.join(HERE, "oracle_v2.npz"), {k: v.shape for k, v in out.items()})
 
 
 if __name__ == "__main__":

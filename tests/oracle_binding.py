@@ -83,6 +83,8 @@ def lib():
         L.mo_sample_radiance.argtypes = [vp, C.POINTER(RenderDesc), C.c_uint64, C.c_uint64, vp, vp]
         L.mo_render_rows.argtypes = [vp, C.POINTER(RenderDesc), C.c_int, C.c_int, vp]
         L.mo_film_develop.argtypes = [vp, C.c_uint64, vp]
+        L.mo_libm_eval.argtypes = [C.c_int, C.c_uint64, vp, vp, vp]
+        L.mo_libm_eval.restype = None
         L.mo_render_adjoint.argtypes = [vp, C.POINTER(RenderDesc), vp, vp, vp, vp, vp]
         L.mo_scene_set_emitter_radiance.argtypes = [vp, C.c_uint32, vp]
         L.mo_render_adjoint_envmap.argtypes = [vp, C.POINTER(RenderDesc), vp, vp, vp]
@@ -379,6 +381,18 @@ def film_develop(xyzaw):
     n = xyzaw.size // 5
     out = np.empty(xyzaw.shape[:-1] + (4,), np.float32)
     lib().mo_film_develop(_p(xyzaw), n, _p(out))
+    return out
+
+
+LIBM_FUNCTIONS = ("sin", "cos", "tan", "exp", "log", "erf", "acos", "atan2")
+
+
+def libm_eval(name, x, y=None):
+    """oracle/mo_libm.h on float32 arrays (atan2: (y, x))"""
+    x = _f(x)
+    y = _f(y) if y is not None else x
+    out = np.empty_like(x)
+    lib().mo_libm_eval(LIBM_FUNCTIONS.index(name), x.size, _p(x), _p(y), _p(out))
     return out
 
 
