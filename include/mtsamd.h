@@ -24,7 +24,9 @@
 extern "C" {
 #endif
 
-#define MTSAMD_ABI_VERSION 5
+#define MTSAMD_ABI_VERSION 6
+/* the library is built with -fvisibility=hidden: only the entry points below are exported */
+#define MTSAMD_API __attribute__((visibility("default")))
 
 typedef enum {
     MTSAMD_OK = 0,
@@ -38,15 +40,15 @@ typedef enum {
 typedef struct mtsamd_scene mtsamd_scene;
 
 /* ---- library ------------------------------------------------------------- */
-int mtsamd_abi_version(void);
-const char *mtsamd_last_error(void);
+MTSAMD_API int mtsamd_abi_version(void);
+MTSAMD_API const char *mtsamd_last_error(void);
 /* Number of HIP devices visible to this process (<0 on error). */
-int mtsamd_device_count(void);
+MTSAMD_API int mtsamd_device_count(void);
 /* Plugin ABI of the reference (include/mitsuba/core/class.h:205-211, MTS_EXPORT_PLUGIN): PluginManager dlopen()s a
  * plugin .so and reads these two symbols (src/libcore/plugin.cpp:19-31).  The library answers for the `path_amd`
  * integrator shim shown in INTEGRATION.md, so that the shim can be this very shared object. */
-const char *plugin_name(void);
-const char *plugin_descr(void);
+MTSAMD_API const char *plugin_name(void);
+MTSAMD_API const char *plugin_descr(void);
 
 /* ---- scene description ----------------------------------------------------
  * Mesh buffers exactly as Mesh exposes them (include/mitsuba/render/mesh.h:80-90,
@@ -140,21 +142,21 @@ typedef struct {
  * `device`, builds the BVH (replaces ShapeKDTree::build, include/mitsuba/render/kdtree.h:1710)
  * and the emitter sampling tables (Mesh::area_distr_build, src/librender/mesh.cpp:284-307).
  * Synchronous. */
-int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene **out);
-void mtsamd_scene_destroy(mtsamd_scene *scene);
+MTSAMD_API int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene **out);
+MTSAMD_API void mtsamd_scene_destroy(mtsamd_scene *scene);
 
 /* Scene::bbox (include/mitsuba/render/scene.h): out6 = min xyz, max xyz (host). */
-int mtsamd_scene_bbox(const mtsamd_scene *scene, float *out6);
+MTSAMD_API int mtsamd_scene_bbox(const mtsamd_scene *scene, float *out6);
 /* Scene info: out[0]=primitive count, [1]=BVH node count, [2]=BVH depth, [3]=shape count,
  * [4]=emitter count, [5]=nodes resident in LDS. */
-int mtsamd_scene_info(const mtsamd_scene *scene, uint32_t *out6);
+MTSAMD_API int mtsamd_scene_info(const mtsamd_scene *scene, uint32_t *out6);
 /* parameters_changed() for constant reflectance / radiance / texture data
  * (src/spectra/srgb.cpp:59-61, src/textures/bitmap.cpp:295-299): host data, synchronous. */
-int mtsamd_scene_set_bsdf_reflectance(mtsamd_scene *scene, uint32_t bsdf, const float *rgb);
-int mtsamd_scene_set_emitter_radiance(mtsamd_scene *scene, uint32_t emitter, const float *rgb);
+MTSAMD_API int mtsamd_scene_set_bsdf_reflectance(mtsamd_scene *scene, uint32_t bsdf, const float *rgb);
+MTSAMD_API int mtsamd_scene_set_emitter_radiance(mtsamd_scene *scene, uint32_t emitter, const float *rgb);
 /* BitmapTexture `data` parameter (bitmap.cpp:295-299): rgb is a host OR device pointer to height*width*3 floats;
  * asynchronous on `stream`. */
-int mtsamd_scene_update_texture(mtsamd_scene *scene, uint32_t texture, const float *rgb, void *stream);
+MTSAMD_API int mtsamd_scene_update_texture(mtsamd_scene *scene, uint32_t texture, const float *rgb, void *stream);
 
 /* ---- scene queries on SoA ray streams --------------------------------------
  * The stream layout follows the reference's device-stream precedent OptixParams
@@ -170,23 +172,23 @@ typedef struct {
 /* Scene::ray_intersect (include/mitsuba/render/scene.h:36; closest hit,
  * ShapeKDTree::ray_intersect_scalar<false>, kdtree.h:2079-2174): t, global primitive
  * index, shape index, barycentric u,v (the kd-tree "cache", kdtree.h:2432-2452). */
-int mtsamd_ray_intersect(const mtsamd_scene *scene, uint64_t n, const mtsamd_rays *rays,
+MTSAMD_API int mtsamd_ray_intersect(const mtsamd_scene *scene, uint64_t n, const mtsamd_rays *rays,
                          float *t, uint32_t *prim, uint32_t *shape, float *u, float *v,
                          void *stream);
 /* Same query answered by brute force over all triangles
  * (Scene::ray_intersect_naive, scene.h:38-44 / kdtree.h:2303-2328) -- test aid. */
-int mtsamd_ray_intersect_naive(const mtsamd_scene *scene, uint64_t n, const mtsamd_rays *rays,
+MTSAMD_API int mtsamd_ray_intersect_naive(const mtsamd_scene *scene, uint64_t n, const mtsamd_rays *rays,
                                float *t, uint32_t *prim, uint32_t *shape, float *u, float *v,
                                void *stream);
 /* Scene::ray_test (scene.h:62; any hit, ray_intersect_scalar<true>). */
-int mtsamd_ray_test(const mtsamd_scene *scene, uint64_t n, const mtsamd_rays *rays,
+MTSAMD_API int mtsamd_ray_test(const mtsamd_scene *scene, uint64_t n, const mtsamd_rays *rays,
                     uint8_t *hit, void *stream);
 /* Full SurfaceInteraction SoA for the closest hit (create_surface_interaction,
  * kdtree.h:2334-2367 + Mesh::fill_surface_interaction, src/librender/mesh.cpp:399-462;
  * GPU twin __closesthit__mesh, src/shapes/optix/mesh.cuh:27-96).  si26 is a device array of
  * 26 planes of n floats each: p(3) n(3) uv(2) sh_frame.s(3) sh_frame.t(3) sh_frame.n(3)
  * dp_du(3) dp_dv(3) wi(3). */
-int mtsamd_ray_intersect_si(const mtsamd_scene *scene, uint64_t n, const mtsamd_rays *rays,
+MTSAMD_API int mtsamd_ray_intersect_si(const mtsamd_scene *scene, uint64_t n, const mtsamd_rays *rays,
                             float *t, uint32_t *prim, uint32_t *shape, float *si26,
                             void *stream);
 
@@ -249,6 +251,10 @@ typedef struct {
                                   image does not depend on it: the RNG streams are seeded per global sample index */
     int32_t profile;           /* != 0: every trace / shade launch of the split pipeline is bracketed by HIP timing events on
                                   the stream it is launched on (stats_host[8..13]) */
+    /* scheduler knobs, continued (ABI 6; 0 = library default).  The image does not depend on them (tests/test_gpu_lifecycle.py). */
+    int32_t max_pass_log2;     /* a pass holds at most 2^max_pass_log2 camera samples (10..30; default 30) */
+    int32_t finish_kernel;     /* end of a pass: 0 = one k_finish launch once few paths are left, 1 = never (launch rounds until the
+                                  pool is empty), 2 = as soon as the sample cursors are dry */
 } mtsamd_render_desc;
 
 /* SamplingIntegrator::render for the `path` integrator (src/librender/integrator.cpp:52-176,
@@ -263,17 +269,17 @@ typedef struct {
  * (HIP events on `stream`), [6] device time of the film gather in ns, [7] triangle tests; with desc->profile and the
  * split pipeline: [8] summed duration of the k_trace<closest> launches in ns, [9] their number, [10] / [11] the same for
  * k_trace<any>, [12] / [13] for k_shade; [14] passes; [15] 1 if the render stopped at its timeout. */
-int mtsamd_render(mtsamd_scene *scene, const mtsamd_render_desc *desc, float *film_xyzaw_dev,
+MTSAMD_API int mtsamd_render(mtsamd_scene *scene, const mtsamd_render_desc *desc, float *film_xyzaw_dev,
                   uint64_t *stats_host, void *stream);
 /* Integrator::cancel (integrator.h:51): thread-safe, makes a running mtsamd_render return
  * MTSAMD_ERR_CANCELLED at the next scheduling step. */
-int mtsamd_cancel(mtsamd_scene *scene);
+MTSAMD_API int mtsamd_cancel(mtsamd_scene *scene);
 
 /* SamplingIntegrator::sample for whole sample indices (integrator.h:114-119): per-sample radiance
  * of samples [first, first+count) of the render described by desc, without film accumulation.
  * rgba_dev: count*4 floats (R,G,B, valid_ray mask); pos_dev (may be NULL): count*2 floats film
  * position sample.  Synchronous. */
-int mtsamd_sample_radiance(mtsamd_scene *scene, const mtsamd_render_desc *desc, uint64_t first,
+MTSAMD_API int mtsamd_sample_radiance(mtsamd_scene *scene, const mtsamd_render_desc *desc, uint64_t first,
                            uint64_t count, float *rgba_dev, float *pos_dev, void *stream);
 
 /* Reverse-mode derivative of mitsuba.python.autodiff.render (src/python/python/autodiff.py:6-91,121-194) with respect
@@ -285,37 +291,37 @@ int mtsamd_sample_radiance(mtsamd_scene *scene, const mtsamd_render_desc *desc, 
  * mtsamd_scene_texture_info) and grad_emitters_dev (emitter_count*3: the radiance of area lights,
  * 'shape.emitter.radiance.value', docs/src/inverse_rendering/diff_render.rst:76) are ACCUMULATED into; each may be NULL.
  * Needs 0 <= max_depth <= 16. */
-int mtsamd_render_adjoint(mtsamd_scene *scene, const mtsamd_render_desc *desc, const float *dloss_dimage_dev,
+MTSAMD_API int mtsamd_render_adjoint(mtsamd_scene *scene, const mtsamd_render_desc *desc, const float *dloss_dimage_dev,
                           const float *film_dev, float *grad_bsdf_dev, float *grad_textures_dev, float *grad_emitters_dev,
                           void *stream);
 /* The same derivative with respect to the texels of the `envmap` emitter -- 'my_envmap.data' (src/emitters/envmap.cpp:214-218), the
  * parameter docs/examples/10_inverse_rendering/invert_bunny.py optimises.  The radiance is linear in the texels; the sampling
  * distribution built from their luminances is not differentiated (envmap.cpp:220-253 rebuilds it from plain floats).  Any BSDF,
  * any max_depth, RGB variant.  grad_envmap_dev: envmap height * width * 3 floats, ACCUMULATED into. */
-int mtsamd_render_adjoint_envmap(mtsamd_scene *scene, const mtsamd_render_desc *desc, const float *dloss_dimage_dev,
+MTSAMD_API int mtsamd_render_adjoint_envmap(mtsamd_scene *scene, const mtsamd_render_desc *desc, const float *dloss_dimage_dev,
                                  const float *film_dev, float *grad_envmap_dev, void *stream);
 /* New texels for the envmap emitter (host pointer, height * width * 3 linear RGB; parameters_changed of envmap.cpp:220-253).
  * rebuild_distribution = 0 keeps the importance-sampling hierarchy of the previous texels (a render is then exactly linear in the
  * texels: finite-difference tests); the reference always rebuilds.  Synchronises the device.  RGB variant. */
-int mtsamd_scene_update_envmap(mtsamd_scene *scene, const float *rgb, int32_t rebuild_distribution);
+MTSAMD_API int mtsamd_scene_update_envmap(mtsamd_scene *scene, const float *rgb, int32_t rebuild_distribution);
 /* Size of a bitmap texture and its float offset inside the concatenated texture-gradient buffer. */
 /* RoughPlastic precomputation (roughplastic.cpp:380-399) of BSDF `bsdf`: out65[0..63] = external transmittance at
  * cos(theta) = i / 63, out65[64] = internal diffuse reflectance.  Host pointer. */
-int mtsamd_scene_roughplastic_tables(const mtsamd_scene *scene, uint32_t bsdf, float *out65);
-int mtsamd_scene_texture_info(const mtsamd_scene *scene, uint32_t texture, int32_t *width, int32_t *height,
+MTSAMD_API int mtsamd_scene_roughplastic_tables(const mtsamd_scene *scene, uint32_t bsdf, float *out65);
+MTSAMD_API int mtsamd_scene_texture_info(const mtsamd_scene *scene, uint32_t texture, int32_t *width, int32_t *height,
                               uint64_t *grad_offset);
 
 /* Generates the RGB -> spectrum coefficient table (the reference builds it at compile time with
  * ext/rgb2spec/rgb2spec_opt.cpp <resolution = 64> srgb.coeff, ext/rgb2spec/CMakeLists.txt:49-54) and writes it to
  * `path` in the same "SPEC" file format.  Host only; takes about a minute at resolution 64 on 8 threads. */
-int mtsamd_rgb2spec_build(const char *path, int32_t resolution, int32_t threads);
+MTSAMD_API int mtsamd_rgb2spec_build(const char *path, int32_t resolution, int32_t threads);
 /* srgb_model_fetch (src/librender/srgb.cpp:14-40): coefficients of the smooth spectrum for a linear sRGB colour. */
-int mtsamd_srgb_model_fetch(const char *path, const float *rgb3, float *coeff3);
+MTSAMD_API int mtsamd_srgb_model_fetch(const char *path, const float *rgb3, float *coeff3);
 
 /* PerspectiveCamera::sample_ray (perspective.cpp:153-188) / ThinLensCamera::sample_ray (thinlens.cpp:175-214) for n
  * film-plane samples in [0,1)^2 and, for a thin lens, n aperture samples (NULL: 0.5, as integrator.cpp:229 initialises them)
  * (device SoA in, device SoA out). */
-int mtsamd_camera_sample_rays(const mtsamd_render_desc *desc, uint64_t n, const float *sx,
+MTSAMD_API int mtsamd_camera_sample_rays(const mtsamd_render_desc *desc, uint64_t n, const float *sx,
                               const float *sy, const float *aperture_x, const float *aperture_y, float *ox, float *oy, float *oz, float *dx,
                               float *dy, float *dz, float *mint, float *maxt, void *stream);
 
@@ -325,27 +331,27 @@ int mtsamd_camera_sample_rays(const mtsamd_render_desc *desc, uint64_t n, const 
  * (0, or the filter's border_size); data_dev holds (height+2b)*(width+2b)*channels floats
  * and is accumulated into (float atomics, as the reference's scatter_add).
  * pos_dev: n*2 floats, values_dev: n*channels floats. */
-int mtsamd_imageblock_put(int32_t width, int32_t height, int32_t offset_x, int32_t offset_y,
+MTSAMD_API int mtsamd_imageblock_put(int32_t width, int32_t height, int32_t offset_x, int32_t offset_y,
                           int32_t channels, int32_t rfilter, float rfilter_param, float rfilter_param2,
                           int32_t rfilter_analytic, int32_t border, uint64_t n,
                           const float *pos_dev, const float *values_dev, float *data_dev,
                           void *stream);
 /* ImageBlock::put(const ImageBlock*) (imageblock.cpp:49-77, accumulate_2d bitmap.h:657-716):
  * target += source with clipping; both described by (w,h,offset,border). */
-int mtsamd_imageblock_put_block(const float *src_dev, int32_t src_w, int32_t src_h, int32_t src_ox,
+MTSAMD_API int mtsamd_imageblock_put_block(const float *src_dev, int32_t src_w, int32_t src_h, int32_t src_ox,
                                 int32_t src_oy, int32_t src_border, float *dst_dev, int32_t dst_w,
                                 int32_t dst_h, int32_t dst_ox, int32_t dst_oy, int32_t dst_border,
                                 int32_t channels, void *stream);
 /* ReconstructionFilter discretisation (src/libcore/rfilter.cpp:9-20): host outputs. */
-int mtsamd_rfilter_info(int32_t rfilter, float rfilter_param, float rfilter_param2, float *table32_host,
+MTSAMD_API int mtsamd_rfilter_info(int32_t rfilter, float rfilter_param, float rfilter_param2, float *table32_host,
                         float *radius_host, int32_t *border_host);
 /* HDRFilm::bitmap (src/films/hdrfilm.cpp:249-320): XYZAW -> RGBA float32, n pixels. */
-int mtsamd_film_develop(const float *xyzaw_dev, uint64_t n_pixels, float *rgba_dev, void *stream);
+MTSAMD_API int mtsamd_film_develop(const float *xyzaw_dev, uint64_t n_pixels, float *rgba_dev, void *stream);
 /* Elementary functions of the kernels (csrc/device_libm.h: the reference gets them from Enoki's polynomial kernels, e.g.
  * enoki::sincos in include/mitsuba/core/warp.h:54-90, exp / log / erf in include/mitsuba/render/microfacet.h:187-493), evaluated on
  * the device for n arguments.  fn: 0 sin, 1 cos, 2 tan, 3 exp, 4 log, 5 erf, 6 acos, 7 atan2(x = y-coordinate, y = x-coordinate);
  * y_dev is read by fn 7 only.  Lets a test prove that host and device produce the same bits. */
-int mtsamd_libm_eval(int32_t fn, uint64_t n, const float *x_dev, const float *y_dev, float *out_dev, void *stream);
+MTSAMD_API int mtsamd_libm_eval(int32_t fn, uint64_t n, const float *x_dev, const float *y_dev, float *out_dev, void *stream);
 
 #ifdef __cplusplus
 }

@@ -62,7 +62,8 @@ class RenderDesc(C.Structure):
                 ("pipeline", C.c_int32), ("film_rgb", C.c_int32), ("integrator", C.c_int32), ("emitter_samples", C.c_int32),
                 ("bsdf_samples", C.c_int32), ("hide_emitters", C.c_int32), ("moment", C.c_int32),
                 ("aperture_radius", C.c_float), ("focus_distance", C.c_float),
-                ("timeout", C.c_float), ("samples_per_pass", C.c_int32), ("profile", C.c_int32)]
+                ("timeout", C.c_float), ("samples_per_pass", C.c_int32), ("profile", C.c_int32),
+                ("max_pass_log2", C.c_int32), ("finish_kernel", C.c_int32)]
 
 
 # every symbol include/mtsamd.h declares: name -> (restype, argtypes)
@@ -117,7 +118,7 @@ def lib():
             fn = getattr(handle, name)      # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if handle.mtsamd_abi_version() != 5:
+        if handle.mtsamd_abi_version() != 6:
             raise RuntimeError("libmtsamd.so ABI version mismatch")
         _lib = handle
     return _lib

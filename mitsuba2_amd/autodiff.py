@@ -33,7 +33,10 @@ class ParameterMap:
         self._kind = {}
         dev = torch.device("cuda", scene._device_index)
         emitters = scene._dict.get("emitters", [])
-        # 'my_envmap.data' (envmap.cpp:214-218): differentiable in any scene (any BSDF); shape (H, W, 3) linear RGB
+        # 'my_envmap.data' (envmap.cpp:214-218): differentiable in any scene (any BSDF).  Layout: (H, W, 3) linear RGB here; the
+        # reference's traverse() exposes the flat H * W * 4 buffer of its bitmap (RGB + a padding channel that carries no parameter,
+        # envmap.cpp:216): a script written like invert_bunny.py reshapes with .reshape(H, W, 4)[..., :3] ("parity unpinned": no
+        # reference test fixes the layout)
         for e, em in enumerate(emitters):
             if em.get("type", "area") == "envmap":
                 key = em.get("id", "emitter_%d" % e) + ".data"

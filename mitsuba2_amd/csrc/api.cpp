@@ -31,6 +31,14 @@ namespace {
 
 thread_local std::string g_last_error;
 
+// Experiment switches (scheduler geometry, BVH leaf size, ...) read from the environment exist only in builds made with
+// -DMTSAMD_EXPERIMENTS (scripts/ab_build.sh); the release library never looks at the process environment.
+#ifdef MTSAMD_EXPERIMENTS
+static const char *exp_env(const char *name) { return std::getenv(name); }
+#else
+static const char *exp_env(const char *) { return nullptr; }
+#endif
+
 int fail(int code, const char *fmt, ...) {
     char buf[1024];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
@@ -171,6 +179,20 @@ template <typename T> int upload(T **dst, const std::vector<T> &src) {
     size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
     HIP_TRY(hipMalloc((void **) dst, bytes));
     if (!src.empty()) HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// Every workspace buffer is zeroed when it is allocated: a kernel that reads a slot before the first write of a render (a count, a
+// cursor, the spill area, a pool slot beyond a stale count) then reads zeros on every run, not whatever the allocator handed out
+// (round 2's fault came from exactly such a read; tests/conftest.py still dirties device memory before every GPU session).
+// Out of device memory is reported as MTSAMD_ERR_NOMEM so that callers can retry with a smaller pass.
+static int ws_alloc(void **p, size_t bytes) {
+    *p = nullptr;
+    bytes = std::max<size_t>(bytes, 4);
+    const hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory) { (void) hipGetLastError(); *p = nullptr; return fail(MTSAMD_ERR_NOMEM, "out of device memory (%zu bytes of workspace)", bytes); }
+    HIP_TRY(e);
+    HIP_TRY(hipMemset(*p, 0, bytes));
     return 0;
 }
 
@@ -689,7 +711,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
 
     // ---- accelerator -------------------------------------------------------------------------
     uint32_t max_leaf = 4;
-    if (const char *e = std::getenv("MTSAMD_BVH_LEAF")) max_leaf = (uint32_t) std::min(15, std::max(1, atoi(e)));      // experiment switch
+    if (const char *e = exp_env("MTSAMD_BVH_LEAF")) max_leaf = (uint32_t) std::min(15, std::max(1, atoi(e)));      // experiment switch
     if (s->n_prims > 0) build_bvh(tri_pos.data(), s->n_prims, max_leaf, s->bvh);
     else { s->bvh = BvhOutput{}; s->bvh.root = s->bvh.wroot = 0x80000000u; s->bvh.wdepth = 1; }       // a leaf with no triangles (BVH2 and BVH4 root: without wroot the walks of the split pipeline started at node 0 of an empty node array)
     if (s->environment >= 0) {       // ConstantBackgroundEmitter::set_scene (constant.cpp:47-51): bounding sphere of Scene::bbox()
@@ -725,7 +747,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     std::memcpy(tris.data(), s->bvh.tris.data(), s->bvh.tris.size() * sizeof(float));
     // flat scenes: 64-byte records in primitive order (device_scene.h)
     uint32_t flat_max = kFlatMaxPrims;
-    if (const char *e = std::getenv("MTSAMD_FLAT_MAX")) flat_max = std::min<uint32_t>(kFlatMaxPrims, (uint32_t) std::strtoul(e, nullptr, 10));   // experiment switch
+    if (const char *e = exp_env("MTSAMD_FLAT_MAX")) flat_max = std::min<uint32_t>(kFlatMaxPrims, (uint32_t) std::strtoul(e, nullptr, 10));   // experiment switch
     const bool flat = s->n_prims <= flat_max;
     std::vector<float4> flat_recs(flat ? 4 * (size_t) s->n_prims : 0);
     for (uint32_t gp = 0; flat && gp < s->n_prims; ++gp) {
@@ -867,7 +889,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     v.walk_blocks = 8u * (uint32_t) s->cu_count;
     if (!flat && v.stack_depth > v.walk_lds_depth) {
         const size_t entries = (size_t) v.walk_blocks * (v.stack_depth - v.walk_lds_depth) * 256u;
-        if (hipMalloc((void **) &s->d_walk_spill, entries * sizeof(StackEntry)) != hipSuccess) { mtsamd_scene_destroy(s); return fail(MTSAMD_ERR_NOMEM, "traversal spill area"); }
+        if (ws_alloc((void **) &s->d_walk_spill, entries * sizeof(StackEntry))) { mtsamd_scene_destroy(s); return fail(MTSAMD_ERR_NOMEM, "traversal spill area"); }
     }
     v.walk_spill = s->d_walk_spill;
     v.tri_pos = s->d_tri_pos; v.tri_nrm = any_nrm ? s->d_tri_nrm : nullptr; v.tri_uv = any_uv ? s->d_tri_uv : nullptr;
@@ -1030,33 +1052,34 @@ static int ensure_workspace(mtsamd_scene *s, uint32_t n_waves, uint32_t seg_cap,
     Workspace &w = s->ws;
     if (w.n_waves == n_waves && w.seg_cap == seg_cap && w.pass_cap >= pass_cap && w.spectral == s->spectral && (w.split || !split)) return 0;
     w.release();
+    struct Guard { Workspace &w; bool ok = false; ~Guard() { if (!ok) w.release(); } } guard{ w };      // nothing half-allocated survives an error
     size_t slots = (size_t) n_waves * seg_cap;
     for (int k = 0; k < 2; ++k) {
-        HIP_TRY(hipMalloc((void **) &w.pool[k].ray_o, slots * sizeof(float4)));
-        HIP_TRY(hipMalloc((void **) &w.pool[k].ray_d, slots * sizeof(float4)));
-        HIP_TRY(hipMalloc((void **) &w.pool[k].thr, slots * sizeof(float4)));
-        HIP_TRY(hipMalloc((void **) &w.pool[k].res, slots * sizeof(float4)));
-        HIP_TRY(hipMalloc((void **) &w.pool[k].rng, slots * sizeof(uint4)));
-        HIP_TRY(hipMalloc((void **) &w.pool[k].misc, slots * sizeof(uint2)));
-        HIP_TRY(hipMalloc((void **) &w.count[k], 2 * (size_t) n_waves * sizeof(uint32_t)));      // counts + survivor borders (k_shade, flat scenes)
+        if (int rc = ws_alloc((void **) &w.pool[k].ray_o, slots * sizeof(float4))) return rc;
+        if (int rc = ws_alloc((void **) &w.pool[k].ray_d, slots * sizeof(float4))) return rc;
+        if (int rc = ws_alloc((void **) &w.pool[k].thr, slots * sizeof(float4))) return rc;
+        if (int rc = ws_alloc((void **) &w.pool[k].res, slots * sizeof(float4))) return rc;
+        if (int rc = ws_alloc((void **) &w.pool[k].rng, slots * sizeof(uint4))) return rc;
+        if (int rc = ws_alloc((void **) &w.pool[k].misc, slots * sizeof(uint2))) return rc;
+        if (int rc = ws_alloc((void **) &w.count[k], 2 * (size_t) n_waves * sizeof(uint32_t))) return rc;      // counts + survivor borders (k_shade, flat scenes)
         if (s->spectral) {
-            HIP_TRY(hipMalloc((void **) &w.pool[k].wav, slots * sizeof(float4)));
-            HIP_TRY(hipMalloc((void **) &w.pool[k].aux, slots * sizeof(float2)));
+            if (int rc = ws_alloc((void **) &w.pool[k].wav, slots * sizeof(float4))) return rc;
+            if (int rc = ws_alloc((void **) &w.pool[k].aux, slots * sizeof(float2))) return rc;
         }
         if (split) {
-            HIP_TRY(hipMalloc((void **) &w.pool[k].hit, slots * sizeof(float4)));
-            HIP_TRY(hipMalloc((void **) &w.pool[k].sh_o, slots * sizeof(float4)));
-            HIP_TRY(hipMalloc((void **) &w.pool[k].sh_d, slots * sizeof(float4)));
-            HIP_TRY(hipMalloc((void **) &w.pool[k].nee, slots * sizeof(float4)));
-            HIP_TRY(hipMalloc((void **) &w.pool[k].sh_slot, slots * sizeof(uint32_t)));
+            if (int rc = ws_alloc((void **) &w.pool[k].hit, slots * sizeof(float4))) return rc;
+            if (int rc = ws_alloc((void **) &w.pool[k].sh_o, slots * sizeof(float4))) return rc;
+            if (int rc = ws_alloc((void **) &w.pool[k].sh_d, slots * sizeof(float4))) return rc;
+            if (int rc = ws_alloc((void **) &w.pool[k].nee, slots * sizeof(float4))) return rc;
+            if (int rc = ws_alloc((void **) &w.pool[k].sh_slot, slots * sizeof(uint32_t))) return rc;
         }
     }
-    HIP_TRY(hipMalloc((void **) &w.cursor, n_waves * sizeof(uint64_t)));
-    HIP_TRY(hipMalloc((void **) &w.cursor_end, n_waves * sizeof(uint64_t)));
-    HIP_TRY(hipMalloc((void **) &w.wave_stats, 4 * (size_t) n_waves * sizeof(uint64_t)));
-    HIP_TRY(hipMalloc((void **) &w.count_shadow, n_waves * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **) &w.out_rgba, pass_cap * sizeof(float4)));
-    HIP_TRY(hipMalloc((void **) &w.out_pos, pass_cap * sizeof(float2)));
+    if (int rc = ws_alloc((void **) &w.cursor, n_waves * sizeof(uint64_t))) return rc;
+    if (int rc = ws_alloc((void **) &w.cursor_end, n_waves * sizeof(uint64_t))) return rc;
+    if (int rc = ws_alloc((void **) &w.wave_stats, 4 * (size_t) n_waves * sizeof(uint64_t))) return rc;
+    if (int rc = ws_alloc((void **) &w.count_shadow, n_waves * sizeof(uint32_t))) return rc;
+    if (int rc = ws_alloc((void **) &w.out_rgba, pass_cap * sizeof(float4))) return rc;
+    if (int rc = ws_alloc((void **) &w.out_pos, pass_cap * sizeof(float2))) return rc;
     HIP_TRY(hipHostMalloc((void **) &w.h_counts, 4 * (size_t) n_waves * sizeof(uint32_t), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **) &w.h_cursor, 3 * (size_t) n_waves * sizeof(uint64_t), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **) &w.h_cursor_rb, 2 * (size_t) n_waves * sizeof(uint64_t), hipHostMallocDefault));
@@ -1067,6 +1090,7 @@ static int ensure_workspace(mtsamd_scene *s, uint32_t n_waves, uint32_t seg_cap,
     for (auto &e : w.tev) HIP_TRY(hipEventCreate(&e));
     w.have_events = true;
     w.n_waves = n_waves; w.seg_cap = seg_cap; w.pass_cap = pass_cap; w.spectral = s->spectral; w.split = split;
+    guard.ok = true;
     return 0;
 }
 
@@ -1103,12 +1127,12 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     // every wave sees four regions of the film, which evens out when the waves run dry: 1 / 4 / 16 / 64 chunks: 0 / +2.1 / +2.3 / +1.3 %
     // on the 261 k-triangle mesh at 1024 spp; 64-sample chunks as on flat scenes cost 5 %), at least 256 samples each
     uint64_t cpw = 4;
-    if (const char *e = getenv("MTSAMD_CHUNKS_PER_WAVE")) cpw = (uint64_t) std::min(64, std::max(1, atoi(e)));      // experiment switch
+    if (const char *e = exp_env("MTSAMD_CHUNKS_PER_WAVE")) cpw = (uint64_t) std::min(64, std::max(1, atoi(e)));      // experiment switch
     const uint64_t chunk = j.s->view.flat ? 64u : std::max<uint64_t>({ (n + nw * cpw - 1) / (nw * cpw), std::min<uint64_t>(256u, (n + nw - 1) / nw), 1u });
     const uint64_t n_chunks = (n + chunk - 1u) / chunk, last_size = n - (n_chunks - 1u) * chunk;
     // hierarchy scenes run two launch chains over the halves of the scheduling waves: their chunks alternate (kernels.h, chunk_owner)
     uint32_t chain_split = 0;
-    if (!j.s->view.flat && j.split && nw >= 256u && !getenv("MTSAMD_ONE_CHAIN") && !getenv("MTSAMD_NO_CHAIN_INTERLEAVE")) chain_split = (nw / 2u + trace_group() - 1u) & ~(trace_group() - 1u);
+    if (!j.s->view.flat && j.split && nw >= 256u && !exp_env("MTSAMD_ONE_CHAIN") && !exp_env("MTSAMD_NO_CHAIN_INTERLEAVE")) chain_split = (nw / 2u + trace_group() - 1u) & ~(trace_group() - 1u);
     for (uint32_t k = 0; k < nw; ++k) {
         const uint64_t c0 = chunk_owner(k, nw, chain_split);      // this wave owns the chunks c0, c0 + nw, ...
         const uint64_t mine = c0 < n_chunks ? (n_chunks - 1u - c0) / nw + 1u : 0u;
@@ -1142,7 +1166,7 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
         const size_t words = trace_spill_words(p.sv, nw);
         if (words > w.trace_spill_words) {
             (void) hipFree(w.trace_spill); w.trace_spill = nullptr; w.trace_spill_words = 0;
-            HIP_TRY(hipMalloc((void **) &w.trace_spill, std::max<size_t>(words, 1) * sizeof(uint32_t)));
+            if (int rc = ws_alloc((void **) &w.trace_spill, std::max<size_t>(words, 1) * sizeof(uint32_t))) return rc;
             w.trace_spill_words = words;
         }
         p.trace_lds_depth = trace_lds_depth(p.sv); p.trace_top_nodes = trace_top_nodes(p.sv); p.trace_spill = w.trace_spill;
@@ -1160,7 +1184,8 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
         return 0;
     }
 
-    if (getenv("MTSAMD_MEGA") && (p.split == 1 || p.split == 3)) {          // experiment: one persistent launch, no pool
+#ifdef MTSAMD_EXPERIMENTS
+    if (exp_env("MTSAMD_MEGA") && (p.split == 1 || p.split == 3) && !j.s->nested_bsdfs) {          // experiment: one persistent launch, no pool
         HIP_TRY(hipEventRecord(w.tev[0], j.stream));
         HIP_TRY(launch_mega(p, j.stream));
         HIP_TRY(hipEventRecord(w.tev[1], j.stream));
@@ -1170,6 +1195,7 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
         j.bounce_ms += ms; j.iterations += 1;
         return 0;
     }
+#endif
     // the sample cursors cannot run dry before this many launches
     const uint64_t min_iters = (n + (uint64_t) nw * j.target - 1) / ((uint64_t) nw * j.target);
     uint64_t it = 0;
@@ -1183,7 +1209,7 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     int pending = -1, slot = 0;
     HIP_TRY(hipEventRecord(w.tev[0], j.stream));
     uint32_t n_parts = 2;
-    if (const char *e = getenv("MTSAMD_STREAMS")) n_parts = (uint32_t) std::min(4, std::max(1, atoi(e)));      // experiment switch
+    if (const char *e = exp_env("MTSAMD_STREAMS")) n_parts = (uint32_t) std::min(4, std::max(1, atoi(e)));      // experiment switch
     if (p.split != 3 || nw < 256u) n_parts = 1;
     uint32_t part_lo[5] = { 0, nw, nw, nw, nw };
     for (uint32_t k = 1; k < n_parts; ++k) part_lo[k] = (uint32_t) (((uint64_t) nw * k / n_parts + 3u) & ~3ull);
@@ -1195,16 +1221,18 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     // keeps up with the launch rounds of the split pipeline once they are no longer full): 2^22; LDS-resident scenes, whose drain is
     // already compacted by the gathering below: 2^18
     uint64_t finish_at = p.split == 1 ? (1ull << 22) : (p.split == 3 ? (1ull << 18) : 0ull);
-    if (const char *e = getenv("MTSAMD_FINISH_AT")) finish_at = (uint64_t) std::max(0ll, atoll(e));      // experiment switch
+    if (j.d->finish_kernel == 1) finish_at = 0;                      // never (tests: the launch rounds run the pool dry)
+    else if (j.d->finish_kernel == 2) finish_at = 1ull << 40;       // as soon as the cursors are dry
+    if (j.s->nested_bsdfs) finish_at = 0;                            // blendbsdf / mask: only the fused kernels carry the nesting code
     bool finish = false;
     uint64_t finish_alive = 0;
     uint32_t gather_max = 4u, gather_w = 4u;
-    if (p.split == 3 && !getenv("MTSAMD_NO_GATHER")) {
+    if (p.split == 3 && !exp_env("MTSAMD_NO_GATHER")) {
         gather_max = 1024u;
         for (uint32_t k = 0; k <= n_parts; ++k) while (gather_max > 4u && part_lo[k] % gather_max) gather_max >>= 2;
     }
     uint32_t split_parts = p.split == 1 && nw >= 256u ? 2u : 1u;
-    if (getenv("MTSAMD_ONE_CHAIN")) split_parts = 1;      // experiment switch
+    if (exp_env("MTSAMD_ONE_CHAIN")) split_parts = 1;      // experiment switch
     uint32_t split_lo[3] = { 0, nw, nw };
     if (split_parts == 2) split_lo[1] = (nw / 2u + trace_group() - 1u) & ~(trace_group() - 1u);      // multiple of the k_trace group size
     if (split_parts == 2) {      // the second chain starts after the cursors and counts are in place
@@ -1296,7 +1324,7 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
             HIP_TRY(launch_bounce(p, j.stream));
         }
         cur ^= 1; ++it;
-        if (getenv("MTSAMD_TRACE_ITERS")) {      // diagnostic: alive paths and wall time of every scheduler iteration (serialises the loop)
+        if (exp_env("MTSAMD_TRACE_ITERS")) {      // diagnostic: alive paths and wall time of every scheduler iteration (serialises the loop)
             sync_all();
             static thread_local std::vector<uint32_t> hc;
             hc.resize(nw);
@@ -1328,7 +1356,7 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
                 if (dry && alive <= finish_at) { finish = true; finish_alive = alive; break; }
                 if (dry && finish_at) { stride = 1; next_check = it + 1; }
                 if (gather_w < gather_max) {
-                    if (getenv("MTSAMD_TRACE_ITERS")) {
+                    if (exp_env("MTSAMD_TRACE_ITERS")) {
                         uint32_t wet = 0, first_wet = 0;
                         for (uint32_t k = 0; k < nw; ++k) if (hcur[k] < w.h_cursor[nw + k]) { if (!wet) first_wet = k; ++wet; }
                         fprintf(stderr, "check at it %llu: alive %llu wet %u first_wet %u cur %llu end %llu\n", (unsigned long long) it, (unsigned long long) alive, wet, first_wet,
@@ -1389,7 +1417,12 @@ int setup_job(Job &j, mtsamd_scene *s, const mtsamd_render_desc *d, hipStream_t 
     // beside the tracing of the next): every pass ends with a drain phase in which the pool empties, so fewer, larger passes waste
     // less (cbox 1024^2 @ 256 spp: 4 passes of 2^26 -> 1 pass: +7 %).
     uint64_t pass_limit = 1ull << 30;
-    if (const char *e = getenv("MTSAMD_PASS_LOG2")) pass_limit = 1ull << std::min(31, std::max(10, atoi(e)));      // experiment switch
+    if (d->max_pass_log2 > 0) pass_limit = 1ull << std::min(30, std::max(10, d->max_pass_log2));
+    // samples_per_pass (integrator.cpp:59-66): a pass holds at most that many samples of every pixel of the crop window -- it bounds the
+    // memory of a pass and is where a timeout / cancel can stop; the image does not depend on it (per-sample RNG streams)
+    if (d->samples_per_pass > 0)
+        pass_limit = std::min<uint64_t>(pass_limit, std::max<uint64_t>((uint64_t) d->crop_width * d->crop_height * (uint64_t) d->samples_per_pass,
+                                                                        (uint64_t) d->crop_width * (uint64_t) d->sample_count));
     // pipeline 0: one kernel with the in-kernel shadow ring (4) for LDS-resident (flat) scenes, split kernels (2) for hierarchy
     // scenes; 1 / 2 / 3 / 4 force one schedule
     if (s->spectral && d->integrator != 0) return fail(MTSAMD_ERR_UNSUPPORTED, "the direct and depth integrators are implemented for the RGB variant only");
@@ -1416,10 +1449,17 @@ int setup_job(Job &j, mtsamd_scene *s, const mtsamd_render_desc *d, hipStream_t 
         const uint64_t lo = (uint64_t) s->cu_count * 16u, hi = (uint64_t) s->cu_count * (j.split ? 416u : (j.shadow_ring ? 208u : 104u));
         j.n_waves = (uint32_t) std::min<uint64_t>(std::max<uint64_t>(want, lo), hi);
     }
-    if (const char *e = getenv("MTSAMD_WAVES_PER_CU")) j.n_waves = (uint32_t) s->cu_count * (uint32_t) std::max(1, atoi(e));    // experiment switch
-    j.pass_cap = std::max<uint64_t>(std::min<uint64_t>(max_pass, pass_limit), 1);
-    // segments hold a multiple of 64 slots: k_shade deals whole 64-path chunks of a workgroup's list to its waves
-    if (int rc = ensure_workspace(s, j.n_waves, (j.target + 63u) & ~63u, j.pass_cap, j.split || j.shadow_queue)) return rc;
+    if (const char *e = exp_env("MTSAMD_WAVES_PER_CU")) j.n_waves = (uint32_t) s->cu_count * (uint32_t) std::max(1, atoi(e));    // experiment switch
+    // segments hold a multiple of 64 slots: k_shade deals whole 64-path chunks of a workgroup's list to its waves.
+    // The sample stream of a 2^30-sample pass is 24 GiB (twice that with the overlap buffer of multi-pass renders): when the device
+    // cannot provide it -- other scenes, the caller's own tensors -- the pass is halved until the workspace fits.
+    for (;;) {
+        j.pass_cap = std::max<uint64_t>(std::min<uint64_t>(max_pass, pass_limit), 1);
+        const int rc = ensure_workspace(s, j.n_waves, (j.target + 63u) & ~63u, j.pass_cap, j.split || j.shadow_queue);
+        if (rc == MTSAMD_ERR_NOMEM && pass_limit > (1ull << 22) && max_pass > (1ull << 22)) { pass_limit = std::min(pass_limit, max_pass) >> 1; continue; }
+        if (rc) return rc;
+        break;
+    }
     HIP_TRY(hipMemsetAsync(s->ws.wave_stats, 0, 4 * (size_t) j.n_waves * sizeof(uint64_t), stream));
     s->cancel.store(0);
     j.t_start = std::chrono::steady_clock::now();
@@ -1496,7 +1536,7 @@ int mtsamd_render(mtsamd_scene *s, const mtsamd_render_desc *d, float *film, uin
         Workspace &w = s->ws;
         if (w.moment_pixels < n_pixels) {
             (void) hipFree(w.moment_film); w.moment_film = nullptr; w.moment_pixels = 0;
-            HIP_TRY(hipMalloc((void **) &w.moment_film, 2 * 5 * n_pixels * sizeof(float)));
+            if (int rc = ws_alloc((void **) &w.moment_film, 2 * 5 * n_pixels * sizeof(float))) return rc;
             w.moment_pixels = n_pixels;
         }
         HIP_TRY(hipMemsetAsync(w.moment_film, 0, 2 * 5 * n_pixels * sizeof(float), stream));
@@ -1505,16 +1545,22 @@ int mtsamd_render(mtsamd_scene *s, const mtsamd_render_desc *d, float *film, uin
     // Several passes: the film splat of pass k runs on its own stream while pass k + 1 is traced into the other sample stream buffer.
     Workspace &ws = s->ws;
     const uint64_t n_passes = ((uint64_t) rows.local_rows + rows_per_pass - 1) / rows_per_pass;
-    const bool overlap = n_passes > 1;
+    bool overlap = n_passes > 1;
     hipStream_t fstream = stream;
     if (overlap) {
         const uint64_t cap2 = std::min<uint64_t>(rows_per_pass * per_row, j.pass_cap);
         if (ws.pass_cap2 < cap2) {
             (void) hipFree(ws.out_rgba2); (void) hipFree(ws.out_pos2); ws.out_rgba2 = nullptr; ws.out_pos2 = nullptr; ws.pass_cap2 = 0;
-            HIP_TRY(hipMalloc((void **) &ws.out_rgba2, cap2 * sizeof(float4)));
-            HIP_TRY(hipMalloc((void **) &ws.out_pos2, cap2 * sizeof(float2)));
-            ws.pass_cap2 = cap2;
+            const int rc = ws_alloc((void **) &ws.out_rgba2, cap2 * sizeof(float4));
+            const int rc2 = rc ? rc : ws_alloc((void **) &ws.out_pos2, cap2 * sizeof(float2));
+            if (rc2 == MTSAMD_ERR_NOMEM) {          // no room for the second sample stream: the splat of a pass runs before the next pass
+                (void) hipFree(ws.out_rgba2); (void) hipFree(ws.out_pos2); ws.out_rgba2 = nullptr; ws.out_pos2 = nullptr;
+                overlap = false;
+            } else if (rc2) return rc2;
+            else ws.pass_cap2 = cap2;
         }
+    }
+    if (overlap) {
         if (!ws.film_stream) HIP_TRY(hipStreamCreateWithFlags(&ws.film_stream, hipStreamNonBlocking));
         for (auto &e : ws.film_done) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         fstream = ws.film_stream;
@@ -1532,7 +1578,7 @@ int mtsamd_render(mtsamd_scene *s, const mtsamd_render_desc *d, float *film, uin
         if (last_rows) { f.pass_rows = (int32_t) last_rows; film_tile_grid(f); need = std::max(need, film_partial_floats(f)); }
         if (need > ws.film_partial_floats) {
             (void) hipFree(ws.film_partials); ws.film_partials = nullptr; ws.film_partial_floats = 0;
-            HIP_TRY(hipMalloc((void **) &ws.film_partials, need * sizeof(float)));
+            if (int rc = ws_alloc((void **) &ws.film_partials, need * sizeof(float))) return rc;
             ws.film_partial_floats = need;
         }
     }

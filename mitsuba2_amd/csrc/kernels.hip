@@ -1194,7 +1194,7 @@ void k_shade(const RenderParams P) {
 // one hardware wave gathers the paths of `per` consecutive scheduling waves (prefix sums in LDS), a lane that finishes a path takes
 // the next one of the workgroup's list at once, every loop trip is one path.cpp iteration (both ray queries inline, as in k_bounce:
 // the floating-point operations on a sample and their order are those of the other schedules, the film is unchanged).
-constexpr uint32_t kFinishMaxPer = 1024u, kFinishLdsDepth = 8u;
+constexpr uint32_t kFinishMaxPer = 1024u, kFinishLdsDepth = 8u;      // the spill area is sized for k_trace AND for this depth (trace_spill_words)
 template <bool GENERAL, bool FLAT>
 MTS_DEV bool step_fused(const RenderParams &P, const LdsView &lds, PathState &s, Counters &c) { return bounce_step<FLAT, false, 0, GENERAL>(P, lds, s, c); }
 template <bool GENERAL, bool FLAT>
@@ -1261,6 +1261,7 @@ __global__ __launch_bounds__(64) void k_finish(const RenderParams P, uint32_t pe
     }
 }
 
+#ifdef MTSAMD_EXPERIMENTS
 // Experiment (MTSAMD_MEGA=1): the whole pass as ONE launch of persistent lanes -- no pool, no launch rounds.  A workgroup (one hardware
 // wave) owns the samples of one scheduling wave; a lane whose path ends starts the next sample at once.
 template <typename State, bool GENERAL, bool FLAT>
@@ -1326,6 +1327,7 @@ hipError_t launch_mega(const RenderParams &p, hipStream_t s) {
     }
     return hipGetLastError();
 }
+#endif
 
 hipError_t launch_finish(const RenderParams &p, uint64_t alive, hipStream_t s) {
     // about four paths per lane (alive: upper bound of the paths left), at least 2048 workgroups if there are that many scheduling waves
@@ -1355,7 +1357,7 @@ hipError_t launch_finish(const RenderParams &p, uint64_t alive, hipStream_t s) {
 // lane).  1024 threads = two workgroups per CU: each has 80 KB of LDS, enough for the first kTraceLdsDepth stack entries of every lane
 // AND a copy of the top of the BVH (round 3; with 256-thread workgroups eight copies would have to share the same 160 KB).
 #ifndef MTS_TRACE_BLOCK
-#define MTS_TRACE_BLOCK 1024
+#define MTS_TRACE_BLOCK 256
 #endif
 #ifndef MTS_TRACE_GROUP
 #define MTS_TRACE_GROUP (MTS_TRACE_BLOCK / 32)
@@ -1371,7 +1373,7 @@ static_assert((kShadowGroup & (kShadowGroup - 1u)) == 0u, "locate() searches a p
 constexpr uint32_t kTraceLdsDepth = MTS_TRACE_LDS_DEPTH;
 // Top of the BVH4 staged in LDS by every k_trace workgroup: the first kTraceTopNodes nodes in BFS order (64 B each).
 #ifndef MTS_TRACE_TOP_NODES
-#define MTS_TRACE_TOP_NODES (MTS_BVH4 && MTS_TRACE_BLOCK >= 1024 ? 360 : 0)
+#define MTS_TRACE_TOP_NODES 0
 #endif
 constexpr uint32_t kTraceTopNodes = MTS_TRACE_TOP_NODES;
 
@@ -1390,7 +1392,7 @@ void k_trace(const RenderParams P) {
     extern __shared__ float4 smem[];
     __shared__ uint32_t s_pre[kShadowGroup + 1u];            // s_pre[g] = work items of the group's scheduling waves before the g-th
     LdsView lds = {};
-    const uint32_t n_top = FLAT ? 0u : P.trace_top_nodes;
+    const uint32_t n_top = (FLAT || kTraceTopNodes == 0u) ? 0u : P.trace_top_nodes;
     if (FLAT) {
         lds = lds_stage<true>(P.sv, smem);
     } else {
@@ -1408,22 +1410,37 @@ void k_trace(const RenderParams P) {
     const uint32_t group = P.wave_first / kShadowGroup + blockIdx.x;      // global group index
     const uint32_t w0 = group * kShadowGroup;
     const uint32_t *counts = ANY ? P.count_shadow : P.count_in;
-    if (threadIdx.x < 64u) {                                 // prefix sums of the group's counts by the first wave
-        const uint32_t ln = threadIdx.x;
-        uint32_t incl = (ln < kShadowGroup && w0 + ln < wave_last) ? counts[w0 + ln] : 0u;
-        for (uint32_t off = 1u; off < kShadowGroup; off <<= 1) { const uint32_t v = __shfl_up(incl, off); if (ln >= off) incl += v; }
-        if (ln < kShadowGroup) s_pre[ln + 1u] = incl;
-        if (ln == 0u) s_pre[0] = 0u;
+    // small groups: the counts are wave-uniform and stay in scalar registers; large groups (1024-thread workgroups): prefix sums in LDS
+    constexpr bool kCountsInLds = kShadowGroup > 8u;
+    uint32_t cnt[kCountsInLds ? 1u : kShadowGroup], total = 0;
+    if (kCountsInLds) {
+        if (threadIdx.x < 64u) {                             // prefix sums of the group's counts by the first wave
+            const uint32_t ln = threadIdx.x;
+            uint32_t incl = (ln < kShadowGroup && w0 + ln < wave_last) ? counts[w0 + ln] : 0u;
+            for (uint32_t off = 1u; off < kShadowGroup; off <<= 1) { const uint32_t v = __shfl_up(incl, off); if (ln >= off) incl += v; }
+            if (ln < kShadowGroup) s_pre[ln + 1u] = incl;
+            if (ln == 0u) s_pre[0] = 0u;
+        }
+    } else {
+#pragma unroll
+        for (uint32_t g = 0; g < kShadowGroup; ++g) { cnt[g] = (w0 + g < wave_last) ? counts[w0 + g] : 0u; total += cnt[g]; }
     }
     __shared__ uint32_t s_next;
     if (threadIdx.x == 0) s_next = 0u;
     __syncthreads();
-    const uint32_t total = s_pre[kShadowGroup];
-    auto locate = [&](uint32_t idx) -> size_t {              // work item -> pool index: s_pre[g] <= idx < s_pre[g + 1]
-        uint32_t g = 0u;
+    if (kCountsInLds) total = s_pre[kShadowGroup];
+    auto locate = [&](uint32_t idx) -> size_t {              // work item -> pool index
+        if (kCountsInLds) {                                  // s_pre[g] <= idx < s_pre[g + 1]
+            uint32_t g = 0u;
 #pragma unroll
-        for (uint32_t step = kShadowGroup >> 1; step; step >>= 1) if (s_pre[g + step] <= idx) g += step;
-        return (size_t) (w0 + g) * P.seg_cap + (idx - s_pre[g]);
+            for (uint32_t step = kShadowGroup >> 1; step; step >>= 1) if (s_pre[g + step] <= idx) g += step;
+            return (size_t) (w0 + g) * P.seg_cap + (idx - s_pre[g]);
+        }
+        uint32_t wave = w0, i = idx;
+#pragma unroll
+        for (uint32_t g = 0; g + 1 < kShadowGroup; ++g)
+            if (wave == w0 + g && i >= cnt[g]) { i -= cnt[g]; ++wave; }
+        return (size_t) wave * P.seg_cap + i;
     };
     constexpr bool kNT = !FLAT && (MTS_NT_STREAMS & 1) != 0;
     auto retire_any = [&](size_t k) {                        // unoccluded shadow ray: radiance[slot] += nee

@@ -619,6 +619,10 @@ class Scene:
             data = data.detach().cpu().numpy()
         a = _f32(data)
         L.check(L.lib().mtsamd_scene_update_envmap(self._handle, a.ctypes.data_as(L.f32p), 1 if rebuild_distribution else 0))
+        # the scene description follows the device: a ParameterMap built after an optimisation step starts from the new texels
+        for em in self._dict.get("emitters", []):
+            if em.get("type", "area") == "envmap":
+                em["data"] = a.reshape(np.asarray(em["data"]).shape).copy()
 
     def set_emitter_radiance(self, index, rgb):
         L.check(L.lib().mtsamd_scene_set_emitter_radiance(self._handle, int(index), (C.c_float * 3)(*[float(x) for x in rgb])))
@@ -687,6 +691,9 @@ class PathIntegrator:
         # SamplingIntegrator properties (integrator.cpp:27-39): samples_per_pass (-1: all), timeout in seconds (-1: none)
         self.samples_per_pass, self.timeout = int(samples_per_pass), float(timeout)
         self.profile = bool(profile)           # per-launch HIP event timing of the split pipeline (stats: trace_*_ns)
+        # scheduler knobs of mtsamd_render_desc (0 = library default; the image does not depend on them): a pass holds at most
+        # 2^max_pass_log2 samples; finish_kernel 1 = never end a pass with k_finish, 2 = as soon as the sample cursors are dry
+        self.max_pass_log2, self.finish_kernel = 0, 0
         self._scene = None
         self.stats = None
 
@@ -700,6 +707,7 @@ class PathIntegrator:
         d.paths_per_wave = self.paths_per_wave
         d.pipeline = self.pipeline
         d.samples_per_pass, d.timeout, d.profile = self.samples_per_pass, self.timeout, int(self.profile)
+        d.max_pass_log2, d.finish_kernel = int(self.max_pass_log2), int(self.finish_kernel)
         self._fill_integrator(d)
         return d
 

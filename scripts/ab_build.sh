@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../mitsuba2_amd/csrc"
 name=$1; shift
 out=../../build/ab
 mkdir -p $out
-FLAGS="--offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -std=c++17 -O3 -fPIC -fvisibility=hidden -DMTSAMD_EXPERIMENTS -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wno-unused-function"
 /opt/rocm/bin/hipcc $FLAGS "$@" -c -o $out/kernels_$name.o kernels.hip &
 /opt/rocm/bin/hipcc $FLAGS "$@" -x hip -c -o $out/api_$name.o api.cpp &
 wait

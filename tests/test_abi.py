@@ -26,7 +26,13 @@ def test_header_symbols_are_exported():
     handle = C.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(handle, name), "libmtsamd.so does not export %s" % name
-    assert _lib.lib().mtsamd_abi_version() == 5
+    assert _lib.lib().mtsamd_abi_version() == 6
+    # ... and nothing else: the library is built with -fvisibility=hidden, internals (scheduler, kernel launchers) stay private
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    # exported *functions* (hipcc keeps the handle objects of __global__ kernels visible for its own registration: data, not code)
+    exported = sorted(ln.split()[-1] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] == "T")
+    assert [s for s in exported if not s.startswith("__")] == declared, sorted(set(exported) ^ set(declared))
     # the two symbols PluginManager reads from a plugin .so (class.h:205-211, plugin.cpp:19-31)
     assert _lib.lib().plugin_name() == b"path_amd" and len(_lib.lib().plugin_descr()) > 0
 
