@@ -349,7 +349,7 @@ MTSAMD_API int mtsamd_rfilter_info(int32_t rfilter, float rfilter_param, float r
 MTSAMD_API int mtsamd_film_develop(const float *xyzaw_dev, uint64_t n_pixels, float *rgba_dev, void *stream);
 /* Elementary functions of the kernels (csrc/device_libm.h: the reference gets them from Enoki's polynomial kernels, e.g.
  * enoki::sincos in include/mitsuba/core/warp.h:54-90, exp / log / erf in include/mitsuba/render/microfacet.h:187-493), evaluated on
- * the device for n arguments.  fn: 0 sin, 1 cos, 2 tan, 3 exp, 4 log, 5 erf, 6 acos, 7 atan2(x = y-coordinate, y = x-coordinate);
+ * the device for n arguments.  fn: 0 sin, 1 cos, 2 tan, 3 exp, 4 log, 5 erf, 6 acos, 7 atan2(x = y-coordinate, y = x-coordinate), 8 atanh, 9 cosh;
  * y_dev is read by fn 7 only.  Lets a test prove that host and device produce the same bits. */
 MTSAMD_API int mtsamd_libm_eval(int32_t fn, uint64_t n, const float *x_dev, const float *y_dev, float *out_dev, void *stream);
 

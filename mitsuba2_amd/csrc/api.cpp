@@ -225,7 +225,7 @@ struct Workspace {
         for (int k = 0; k < 2; ++k) {
             (void) hipFree(pool[k].ray_o); (void) hipFree(pool[k].ray_d); (void) hipFree(pool[k].thr); (void) hipFree(pool[k].res);
             (void) hipFree(pool[k].rng); (void) hipFree(pool[k].misc); (void) hipFree(count[k]);
-            (void) hipFree(pool[k].wav); (void) hipFree(pool[k].aux);
+            (void) hipFree(pool[k].xi); (void) hipFree(pool[k].aux);
             (void) hipFree(pool[k].hit); (void) hipFree(pool[k].sh_o); (void) hipFree(pool[k].sh_d); (void) hipFree(pool[k].nee); (void) hipFree(pool[k].sh_slot);
             pool[k] = PoolView{}; count[k] = nullptr;
         }
@@ -1063,7 +1063,7 @@ static int ensure_workspace(mtsamd_scene *s, uint32_t n_waves, uint32_t seg_cap,
         if (int rc = ws_alloc((void **) &w.pool[k].misc, slots * sizeof(uint2))) return rc;
         if (int rc = ws_alloc((void **) &w.count[k], 2 * (size_t) n_waves * sizeof(uint32_t))) return rc;      // counts + survivor borders (k_shade, flat scenes)
         if (s->spectral) {
-            if (int rc = ws_alloc((void **) &w.pool[k].wav, slots * sizeof(float4))) return rc;
+            if (int rc = ws_alloc((void **) &w.pool[k].xi, slots * sizeof(float))) return rc;
             if (int rc = ws_alloc((void **) &w.pool[k].aux, slots * sizeof(float2))) return rc;
         }
         if (split) {
@@ -1822,7 +1822,7 @@ int mtsamd_film_develop(const float *xyzaw, uint64_t n, float *rgba, void *strea
 }
 
 int mtsamd_libm_eval(int32_t fn, uint64_t n, const float *x, const float *y, float *out, void *stream) {
-    if (fn < 0 || fn > 7) return fail(MTSAMD_ERR_INVALID, "libm_eval: unknown function %d", fn);
+    if (fn < 0 || fn > 9) return fail(MTSAMD_ERR_INVALID, "libm_eval: unknown function %d", fn);
     if (n && (!x || !out || (fn == 7 && !y))) return fail(MTSAMD_ERR_INVALID, "libm_eval: null buffer");
     if (n >> 40) return fail(MTSAMD_ERR_INVALID, "libm_eval: too many arguments");
     HIP_TRY(launch_libm_eval(fn, n, x, y, out, (hipStream_t) stream));

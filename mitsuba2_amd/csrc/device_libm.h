@@ -195,4 +195,23 @@ MTS_LM float lm_atan2(float y, float x) {
     return lm_u2f(lm_f2u(r) | (lm_f2u(y) & 0x80000000u));
 }
 
+// atanh on (-1, 1) (Cephes atanhf.c) and cosh (coshf.c): sample_rgb_spectrum / its pdf, include/mitsuba/core/spectrum.h:270-314
+MTS_LM float lm_atanh(float x) {
+    const float ax = __builtin_fabsf(x);
+    if (ax < 0.5f) {
+        const float z = x * x;
+        float p = __builtin_fmaf(1.81740078349e-1f, z, 8.24370301058e-2f);
+        p = __builtin_fmaf(p, z, 1.46691431730e-1f);
+        p = __builtin_fmaf(p, z, 1.99782164500e-1f);
+        p = __builtin_fmaf(p, z, 3.33337300303e-1f);
+        return __builtin_fmaf(p * z, x, x);
+    }
+    if (!(ax < 1.0f)) return ax == 1.0f ? __builtin_copysignf(__builtin_inff(), x) : __builtin_nanf("");
+    return 0.5f * lm_log((1.0f + x) / (1.0f - x));
+}
+MTS_LM float lm_cosh(float x) {
+    const float e = lm_exp(__builtin_fabsf(x));
+    return __builtin_fmaf(0.5f, e, 0.5f / e);
+}
+
 } // namespace mtsamd

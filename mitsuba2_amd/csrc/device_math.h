@@ -166,6 +166,7 @@ template <bool NT> MTS_DEV uint2 ld_stream(const uint2 *p) {
     return make_uint2(v.x, v.y);
 }
 template <bool NT> MTS_DEV uint32_t ld_stream(const uint32_t *p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT> MTS_DEV float ld_stream(const float *p) { return NT ? __builtin_nontemporal_load(p) : *p; }
 template <bool NT> MTS_DEV void st_stream(float4 *p, float4 v) {
     if (!NT) { *p = v; return; }
     const nt_f4 w = { v.x, v.y, v.z, v.w };
@@ -187,5 +188,6 @@ template <bool NT> MTS_DEV void st_stream(uint2 *p, uint2 v) {
     __builtin_nontemporal_store(w, reinterpret_cast<nt_u2 *>(p));
 }
 template <bool NT> MTS_DEV void st_stream(uint32_t *p, uint32_t v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+template <bool NT> MTS_DEV void st_stream(float *p, float v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
 
 } // namespace mtsamd

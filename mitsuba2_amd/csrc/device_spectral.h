@@ -22,19 +22,21 @@ extern __device__ SpectralTables g_spectral;
 
 struct Spec4 { float v[kWav]; };
 
-// sample_wavelength: shifted samples + the "importance spectrum" of Radziszewski et al.; returns wavelengths and 1/pdf weights
-MTS_DEV void sample_wavelengths(float sample, Spec4 &wav, Spec4 &weight) {
+// sample_wavelength (spectrum.h:270-314): shifted samples (math.h:418-442) + the "importance spectrum" of Radziszewski et al.  The 1 / pdf
+// weights are applied when the path ends (wavelength_weight in store_result_spectral).
+// the four wavelengths of a path as a function of its one wavelength sample: this is what the path pool stores (4 B instead of the
+// 16 B of the wavelengths themselves); recomputed when a path record is loaded -- the same operations on the same number, so the bits
+// are those of sample_wavelengths
+MTS_DEV void wavelengths_from_sample(float sample, Spec4 &wav) {
 #pragma unroll
     for (int k = 0; k < kWav; ++k) {
         float v = sample + (float) k / (float) kWav;
         if (v > 1.0f) v -= 1.0f;
-        float l = 538.0f - atanhf(0.8569106254698279f - 1.8275019724092267f * v) * 138.88888888888889f;
-        float t = coshf(0.0072f * (l - 538.0f));
-        wav.v[k] = l; weight.v[k] = 253.82f * t * t;
+        wav.v[k] = 538.0f - lm_atanh(0.8569106254698279f - 1.8275019724092267f * v) * 138.88888888888889f;
     }
 }
 MTS_DEV float wavelength_weight(float l) {
-    float t = coshf(0.0072f * (l - 538.0f));
+    float t = lm_cosh(0.0072f * (l - 538.0f));
     return 253.82f * t * t;
 }
 

@@ -13,8 +13,9 @@ struct PoolView {
     float4 *ray_o, *ray_d, *thr, *res;
     uint4 *rng;
     uint2 *misc;
-    // spectral variant (112 B per path): thr / res hold 4 spectral samples, wav the wavelengths, aux = (bs_pdf, eta)
-    float4 *wav;
+    // spectral variant (100 B per path): thr / res hold 4 spectral samples, aux = (bs_pdf, eta), xi = the wavelength sample the path's
+    // four wavelengths are a function of (wavelengths_from_sample; round 2 stored the wavelengths: 112 B)
+    float *xi;
     float2 *aux;
     // split pipeline (hierarchy scenes): hit = (t, prim bits, u, v) of the path's ray; per-wave dense queue of
     // pending shadow rays sh_o = (o, mint), sh_d = (d, maxt), the contribution `nee` each guards and the slot it belongs to

@@ -419,20 +419,21 @@ hipError_t upload_spectral_tables(const float *x, const float *y, const float *z
 
 struct PathStateS {
     f3 o, d; float mint, maxt;
-    Spec4 thr, res, wav; float bs_pdf, eta;
+    Spec4 thr, res, wav; float bs_pdf, eta, xi;      // wav = wavelengths_from_sample(xi): not stored
     Pcg32 rng;
     uint32_t ordinal, depth, flags;
 };
 
 template <bool NT = false>
 MTS_DEV void load_state(const PoolView &p, size_t i, PathStateS &s) {
-    float4 a = ld_stream<NT>(p.ray_o + i), b = ld_stream<NT>(p.ray_d + i), c = ld_stream<NT>(p.thr + i), e = ld_stream<NT>(p.res + i), w = ld_stream<NT>(p.wav + i);
+    float4 a = ld_stream<NT>(p.ray_o + i), b = ld_stream<NT>(p.ray_d + i), c = ld_stream<NT>(p.thr + i), e = ld_stream<NT>(p.res + i);
+    s.xi = ld_stream<NT>(p.xi + i);
+    wavelengths_from_sample(s.xi, s.wav);
     float2 x = ld_stream<NT>(p.aux + i); uint4 r = ld_stream<NT>(p.rng + i); uint2 m = ld_stream<NT>(p.misc + i);
     s.o = mk3(a.x, a.y, a.z); s.mint = a.w;
     s.d = mk3(b.x, b.y, b.z); s.maxt = b.w;
     s.thr.v[0] = c.x; s.thr.v[1] = c.y; s.thr.v[2] = c.z; s.thr.v[3] = c.w;
     s.res.v[0] = e.x; s.res.v[1] = e.y; s.res.v[2] = e.z; s.res.v[3] = e.w;
-    s.wav.v[0] = w.x; s.wav.v[1] = w.y; s.wav.v[2] = w.z; s.wav.v[3] = w.w;
     s.bs_pdf = x.x; s.eta = x.y;
     s.rng.state = (uint64_t) r.x | ((uint64_t) r.y << 32);
     s.rng.inc = (uint64_t) r.z | ((uint64_t) r.w << 32);
@@ -444,7 +445,7 @@ MTS_DEV void store_state(const PoolView &p, size_t i, const PathStateS &s) {
     st_stream<NT>(p.ray_d + i, make_float4(s.d.x, s.d.y, s.d.z, s.maxt));
     st_stream<NT>(p.thr + i, make_float4(s.thr.v[0], s.thr.v[1], s.thr.v[2], s.thr.v[3]));
     p.res[i] = make_float4(s.res.v[0], s.res.v[1], s.res.v[2], s.res.v[3]);      // read-modify-written by the shadow-ray stage
-    st_stream<NT>(p.wav + i, make_float4(s.wav.v[0], s.wav.v[1], s.wav.v[2], s.wav.v[3]));
+    st_stream<NT>(p.xi + i, s.xi);
     st_stream<NT>(p.aux + i, make_float2(s.bs_pdf, s.eta));
     st_stream<NT>(p.rng + i, make_uint4((uint32_t) s.rng.state, (uint32_t) (s.rng.state >> 32), (uint32_t) s.rng.inc,
                                         (uint32_t) (s.rng.inc >> 32)));
@@ -690,8 +691,8 @@ MTS_DEV void generate_path_spectral(const RenderParams &P, uint64_t ordinal, uin
     float psx = ((float) px + (float) P.crop_x) + jx, psy = ((float) py + (float) P.crop_y) + jy;
     f2 ap; ap.x = ap.y = 0.5f;
     if (P.cam.aperture_radius > 0.0f) { ap.x = pcg_next_f32(s.rng); ap.y = pcg_next_f32(s.rng); }
-    Spec4 weight;
-    sample_wavelengths(pcg_next_f32(s.rng), s.wav, weight);    // integrator.cpp:237, perspective.cpp:196
+    s.xi = pcg_next_f32(s.rng);                                // integrator.cpp:237, perspective.cpp:196: sample_wavelength(sample)
+    wavelengths_from_sample(s.xi, s.wav);
     float ax = (psx - (float) P.crop_x) / (float) P.crop_w, ay = (psy - (float) P.crop_y) / (float) P.crop_h;
     camera_ray(P.cam, ax, ay, ap, s.o, s.d, s.mint, s.maxt);
 #pragma unroll
@@ -2431,6 +2432,8 @@ __global__ __launch_bounds__(kBlock) void k_libm_eval(int fn, uint64_t n, const 
     case 4: r = lm_log(a); break;
     case 5: r = lm_erf(a); break;
     case 6: r = lm_acos(a); break;
+    case 8: r = lm_atanh(a); break;
+    case 9: r = lm_cosh(a); break;
     default: r = lm_atan2(a, y[i]); break;
     }
     out[i] = r;

@@ -192,4 +192,22 @@ static inline float mo_lm_atan2(float y, float x) {
     }
     return mo_lm_u2f(mo_lm_f2u(r) | (mo_lm_f2u(y) & 0x80000000u));
 }
+/* atanh on (-1, 1) (Cephes atanhf.c) and cosh (coshf.c): sample_rgb_spectrum / its pdf, include/mitsuba/core/spectrum.h:270-314 */
+static inline float mo_lm_atanh(float x) {
+    const float ax = fabsf(x);
+    if (ax < 0.5f) {
+        const float z = x * x;
+        float p = fmaf(1.81740078349e-1f, z, 8.24370301058e-2f);
+        p = fmaf(p, z, 1.46691431730e-1f);
+        p = fmaf(p, z, 1.99782164500e-1f);
+        p = fmaf(p, z, 3.33337300303e-1f);
+        return fmaf(p * z, x, x);
+    }
+    if (!(ax < 1.0f)) return ax == 1.0f ? copysignf(INFINITY, x) : NAN;
+    return 0.5f * mo_lm_log((1.0f + x) / (1.0f - x));
+}
+static inline float mo_lm_cosh(float x) {
+    const float e = mo_lm_exp(fabsf(x));
+    return fmaf(0.5f, e, 0.5f / e);
+}
 #endif

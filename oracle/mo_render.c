@@ -1393,6 +1393,8 @@ void mo_libm_eval(int fn, uint64_t n, const float *x, const float *y, float *out
         case 4: out[i] = mo_lm_log(a); break;
         case 5: out[i] = mo_lm_erf(a); break;
         case 6: out[i] = mo_lm_acos(a); break;
+        case 8: out[i] = mo_lm_atanh(a); break;
+        case 9: out[i] = mo_lm_cosh(a); break;
         default: out[i] = mo_lm_atan2(a, y[i]); break;
         }
     }

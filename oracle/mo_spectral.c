@@ -23,8 +23,8 @@ void mo_sample_wavelengths(float sample, float wav[MO_WAV], float weight[MO_WAV]
     for (int k = 0; k < MO_WAV; ++k) {
         float v = sample + (float) k / (float) MO_WAV;
         if (v > 1.0f) v -= 1.0f;
-        float l = 538.0f - atanhf(0.8569106254698279f - 1.8275019724092267f * v) * 138.88888888888889f;
-        float t = coshf(0.0072f * (l - 538.0f));
+        float l = 538.0f - mo_lm_atanh(0.8569106254698279f - 1.8275019724092267f * v) * 138.88888888888889f;
+        float t = mo_lm_cosh(0.0072f * (l - 538.0f));
         wav[k] = l; weight[k] = 253.82f * t * t;
     }
 }

@@ -384,7 +384,7 @@ def film_develop(xyzaw):
     return out
 
 
-LIBM_FUNCTIONS = ("sin", "cos", "tan", "exp", "log", "erf", "acos", "atan2")
+LIBM_FUNCTIONS = ("sin", "cos", "tan", "exp", "log", "erf", "acos", "atan2", "atanh", "cosh")
 
 
 def libm_eval(name, x, y=None):

@@ -7,10 +7,11 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-RANGES = {"sin": (-30.0, 30.0), "cos": (-30.0, 30.0), "tan": (-7.0, 7.0), "exp": (-100.0, 95.0), "erf": (-12.0, 12.0), "acos": (-1.0, 1.0)}
+RANGES = {"sin": (-30.0, 30.0), "cos": (-30.0, 30.0), "tan": (-7.0, 7.0), "exp": (-100.0, 95.0), "erf": (-12.0, 12.0), "acos": (-1.0, 1.0),
+          "atanh": (-1.0, 1.0), "cosh": (-20.0, 20.0)}
 
 
-@pytest.mark.parametrize("name", ["sin", "cos", "tan", "exp", "log", "erf", "acos", "atan2"])
+@pytest.mark.parametrize("name", ["sin", "cos", "tan", "exp", "log", "erf", "acos", "atan2", "atanh", "cosh"])
 def test_device_equals_host_bitwise(gpu, oracle, name):
     rng = np.random.RandomState(11)
     n = 1 << 22

@@ -13,7 +13,8 @@ def _ulp(got, want64):
 
 @pytest.mark.parametrize("name,lo,hi,ref,max_ulp", [
     ("sin", -20.0, 20.0, np.sin, 2.0), ("cos", -20.0, 20.0, np.cos, 2.0), ("tan", -1.5, 1.5, np.tan, 3.0),
-    ("exp", -80.0, 80.0, np.exp, 1.5), ("acos", -1.0, 1.0, np.arccos, 2.0)])
+    ("exp", -80.0, 80.0, np.exp, 1.5), ("acos", -1.0, 1.0, np.arccos, 2.0),
+    ("atanh", -0.999, 0.999, np.arctanh, 3.0), ("cosh", -10.0, 10.0, np.cosh, 2.5)])
 def test_against_float64(oracle, name, lo, hi, ref, max_ulp):
     rng = np.random.RandomState(7)
     x = rng.uniform(lo, hi, 400000).astype(np.float32)
