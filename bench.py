@@ -264,12 +264,16 @@ def run_cbox(args, R, strong=False):
     # (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3 passes, scripts/collect_profiles.sh) is committed under profiles/
     # and scaled to this run's bytes per launch.  `traffic_source` says so; it is an OFFLINE figure.
     traffic, traffic_src = None, None
-    import glob
     pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bounce_kernel.json")))
+    valu = {}
     if pmc and not strong:
         try:
-            traffic = json.load(open(pmc[-1]))["traffic_over_algorithmic"] * (alg_bytes / launches)
+            prof = json.load(open(pmc[-1]))
+            traffic = prof["traffic_over_algorithmic"] * (alg_bytes / launches)
             traffic_src = "offline profile " + os.path.relpath(pmc[-1], ROOT) + " (counted / algorithmic bytes of this kernel), scaled to this run"
+            # what really bounds the kernel of an LDS-resident scene: VALU issue; same offline profile
+            valu = {"valu_per_wave_segment": prof.get("valu_instructions_per_wave_segment"), "lane_utilisation": prof.get("valu_lane_utilisation"),
+                    "bound_in_practice": "VALU issue: the 36-triangle scene lives in LDS, HBM only carries the path-state streams"}
         except (OSError, ValueError, KeyError):
             pass
     out = {
@@ -286,7 +290,7 @@ def run_cbox(args, R, strong=False):
         "data": "synthetic",
         "config": {"workload": "synthetic Cornell box (36 triangles, diffuse, 1 area light), %dx%d film, %d spp total%s, "
                                "gaussian rfilter, independent sampler" % (width, height, spp_total, "" if strong else " (%d per GPU)" % args.spp),
-                   "partition": "interleaved 16-row film tiles + RCCL reduce" if n > 1 else "single GPU",
+                   "partition": ("interleaved 16-row film tiles + %s" % ("RCCL reduce over xGMI" if args.backend == "nccl" else "%s reduce through host memory (rehearsal)" % args.backend)) if n > 1 else "single GPU",
                    "backend": (args.backend if n > 1 else None)},
         "mray_per_s": (tot_closest + tot_any) / dt / 1e6,
         "segments_per_sample": acc["segments"] / max(acc["samples"], 1),
@@ -298,7 +302,7 @@ def run_cbox(args, R, strong=False):
                       "bounce_kernel_concurrent": concurrent, "passes_per_step": acc["passes"] / steps},
         "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "alg_bytes_per_launch": alg_bytes / launches},
+                     "alg_bytes_per_launch": alg_bytes / launches, **valu},
     }
     if n == 1 and not strong and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sd, lambda spp: scenes.cornell_box_sensor(width, height, spp), "cbox", seconds=args.cpu_seconds)
@@ -389,62 +393,86 @@ def run_mesh(args, R, matpreview=False):
 
 def run_autodiff(args, R):
     """configs[3]: the loop of docs/examples/10_inverse_rendering/invert_cbox.py (diff_render.rst:11-28: path max_depth=3, box
-    filter; spp=1, unbiased=True, write_bitmap commented out), recovering the red wall's reflectance with Adam.  The reference
-    quotes ~50 ms (unbiased) / ~27 ms (biased) per iteration on a Titan RTX (diff_render.rst:311-314), film size not stated."""
+    filter; spp=1, unbiased=True, write_bitmap commented out) in two variants: recovering the red wall's constant reflectance
+    ('red.reflectance.value', the reference's example) and -- BASELINE config 4 as worded, "optimise diffuse-albedo texture" -- the
+    256 x 256 texels of a bitmap albedo on the back wall and the floor ('tex.reflectance.data', src/textures/bitmap.cpp:250-299: the
+    adjoint scatters 12 float atomics per textured path vertex).  The reference quotes ~50 ms (unbiased) / ~27 ms (biased) per
+    iteration on a Titan RTX (diff_render.rst:311-314), film size not stated."""
     import numpy as np
     import torch
     from mitsuba2_amd import render, scenes, autodiff
     res, iters = args.ad_res, args.ad_iters
-    sd = scenes.cornell_box()
-    for b, nm in zip(sd["bsdfs"], ["white", "red", "green", "light"]):
-        b["id"] = nm
     p = scenes.cornell_box_sensor(res, res, 1, max_depth=3, rfilter="box")
-    scene = render.Scene(sd, device=R.device, sensor=render.make_sensor(p), integrator=render.PathIntegrator(max_depth=3))
-    params = autodiff.traverse(scene)
-    key = "red.reflectance.value"
-    params.keep([key])
-    ref = params[key].clone()
-    image_ref = autodiff.render(scene, spp=8).detach()
-    result = {}
-    for unbiased in (True, False):
-        params[key] = torch.full_like(ref, 0.9)
+
+    def build(texture):
+        sd = scenes.cornell_box(texture=texture)
+        for b, nm in zip(sd["bsdfs"], ["white", "red", "green", "light", "tex"]):
+            b["id"] = nm
+        return sd, render.Scene(sd, device=R.device, sensor=render.make_sensor(p), integrator=render.PathIntegrator(max_depth=3))
+
+    def optimise(scene, key, start, lr):
+        """times `iters` iterations (after 5 warm-up ones) in the unbiased and the biased form; then the stream time of the primal render
+        and of the backward pass of one biased iteration (HIP events on the current stream)"""
+        params = autodiff.traverse(scene)
+        params.keep([key])
+        ref = params[key].clone()
+        image_ref = autodiff.render(scene, spp=8).detach()
+        result = {}
+        for unbiased in (True, False):
+            params[key] = start(ref)
+            params.update()
+            opt = autodiff.Adam(params, lr=lr)
+
+            def iteration():
+                img = autodiff.render(scene, optimizer=opt, unbiased=unbiased, spp=1)
+                (((img - image_ref) ** 2).sum() / img.numel()).backward()
+                opt.step()
+
+            before = float(((ref - params[key].detach()) ** 2).mean().item())
+            for _ in range(5):
+                iteration()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                iteration()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) * 1e3 / iters
+            result["unbiased" if unbiased else "biased"] = {"ms_per_iteration": ms, "param_mse_at_start": before,
+                                                            "param_mse_after_run": float(((ref - params[key].detach()) ** 2).mean().item())}
+        params[key] = start(ref)
         params.update()
-        opt = autodiff.Adam(params, lr=0.2)
-
-        def iteration():
-            img = autodiff.render(scene, optimizer=opt, unbiased=unbiased, spp=1)
+        opt = autodiff.Adam(params, lr=lr)
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        fwd = adj = 0.0
+        for _ in range(20):
+            e[0].record()
+            img = autodiff.render(scene, optimizer=opt, unbiased=False, spp=1)
+            e[1].record()
             (((img - image_ref) ** 2).sum() / img.numel()).backward()
+            e[2].record()
+            torch.cuda.synchronize()
+            fwd += e[0].elapsed_time(e[1]); adj += e[1].elapsed_time(e[2])
             opt.step()
+        params[key] = ref
+        params.update()
+        return result, fwd / 20, adj / 20, image_ref
 
-        for _ in range(5):
-            iteration()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            iteration()
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) * 1e3 / iters
-        result["unbiased" if unbiased else "biased"] = {"ms_per_iteration": ms, "param_mse_after_run": float(((ref - params[key].detach()) ** 2).mean().item())}
-    # device time of the two kernels of one biased iteration (primal render, adjoint), HIP events on the current stream
-    params[key] = torch.full_like(ref, 0.9)
-    params.update()
-    opt = autodiff.Adam(params, lr=0.2)
-    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    fwd = adj = 0.0
-    for _ in range(20):
-        e[0].record()
-        img = autodiff.render(scene, optimizer=opt, unbiased=False, spp=1)
-        e[1].record()
-        (((img - image_ref) ** 2).sum() / img.numel()).backward()
-        e[2].record()
-        torch.cuda.synchronize()
-        fwd += e[0].elapsed_time(e[1]); adj += e[1].elapsed_time(e[2])
-        opt.step()
-    fwd /= 20; adj /= 20
+    sd, scene = build(None)
+    result, fwd, adj, image_ref = optimise(scene, "red.reflectance.value", lambda ref: torch.full_like(ref, 0.9), 0.2)
+    # texture variant: a smooth 256 x 256 albedo pattern is the target, a uniform grey the starting point
+    yy, xx = np.meshgrid(np.linspace(0, 1, 256, dtype=np.float32), np.linspace(0, 1, 256, dtype=np.float32), indexing="ij")
+    tex = np.stack([0.5 + 0.35 * np.sin(9 * xx) * np.cos(7 * yy), 0.45 + 0.3 * np.cos(5 * xx + 3 * yy), 0.4 + 0.3 * np.sin(11 * yy)], -1).astype(np.float32)
+    sd_t, scene_t = build(tex)
+    res_t, fwd_t, adj_t, _ = optimise(scene_t, "tex.reflectance.data", lambda ref: torch.full_like(ref, 0.5), 0.05)
+    # textured path vertices of one render (upper bound: every vertex of a path lies on a textured surface): segments per sample
+    st_integ = render.PathIntegrator(max_depth=3)
+    st_integ.render(scene_t, render.make_sensor(p))
+    seg_per_sample = st_integ.stats["segments"] / max(st_integ.stats["samples"], 1)
     n_samples = res * res
     # k_adjoint: per camera sample 12 B dLoss/dImage + 4 B film weight of its box-filter pixel; the gradient of a constant reflectance
-    # is reduced in LDS (one atomic per workgroup)
+    # is reduced in LDS (one atomic per workgroup); a textured vertex adds 12 float atomics (4 texels x 3 channels) = 48 B
     adj_bytes = 16 * n_samples
+    adj_bytes_t = 16 * n_samples + int(48 * seg_per_sample * n_samples)
     ub = result["unbiased"]["ms_per_iteration"]
     out = {
         "metric": "ms per optimisation iteration (primal + derivative render + adjoint + Adam), differentiable cbox %dx%d, spp 1, max_depth 3, box filter, unbiased=True" % (res, res),
@@ -459,6 +487,17 @@ def run_autodiff(args, R):
         "roofline": {"bound": "hbm", "kernel": "k_adjoint<true>", "achieved": adj_bytes / max(adj * 1e-3, 1e-12) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": adj_bytes / max(adj * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_launch": adj_bytes,
                      "note": "%d camera samples per launch: the iteration is launch-latency bound (a handful of ~10 us kernels), not bandwidth bound" % n_samples},
+        # BASELINE config 4 as worded: the albedo TEXTURE (256 x 256 x 3 texels on the back wall and the floor) is the parameter
+        "texture": {
+            "workload": "same setup, optimise the 256x256x3 texels of 'tex.reflectance.data' (back wall + floor) from uniform 0.5 with Adam(lr=0.05)",
+            "ms_per_iteration": res_t["unbiased"]["ms_per_iteration"], "biased_ms_per_iteration": res_t["biased"]["ms_per_iteration"],
+            "vs_baseline": res_t["unbiased"]["ms_per_iteration"] / 50.0,
+            "texel_mse_at_start": res_t["unbiased"]["param_mse_at_start"], "texel_mse_after_run": res_t["unbiased"]["param_mse_after_run"],
+            "kernel_ms": {"forward_render_stream_ms": fwd_t, "backward_stream_ms": adj_t},
+            "roofline": {"bound": "hbm", "kernel": "k_adjoint<true> (float atomics into the texel gradient)", "achieved": adj_bytes_t / max(adj_t * 1e-3, 1e-12) / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": adj_bytes_t / max(adj_t * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "alg_bytes_per_launch": adj_bytes_t, "atomic_bytes_per_launch_upper_bound": int(48 * seg_per_sample * n_samples),
+                         "note": "48 B of float atomics per textured path vertex, counted for every vertex (%.2f per sample): an upper bound" % seg_per_sample}},
     }
     if not args.no_cpu_baseline:
         ob = _oracle()

@@ -96,8 +96,15 @@ class ParameterMap:
         return True
 
     def update(self):
-        """util.py:103-118: push the current values into the scene (parameters_changed)."""
+        """util.py:103-118: push the current values into the scene (parameters_changed).  A value the scene has already seen -- the same
+        tensor at the same version -- is not pushed again: render() calls this before every primal pass, and reading a constant back
+        to the host costs a device synchronisation."""
+        seen = self.__dict__.setdefault("_pushed", {})
         for k, v in self.properties.items():
+            stamp = (id(v), v._version)
+            if seen.get(k) == stamp:
+                continue
+            seen[k] = stamp
             kind, idx, _ = self._kind[k]
             if kind == "texture":
                 self._scene.update_texture(idx, v)
@@ -254,7 +261,7 @@ class Optimizer:
                 p.requires_grad_(True)
 
     def _replace(self, key, value):
-        value = value.detach().clone()
+        value = value.detach()           # a fresh tensor (the result of the update expression): no copy needed
         value.requires_grad_(True)
         self.params.properties[key] = value
 
@@ -306,11 +313,10 @@ class Adam(Optimizer):
             g = p.grad
             if g is None:
                 continue
-            m_tp, v_tp = self.state[k]
-            m_t = self.beta_1 * m_tp + (1 - self.beta_1) * g
-            v_t = self.beta_2 * v_tp + (1 - self.beta_2) * g * g
-            self.state[k] = (m_t, v_t)
-            self._replace(k, p.detach() - lr_t * m_t / (torch.sqrt(v_t) + self.epsilon))
+            m_t, v_t = self.state[k]                       # updated in place: m <- b1 m + (1 - b1) g, v <- b2 v + (1 - b2) g^2
+            m_t.mul_(self.beta_1).add_(g, alpha=1 - self.beta_1)
+            v_t.mul_(self.beta_2).addcmul_(g, g, value=1 - self.beta_2)
+            self._replace(k, torch.addcdiv(p.detach(), m_t, torch.sqrt(v_t).add_(self.epsilon), value=-lr_t))
         self.params.update()      # the reference leaves this to the next render's parameters_changed(); explicit here
 
     def _reset(self, key):

@@ -1184,8 +1184,11 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
         return 0;
     }
 
-#ifdef MTSAMD_EXPERIMENTS
-    if (exp_env("MTSAMD_MEGA") && (p.split == 1 || p.split == 3) && !j.s->nested_bsdfs) {          // experiment: one persistent launch, no pool
+    // Small passes of the automatic schedule: one launch of persistent lanes instead of launch rounds (kernels.hip, k_mega).  At most a
+    // few samples per lane the launch count, not the kernel, sets the time: differentiable cbox 256^2 @ 1 spp, forward render
+    // 0.33 ms of launch rounds.  LDS-resident scenes up to 2^19 samples, hierarchy scenes (where the wavefront kernels win sooner) 2^17.
+    const uint64_t small_pass = j.s->view.flat ? (1ull << 19) : (1ull << 17);
+    if (((j.d->pipeline == 0 && n <= small_pass) || exp_env("MTSAMD_MEGA")) && (p.split == 1 || p.split == 3) && !j.s->nested_bsdfs) {
         HIP_TRY(hipEventRecord(w.tev[0], j.stream));
         HIP_TRY(launch_mega(p, j.stream));
         HIP_TRY(hipEventRecord(w.tev[1], j.stream));
@@ -1195,7 +1198,6 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
         j.bounce_ms += ms; j.iterations += 1;
         return 0;
     }
-#endif
     // the sample cursors cannot run dry before this many launches
     const uint64_t min_iters = (n + (uint64_t) nw * j.target - 1) / ((uint64_t) nw * j.target);
     uint64_t it = 0;

@@ -141,9 +141,7 @@ hipError_t launch_adjoint(const AdjointParams &a, hipStream_t s);
 hipError_t launch_adjoint_env(const AdjointParams &a, hipStream_t s);
 // end of a pass: every path of p.in (counts p.count_in) is run to its end in one launch; needs dry sample cursors (kernels.hip, k_finish)
 hipError_t launch_finish(const RenderParams &p, uint64_t alive, hipStream_t s);
-#ifdef MTSAMD_EXPERIMENTS
-hipError_t launch_mega(const RenderParams &p, hipStream_t s);      // experiment: the whole pass in one launch of persistent lanes
-#endif
+hipError_t launch_mega(const RenderParams &p, hipStream_t s);      // small passes: the whole pass in one launch of persistent lanes
 // CIE x, y, z and D65 tables (95 floats each) -> device; call once before the first spectral launch
 hipError_t upload_spectral_tables(const float *x, const float *y, const float *z, const float *d65);
 hipError_t launch_film_gather(const FilmParams &p, hipStream_t s);

@@ -1262,9 +1262,11 @@ __global__ __launch_bounds__(64) void k_finish(const RenderParams P, uint32_t pe
     }
 }
 
-#ifdef MTSAMD_EXPERIMENTS
-// Experiment (MTSAMD_MEGA=1): the whole pass as ONE launch of persistent lanes -- no pool, no launch rounds.  A workgroup (one hardware
-// wave) owns the samples of one scheduling wave; a lane whose path ends starts the next sample at once.
+// Small passes (and, in experiment builds, MTSAMD_MEGA=1 for any pass): the whole pass as ONE launch of persistent lanes -- no pool, no
+// launch rounds, no host polling.  A workgroup (one hardware wave) owns the samples of one scheduling wave; a lane whose path ends starts
+// the next sample at once.  In steady state the wavefront schedule is faster (1.9 x on the 261 k-triangle mesh, 2 % on
+// the Cornell box); a pass of a few samples per lane -- one iteration of an inverse-rendering loop at 1 spp -- is bound by the number of
+// launches instead: a dozen launch rounds against one launch.  Same floating-point operations per sample in the same order.
 template <typename State, bool GENERAL, bool FLAT>
 __global__ __launch_bounds__(64) void k_mega(const RenderParams P) {
     extern __shared__ float4 smem[];
@@ -1328,7 +1330,6 @@ hipError_t launch_mega(const RenderParams &p, hipStream_t s) {
     }
     return hipGetLastError();
 }
-#endif
 
 hipError_t launch_finish(const RenderParams &p, uint64_t alive, hipStream_t s) {
     // about four paths per lane (alive: upper bound of the paths left), at least 2048 workgroups if there are that many scheduling waves

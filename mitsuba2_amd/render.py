@@ -603,8 +603,9 @@ class Scene:
             t = data.detach().to(torch.device("cuda", self._device_index), torch.float32).contiguous()
             if tuple(t.shape) != tuple(shape):
                 raise RuntimeError("texture data has shape %s, expected %s" % (tuple(t.shape), tuple(shape)))
+            # device-to-device copy enqueued on the current stream: stream-ordered with whatever wrote `t` and with the next render; a
+            # temporary `t` is safe too (the caching allocator reuses its memory on this stream only after the copy)
             L.check(L.lib().mtsamd_scene_update_texture(self._handle, int(texture), _ptr(t), _stream()))
-            torch.cuda.current_stream().synchronize()       # `t` may be a temporary
         else:
             a = _f32(data)
             if tuple(a.shape) != tuple(shape):

@@ -3,6 +3,7 @@ conductor / roughconductor / dielectric / plastic / twosided materials in the Co
 both sides; the only unshared arithmetic is libm vs OCML exp / log / erf / sincos), through the fused and the split
 pipeline, plus the film-level relMSE bar of north_star (< 1e-3)."""
 import numpy as np
+import parity_util
 import pytest
 import torch
 
@@ -83,6 +84,7 @@ def test_sample_radiance_matches_oracle(material, pipeline):
     want, wpos = oracle.sample_radiance(ob.make_desc(sp), 0, n)
     assert np.array_equal(pos, wpos) and np.array_equal(mask, want[:, 3] > 0.5)
     close = np.isclose(rgb, want[:, :3], rtol=5e-3, atol=1e-4).all(1)
+    parity_util.record("", rgb, want[:, :3])
     # transcendental functions differ in the last bits between libm and OCML; a sample whose path takes another branch
     # because of that (lobe choice, Russian roulette, shadow test) may differ: they are rare and unbiased
     assert close.mean() > 0.995, (material, close.mean())
@@ -161,6 +163,7 @@ def test_procedural_and_transformed_textures(kind):
     want, wpos = ob.OracleScene(cb).sample_radiance(ob.make_desc(sp), 0, n)
     assert np.array_equal(pos.cpu().numpy(), wpos)
     close = np.isclose(rgb.cpu().numpy(), want[:, :3], rtol=2e-3, atol=1e-5).all(1)
+    parity_util.record("", rgb.cpu().numpy(), want[:, :3])
     assert close.mean() > 0.999, close.mean()
     plain, _, _ = R.PathIntegrator(max_depth=4).sample(R.Scene(scenes.cornell_box(texture=tex)), sensor, 0, n)
     assert not torch.equal(plain, rgb)                       # the transform / pattern really changes the picture

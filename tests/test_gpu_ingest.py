@@ -4,6 +4,7 @@ contents (src/films/tests/test_hdrfilm.py:74-160)."""
 import os
 
 import numpy as np
+import parity_util
 import pytest
 import torch
 
@@ -163,6 +164,7 @@ def test_matpreview_style_scene_from_files(tmp_path):
     want, wpos = ob.OracleScene(desc.scene_dict).sample_radiance(ob.make_desc(op), 0, n)
     assert np.array_equal(pos.cpu().numpy(), wpos) and np.array_equal(mask.cpu().numpy(), want[:, 3] > 0.5)
     close = np.isclose(rgb.cpu().numpy(), want[:, :3], rtol=5e-3, atol=2e-4).all(1)
+    parity_util.record("", rgb.cpu().numpy(), want[:, :3])
     assert close.mean() > 0.99, close.mean()
     assert scene.integrator().render(scene, sensor)
     img = sensor.film().bitmap().cpu().numpy()

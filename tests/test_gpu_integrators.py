@@ -1,5 +1,6 @@
 """`direct` and `depth` integrators on the GPU against the oracle, sample by sample (same PCG32 streams)."""
 import numpy as np
+import parity_util
 import pytest
 import torch
 
@@ -33,6 +34,7 @@ def test_direct_matches_oracle(general, cfg):
     want, wpos = ob.OracleScene(cb).sample_radiance(ob.make_desc(op), 0, n)
     assert np.array_equal(pos.cpu().numpy(), wpos) and np.array_equal(mask.cpu().numpy(), want[:, 3] > 0.5)
     close = np.isclose(rgb.cpu().numpy(), want[:, :3], rtol=5e-3, atol=1e-4).all(1)
+    parity_util.record("", rgb.cpu().numpy(), want[:, :3])
     assert close.mean() > (0.995 if general else 0.9995), close.mean()
 
 
@@ -133,6 +135,7 @@ def test_constant_emitter_matches_oracle(with_area, integrator):
     assert np.array_equal(pos.cpu().numpy(), wpos) and np.array_equal(mask.cpu().numpy(), want[:, 3] > 0.5)
     assert (~mask.cpu().numpy()).any() and (rgb.cpu().numpy()[~mask.cpu().numpy()] == np.float32([0.4, 0.6, 1.0])).all()
     close = np.isclose(rgb.cpu().numpy(), want[:, :3], rtol=5e-3, atol=1e-4).all(1)
+    parity_util.record("", rgb.cpu().numpy(), want[:, :3])
     assert close.mean() > 0.995, close.mean()
     if integrator == "path":
         a, _, _ = R.PathIntegrator(max_depth=5, pipeline=2).sample(scene, sensor, 0, n)
@@ -172,6 +175,7 @@ def test_envmap_emitter_matches_oracle(with_area, integrator):
     want, wpos = ob.OracleScene(cb).sample_radiance(ob.make_desc(op), 0, n)
     assert np.array_equal(pos.cpu().numpy(), wpos) and np.array_equal(mask.cpu().numpy(), want[:, 3] > 0.5)
     close = np.isclose(rgb.cpu().numpy(), want[:, :3], rtol=5e-3, atol=2e-4).all(1)
+    parity_util.record("", rgb.cpu().numpy(), want[:, :3])
     assert close.mean() > 0.99, close.mean()
     assert abs(rgb.cpu().numpy().mean() - want[:, :3].mean()) < 0.02 * want[:, :3].mean()
     if integrator == "path":
@@ -231,6 +235,7 @@ def test_delta_emitters_match_oracle(lights, integrator):
     got = rgb.cpu().numpy()
     assert want[:, :3].mean() > 1e-3
     close = np.isclose(got, want[:, :3], rtol=5e-3, atol=1e-4 * max(1.0, want[:, :3].mean())).all(1)
+    parity_util.record("", got, want[:, :3])
     assert close.mean() > 0.99, close.mean()
     assert abs(got.mean() - want[:, :3].mean()) < 0.02 * want[:, :3].mean()
     if integrator == "path":
@@ -242,6 +247,7 @@ def test_delta_emitters_match_oracle(lights, integrator):
         assert torch.equal(xyz, xyz2)
         swant, _ = ob.OracleScene(cb, spectral_path=R.srgb_coeff_path()).sample_radiance(ob.make_desc(sp), 0, n)
         sclose = np.isclose(xyz.cpu().numpy(), swant[:, :3], rtol=5e-3, atol=1e-4 * max(1.0, swant[:, :3].mean())).all(1)
+        parity_util.record("", xyz.cpu().numpy(), swant[:, :3])
         assert sclose.mean() > 0.99, sclose.mean()
 
 
@@ -285,4 +291,5 @@ def test_cluster_culling_on_random_flat_scenes(seed):
         want, wpos = oracle.sample_radiance(ob.make_desc(sp), 0, n)
         assert np.array_equal(pos.cpu().numpy(), wpos) and np.array_equal(mask.cpu().numpy(), want[:, 3] > 0.5)
         close = np.isclose(rgb.cpu().numpy(), want[:, :3], rtol=2e-3, atol=1e-4).all(1)
+        parity_util.record("", rgb.cpu().numpy(), want[:, :3])
         assert close.mean() > 0.999, (pipeline, close.mean())

@@ -159,8 +159,8 @@ def test_thinlens_rays_and_render(gpu, oracle, aperture, focus):
         S = oracle.OracleScene(sd, spectral_path=gpu.srgb_coeff_path() if variant == "spectral" else None)
         want, wpos = S.sample_radiance(oracle.make_desc(p), 0, n)
         assert (pos.cpu().numpy() == wpos).all()
-        close = np.isclose(a.cpu().numpy(), want[:, :3], rtol=5e-3, atol=2e-4).all(1)
-        assert close.mean() > 0.995, (variant, close.mean())
+        exact = (a.cpu().numpy() == want[:, :3]).all(1)      # aperture samples go through the same concentric warp: bit-exact, both variants
+        assert exact.all(), (variant, int((~exact).sum()))
     if aperture == 25.0:                                                    # a wide lens really defocuses the picture
         pin, _, _ = gpu.PathIntegrator(max_depth=5).sample(gpu.Scene(sd), gpu.make_sensor(dict(p, aperture_radius=None)), 0, n)
         assert not torch.equal(pin, gpu.PathIntegrator(max_depth=5).sample(gpu.Scene(sd), sensor, 0, n)[0])
@@ -179,12 +179,11 @@ def test_per_sample_radiance(gpu, oracle, max_depth):
     assert (pos == ref_pos).all()                               # same RNG stream, same arithmetic
     assert (mask == (ref_rgba[:, 3] > 0.5)).all()
     ref = ref_rgba[:, :3]
-    close = np.isclose(rgb, ref, rtol=2e-3, atol=1e-4).all(axis=1)
-    # sin/cos differ by an ulp between OCML and libm; a path whose decision flips (RR, grazing hit) diverges
-    assert close.mean() > 0.999, close.mean()
+    # Every operation on the path is shared bit for bit since round 3 (sin / cos of the concentric disk warp come from the explicit
+    # Cephes restatement both sides carry, csrc/device_libm.h == oracle/mo_libm.h): not one of the 40 000 samples may differ.  Rounds 1-2
+    # accepted "99.9 % close": 0.1 % is where a scheduling or zombie-path bug would hide.
     exact = (rgb == ref).all(axis=1)
-    assert exact.mean() > 0.5
-    assert abs(rgb.mean() - ref.mean()) / max(ref.mean(), 1e-6) < 2e-3
+    assert exact.all(), (int((~exact).sum()), np.nonzero(~exact)[0][:8], rgb[~exact][:4], ref[~exact][:4])
 
 
 def _relmse(a, b):
@@ -206,10 +205,12 @@ def test_film_matches_oracle(gpu, oracle, rfilter):
     rgba, ref_rgba = sensor.film().bitmap().cpu().numpy(), oracle.film_develop(ref)
     # north_star tolerance: per-pixel relMSE < 1e-3 against the CPU path on identical sampler seeds
     assert _relmse(rgba[..., :3], ref_rgba[..., :3]) < 1e-3
-    assert _relmse(rgba[..., :3], ref_rgba[..., :3]) < 1e-5      # what the shared arithmetic actually achieves
+    # the samples are bit-identical (test_per_sample_radiance); what is left is the order in which a pixel's splats are added
+    assert _relmse(rgba[..., :3], ref_rgba[..., :3]) < 1e-10
+    assert np.allclose(film[..., :3], ref[..., :3], rtol=2e-5, atol=1e-6)
     assert integ.stats["samples"] == 96 * 64 * 8 == stats[2]
     assert integ.stats["closest_hit_rays"] == integ.stats["segments"]
-    assert abs(int(integ.stats["closest_hit_rays"]) - int(stats[0])) <= 0.001 * stats[0]
+    assert int(integ.stats["closest_hit_rays"]) == int(stats[0])      # identical paths: identical ray counts
     assert integ.stats["any_hit_rays"] <= stats[1]              # zero-contribution shadow rays are skipped
 
 

@@ -1,6 +1,7 @@
 """Spectral variant on the GPU (BASELINE config 3 semantics): k_bounce_spectral against the oracle's spectral path on
 identical sampler seeds and the same coefficient table."""
 import numpy as np
+import parity_util
 import pytest
 
 from mitsuba2_amd import scenes
@@ -37,6 +38,7 @@ def test_spectral_render_matches_oracle(gpu, oracle, scene_name):
     ref_rgba, ref_pos = S.sample_radiance(oracle.make_desc(p), first, count)
     assert (pos.cpu().numpy() == ref_pos).all()
     close = np.isclose(xyz.cpu().numpy(), ref_rgba[:, :3], rtol=5e-3, atol=2e-4).all(axis=1)
+    parity_util.record("", xyz.cpu().numpy(), ref_rgba[:, :3])
     assert close.mean() > 0.995, close.mean()
 
 
@@ -96,6 +98,7 @@ def test_spectral_materials_match_oracle(gpu, oracle, material):
     ref, ref_pos = oracle.OracleScene(cb, spectral_path=path).sample_radiance(oracle.make_desc(p), 0, n)
     assert (pos.cpu().numpy() == ref_pos).all() and ((ref[:, 3] > 0.5) == mask.cpu().numpy()).all()
     close = np.isclose(xyz.cpu().numpy(), ref[:, :3], rtol=5e-3, atol=2e-4).all(axis=1)
+    parity_util.record("", xyz.cpu().numpy(), ref[:, :3])
     assert close.mean() > 0.995, (material, close.mean())
 
 
@@ -131,6 +134,7 @@ def test_spectral_environment_emitters(gpu, oracle, kind, with_area):
     got = xyz.cpu().numpy()
     assert np.isfinite(got).all() and (got[~m].sum(1) > 0).all()          # escaped camera rays see the environment
     close = np.isclose(got, ref[:, :3], rtol=5e-3, atol=2e-4).all(axis=1)
+    parity_util.record("", got, ref[:, :3])
     assert close.mean() > 0.99, (kind, with_area, close.mean())
     assert abs(got.mean() - ref[:, :3].mean()) < 0.02 * ref[:, :3].mean()
     # the spectral rendering agrees with the RGB one up to the upsampling model (film: XYZ -> RGB on both sides)
@@ -175,9 +179,11 @@ def test_spectral_textures_match_oracle(gpu, oracle, kind):
     got = xyz.cpu().numpy()
     assert np.isfinite(got).all()
     close = np.isclose(got, ref[:, :3], rtol=5e-3, atol=2e-4).all(axis=1)
+    parity_util.record("", got, ref[:, :3])
     assert close.mean() > 0.995, (kind, close.mean())
     # and the RGB variant of the same scene (textured plastic weights from the texture's mean luminance)
     rgb, _, _ = gpu.PathIntegrator(max_depth=5).sample(gpu.Scene(cb), sensor, 0, n)
     want, _ = oracle.OracleScene(cb).sample_radiance(oracle.make_desc(p), 0, n)
     close = np.isclose(rgb.cpu().numpy(), want[:, :3], rtol=5e-3, atol=2e-4).all(axis=1)
+    parity_util.record("", rgb.cpu().numpy(), want[:, :3])
     assert close.mean() > 0.995, (kind, "rgb", close.mean())
