@@ -149,6 +149,39 @@ def _envmap_scene(gpu, w, h, spp, max_depth, with_area, rfilter="box", seed=9):
     return sd, img, p, scene
 
 
+def test_invert_cbox_texture(gpu):
+    """BASELINE config 4 as worded ("optimise diffuse-albedo texture on cbox"): the texels of the bitmap albedo on the back wall and the
+    floor ('textured.reflectance.data', src/textures/bitmap.cpp:250-299) are recovered from a uniform grey by the loop of invert_cbox.py.
+    A 16 x 16 texture seen by a 96 x 96 film: every texel is covered by many pixels, so the inverse problem is well posed."""
+    from mitsuba2_amd import autodiff
+    yy, xx = np.meshgrid(np.linspace(0, 1, 16, dtype=np.float32), np.linspace(0, 1, 16, dtype=np.float32), indexing="ij")
+    tex = np.stack([0.5 + 0.35 * np.sin(6 * xx) * np.cos(5 * yy), 0.45 + 0.3 * np.cos(4 * xx + 3 * yy), 0.4 + 0.3 * np.sin(7 * yy)], -1).astype(np.float32)
+    sd = scenes.cornell_box(texture=tex)
+    for b, n in zip(sd["bsdfs"], ["white", "red", "green", "light", "textured"]):
+        b["id"] = n
+    p = scenes.cornell_box_sensor(96, 96, 8, seed=2, max_depth=3, rfilter="box")
+    scene = gpu.Scene(sd, sensor=gpu.make_sensor(p), integrator=gpu.PathIntegrator(max_depth=3))
+    params = autodiff.traverse(scene)
+    key = "textured.reflectance.data"
+    params.keep([key])
+    ref = params[key].clone()
+    assert tuple(ref.shape) == (16, 16, 3)
+    image_ref = autodiff.render(scene, spp=64).detach()
+    params[key] = torch.full_like(ref, 0.5)
+    params.update()
+    opt = autodiff.Adam(params, lr=0.03)
+    errs = []
+    for it in range(150):
+        image = autodiff.render(scene, optimizer=opt, unbiased=True, spp=8)
+        (((image - image_ref) ** 2).sum() / image.numel()).backward()
+        opt.step()
+        errs.append(((ref - params[key].detach()) ** 2).mean().item())
+    # texels the camera sees (the floor is seen at a grazing angle, parts of both walls are hidden by the boxes): the bulk is recovered
+    assert errs[-1] < 0.25 * errs[0], errs[::15]
+    params[key] = ref
+    params.update()
+
+
 @pytest.mark.parametrize("with_area,rfilter,max_depth", [(False, "box", 4), (True, "gaussian", 6)])
 def test_envmap_adjoint_matches_oracle(gpu, oracle, with_area, rfilter, max_depth):
     """mtsamd_render_adjoint_envmap ('my_envmap.data', invert_bunny.py) against the oracle's path replay: glossy + dielectric boxes,

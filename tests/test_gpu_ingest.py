@@ -163,9 +163,9 @@ def test_matpreview_style_scene_from_files(tmp_path):
               crop=(0, 0, 64, 48), rfilter="gaussian", rfilter_param=0.5, sample_count=16, seed=3, max_depth=6, rr_depth=5)
     want, wpos = ob.OracleScene(desc.scene_dict).sample_radiance(ob.make_desc(op), 0, n)
     assert np.array_equal(pos.cpu().numpy(), wpos) and np.array_equal(mask.cpu().numpy(), want[:, 3] > 0.5)
-    close = np.isclose(rgb.cpu().numpy(), want[:, :3], rtol=5e-3, atol=2e-4).all(1)
-    parity_util.record("", rgb.cpu().numpy(), want[:, :3])
-    assert close.mean() > 0.99, close.mean()
+    # every operation of the path is shared bit for bit with the oracle (round 3: explicit elementary functions on both sides):
+    # all samples identical -- rounds 1-2 accepted 99-99.9 % "close" here
+    parity_util.check("per-sample radiance", rgb.cpu().numpy(), want[:, :3])
     assert scene.integrator().render(scene, sensor)
     img = sensor.film().bitmap().cpu().numpy()
     assert np.isfinite(img).all() and img[..., :3].mean() > 0.05 and img[..., 3].min() >= 0

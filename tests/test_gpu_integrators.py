@@ -33,9 +33,9 @@ def test_direct_matches_oracle(general, cfg):
     op = dict(sp, integrator="direct", emitter_samples=integ.emitter_samples, bsdf_samples=integ.bsdf_samples, hide_emitters=integ.hide_emitters)
     want, wpos = ob.OracleScene(cb).sample_radiance(ob.make_desc(op), 0, n)
     assert np.array_equal(pos.cpu().numpy(), wpos) and np.array_equal(mask.cpu().numpy(), want[:, 3] > 0.5)
-    close = np.isclose(rgb.cpu().numpy(), want[:, :3], rtol=5e-3, atol=1e-4).all(1)
-    parity_util.record("", rgb.cpu().numpy(), want[:, :3])
-    assert close.mean() > (0.995 if general else 0.9995), close.mean()
+    # every operation of the path is shared bit for bit with the oracle (round 3: explicit elementary functions on both sides):
+    # all samples identical -- rounds 1-2 accepted 99-99.9 % "close" here
+    parity_util.check("per-sample radiance", rgb.cpu().numpy(), want[:, :3])
 
 
 def test_direct_film_and_stats():
@@ -134,9 +134,9 @@ def test_constant_emitter_matches_oracle(with_area, integrator):
     want, wpos = ob.OracleScene(cb).sample_radiance(ob.make_desc(op), 0, n)
     assert np.array_equal(pos.cpu().numpy(), wpos) and np.array_equal(mask.cpu().numpy(), want[:, 3] > 0.5)
     assert (~mask.cpu().numpy()).any() and (rgb.cpu().numpy()[~mask.cpu().numpy()] == np.float32([0.4, 0.6, 1.0])).all()
-    close = np.isclose(rgb.cpu().numpy(), want[:, :3], rtol=5e-3, atol=1e-4).all(1)
-    parity_util.record("", rgb.cpu().numpy(), want[:, :3])
-    assert close.mean() > 0.995, close.mean()
+    # every operation of the path is shared bit for bit with the oracle (round 3: explicit elementary functions on both sides):
+    # all samples identical -- rounds 1-2 accepted 99-99.9 % "close" here
+    parity_util.check("per-sample radiance", rgb.cpu().numpy(), want[:, :3])
     if integrator == "path":
         a, _, _ = R.PathIntegrator(max_depth=5, pipeline=2).sample(scene, sensor, 0, n)
         assert torch.equal(a, rgb)
@@ -174,9 +174,9 @@ def test_envmap_emitter_matches_oracle(with_area, integrator):
     op = dict(sp, integrator=integrator, emitter_samples=2 if integrator == "direct" else 0, bsdf_samples=2 if integrator == "direct" else 0)
     want, wpos = ob.OracleScene(cb).sample_radiance(ob.make_desc(op), 0, n)
     assert np.array_equal(pos.cpu().numpy(), wpos) and np.array_equal(mask.cpu().numpy(), want[:, 3] > 0.5)
-    close = np.isclose(rgb.cpu().numpy(), want[:, :3], rtol=5e-3, atol=2e-4).all(1)
-    parity_util.record("", rgb.cpu().numpy(), want[:, :3])
-    assert close.mean() > 0.99, close.mean()
+    # every operation of the path is shared bit for bit with the oracle (round 3: explicit elementary functions on both sides):
+    # all samples identical -- rounds 1-2 accepted 99-99.9 % "close" here
+    parity_util.check("per-sample radiance", rgb.cpu().numpy(), want[:, :3])
     assert abs(rgb.cpu().numpy().mean() - want[:, :3].mean()) < 0.02 * want[:, :3].mean()
     if integrator == "path":
         a, _, _ = R.PathIntegrator(max_depth=5, pipeline=2).sample(scene, sensor, 0, n)
@@ -234,9 +234,9 @@ def test_delta_emitters_match_oracle(lights, integrator):
     assert np.array_equal(pos.cpu().numpy(), wpos) and np.array_equal(mask.cpu().numpy(), want[:, 3] > 0.5)
     got = rgb.cpu().numpy()
     assert want[:, :3].mean() > 1e-3
-    close = np.isclose(got, want[:, :3], rtol=5e-3, atol=1e-4 * max(1.0, want[:, :3].mean())).all(1)
-    parity_util.record("", got, want[:, :3])
-    assert close.mean() > 0.99, close.mean()
+    # every operation of the path is shared bit for bit with the oracle (round 3: explicit elementary functions on both sides):
+    # all samples identical -- rounds 1-2 accepted 99-99.9 % "close" here
+    parity_util.check("per-sample radiance", got, want[:, :3])
     assert abs(got.mean() - want[:, :3].mean()) < 0.02 * want[:, :3].mean()
     if integrator == "path":
         a, _, _ = R.PathIntegrator(max_depth=5, pipeline=2).sample(scene, sensor, 0, n)
@@ -246,9 +246,9 @@ def test_delta_emitters_match_oracle(lights, integrator):
         xyz2, _, _ = R.PathIntegrator(max_depth=5, pipeline=2).sample(sscene, sensor, 0, n)
         assert torch.equal(xyz, xyz2)
         swant, _ = ob.OracleScene(cb, spectral_path=R.srgb_coeff_path()).sample_radiance(ob.make_desc(sp), 0, n)
-        sclose = np.isclose(xyz.cpu().numpy(), swant[:, :3], rtol=5e-3, atol=1e-4 * max(1.0, swant[:, :3].mean())).all(1)
-        parity_util.record("", xyz.cpu().numpy(), swant[:, :3])
-        assert sclose.mean() > 0.99, sclose.mean()
+        # every operation of the path is shared bit for bit with the oracle (round 3: explicit elementary functions on both sides):
+        # all samples identical -- rounds 1-2 accepted 99-99.9 % "close" here
+        parity_util.check("per-sample radiance", xyz.cpu().numpy(), swant[:, :3])
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])
@@ -290,6 +290,6 @@ def test_cluster_culling_on_random_flat_scenes(seed):
         rgb, mask, pos = R.PathIntegrator(max_depth=4, pipeline=pipeline).sample(scene, sensor, 0, n)
         want, wpos = oracle.sample_radiance(ob.make_desc(sp), 0, n)
         assert np.array_equal(pos.cpu().numpy(), wpos) and np.array_equal(mask.cpu().numpy(), want[:, 3] > 0.5)
-        close = np.isclose(rgb.cpu().numpy(), want[:, :3], rtol=2e-3, atol=1e-4).all(1)
-        parity_util.record("", rgb.cpu().numpy(), want[:, :3])
-        assert close.mean() > 0.999, (pipeline, close.mean())
+        # every operation of the path is shared bit for bit with the oracle (round 3: explicit elementary functions on both sides):
+        # all samples identical -- rounds 1-2 accepted 99-99.9 % "close" here
+        parity_util.check("per-sample radiance", rgb.cpu().numpy(), want[:, :3])

@@ -37,9 +37,9 @@ def test_spectral_render_matches_oracle(gpu, oracle, scene_name):
     xyz, mask, pos = integ.sample(scene, sensor, first, count)
     ref_rgba, ref_pos = S.sample_radiance(oracle.make_desc(p), first, count)
     assert (pos.cpu().numpy() == ref_pos).all()
-    close = np.isclose(xyz.cpu().numpy(), ref_rgba[:, :3], rtol=5e-3, atol=2e-4).all(axis=1)
-    parity_util.record("", xyz.cpu().numpy(), ref_rgba[:, :3])
-    assert close.mean() > 0.995, close.mean()
+    # every operation of the path is shared bit for bit with the oracle (round 3: explicit elementary functions on both sides):
+    # all samples identical -- rounds 1-2 accepted 99-99.9 % "close" here
+    parity_util.check("per-sample radiance", xyz.cpu().numpy(), ref_rgba[:, :3])
 
 
 def test_spectral_vs_rgb_and_errors(gpu):
@@ -97,9 +97,9 @@ def test_spectral_materials_match_oracle(gpu, oracle, material):
     assert (xyz == xyz0).all()
     ref, ref_pos = oracle.OracleScene(cb, spectral_path=path).sample_radiance(oracle.make_desc(p), 0, n)
     assert (pos.cpu().numpy() == ref_pos).all() and ((ref[:, 3] > 0.5) == mask.cpu().numpy()).all()
-    close = np.isclose(xyz.cpu().numpy(), ref[:, :3], rtol=5e-3, atol=2e-4).all(axis=1)
-    parity_util.record("", xyz.cpu().numpy(), ref[:, :3])
-    assert close.mean() > 0.995, (material, close.mean())
+    # every operation of the path is shared bit for bit with the oracle (round 3: explicit elementary functions on both sides):
+    # all samples identical -- rounds 1-2 accepted 99-99.9 % "close" here
+    parity_util.check("per-sample radiance", xyz.cpu().numpy(), ref[:, :3])
 
 
 def test_spectral_conductor_needs_uniform_ior(gpu):
@@ -133,9 +133,9 @@ def test_spectral_environment_emitters(gpu, oracle, kind, with_area):
     assert (pos.cpu().numpy() == ref_pos).all() and ((ref[:, 3] > 0.5) == m).all() and (~m).any()
     got = xyz.cpu().numpy()
     assert np.isfinite(got).all() and (got[~m].sum(1) > 0).all()          # escaped camera rays see the environment
-    close = np.isclose(got, ref[:, :3], rtol=5e-3, atol=2e-4).all(axis=1)
-    parity_util.record("", got, ref[:, :3])
-    assert close.mean() > 0.99, (kind, with_area, close.mean())
+    # every operation of the path is shared bit for bit with the oracle (round 3: explicit elementary functions on both sides):
+    # all samples identical -- rounds 1-2 accepted 99-99.9 % "close" here
+    parity_util.check("per-sample radiance", got, ref[:, :3])
     assert abs(got.mean() - ref[:, :3].mean()) < 0.02 * ref[:, :3].mean()
     # the spectral rendering agrees with the RGB one up to the upsampling model (film: XYZ -> RGB on both sides)
     out = {}
@@ -178,12 +178,12 @@ def test_spectral_textures_match_oracle(gpu, oracle, kind):
     assert (pos.cpu().numpy() == ref_pos).all()
     got = xyz.cpu().numpy()
     assert np.isfinite(got).all()
-    close = np.isclose(got, ref[:, :3], rtol=5e-3, atol=2e-4).all(axis=1)
-    parity_util.record("", got, ref[:, :3])
-    assert close.mean() > 0.995, (kind, close.mean())
+    # every operation of the path is shared bit for bit with the oracle (round 3: explicit elementary functions on both sides):
+    # all samples identical -- rounds 1-2 accepted 99-99.9 % "close" here
+    parity_util.check("per-sample radiance", got, ref[:, :3])
     # and the RGB variant of the same scene (textured plastic weights from the texture's mean luminance)
     rgb, _, _ = gpu.PathIntegrator(max_depth=5).sample(gpu.Scene(cb), sensor, 0, n)
     want, _ = oracle.OracleScene(cb).sample_radiance(oracle.make_desc(p), 0, n)
-    close = np.isclose(rgb.cpu().numpy(), want[:, :3], rtol=5e-3, atol=2e-4).all(axis=1)
-    parity_util.record("", rgb.cpu().numpy(), want[:, :3])
-    assert close.mean() > 0.995, (kind, "rgb", close.mean())
+    # every operation of the path is shared bit for bit with the oracle (round 3: explicit elementary functions on both sides):
+    # all samples identical -- rounds 1-2 accepted 99-99.9 % "close" here
+    parity_util.check("per-sample radiance", rgb.cpu().numpy(), want[:, :3])
