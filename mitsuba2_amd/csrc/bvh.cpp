@@ -267,7 +267,7 @@ void build_bvh(const float *tri_pos, uint32_t n_prims, uint32_t max_leaf, BvhOut
     if (bfs.empty()) out.root = emit_leaf(b.nodes[root]);   // whole scene is one leaf
     else out.root = 0;
     // ---- BVH4: collapse (open the child of largest surface area until four children), BFS order, same grid
-    out.wnodes.clear(); out.wroot = out.root; out.n_wnodes = 0; out.wdepth = 1;
+    out.wnodes.clear(); out.wnodes_h.clear(); out.wroot = out.root; out.n_wnodes = 0; out.wdepth = 1;
     if (!bfs.empty()) {
         double glo[3], gstep[3];
         for (int k = 0; k < 3; ++k) { glo[k] = (double) out.q_lo[k]; gstep[k] = (double) out.q_step[k]; }
@@ -296,7 +296,36 @@ void build_bvh(const float *tri_pos, uint32_t n_prims, uint32_t max_leaf, BvhOut
             wide[wide_of[t]] = wn;
             out.wdepth = std::max(out.wdepth, depth);
         }
+        // fp16 with directed rounding: the largest half <= v / the smallest half >= v (v an integer in [-32768, 32768])
+        auto half_of = [](float v, bool up) -> uint32_t {
+            uint32_t sign = v < 0.0f ? 0x8000u : 0u;
+            float a = std::fabs(v);
+            if (a == 0.0f) return sign;
+            int e; float m = std::frexp(a, &e);                       // a = m 2^e, m in [0.5, 1)
+            // 11 significant bits: a = k 2^(e - 11), k in [1024, 2048)
+            const float scaled = std::ldexp(m, 11);
+            const bool away = (v >= 0.0f) == up;                       // towards +inf of a positive / -inf of a negative value: magnitude up
+            float k = away ? std::ceil(scaled) : std::floor(scaled);
+            if (k >= 2048.0f) { k = 1024.0f; ++e; }
+            const int be = e - 1 + 15;                                // biased exponent of k 2^(e - 11) = (k / 1024) 2^(e - 1)
+            return sign | ((uint32_t) be << 10) | ((uint32_t) k - 1024u);
+        };
         out.n_wnodes = (uint32_t) wide.size();
+        out.wnodes_h.assign(16 * wide.size(), 0u);
+        for (size_t i = 0; i < wide.size(); ++i) {
+            uint32_t *w = out.wnodes_h.data() + 16 * i;
+            for (int c = 0; c < 4; ++c) {
+                if (c >= wide[i].n) { w[4 * c] = w[4 * c + 1] = w[4 * c + 2] = 0x7800u | (0xf800u << 16); w[4 * c + 3] = 0x7fffffffu; continue; }      // lo = +32768, hi = -32768
+                const int32_t t = wide[i].child[c];
+                float lo[3], hi[3];
+                padded(b.nodes[t].box, extent, lo, hi);
+                for (int k = 0; k < 3; ++k) {
+                    const float vlo = (float) qlo(lo[k], k) - 32768.0f, vhi = (float) qhi(hi[k], k) - 32768.0f;
+                    w[4 * c + k] = half_of(vlo, false) | (half_of(vhi, true) << 16);
+                }
+                w[4 * c + 3] = b.nodes[t].left >= 0 ? (uint32_t) wide_of[t] : leaf_ref[t];
+            }
+        }
         out.wnodes.assign(16 * wide.size(), 0u);
         for (size_t i = 0; i < wide.size(); ++i) {
             uint32_t *w = out.wnodes.data() + 16 * i;

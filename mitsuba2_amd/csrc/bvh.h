@@ -18,6 +18,9 @@ struct BvhOutput {
     // BVH4 collapsed from the BVH2 (the child of largest surface area is opened until a node has four children): 16 words per node,
     // per child (lo | hi << 16) x, y, z on the grid + child reference; an absent child has reference 0x7fffffff and an inverted box
     std::vector<uint32_t> wnodes;
+    // the same BVH4 with the planes as fp16 values of (grid coordinate - 32768), rounded outward (lo down, hi up): the walk reads them
+    // straight into v_fma_mix_f32 (no integer -> float conversion); an absent child has lo = +32768, hi = -32768
+    std::vector<uint32_t> wnodes_h;
     uint32_t wroot = 0, n_wnodes = 0, wdepth = 0;
     std::vector<float> tris;       // 12 floats per triangle slot
     uint32_t root = 0;             // child reference of the root

@@ -246,8 +246,10 @@ static size_t iblock_floats(const iblock *b) {
     return (size_t) b->ch * (size_t) (b->w + 2 * b->border) * (size_t) (b->h + 2 * b->border);
 }
 
-/* imageblock.cpp:80-172 (warn_negative = warn_invalid = true, normalize = false) */
-static int iblock_put(iblock *b, float px, float py, const float *value) {
+/* imageblock.cpp:80-172 (warn_negative = warn_invalid = true, normalize = false).
+ * n_stripes > 0: only the film columns x with (x / 16) % n_stripes == stripe are touched -- n_stripes threads that each run over the
+ * same samples in the same order add up exactly what one thread would (every pixel belongs to one stripe and keeps its order). */
+static int iblock_put_stripe(iblock *b, float px, float py, const float *value, uint32_t stripe, uint32_t n_stripes) {
     for (int k = 0; k < b->ch; ++k)
         if (!(value[k] >= -1e-5f) || !isfinite(value[k])) return 0;
     const rfilter *f = b->filter;
@@ -275,6 +277,7 @@ static int iblock_put(iblock *b, float px, float py, const float *value) {
             for (uint32_t xr = 0; xr < n; ++xr) {
                 uint32_t x = (uint32_t) lox + xr;
                 if (!(x <= (uint32_t) hix) || hix < 0) break;
+                if (n_stripes && (x >> 4) % n_stripes != stripe) continue;
                 size_t off = (size_t) b->ch * ((size_t) y * (size_t) sx + x);
                 float weight = wy[yr] * wx[xr];
                 for (int k = 0; k < b->ch; ++k) b->data[off + k] += value[k] * weight;
@@ -282,13 +285,14 @@ static int iblock_put(iblock *b, float px, float py, const float *value) {
         }
     } else {
         int lox = (int) ceilf(posx - 0.5f), loy = (int) ceilf(posy - 0.5f);
-        if (lox >= 0 && loy >= 0 && lox < sx && loy < sy) {
+        if (lox >= 0 && loy >= 0 && lox < sx && loy < sy && !(n_stripes && ((uint32_t) lox >> 4) % n_stripes != stripe)) {
             size_t off = (size_t) b->ch * ((size_t) loy * (size_t) sx + (size_t) lox);
             for (int k = 0; k < b->ch; ++k) b->data[off + k] += value[k];
         }
     }
     return 1;
 }
+static int iblock_put(iblock *b, float px, float py, const float *value) { return iblock_put_stripe(b, px, py, value, 0u, 0u); }
 
 int mo_imageblock_put(int w, int h, int ox, int oy, int ch, int kind, float param, float param2, int border,
                       int analytic, uint64_t n, const float *pos, const float *values, float *data) {
@@ -931,7 +935,12 @@ static int render_wavefront_rows(const mo_scene *s, const mo_render_desc *d, int
             cl += st.closest; an += st.any;
         }
         total.closest += cl; total.any += an;
-        for (uint64_t k = 0; k < cn; ++k) iblock_put(&blk, buf[7 * k + 5], buf[7 * k + 6], buf + 7 * k);
+        /* splat in sample order; column stripes in parallel (bit-identical to the serial loop, see iblock_put_stripe) */
+#pragma omp parallel
+        {
+            const uint32_t nt = (uint32_t) omp_get_num_threads(), tid = (uint32_t) omp_get_thread_num();
+            for (uint64_t k = 0; k < cn; ++k) iblock_put_stripe(&blk, buf[7 * k + 5], buf[7 * k + 6], buf + 7 * k, tid, nt);
+        }
     }
     free(buf);
     memset(film, 0, sizeof(float) * 5 * (size_t) d->crop_w * d->crop_h);
