@@ -167,6 +167,8 @@ int mo_sample_radiance(const mo_scene *s, const mo_render_desc *d, uint64_t firs
  * [row0,row1) are traced; splats land in the full crop-sized film (for multi-GPU tests). */
 int mo_render_rows(const mo_scene *s, const mo_render_desc *d, int row0, int row1,
                    float *film_xyzaw);
+/* the same for the pixels of the columns [col0, col1) of those rows only */
+int mo_render_window(const mo_scene *s, const mo_render_desc *d, int row0, int row1, int col0, int col1, float *film);
 /* Derivative of the same image w.r.t. the texels of the `envmap` emitter ('data', envmap.cpp:214-218; the inverse-rendering example
  * docs/examples/10_inverse_rendering/invert_bunny.py): radiance is linear in them, the sampling distribution built from their
  * luminances is not differentiated (envmap.cpp:220-253 rebuilds it from plain floats).  Any BSDF, any depth.  grad_env: h*w*3,

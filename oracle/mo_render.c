@@ -19,7 +19,6 @@
 #include <stdlib.h>
 #include <stdio.h>
 #ifdef _OPENMP
-#include <omp.h>
 #endif
 
 /* ================================================================== */
@@ -246,10 +245,8 @@ static size_t iblock_floats(const iblock *b) {
     return (size_t) b->ch * (size_t) (b->w + 2 * b->border) * (size_t) (b->h + 2 * b->border);
 }
 
-/* imageblock.cpp:80-172 (warn_negative = warn_invalid = true, normalize = false).
- * n_stripes > 0: only the film columns x with (x / 16) % n_stripes == stripe are touched -- n_stripes threads that each run over the
- * same samples in the same order add up exactly what one thread would (every pixel belongs to one stripe and keeps its order). */
-static int iblock_put_stripe(iblock *b, float px, float py, const float *value, uint32_t stripe, uint32_t n_stripes) {
+/* imageblock.cpp:80-172 (warn_negative = warn_invalid = true, normalize = false) */
+static int iblock_put(iblock *b, float px, float py, const float *value) {
     for (int k = 0; k < b->ch; ++k)
         if (!(value[k] >= -1e-5f) || !isfinite(value[k])) return 0;
     const rfilter *f = b->filter;
@@ -277,7 +274,6 @@ static int iblock_put_stripe(iblock *b, float px, float py, const float *value, 
             for (uint32_t xr = 0; xr < n; ++xr) {
                 uint32_t x = (uint32_t) lox + xr;
                 if (!(x <= (uint32_t) hix) || hix < 0) break;
-                if (n_stripes && (x >> 4) % n_stripes != stripe) continue;
                 size_t off = (size_t) b->ch * ((size_t) y * (size_t) sx + x);
                 float weight = wy[yr] * wx[xr];
                 for (int k = 0; k < b->ch; ++k) b->data[off + k] += value[k] * weight;
@@ -285,14 +281,13 @@ static int iblock_put_stripe(iblock *b, float px, float py, const float *value, 
         }
     } else {
         int lox = (int) ceilf(posx - 0.5f), loy = (int) ceilf(posy - 0.5f);
-        if (lox >= 0 && loy >= 0 && lox < sx && loy < sy && !(n_stripes && ((uint32_t) lox >> 4) % n_stripes != stripe)) {
+        if (lox >= 0 && loy >= 0 && lox < sx && loy < sy) {
             size_t off = (size_t) b->ch * ((size_t) loy * (size_t) sx + (size_t) lox);
             for (int k = 0; k < b->ch; ++k) b->data[off + k] += value[k];
         }
     }
     return 1;
 }
-static int iblock_put(iblock *b, float px, float py, const float *value) { return iblock_put_stripe(b, px, py, value, 0u, 0u); }
 
 int mo_imageblock_put(int w, int h, int ox, int oy, int ch, int kind, float param, float param2, int border,
                       int analytic, uint64_t n, const float *pos, const float *values, float *data) {
@@ -910,8 +905,10 @@ int mo_sample_radiance(const mo_scene *s, const mo_render_desc *d, uint64_t firs
     return 0;
 }
 
-static int render_wavefront_rows(const mo_scene *s, const mo_render_desc *d, int row0, int row1,
-                                 float *film, uint64_t *stats) {
+/* col0 / col1: only the pixels of the columns [col0, col1) are sampled (tests of very large films: the film pixels at least a filter
+ * radius inside the window still receive every sample that reaches them) */
+static int render_wavefront_window(const mo_scene *s, const mo_render_desc *d, int row0, int row1, int col0, int col1,
+                                   float *film, uint64_t *stats) {
     camera cam; camera_init(d, &cam);
     rfilter f; rfilter_init(&f, d->rfilter, d->rfilter_param, d->rfilter_param2);
     /* ImageBlock(film_size, 5, filter, border = true) then film->put(block) (integrator.cpp:156-168) */
@@ -929,18 +926,16 @@ static int render_wavefront_rows(const mo_scene *s, const mo_render_desc *d, int
             uint64_t i = c0 + (uint64_t) k;
             mo_pcg32 rng; seed_wavefront(&rng, i, d->base_seed);
             uint64_t pixel = i / (uint64_t) d->spp;
-            float px = (float) (uint32_t) (pixel % (uint64_t) d->crop_w), py = (float) (uint32_t) (pixel / (uint64_t) d->crop_w);
+            const int pxi = (int) (pixel % (uint64_t) d->crop_w);
+            if (pxi < col0 || pxi >= col1) { buf[7 * k + 3] = -2.0f; continue; }      /* outside the window: no sample (alpha is never -2) */
+            float px = (float) (uint32_t) pxi, py = (float) (uint32_t) (pixel / (uint64_t) d->crop_w);
             ray_stats st = { 0, 0 };
             render_sample(s, d, &cam, &rng, px + (float) d->crop_x, py + (float) d->crop_y, buf + 7 * k, buf + 7 * k + 5, NULL, NULL, &st);
             cl += st.closest; an += st.any;
         }
         total.closest += cl; total.any += an;
-        /* splat in sample order; column stripes in parallel (bit-identical to the serial loop, see iblock_put_stripe) */
-#pragma omp parallel
-        {
-            const uint32_t nt = (uint32_t) omp_get_num_threads(), tid = (uint32_t) omp_get_thread_num();
-            for (uint64_t k = 0; k < cn; ++k) iblock_put_stripe(&blk, buf[7 * k + 5], buf[7 * k + 6], buf + 7 * k, tid, nt);
-        }
+        for (uint64_t k = 0; k < cn; ++k)
+            if (buf[7 * k + 3] != -2.0f) iblock_put(&blk, buf[7 * k + 5], buf[7 * k + 6], buf + 7 * k);
     }
     free(buf);
     memset(film, 0, sizeof(float) * 5 * (size_t) d->crop_w * d->crop_h);
@@ -951,9 +946,16 @@ static int render_wavefront_rows(const mo_scene *s, const mo_render_desc *d, int
     return 0;
 }
 
+static int render_wavefront_rows(const mo_scene *s, const mo_render_desc *d, int row0, int row1, float *film, uint64_t *stats) {
+    return render_wavefront_window(s, d, row0, row1, 0, d->crop_w, film, stats);
+}
 int mo_render_rows(const mo_scene *s, const mo_render_desc *d, int row0, int row1, float *film) {
     if (desc_check(d) || row0 < 0 || row1 > d->crop_h || row0 > row1) return -1;
     return render_wavefront_rows(s, d, row0, row1, film, NULL);
+}
+int mo_render_window(const mo_scene *s, const mo_render_desc *d, int row0, int row1, int col0, int col1, float *film) {
+    if (desc_check(d) || row0 < 0 || row1 > d->crop_h || row0 > row1 || col0 < 0 || col1 > d->crop_w || col0 > col1) return -1;
+    return render_wavefront_window(s, d, row0, row1, col0, col1, film, NULL);
 }
 
 /* scalar_rgb branch of SamplingIntegrator::render (integrator.cpp:76-143) + render_block (:178-203) */

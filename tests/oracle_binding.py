@@ -82,6 +82,7 @@ def lib():
         L.mo_render.argtypes = [vp, C.POINTER(RenderDesc), C.c_int, C.c_int, C.c_int, vp, vp]
         L.mo_sample_radiance.argtypes = [vp, C.POINTER(RenderDesc), C.c_uint64, C.c_uint64, vp, vp]
         L.mo_render_rows.argtypes = [vp, C.POINTER(RenderDesc), C.c_int, C.c_int, vp]
+        L.mo_render_window.argtypes = [vp, C.POINTER(RenderDesc), C.c_int, C.c_int, C.c_int, C.c_int, vp]
         L.mo_film_develop.argtypes = [vp, C.c_uint64, vp]
         L.mo_libm_eval.argtypes = [C.c_int, C.c_uint64, vp, vp, vp]
         L.mo_libm_eval.restype = None
@@ -301,6 +302,12 @@ class OracleScene:
     def render_rows(self, desc, row0, row1):
         film = np.empty((desc.crop_h, desc.crop_w, 5), np.float32)
         assert lib().mo_render_rows(self.h, C.byref(desc), row0, row1, _p(film)) == 0
+        return film
+
+    def render_window(self, desc, row0, row1, col0, col1):
+        """wavefront-mode film of the samples of the pixels [row0, row1) x [col0, col1) only (full-size film array)"""
+        film = np.empty((desc.crop_h, desc.crop_w, 5), np.float32)
+        assert lib().mo_render_window(self.h, C.byref(desc), row0, row1, col0, col1, _p(film)) == 0
         return film
 
     def render_image(self, desc):

@@ -112,9 +112,9 @@ def test_config5_rank_partition_at_full_spp_against_oracle_rows():
     """BASELINE config 5 as stated -- cbox 4096 x 4096 @ 4096 spp, film tile-partitioned over 8 GPUs -- at the per-pixel sample count of
     the configuration: rank 3 of 8 renders its partition (interleaved 16-row tiles, mitsuba2_amd/dist.py: 512 rows = 8.6e9 camera
     samples, 8 passes of 2^30) exactly as `bench.py --config cbox4k --gpus 8` would on that rank.  The oracle renders, with the same
-    per-sample seeds, the six film rows 564..569 inside the first tile of the rank's SECOND pass (1.0e8 samples); film rows 566 and 567
-    receive splats from exactly those source rows (gaussian radius 2) and all of them belong to this rank, so there the partition's film
-    and the oracle's hold the same sum.  Rounds 1-2 checked this shape at 2 spp against itself."""
+    per-sample seeds, the window of film rows 564..569 x columns 1536..2303 inside the first tile of the rank's SECOND pass (1.9e7 samples);
+    the film pixels of rows 566 and 567, columns 1538..2301 receive splats from exactly that window (gaussian radius 2) and all of its
+    rows belong to this rank, so there the partition's film and the oracle's hold the same sum.  Rounds 1-2 checked this shape at 2 spp against itself."""
     from mitsuba2_amd import render as R, scenes, dist as mdist
     cb = scenes.cornell_box()
     sp = scenes.cornell_box_sensor(4096, 4096, spp=4096, seed=0)
@@ -129,10 +129,10 @@ def test_config5_rank_partition_at_full_spp_against_oracle_rows():
     assert own[64] == 560 and own[79] == 575
     film = sensor.film().bitmap(raw=True)
     assert torch.isfinite(film).all()
-    got = film[566:568].cpu().numpy()
+    got = film[566:568, 1538:2302].cpu().numpy()
     # nothing of another rank's tiles: rows beyond the 2-pixel apron of this rank's tiles stay empty
     assert float(film[544 + 2: 560 - 2].abs().max()) == 0.0
-    ref = ob.OracleScene(cb).render_rows(ob.make_desc(sp), 564, 570)[566:568]
+    ref = ob.OracleScene(cb).render_window(ob.make_desc(sp), 564, 570, 1536, 2304)[566:568, 1538:2302]
     assert ref[..., 4].min() > 0
     assert np.allclose(got[..., 3:], ref[..., 3:], rtol=2e-4, atol=1e-2)   # alpha and weight: sums of 4096 x ~12 filter taps
     rgb_g, rgb_r = ob.film_develop(got)[..., :3], ob.film_develop(ref)[..., :3]
