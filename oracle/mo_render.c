@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include <stdio.h>
 #ifdef _OPENMP
+#include <omp.h>
 #endif
 
 /* ================================================================== */
