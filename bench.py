@@ -342,14 +342,22 @@ def run_mesh(args, R, matpreview=False):
     achieved = alg_bytes / max(trace_s, 1e-12) / 1e9
     any_launches = max(acc["trace_any_launches"], 1)
     any_bytes = 36 * acc["any_hit_rays"] + geometry * any_launches
-    # HBM traffic of the closest-hit walk: PMC counters cannot be read inside this process; the ratio counted / algorithmic bytes of the
-    # kernel comes from the committed rocprofv3 --pmc summary of the same scene (RGB, 64 spp: the walk is the same) -- an OFFLINE figure
-    traffic, traffic_src = None, None
-    pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mesh_pmc.json")))
+    # Fabric traffic of the walks: PMC counters cannot be read inside this process; the ratio counted / algorithmic bytes of each kernel comes
+    # from the committed rocprofv3 --pmc summary of the same scene AND variant (1920x1080 @ 64 spp: the kernels are the same) -- an OFFLINE
+    # figure.  FETCH_SIZE counts the L2's memory-side requests, Infinity-Cache hits included (MI355X_MICROARCH.md): for a 17.7 MB scene the
+    # excess over the algorithmic bytes is node / triangle lines that miss the 4 MB L2 of an XCD, served on-die -- not HBM reads.
+    traffic, traffic_src, pmc_extra = None, None, {}
+    pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mesh_spectral_pmc.json" if variant == "spectral" else "r[0-9][0-9]_mesh_pmc.json")))
     if pmc and not matpreview:
         try:
-            traffic = json.load(open(pmc[-1]))["k_trace_closest"]["traffic_over_algorithmic"] * (alg_bytes / launches)
-            traffic_src = "offline profile " + os.path.relpath(pmc[-1], ROOT) + " (counted / algorithmic bytes of this kernel on the RGB 64-spp render), scaled to this run"
+            prof = json.load(open(pmc[-1]))
+            traffic = prof["k_trace_closest"]["traffic_over_algorithmic"] * (alg_bytes / launches)
+            traffic_src = ("offline profile " + os.path.relpath(pmc[-1], ROOT) + " (counted / algorithmic bytes of this kernel on the %s 64-spp render; "
+                           "L2-miss traffic, Infinity-Cache hits included), scaled to this run" % variant)
+            pmc_extra = {"k_trace_any_traffic_over_algorithmic": prof.get("k_trace_any", {}).get("traffic_over_algorithmic"),
+                         "k_shade_bytes_per_segment": prof.get("k_shade", {}).get("bytes_per_segment"),
+                         "k_shade_traffic_over_algorithmic": prof.get("k_shade", {}).get("traffic_over_algorithmic"),
+                         "k_trace_closest_lane_utilisation": prof["kernels"].get("k_trace<false, false>", {}).get("valu_lane_utilisation")}
         except (KeyError, ValueError, OSError):
             traffic, traffic_src = None, None
     out = {
@@ -372,7 +380,9 @@ def run_mesh(args, R, matpreview=False):
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "alg_bytes_per_launch": alg_bytes / launches,
                      "gray_per_s_in_kernel": acc["closest_hit_rays"] / max(trace_s, 1e-12) / 1e9,
                      "k_trace_any": {"achieved": any_bytes / max(acc["trace_any_ns"] * 1e-9, 1e-12) / 1e9,
-                                     "gray_per_s_in_kernel": acc["any_hit_rays"] / max(acc["trace_any_ns"] * 1e-9, 1e-12) / 1e9}},
+                                     "gray_per_s_in_kernel": acc["any_hit_rays"] / max(acc["trace_any_ns"] * 1e-9, 1e-12) / 1e9},
+                     "offline_counters": pmc_extra,
+                     "bound_in_practice": "VALU issue for half-empty waves (lane utilisation 0.48) and the latency of dependent node fetches; the 17.7 MB of geometry are served by L2 and the Infinity Cache, HBM carries the ray / hit streams only"},
     }
     if not args.no_cpu_baseline:
         path = render.srgb_coeff_path() if variant == "spectral" else None

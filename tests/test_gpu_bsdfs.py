@@ -70,7 +70,7 @@ def _scene(material):
 
 
 @pytest.mark.parametrize("material", sorted(MATERIALS))
-@pytest.mark.parametrize("pipeline", [0, 1, 2])          # 0: the default schedule (in-kernel shadow ring for this LDS-resident scene)
+@pytest.mark.parametrize("pipeline", [0, 1, 2, 4])       # 0: automatic (a pass this small: one launch of persistent lanes); 4: the in-kernel shadow ring, the default of LDS-resident scenes
 def test_sample_radiance_matches_oracle(material, pipeline):
     from mitsuba2_amd import render as R, scenes
     cb, sp = _scene(material), scenes.cornell_box_sensor(64, 64, spp=8, seed=21)

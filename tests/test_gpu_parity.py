@@ -171,10 +171,14 @@ def test_per_sample_radiance(gpu, oracle, max_depth):
     sd = scenes.cornell_box()
     p = scenes.cornell_box_sensor(64, 48, 16, seed=3, max_depth=max_depth)
     scene, sensor = gpu.Scene(sd), gpu.make_sensor(p)
-    integ = gpu.PathIntegrator(max_depth=max_depth, rr_depth=5)
     first, count = 1000, 40000
-    rgb, mask, pos = integ.sample(scene, sensor, first, count)
     ref_rgba, ref_pos = oracle.OracleScene(sd, naive=True).sample_radiance(oracle.make_desc(p), first, count)
+    # pipeline 0 picks the single-launch schedule for a pass this small; 4 is the headline schedule (k_shade with the in-kernel shadow
+    # ring), 1 the fused kernel, 2 the split pipeline: all four must return the oracle's bits
+    for pipeline in (4, 1, 2, 0):
+        integ = gpu.PathIntegrator(max_depth=max_depth, rr_depth=5, pipeline=pipeline)
+        rgb, mask, pos = integ.sample(scene, sensor, first, count)
+        assert (rgb.cpu().numpy() == ref_rgba[:, :3]).all(), pipeline
     rgb, mask, pos = rgb.cpu().numpy(), mask.cpu().numpy(), pos.cpu().numpy()
     assert (pos == ref_pos).all()                               # same RNG stream, same arithmetic
     assert (mask == (ref_rgba[:, 3] > 0.5)).all()
