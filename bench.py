@@ -58,8 +58,8 @@ def _oracle():
 # CPU baselines: the oracle (checker code) timed as a *reported baseline* on a bounded sample of the same workload
 def cpu_baseline(sd, sensor_fn, label, spectral_path=None, seconds=10.0, max_spp=64, packet=True):
     """The CPU port (oracle, scalar_rgb block mode: spiral 32x32 blocks, one PCG32 stream per block, BVH, all host cores) and
-    its 8-wide packet variant (packet_rgb-equivalent restatement: Morton-ordered 8-ray packets, lane voting at inner nodes,
-    kdtree.h:2176-2300) on the same film at a reduced sample count."""
+    its 8-wide packet variant (packet_rgb / packet_spectral-equivalent restatement: Morton-ordered 8-ray packets, lane voting at inner
+    nodes, kdtree.h:2176-2300) on the same film at a reduced sample count."""
     ob = _oracle()
     S = ob.OracleScene(sd, spectral_path=spectral_path)
     cores = host_cores()
@@ -77,7 +77,7 @@ def cpu_baseline(sd, sensor_fn, label, spectral_path=None, seconds=10.0, max_spp
     out = {"value": samples / dt / 1e6, "unit": "Msample/s", "cores": cores, "kind": "port",
            "sample": "%s %dx%d@%dspp, oracle scalar block mode (spiral 32x32 blocks, BVH), %.1f s" % (label, p["crop"][2], p["crop"][3], spp, dt),
            "mray_per_s": float(stats[0] + stats[1]) / dt / 1e6, "scalar": samples / dt / 1e6}
-    if packet and hasattr(ob, "PACKET_MODE") and spectral_path is None:
+    if packet and hasattr(ob, "PACKET_MODE"):
         dtp, stp, _ = timed(ob.PACKET_MODE, spp)
         out["packet"] = samples / dtp / 1e6
         out["packet_mray_per_s"] = float(stp[0] + stp[1]) / dtp / 1e6

@@ -827,6 +827,122 @@ static void path_sample_spectral(const mo_scene *s, mo_pcg32 *rng, const mo_ray 
     }
 }
 
+/* The same for the spectral variant: 8 lanes, each with its own 4 wavelengths; ray queries 8 wide (lane voting), shading per lane with
+ * the scalar code of path_sample_spectral -- every lane computes exactly what the scalar path computes for its ray and stream. */
+static void path_sample_packet_spectral(const mo_scene *s, const mo_packet_accel *acc, mo_pcg32 *rng, const mo_ray *rays_in, uint32_t lanes,
+                                        float (*wav)[MO_WAV], int max_depth, int rr_depth, float (*result)[MO_WAV], int *valid_ray,
+                                        ray_stats *st) {
+    mo_ray ray[8]; mo_si si[8], si_bsdf[8]; int si_valid[8], v2[8], emitter[8], active[8];
+    float eta[8], emission_weight[8], throughput[8][MO_WAV];
+    mo_bsdf_chan chan[8]; mo_dsample ds[8]; int active_e[8], smooth[8]; mo_bsample bs[8];
+    for (int l = 0; l < 8; ++l) {
+        ray[l] = rays_in[l]; eta[l] = 1.0f; emission_weight[l] = 1.0f; active[l] = 1; active_e[l] = 0; smooth[l] = 0;
+        for (int k = 0; k < MO_WAV; ++k) { throughput[l][k] = 1.0f; result[l][k] = 0.0f; }
+    }
+    packet_scene_intersect(s, acc, ray, lanes, si, si_valid, st);
+    for (int l = 0; l < 8; ++l) {
+        if (!((lanes >> l) & 1u)) continue;
+        valid_ray[l] = si_valid[l];
+        emitter[l] = si_valid[l] ? s->meshes[si[l].shape].emitter : s->environment;
+    }
+    uint32_t alive = lanes;
+    for (int depth = 1; alive; ++depth) {
+        mo_ray shadow[8]; uint32_t shadow_lanes = 0;
+        for (int l = 0; l < 8; ++l) {
+            if (!((alive >> l) & 1u)) continue;
+            if (emitter[l] >= 0 && active[l] && (s->emitters[emitter[l]].type != 0 || si[l].wi.z > 0.0f)) {
+                float le[MO_WAV];
+                mo_v3 d = mo_neg(si[l].wi);
+                emitter_spectrum(&s->emitters[emitter[l]], wav[l], &d, NULL, le);
+                for (int k = 0; k < MO_WAV; ++k) result[l][k] += (emission_weight[l] * throughput[l][k]) * le[k];
+            }
+            active[l] = active[l] && si_valid[l];
+            if (depth > rr_depth) {
+                float hm = fmaxf(fmaxf(throughput[l][0], throughput[l][1]), fmaxf(throughput[l][2], throughput[l][3]));
+                float q = fminf(hm * (eta[l] * eta[l]), 0.95f);
+                if (active[l]) active[l] = mo_pcg32_next_f32(&rng[l]) < q;
+                float rq = mo_rcp(q);
+                for (int k = 0; k < MO_WAV; ++k) throughput[l][k] *= rq;
+            }
+            if ((uint32_t) depth >= (uint32_t) max_depth || !active[l]) { alive &= ~(1u << l); continue; }
+            const mo_mesh *mesh = &s->meshes[si[l].shape];
+            mo_bsdf_spectral_channels(&mesh->bsdf, wav[l], &chan[l]);
+            if (mesh->texture >= 0) mo_reflectance_spectral(s, mesh, si[l].uv, wav[l], chan[l].refl);
+            smooth[l] = mo_bsdf_is_smooth(&mesh->bsdf);
+            active_e[l] = 0;
+            if (smooth[l]) {
+                mo_v2 s2; s2.x = mo_pcg32_next_f32(&rng[l]); s2.y = mo_pcg32_next_f32(&rng[l]);
+                float rgb_spec[3];
+                mo_sample_emitter_direction(s, si[l].p, s2, &ds[l], rgb_spec);
+                active_e[l] = ds[l].pdf != 0.0f && s->n_emitters > 0;
+                if (active_e[l]) {
+                    shadow[l].o = si[l].p; shadow[l].d = ds[l].d;
+                    shadow[l].mint = MO_RAY_EPSILON * (1.0f + mo_hmax_abs(si[l].p));
+                    shadow[l].maxt = ds[l].dist * (1.0f - MO_SHADOW_EPSILON);
+                    shadow_lanes |= 1u << l;
+                }
+            }
+        }
+        if (!alive) break;
+        uint32_t occluded = 0;
+        if (shadow_lanes) {
+            st->any += (uint64_t) __builtin_popcount(shadow_lanes);
+            occluded = mo_packet_intersect(s, acc, shadow, shadow_lanes, 1, NULL);
+        }
+        uint32_t next_lanes = 0;
+        for (int l = 0; l < 8; ++l) {
+            if (!((alive >> l) & 1u)) continue;
+            const mo_bsdf *bsdf = &s->meshes[si[l].shape].bsdf;
+            if (smooth[l] && active_e[l]) {
+                const mo_emitter *e = &s->emitters[ds[l].emitter];
+                float r2 = s->n_emitters > 1 ? mo_rcp(1.0f / (float) s->n_emitters) : 1.0f;
+                float pdf_single = s->n_emitters > 1 ? ds[l].pdf_single : ds[l].pdf;
+                int act = e->type != 0 || (mo_dot(ds[l].d, ds[l].n) < 0.0f && pdf_single != 0.0f);
+                float r1 = act ? mo_rcp(pdf_single) : 0.0f;
+                mo_v3 wo = mo_to_local(&si[l].sh, ds[l].d);
+                float bv[MO_WAV], bsdf_pdf, le[MO_WAV];
+                mo_bsdf_eval_pdf_spec(bsdf, wav[l], &chan[l], si[l].wi, wo, bv, &bsdf_pdf);
+                float mis = ds[l].delta ? 1.0f : mis_weight(ds[l].pdf, bsdf_pdf);
+                emitter_spectrum(e, wav[l], &ds[l].d, &ds[l].uv, le);
+                for (int k = 0; k < MO_WAV; ++k) {
+                    float spec = ds[l].delta ? (le[k] * ds[l].falloff) * ds[l].scale : le[k] * r1;
+                    if (s->n_emitters > 1) spec *= r2;
+                    if ((occluded >> l) & 1u) spec = 0.0f;
+                    result[l][k] += ((mis * throughput[l][k]) * bv[k]) * spec;
+                }
+            }
+            float s1 = mo_pcg32_next_f32(&rng[l]);
+            mo_v2 s2; s2.x = mo_pcg32_next_f32(&rng[l]); s2.y = mo_pcg32_next_f32(&rng[l]);
+            float bsdf_w[MO_WAV];
+            mo_bsdf_sample_spec(bsdf, wav[l], &chan[l], si[l].wi, s1, s2, &bs[l], bsdf_w);
+            int nz = 0;
+            for (int k = 0; k < MO_WAV; ++k) { throughput[l][k] = throughput[l][k] * bsdf_w[k]; nz = nz || throughput[l][k] != 0.0f; }
+            active[l] = active[l] && nz;
+            if (!active[l]) { alive &= ~(1u << l); continue; }
+            eta[l] *= bs[l].eta;
+            ray[l].o = si[l].p; ray[l].d = mo_to_world(&si[l].sh, bs[l].wo);
+            ray[l].mint = (1.0f + mo_hmax_abs(si[l].p)) * MO_RAY_EPSILON;
+            ray[l].maxt = INFINITY;
+            next_lanes |= 1u << l;
+        }
+        if (!next_lanes) break;
+        packet_scene_intersect(s, acc, ray, next_lanes, si_bsdf, v2, st);
+        for (int l = 0; l < 8; ++l) {
+            if (!((next_lanes >> l) & 1u)) continue;
+            emitter[l] = v2[l] ? s->meshes[si_bsdf[l].shape].emitter : s->environment;
+            if (emitter[l] >= 0) {
+                mo_v3 d = mo_sub(si_bsdf[l].p, si[l].p);
+                float dist = mo_norm(d);
+                d = mo_div_s(d, dist);
+                if (!v2[l]) { d = mo_neg(si_bsdf[l].wi); dist = 0.0f; si_bsdf[l].sh.n = d; }
+                float emitter_pdf = bs[l].delta ? 0.0f : mo_pdf_emitter_direction(s, (uint32_t) emitter[l], d, si_bsdf[l].sh.n, dist);
+                emission_weight[l] = mis_weight(bs[l].pdf, emitter_pdf);
+            }
+            si[l] = si_bsdf[l]; si_valid[l] = v2[l];
+        }
+    }
+}
+
 /* spectrum.h:220-227 (Matrix * Vector: column-wise fmadd) */
 static inline void srgb_to_xyz(const float rgb[3], float xyz[3]) {
     static const float M[3][3] = { { 0.412453f, 0.357580f, 0.180423f },
@@ -967,7 +1083,7 @@ int mo_render_window(const mo_scene *s, const mo_render_desc *d, int row0, int r
  * flavour 3: the same schedule and streams as 2, every lane traced by the scalar code -- the checker of flavour 2. */
 static int render_blocks(const mo_scene *s, const mo_render_desc *d, int n_threads, int block_size,
                          float *film, uint64_t *stats, int flavour) {
-    if (flavour == 2 && (s->spectral || d->integrator != 0 || d->aperture_radius > 0.0f)) return -2;      /* RGB `path`, pinhole camera */
+    if (flavour == 2 && (d->integrator != 0 || d->aperture_radius > 0.0f)) return -2;      /* `path`, pinhole camera */
     mo_packet_accel *acc = flavour == 2 ? mo_packet_accel_build(s) : NULL;
     camera cam; camera_init(d, &cam);
     rfilter f; rfilter_init(&f, d->rfilter, d->rfilter_param, d->rfilter_param2);
@@ -1030,20 +1146,31 @@ static int render_blocks(const mo_scene *s, const mo_render_desc *d, int n_threa
                             if ((lanes >> l) & 1u) render_sample(s, d, &cam, &lane_rng[l], px[l], py[l], aovs[l], ps[l], NULL, NULL, &st);
                     } else {
                         /* render_sample (integrator.cpp:224-271) around the 8-wide PathIntegrator::sample */
-                        mo_ray rays[8]; float L[8][3]; int valid[8];
+                        mo_ray rays[8]; float L[8][3]; int valid[8]; float wsample[8];
                         for (uint32_t l = 0; l < 8; ++l) {
                             if (!((lanes >> l) & 1u)) continue;
                             float jx = mo_pcg32_next_f32(&lane_rng[l]), jy = mo_pcg32_next_f32(&lane_rng[l]);
                             ps[l][0] = px[l] + jx; ps[l][1] = py[l] + jy;
-                            (void) mo_pcg32_next_f32(&lane_rng[l]);                  /* wavelength sample */
+                            wsample[l] = mo_pcg32_next_f32(&lane_rng[l]);            /* wavelength sample */
                             float ax = (ps[l][0] - (float) d->crop_x) / (float) d->crop_w, ay = (ps[l][1] - (float) d->crop_y) / (float) d->crop_h;
                             camera_sample_ray(&cam, ax, ay, 0.5f, 0.5f, &rays[l]);
                         }
-                        path_sample_packet(s, acc, lane_rng, rays, lanes, d->max_depth, d->rr_depth, L, valid, &st);
+                        if (s->spectral) {      /* sample_wavelength, ray_weight * L, spectrum_to_xyz as render_sample does per lane */
+                            float wav[8][MO_WAV], weight[8][MO_WAV], Ls[8][MO_WAV];
+                            for (uint32_t l = 0; l < 8; ++l)
+                                if ((lanes >> l) & 1u) mo_sample_wavelengths(wsample[l], wav[l], weight[l]);
+                            path_sample_packet_spectral(s, acc, lane_rng, rays, lanes, wav, d->max_depth, d->rr_depth, Ls, valid, &st);
+                            for (uint32_t l = 0; l < 8; ++l) {
+                                if (!((lanes >> l) & 1u)) continue;
+                                for (int k = 0; k < MO_WAV; ++k) Ls[l][k] = weight[l][k] * Ls[l][k];
+                                mo_spectrum_to_xyz(Ls[l], wav[l], L[l]);
+                            }
+                        } else path_sample_packet(s, acc, lane_rng, rays, lanes, d->max_depth, d->rr_depth, L, valid, &st);
                         for (uint32_t l = 0; l < 8; ++l) {
                             if (!((lanes >> l) & 1u)) continue;
                             float xyz[3];
-                            srgb_to_xyz(L[l], xyz);
+                            if (s->spectral) { xyz[0] = L[l][0]; xyz[1] = L[l][1]; xyz[2] = L[l][2]; }
+                            else srgb_to_xyz(L[l], xyz);
                             if (d->film_rgb) { xyz[0] = L[l][0]; xyz[1] = L[l][1]; xyz[2] = L[l][2]; }
                             aovs[l][0] = xyz[0]; aovs[l][1] = xyz[1]; aovs[l][2] = xyz[2]; aovs[l][3] = valid[l] ? 1.0f : 0.0f; aovs[l][4] = 1.0f;
                         }

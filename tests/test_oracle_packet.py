@@ -39,6 +39,20 @@ def test_packet_film_is_the_scalar_film_of_the_same_schedule(oracle, name):
     assert st_s[2] == st_p[2] and abs(int(st_s[0]) - int(st_p[0])) < 0.05 * st_s[0]
 
 
+def test_spectral_packet_film_is_the_scalar_film_of_the_same_schedule(oracle):
+    """the same for the spectral variant (BASELINE config 3's CPU baseline): every lane carries its own four wavelengths, the ray queries
+    are 8 wide, the shading is the scalar spectral code -- bit for bit the film of the schedule traced lane by lane"""
+    from mitsuba2_amd import render
+    path = render.srgb_coeff_path()
+    for sd, p in ((scenes.cornell_box(), scenes.cornell_box_sensor(64, 48, 4, seed=3)), (scenes.bumpy_sphere(32, 64), scenes.bumpy_sphere_sensor(64, 40, 3, seed=4))):
+        S = oracle.OracleScene(sd, spectral_path=path)
+        d = oracle.make_desc(p)
+        packet, st_p = S.render(d, mode=oracle.PACKET_MODE, n_threads=4)
+        check, st_c = S.render(d, mode=oracle.PACKET_CHECK_MODE, n_threads=4)
+        assert (packet == check).all(), float(np.abs(packet - check).max())
+        assert (st_p == st_c).all() and packet[..., :3].max() > 0
+
+
 def test_packet_queries_match_scalar_queries_on_incoherent_rays(oracle):
     # the 8-wide query itself, on random rays through a 7 k-triangle mesh (ragged last packet included): t, primitive, u, v and the
     # any-hit flag equal the scalar BVH walk's
