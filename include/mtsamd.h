@@ -303,6 +303,22 @@ MTSAMD_API int mtsamd_render_adjoint_envmap(mtsamd_scene *scene, const mtsamd_re
 /* New texels for the envmap emitter (host pointer, height * width * 3 linear RGB; parameters_changed of envmap.cpp:220-253).
  * rebuild_distribution = 0 keeps the importance-sampling hierarchy of the previous texels (a render is then exactly linear in the
  * texels: finite-difference tests); the reference always rebuilds.  Synchronises the device.  RGB variant. */
+/* Parameters of the BSDF models beyond `diffuse` (what traverse() exposes of e.g. roughconductor.cpp:393-404, plastic.cpp:299-307):
+ * REFLECTANCE = diffuse.reflectance / (rough)plastic.diffuse_reflectance, SPECULAR_REFLECTANCE, SPECULAR_TRANSMITTANCE (dielectrics),
+ * ETA / K (conductors), ALPHA (isotropic roughness of roughconductor / roughdielectric; one component). */
+typedef enum { MTSAMD_PARAM_REFLECTANCE = 0, MTSAMD_PARAM_SPECULAR_REFLECTANCE = 1, MTSAMD_PARAM_ETA = 2, MTSAMD_PARAM_K = 3, MTSAMD_PARAM_ALPHA = 4,
+               MTSAMD_PARAM_SPECULAR_TRANSMITTANCE = 5 } mtsamd_bsdf_param;
+/* parameters_changed() of a BSDF after one of these parameters was edited (RGB variant; constants): value3 = 3 floats (ALPHA: 1). */
+MTSAMD_API int mtsamd_scene_set_bsdf_param(mtsamd_scene *scene, uint32_t bsdf, int32_t param, const float *value3);
+/* d(loss)/d(component of one such parameter) ADDED to *grad1_dev, for the image of mtsamd_render(film_rgb = 1) normalised as
+ * mitsuba.python.autodiff.render does (src/python/python/autodiff.py:6-91): every camera sample is replayed with its PCG32 stream through
+ * the general path step -- any BSDF, any emitter, any depth -- carrying the derivative forward beside the path.  Sampling is detached:
+ * directions, lobe choices, MIS weights and Russian roulette are those of the primal path; the BSDF value at the fixed directions is
+ * differentiated by a central difference of the model code (step h; <= 0: 1 % of the value).  The reference differentiates the attached
+ * estimator through Enoki's autodiff graph; both are unbiased estimators of the same derivative (up to O(h^2)). */
+MTSAMD_API int mtsamd_render_adjoint_param(mtsamd_scene *scene, const mtsamd_render_desc *desc, const float *dloss_dimage_dev,
+                                const float *film_dev, uint32_t bsdf, int32_t param, int32_t component, float h,
+                                float *grad1_dev, void *stream);
 MTSAMD_API int mtsamd_scene_update_envmap(mtsamd_scene *scene, const float *rgb, int32_t rebuild_distribution);
 /* Size of a bitmap texture and its float offset inside the concatenated texture-gradient buffer. */
 /* RoughPlastic precomputation (roughplastic.cpp:380-399) of BSDF `bsdf`: out65[0..63] = external transmittance at

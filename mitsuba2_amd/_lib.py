@@ -100,6 +100,8 @@ SYMBOLS = {
     "mtsamd_rfilter_info": (C.c_int, [C.c_int32, C.c_float, C.c_float, f32p, f32p, C.POINTER(C.c_int32)]),
     "mtsamd_film_develop": (C.c_int, [vp, C.c_uint64, vp, vp]),
     "mtsamd_libm_eval": (C.c_int, [C.c_int32, C.c_uint64, vp, vp, vp, vp]),
+    "mtsamd_scene_set_bsdf_param": (C.c_int, [vp, C.c_uint32, C.c_int32, f32p]),
+    "mtsamd_render_adjoint_param": (C.c_int, [vp, C.POINTER(RenderDesc), vp, vp, C.c_uint32, C.c_int32, C.c_int32, C.c_float, vp, vp]),
 }
 
 _lib = None

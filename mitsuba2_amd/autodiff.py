@@ -16,10 +16,16 @@ from contextlib import contextmanager
 import numpy as np
 import torch
 
+from . import bsdfs as B
+
 from . import _lib as L
 from .render import PathIntegrator, _ptr, _stream
 
 _DERIV_SEED_OFFSET = 0x9E3779B97F4A7C15      # decorrelates the derivative pass from the primal pass (unbiased=True)
+
+
+def _is_spectral(scene):
+    return getattr(scene, "_variant", getattr(scene, "variant", "rgb")) == "spectral"
 
 
 class ParameterMap:
@@ -29,6 +35,7 @@ class ParameterMap:
     def __init__(self, scene):
         self._scene = scene
         self.rebuild_envmap_distribution = True      # what parameters_changed() does (envmap.cpp:220-253); False: tests of linearity
+        self.fd_step = 0.0                           # BSDF-model parameters: step of the central difference of the model code (0: 1 % of the value)
         self.properties = {}
         self._kind = {}
         dev = torch.device("cuda", scene._device_index)
@@ -63,6 +70,27 @@ class ParameterMap:
                 key = name + ".reflectance.value"
                 self.properties[key] = torch.as_tensor([float(x) for x in refl], dtype=torch.float32, device=dev)
                 self._kind[key] = ("bsdf", i, i)
+        # parameters of the BSDF models beyond `diffuse` (what their traverse() exposes, e.g. roughconductor.cpp:393-404, plastic.cpp:299-307):
+        # differentiated by mtsamd_render_adjoint_param in ANY scene (any emitter, any depth): constants only, RGB variant
+        for i, b in enumerate(scene._bsdf_records if not diffuse_scene and not _is_spectral(scene) else []):
+            name = b.get("id", "bsdf_%d" % i) + (".brdf_0" if b.get("twosided") and b["type"] != B.DIFFUSE else "")
+            flat_index = i                # top-level records keep their place in the table (bsdfs.flatten)
+            for pname, kind, types in (("reflectance", 0, (B.DIFFUSE,)), ("diffuse_reflectance", 0, (B.PLASTIC, B.ROUGHPLASTIC)),
+                                       ("specular_reflectance", 1, (B.CONDUCTOR, B.ROUGHCONDUCTOR, B.PLASTIC, B.ROUGHPLASTIC, B.DIELECTRIC, B.ROUGHDIELECTRIC, B.THINDIELECTRIC)),
+                                       ("specular_transmittance", 5, (B.DIELECTRIC, B.ROUGHDIELECTRIC, B.THINDIELECTRIC)),
+                                       ("eta", 2, (B.CONDUCTOR, B.ROUGHCONDUCTOR)), ("k", 3, (B.CONDUCTOR, B.ROUGHCONDUCTOR))):
+                if b["type"] not in types:
+                    continue
+                src = b["reflectance"] if kind == 0 else b[pname]
+                if isinstance(src, dict):
+                    continue              # textured: no constant parameter
+                key = "%s.%s.value" % (name, pname)
+                self.properties[key] = torch.as_tensor([float(x) for x in src], dtype=torch.float32, device=dev)
+                self._kind[key] = ("bsdf_param", flat_index, kind)
+            if b["type"] in (B.ROUGHCONDUCTOR, B.ROUGHDIELECTRIC) and b["alpha_u"] == b["alpha_v"]:
+                key = name + ".alpha.value"
+                self.properties[key] = torch.as_tensor([float(b["alpha_u"])], dtype=torch.float32, device=dev)
+                self._kind[key] = ("bsdf_param", flat_index, 4)
         # 'shape.emitter.radiance.value' of area lights (docs/src/inverse_rendering/diff_render.rst:76)
         for i, m in enumerate(scene._dict["meshes"] if diffuse_scene else []):
             e = m.get("emitter", -1)
@@ -101,10 +129,10 @@ class ParameterMap:
         to the host costs a device synchronisation."""
         seen = self.__dict__.setdefault("_pushed", {})
         for k, v in self.properties.items():
-            stamp = (id(v), v._version)
-            if seen.get(k) == stamp:
+            last = seen.get(k)
+            if last is not None and last[0] is v and last[1] == v._version:      # (the tensor itself is kept: an id can be reused)
                 continue
-            seen[k] = stamp
+            seen[k] = (v, v._version)
             kind, idx, _ = self._kind[k]
             if kind == "texture":
                 self._scene.update_texture(idx, v)
@@ -112,6 +140,9 @@ class ParameterMap:
                 self._scene.set_emitter_radiance(idx, v.detach().cpu().tolist())
             elif kind == "envmap":
                 self._scene.update_envmap(v, rebuild_distribution=self.rebuild_envmap_distribution)
+            elif kind == "bsdf_param":
+                vals = [float(x) for x in v.detach().cpu().reshape(-1).tolist()]
+                self._scene.set_bsdf_param(idx, self._kind[k][2], vals)
             else:
                 self._scene.set_bsdf_reflectance(idx, v.detach().cpu().tolist())
 
@@ -164,7 +195,7 @@ class _Render(torch.autograd.Function):
         g_em = torch.zeros((max(len(scene._dict.get("emitters", [])), 1), 3), dtype=torch.float32, device=dev)
         gi = grad_image.to(dev, torch.float32).contiguous()
         kinds = {pmap._kind[k][0] for k in keys}
-        if kinds - {"envmap"}:
+        if kinds - {"envmap", "bsdf_param"}:
             L.check(L.lib().mtsamd_render_adjoint(scene._handle, C.byref(d), _ptr(gi), _ptr(film), _ptr(g_bsdf), _ptr(g_tex), _ptr(g_em), _stream()))
         g_env = None
         if "envmap" in kinds:
@@ -173,6 +204,14 @@ class _Render(torch.autograd.Function):
         grads = []
         for k in keys:
             kind, idx, _ = pmap._kind[k]
+            if kind == "bsdf_param":          # one replay per scalar component (forward-mode derivative carried beside the path)
+                n = pmap[k].numel()
+                g = torch.zeros(n, dtype=torch.float32, device=dev)
+                for c in range(n):
+                    L.check(L.lib().mtsamd_render_adjoint_param(scene._handle, C.byref(d), _ptr(gi), _ptr(film), int(idx), int(pmap._kind[k][2]), c,
+                                                                float(pmap.fd_step), _ptr(g[c:c + 1]), _stream()))
+                grads.append(g.reshape(pmap[k].shape))
+                continue
             if kind == "envmap":
                 grads.append(g_env)
             elif kind == "bsdf":

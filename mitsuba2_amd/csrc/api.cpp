@@ -1696,6 +1696,76 @@ int mtsamd_render_adjoint(mtsamd_scene *s, const mtsamd_render_desc *d, const fl
     return MTSAMD_OK;
 }
 
+// One scalar parameter of a BSDF record: which float(s) of DevBsdf it is.  ok = false: the model has no such (differentiable) parameter.
+static bool bsdf_param_fields(const DevBsdf &b, int32_t kind, int32_t comp, float DevBsdf::*&f0, float DevBsdf::*&f1) {
+    static float DevBsdf::*const refl[3] = { &DevBsdf::r, &DevBsdf::g, &DevBsdf::b }, DevBsdf::*const spec[3] = { &DevBsdf::sr, &DevBsdf::sg, &DevBsdf::sb },
+                 DevBsdf::*const eta[3] = { &DevBsdf::er, &DevBsdf::eg, &DevBsdf::eb }, DevBsdf::*const kk[3] = { &DevBsdf::kr, &DevBsdf::kg, &DevBsdf::kb };
+    f1 = nullptr;
+    if (comp < 0 || comp > 2 || b.type >= kBsdfBlend) return false;
+    const bool conductor = b.type == kBsdfConductor || b.type == kBsdfRoughConductor;
+    const bool dielectric = b.type == kBsdfDielectric || b.type == kBsdfRoughDielectric || b.type == kBsdfThinDielectric;
+    switch (kind) {
+    case MTSAMD_PARAM_REFLECTANCE:        // diffuse.reflectance, (rough)plastic.diffuse_reflectance -- constants only
+        if (b.texture >= 0 || !(b.type == kBsdfDiffuse || b.type == kBsdfPlastic || b.type == kBsdfRoughPlastic)) return false;
+        f0 = refl[comp]; return true;
+    case MTSAMD_PARAM_SPECULAR_REFLECTANCE:
+        if (b.type == kBsdfDiffuse) return false;
+        f0 = spec[comp]; return true;
+    case MTSAMD_PARAM_SPECULAR_TRANSMITTANCE:
+        if (!dielectric) return false;
+        f0 = kk[comp]; return true;
+    case MTSAMD_PARAM_ETA: if (!conductor) return false; f0 = eta[comp]; return true;
+    case MTSAMD_PARAM_K: if (!conductor) return false; f0 = kk[comp]; return true;
+    case MTSAMD_PARAM_ALPHA:              // isotropic roughness; roughplastic's alpha also shapes its transmittance tables: not offered
+        if (!(b.type == kBsdfRoughConductor || b.type == kBsdfRoughDielectric) || b.alpha_u != b.alpha_v || comp != 0) return false;
+        f0 = &DevBsdf::alpha_u; f1 = &DevBsdf::alpha_v; return true;
+    default: return false;
+    }
+}
+
+int mtsamd_scene_set_bsdf_param(mtsamd_scene *s, uint32_t bsdf, int32_t kind, const float *value3) {
+    if (!s || !value3 || bsdf >= s->bsdfs.size()) return fail(MTSAMD_ERR_INVALID, "invalid bsdf index");
+    if (s->spectral) return fail(MTSAMD_ERR_UNSUPPORTED, "BSDF parameter updates are implemented for the RGB variant (the spectral records hold model coefficients)");
+    HIP_TRY(hipSetDevice(s->device));
+    DevBsdf &d = s->bsdfs[bsdf];
+    for (int c = 0; c < (kind == MTSAMD_PARAM_ALPHA ? 1 : 3); ++c) {
+        float DevBsdf::*f0, DevBsdf::*f1;
+        if (!bsdf_param_fields(d, kind, c, f0, f1)) return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u (type %d) has no settable parameter of kind %d", bsdf, d.type, kind);
+        d.*f0 = value3[c];
+        if (f1) d.*f1 = value3[c];
+    }
+    if (d.type == kBsdfPlastic || d.type == kBsdfRoughPlastic) {       // parameters_changed(): specular sampling weight (plastic.cpp:170-175)
+        const float d_mean = d.texture >= 0 ? s->textures[d.texture].mean : (d.r + d.g + d.b) * (1.0f / 3.0f), s_mean = (d.sr + d.sg + d.sb) * (1.0f / 3.0f);
+        d.kr = s_mean / (d_mean + s_mean);
+    }
+    HIP_TRY(hipMemcpy(s->d_bsdfs + bsdf, &d, sizeof(DevBsdf), hipMemcpyHostToDevice));
+    return MTSAMD_OK;
+}
+
+int mtsamd_render_adjoint_param(mtsamd_scene *s, const mtsamd_render_desc *d, const float *dimage, const float *film, uint32_t bsdf, int32_t kind,
+                                int32_t component, float h, float *grad1, void *stream_) {
+    AdjointParams a{};
+    if (int rc = fill_adjoint(s, d, dimage, film, a)) return rc;
+    if (!grad1 || bsdf >= s->bsdfs.size()) return fail(MTSAMD_ERR_INVALID, "invalid argument");
+    if (s->nested_bsdfs) return fail(MTSAMD_ERR_UNSUPPORTED, "the parameter adjoint does not handle blendbsdf / mask materials");
+    if (d->integrator != 0) return fail(MTSAMD_ERR_UNSUPPORTED, "the adjoint pass differentiates the path integrator");
+    const DevBsdf &b = s->bsdfs[bsdf];
+    float DevBsdf::*f0, DevBsdf::*f1;
+    if (!bsdf_param_fields(b, kind, component, f0, f1)) return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u (type %d) has no differentiable parameter of kind %d", bsdf, b.type, kind);
+    const float theta = b.*f0;
+    if (!(h > 0.0f)) h = 0.01f * std::max(std::fabs(theta), 0.05f);      // central difference of the model code at fixed directions
+    if ((kind == MTSAMD_PARAM_ALPHA || kind == MTSAMD_PARAM_ETA) && theta - h <= 1e-4f) h = 0.5f * (theta - 1e-4f);
+    if (!(h > 0.0f)) return fail(MTSAMD_ERR_INVALID, "parameter value %g leaves no room for a central difference", theta);
+    a.pg_bsdf = (int32_t) bsdf; a.pg_plus = b; a.pg_minus = b;
+    a.pg_plus.*f0 = theta + h; a.pg_minus.*f0 = theta - h;
+    if (f1) { a.pg_plus.*f1 = theta + h; a.pg_minus.*f1 = theta - h; }
+    a.pg_inv_2h = 1.0f / ((theta + h) - (theta - h));
+    a.grad_param = grad1;
+    a.rp.sv.general = std::max(a.rp.sv.general, 1u);
+    HIP_TRY(launch_adjoint_param(a, (hipStream_t) stream_));
+    return MTSAMD_OK;
+}
+
 int mtsamd_render_adjoint_envmap(mtsamd_scene *s, const mtsamd_render_desc *d, const float *dimage, const float *film, float *grad_envmap,
                                  void *stream_) {
     AdjointParams a{};

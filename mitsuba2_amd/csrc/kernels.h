@@ -121,6 +121,8 @@ struct AdjointParams {
     float *grad_tex;            // all textures concatenated in index order, accumulated (may be null)
     float *grad_emitter;        // n_emitters * 3 (radiance of area lights), accumulated (may be null)
     float *grad_env;            // k_adjoint_env: envmap height * width * 3, accumulated
+    // k_adjoint_param: record `pg_bsdf` of the BSDF table with ONE scalar parameter at +h / -h, 1 / (2 h), and the float the derivative is added to
+    int32_t pg_bsdf; DevBsdf pg_plus, pg_minus; float pg_inv_2h; float *grad_param;
 };
 
 struct RayStreams {
@@ -139,6 +141,7 @@ size_t trace_spill_words(const SceneView &sv, uint32_t n_waves);
 hipError_t launch_direct(const RenderParams &p, uint64_t n, hipStream_t s);
 hipError_t launch_adjoint(const AdjointParams &a, hipStream_t s);
 hipError_t launch_adjoint_env(const AdjointParams &a, hipStream_t s);
+hipError_t launch_adjoint_param(const AdjointParams &a, hipStream_t s);
 // end of a pass: every path of p.in (counts p.count_in) is run to its end in one launch; needs dry sample cursors (kernels.hip, k_finish)
 hipError_t launch_finish(const RenderParams &p, uint64_t alive, hipStream_t s);
 hipError_t launch_mega(const RenderParams &p, hipStream_t s);      // small passes: the whole pass in one launch of persistent lanes

@@ -100,9 +100,21 @@ MTS_DEV void env_grad_add(const DevEnvmap &e, float u, float v, f3 coeff, const 
     }
 }
 
-template <bool FLAT, bool REC = false, int DEFER = 0, bool GENERAL = false, bool ENVGRAD = false, bool NEST = false>
+// PGRAD (k_adjoint_param): derivative of the path's radiance w.r.t. ONE scalar parameter of ONE BSDF record of any model (roughness,
+// complex IOR, reflectances ...), carried forward beside the path as a dual part (dthr = d throughput, dres = d radiance).  Sampling is
+// DETACHED: the replay takes the decisions and directions of the primal path (same PCG32 stream, same parameter value), and
+// differentiates what depends on the parameter for fixed directions -- the BSDF value f(wi, wo) cos in the emitter-sampling term and in
+// the sample weight f cos / pdf (pdf, lobe probabilities, MIS weights and Russian-roulette probabilities are held fixed: any fixed
+// partition of unity keeps the estimator unbiased).  d f / d theta at fixed (wi, wo) is a central difference of the model code itself
+// between two records perturbed by +-h (bp / bm): a smooth closed form at fixed arguments, O(h^2) truncation, no decision can flip.
+// The reference differentiates the attached estimator through Enoki's graph (src/python/python/autodiff.py:6-91); both estimate the same
+// derivative of the image.
+struct ParamGradCtx { int32_t bsdf; DevBsdf bp, bm; float inv_2h; f3 dthr, dres; };
+
+template <bool FLAT, bool REC = false, int DEFER = 0, bool GENERAL = false, bool ENVGRAD = false, bool NEST = false, bool PGRAD = false>
 MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s, Counters &c, VertexRec *rec = nullptr,
-                         Deferred *df = nullptr, const EnvGradCtx *eg = nullptr) {
+                         Deferred *df = nullptr, const EnvGradCtx *eg = nullptr, ParamGradCtx *pg = nullptr) {
+    static_assert(!PGRAD || (GENERAL && DEFER == 0 && !ENVGRAD && !NEST && !REC), "the parameter gradient rides on the general fused step");
     static_assert(!(REC && GENERAL), "the adjoint replay handles diffuse BSDFs only");
     static_assert(!ENVGRAD || (GENERAL && DEFER == 0), "the envmap gradient rides on the general fused step");
     static_assert(!NEST || (GENERAL && DEFER == 0 && !ENVGRAD), "blendbsdf / mask run the general fused step");
@@ -139,6 +151,7 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
             }
             if (si.wi.z > 0.0f) {                           // AreaLight::eval (area.cpp:71-79)
                 s.res.x += (ew * s.thr.x) * e.r; s.res.y += (ew * s.thr.y) * e.g; s.res.z += (ew * s.thr.z) * e.b;
+                if (PGRAD) pg->dres = mk3(pg->dres.x + (ew * pg->dthr.x) * e.r, pg->dres.y + (ew * pg->dthr.y) * e.g, pg->dres.z + (ew * pg->dthr.z) * e.b);
                 if (REC) { rec->E = mk3(ew * e.r, ew * e.g, ew * e.b); rec->ew = ew; rec->em_hit = emitter; }
             }
         }
@@ -149,6 +162,7 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
         if (s.depth > 1u) ew = mis_weight(s.bs_pdf, (GENERAL && (s.flags & kFlagDelta)) ? 0.0f : pdf_environment(sv, e, s.d));
         const f3 le = environment_radiance(sv, e, s.d);
         s.res.x += (ew * s.thr.x) * le.x; s.res.y += (ew * s.thr.y) * le.y; s.res.z += (ew * s.thr.z) * le.z;
+        if (PGRAD) pg->dres = mk3(pg->dres.x + (ew * pg->dthr.x) * le.x, pg->dres.y + (ew * pg->dthr.y) * le.y, pg->dres.z + (ew * pg->dthr.z) * le.z);
         if (ENVGRAD && e.pad0 == kEmitterEnvmap) {
             float u, v;
             env_dir_to_uv(mat3_apply(sv.envmap->to_local, s.d), u, v);
@@ -168,6 +182,7 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
             if (hm * (s.eta * s.eta) < 0.95f) rec->rr_channel = s.thr.x == hm ? 0 : (s.thr.y == hm ? 1 : 2);
         }
         s.thr = s.thr * rq;
+        if (PGRAD) pg->dthr = pg->dthr * rq;
     }
     if (s.depth >= (uint32_t) P.max_depth || !active) return false;
 
@@ -177,6 +192,16 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
     const NestInfo ni = nest_info<NEST>(bsdf, refl.x, refl.y, refl.z);
     auto child_refl = [&](const DevBsdf &rec) { uint32_t t; f2 w; return eval_reflectance(sv, rec, si.uv, t, w); };      // blend / mask children
     const bool smooth = !GENERAL || bsdf_is_smooth(bsdf);
+    // PGRAD: is this the record whose parameter is differentiated?  d(value)/d(theta) of the model at fixed directions
+    const bool pg_here = PGRAD && si.shape_rec.bsdf == pg->bsdf;
+    auto pg_dvalue = [&](f3 wo_l) -> f3 {
+        uint32_t tt; f2 tw;
+        const f3 rp = eval_reflectance(sv, pg->bp, si.uv, tt, tw), rm = eval_reflectance(sv, pg->bm, si.uv, tt, tw);
+        f3 vp, vm; float pp, pm;
+        bsdf_eval_pdf(pg->bp, rp, si.wi, wo_l, vp, pp);      // the model code itself (two-sided adapter included), no nesting
+        bsdf_eval_pdf(pg->bm, rm, si.wi, wo_l, vm, pm);
+        return mk3((vp.x - vm.x) * pg->inv_2h, (vp.y - vm.y) * pg->inv_2h, (vp.z - vm.z) * pg->inv_2h);
+    };
     if (REC) { rec->Tp = s.thr; rec->rho = refl; rec->texel = texel; rec->w1 = tw1; rec->bsdf = si.shape_rec.bsdf; rec->has_bsdf = 1u; }
     // adjoint replay of a `twosided` diffuse BSDF (twosided.cpp:94-175; the primal render of such a scene runs the GENERAL kernels, whose
     // diffuse branch does the same arithmetic): the back side scatters like the front side, mirrored
@@ -229,7 +254,7 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
                     df->smint = kRayEpsilon * (1.0f + hmax_abs(si.p)); df->smaxt = ds.dist * (1.0f - kShadowEpsilon);
                     df->nee[0] = contrib.x; df->nee[1] = contrib.y; df->nee[2] = contrib.z; df->nee[3] = 0.0f;
                 }
-            } else if (contrib.x != 0.0f || contrib.y != 0.0f || contrib.z != 0.0f || ((REC || ENVGRAD) && em_geo != 0.0f)) {
+            } else if (contrib.x != 0.0f || contrib.y != 0.0f || contrib.z != 0.0f || ((REC || ENVGRAD) && em_geo != 0.0f) || pg_here) {
                 Hit sh;
                 ++c.any;
 #if defined(MTS_ABLATE_SHADOW)   // diagnostic build only: wrong image, used to price the any-hit loop in situ
@@ -240,6 +265,13 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
 #endif
                 if (!occluded) {
                     s.res = s.res + contrib;
+                    if (PGRAD) {          // d(mis thr bv spec) with mis and spec fixed
+                        f3 dbv = mk3(0.0f, 0.0f, 0.0f);
+                        if (pg_here) dbv = pg_dvalue(wo);
+                        pg->dres = mk3(pg->dres.x + (mis * fmaf(pg->dthr.x, bv.x, s.thr.x * dbv.x)) * spec.x,
+                                       pg->dres.y + (mis * fmaf(pg->dthr.y, bv.y, s.thr.y * dbv.y)) * spec.y,
+                                       pg->dres.z + (mis * fmaf(pg->dthr.z, bv.z, s.thr.z * dbv.z)) * spec.z);
+                    }
                     if (ENVGRAD && em_geo != 0.0f)
                         env_grad_add(*sv.envmap, ds.uv.x, ds.uv.y, mk3(((mis * s.thr.x) * bv.x) * em_geo, ((mis * s.thr.y) * bv.y) * em_geo,
                                                                          ((mis * s.thr.z) * bv.z) * em_geo), *eg);
@@ -264,6 +296,27 @@ MTS_DEV bool bounce_step(const RenderParams &P, const LdsView &lds, PathState &s
         wo = bs.wo; pdf = bs.pdf;
         s.eta *= bs.eta;                                     // harmless for a failed sample: the path ends below
         s.flags = bs.delta ? (s.flags | kFlagDelta) : (s.flags & ~kFlagDelta);
+        if (PGRAD) {          // d(thr weight) = dthr weight + thr dweight;  dweight = d(value)/d(theta) / pdf at the sampled direction
+            f3 dw = mk3(0.0f, 0.0f, 0.0f);
+            if (pg_here && !bs.delta && bs.pdf > 0.0f) {
+                const f3 dv = pg_dvalue(bs.wo);
+                const float ip = rcp(bs.pdf);
+                dw = mk3(dv.x * ip, dv.y * ip, dv.z * ip);
+            } else if (pg_here && bs.delta) {
+                // a discrete lobe: its weight is a closed form of the parameters (Fresnel term x specular colour / lobe probability);
+                // the same lobe is re-evaluated with the perturbed records and the same random numbers, and counts only if both land on
+                // the very direction of the primal sample (a refracted direction moves with the index of refraction: detached -> no term)
+                uint32_t tt; f2 tw;
+                const f3 rp = eval_reflectance(sv, pg->bp, si.uv, tt, tw), rm = eval_reflectance(sv, pg->bm, si.uv, tt, tw);
+                BsdfSample bp_, bm_; f3 wp, wm;
+                const bool okp = bsdf_sample(pg->bp, rp, si.wi, s1, s2, bp_, wp);
+                const bool okm = bsdf_sample(pg->bm, rm, si.wi, s1, s2, bm_, wm);
+                if (okp && okm && bp_.delta && bm_.delta && bp_.wo.x == bs.wo.x && bp_.wo.y == bs.wo.y && bp_.wo.z == bs.wo.z &&
+                    bm_.wo.x == bs.wo.x && bm_.wo.y == bs.wo.y && bm_.wo.z == bs.wo.z)
+                    dw = mk3((wp.x - wm.x) * pg->inv_2h, (wp.y - wm.y) * pg->inv_2h, (wp.z - wm.z) * pg->inv_2h);
+            }
+            pg->dthr = mk3(fmaf(pg->dthr.x, weight.x, s.thr.x * dw.x), fmaf(pg->dthr.y, weight.y, s.thr.y * dw.y), fmaf(pg->dthr.z, weight.z, s.thr.z * dw.z));
+        }
     } else {
         diffuse_sample(refl, wi_b, s2, wo, pdf, weight);     // eta *= bs.eta (== 1)
         if (flip) wo.z = -wo.z;
@@ -1795,6 +1848,45 @@ hipError_t launch_adjoint_env(const AdjointParams &a, hipStream_t s) {
     if (blocks > 2048) blocks = 2048;
     if (a.rp.sv.flat) hipLaunchKernelGGL(k_adjoint_env<true>, dim3((uint32_t) blocks), dim3(kBlock), bounce_lds_bytes(a.rp.sv), s, a);
     else hipLaunchKernelGGL(k_adjoint_env<false>, dim3((uint32_t) blocks), dim3(kBlock), bounce_lds_bytes(a.rp.sv), s, a);
+    return hipGetLastError();
+}
+
+// d(loss)/d(one scalar BSDF parameter): every camera sample is replayed through the general fused step with the dual part of
+// bounce_step<PGRAD>; its contribution delta . d(radiance)/d(theta) is summed over the workgroup and added to A.grad_param[0].
+template <bool FLAT>
+__global__ __launch_bounds__(kBlock) void k_adjoint_param(const AdjointParams A) {
+    extern __shared__ float4 smem[];
+    __shared__ float s_sum[kBlock / 64];
+    const RenderParams &P = A.rp;
+    const LdsView lds = lds_stage<FLAT>(P.sv, smem);
+    const uint32_t spp = (uint32_t) P.spp;
+    float acc = 0.0f;
+    for (uint64_t k = (uint64_t) blockIdx.x * kBlock + threadIdx.x; k < A.n_samples; k += (uint64_t) gridDim.x * kBlock) {
+        PathState s; float2 pos;
+        generate_path(P, k, (uint32_t) (k / spp), (uint32_t) (k % spp), s, &pos);
+        const f3 delta = adjoint_delta(A, pos);
+        ParamGradCtx pg = { A.pg_bsdf, A.pg_plus, A.pg_minus, A.pg_inv_2h, mk3(0.0f, 0.0f, 0.0f), mk3(0.0f, 0.0f, 0.0f) };
+        Counters c = { 0u, 0u, 0u, 0u };
+        while (bounce_step<FLAT, false, 0, true, false, false, true>(P, lds, s, c, nullptr, nullptr, nullptr, &pg)) { }
+        const float g = fmaf(delta.z, pg.dres.z, fmaf(delta.y, pg.dres.y, delta.x * pg.dres.x));
+        if (isfinite(g)) acc += g;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane_id() == 0u) s_sum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.0f;
+        for (uint32_t w = 0; w < kBlock / 64; ++w) tot += s_sum[w];
+        if (tot != 0.0f) atomicAdd(A.grad_param, tot);
+    }
+}
+
+hipError_t launch_adjoint_param(const AdjointParams &a, hipStream_t s) {
+    if (a.n_samples == 0) return hipSuccess;
+    uint64_t blocks = (a.n_samples + kBlock - 1) / kBlock;
+    if (blocks > 2048) blocks = 2048;
+    if (a.rp.sv.flat) hipLaunchKernelGGL(k_adjoint_param<true>, dim3((uint32_t) blocks), dim3(kBlock), bounce_lds_bytes(a.rp.sv), s, a);
+    else hipLaunchKernelGGL(k_adjoint_param<false>, dim3((uint32_t) blocks), dim3(kBlock), bounce_lds_bytes(a.rp.sv), s, a);
     return hipGetLastError();
 }
 

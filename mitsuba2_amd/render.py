@@ -625,6 +625,12 @@ class Scene:
             if em.get("type", "area") == "envmap":
                 em["data"] = a.reshape(np.asarray(em["data"]).shape).copy()
 
+    def set_bsdf_param(self, index, kind, values):
+        """parameters_changed() after editing a constant parameter of a BSDF record (mtsamd_bsdf_param kinds: 0 (diffuse_)reflectance,
+        1 specular_reflectance, 2 eta, 3 k, 4 alpha, 5 specular_transmittance)"""
+        v = [float(x) for x in values] + [0.0, 0.0]
+        L.check(L.lib().mtsamd_scene_set_bsdf_param(self._handle, int(index), int(kind), (C.c_float * 3)(*v[:3])))
+
     def set_emitter_radiance(self, index, rgb):
         L.check(L.lib().mtsamd_scene_set_emitter_radiance(self._handle, int(index), (C.c_float * 3)(*[float(x) for x in rgb])))
 

@@ -230,6 +230,12 @@ void mo_kat_sample_emitter(const mo_scene *s, const float *ref_p3, const float *
 #ifdef __cplusplus
 }
 #endif
+/* Checker of mtsamd_render_adjoint_param: d(loss)/d(component `comp` of parameter `kind` of the BSDF of the shapes with shape_mask[i] != 0)
+ * (kinds: 0 (diffuse_)reflectance, 1 specular_reflectance, 2 eta, 3 k, 4 alpha, 5 specular_transmittance), forward-mode derivative carried
+ * beside every replayed path, detached sampling, central difference of the model code with step h at fixed directions. */
+int mo_render_adjoint_param(const mo_scene *s, const mo_render_desc *d, const float *dimage, const float *film, const uint8_t *shape_mask,
+                            int kind, int comp, float h, double *grad);
+
 /* mo_libm.h on argument arrays (fn: 0 sin, 1 cos, 2 tan, 3 exp, 4 log, 5 erf, 6 acos, 7 atan2(x[i], y[i])); the counterpart of
  * mtsamd_libm_eval, so that a test can compare host and device bit for bit */
 void mo_libm_eval(int fn, uint64_t n, const float *x, const float *y, float *out);

@@ -416,8 +416,34 @@ static void env_grad_add(const mo_envmap *env, float u, float v, const float coe
     for (int i = 0; i < 4; ++i)
         for (int k = 0; k < 3; ++k) eg->grad[3 * (size_t) idx[i] + k] += (eg->delta[k] * coeff[k]) * w[i];
 }
+/* pg != NULL: forward-mode derivative of the radiance w.r.t. ONE scalar parameter (kind, comp) of the BSDF of the masked shapes, carried
+ * beside the path with DETACHED sampling -- the checker of mtsamd_render_adjoint_param (kernels.hip, bounce_step<PGRAD>): the same terms
+ * in the same order; d(value)/d(theta) at fixed directions = central difference of the model code between records perturbed by +-h */
+typedef struct { const uint8_t *shape_mask; int kind, comp; float h; float dthr[3], dres[3]; } param_grad;
+static void bsdf_perturbed(const mo_bsdf *b, const float refl[3], int kind, int comp, float step, mo_bsdf *out, float refl_out[3]) {
+    *out = *b;
+    for (int k = 0; k < 3; ++k) refl_out[k] = refl[k];
+    switch (kind) {
+    case 0: refl_out[comp] = refl[comp] + step; out->d.reflectance[comp] = refl_out[comp]; break;
+    case 1: out->d.specular_reflectance[comp] += step; break;
+    case 2: out->d.eta[comp] += step; break;
+    case 3: out->d.k[comp] += step; break;
+    case 4: out->d.alpha_u += step; out->d.alpha_v += step; break;
+    default: out->d.specular_transmittance[comp] += step; break;
+    }
+}
+static float param_value(const mo_bsdf *b, const float refl[3], int kind, int comp) {
+    switch (kind) {
+    case 0: return refl[comp];
+    case 1: return b->d.specular_reflectance[comp];
+    case 2: return b->d.eta[comp];
+    case 3: return b->d.k[comp];
+    case 4: return b->d.alpha_u;
+    default: return b->d.specular_transmittance[comp];
+    }
+}
 static void path_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, int max_depth,
-                        int rr_depth, float result[3], int *valid_ray, ray_stats *st, const env_grad *eg) {
+                        int rr_depth, float result[3], int *valid_ray, ray_stats *st, const env_grad *eg, param_grad *pg) {
     mo_ray ray = *ray_in;
     float eta = 1.0f, emission_weight = 1.0f;
     float throughput[3] = { 1.0f, 1.0f, 1.0f };
@@ -438,6 +464,7 @@ static void path_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, 
                 const float *le = s->emitters[emitter].radiance;
                 if (s->emitters[emitter].type == 2) { mo_envmap_eval(s->emitters[emitter].env, mo_neg(si.wi), le_env); le = le_env; }
                 for (int k = 0; k < 3; ++k) result[k] += (emission_weight * throughput[k]) * le[k];
+                if (pg) for (int k = 0; k < 3; ++k) pg->dres[k] = pg->dres[k] + (emission_weight * pg->dthr[k]) * le[k];
                 if (eg && s->emitters[emitter].type == 2) {
                     float u, v, coeff[3];
                     mo_envmap_dir_to_uv(s->emitters[emitter].env, mo_neg(si.wi), &u, &v);
@@ -454,6 +481,7 @@ static void path_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, 
             if (active) active = mo_pcg32_next_f32(rng) < q;
             float rq = mo_rcp(q);
             for (int k = 0; k < 3; ++k) throughput[k] *= rq;
+            if (pg) for (int k = 0; k < 3; ++k) pg->dthr[k] *= rq;
         }
 
         if ((uint32_t) depth >= (uint32_t) max_depth || !active) break;
@@ -463,6 +491,14 @@ static void path_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, 
         const mo_bsdf *bsdf = &mesh->bsdf;
         float refl[9];
         mo_surface_reflectance(s, mesh, si.uv, refl);
+        const int pg_here = pg && pg->shape_mask[si.shape];
+        mo_bsdf b_p, b_m; float refl_p[3], refl_m[3], inv_2h = 0.0f;
+        if (pg_here) {
+            const float theta = param_value(bsdf, refl, pg->kind, pg->comp);
+            bsdf_perturbed(bsdf, refl, pg->kind, pg->comp, (theta + pg->h) - theta, &b_p, refl_p);
+            bsdf_perturbed(bsdf, refl, pg->kind, pg->comp, (theta - pg->h) - theta, &b_m, refl_m);
+            inv_2h = 1.0f / ((theta + pg->h) - (theta - pg->h));
+        }
         if (mo_bsdf_is_smooth(bsdf)) {   /* active_e = active && has_flag(bsdf->flags(), BSDFFlags::Smooth) (path.cpp:154) */
             mo_v2 s2; s2.x = mo_pcg32_next_f32(rng); s2.y = mo_pcg32_next_f32(rng);
             mo_dsample ds; float emitter_val[3];
@@ -484,6 +520,17 @@ static void path_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, 
                 float mis = ds.delta ? 1.0f : mis_weight(ds.pdf, bsdf_pdf);      /* path.cpp:170 */
                 for (int k = 0; k < 3; ++k)
                     result[k] += ((mis * throughput[k]) * bsdf_val[k]) * emitter_val[k];
+                if (pg && !occluded) {
+                    float dbv[3] = { 0.0f, 0.0f, 0.0f };
+                    if (pg_here) {
+                        float vp[3], vm[3], pp, pm;
+                        mo_bsdf_eval_pdf(&b_p, refl_p, si.wi, wo, vp, &pp);
+                        mo_bsdf_eval_pdf(&b_m, refl_m, si.wi, wo, vm, &pm);
+                        for (int k = 0; k < 3; ++k) dbv[k] = (vp[k] - vm[k]) * inv_2h;
+                    }
+                    for (int k = 0; k < 3; ++k)
+                        pg->dres[k] = pg->dres[k] + (mis * fmaf(pg->dthr[k], bsdf_val[k], throughput[k] * dbv[k])) * emitter_val[k];
+                }
                 if (eg && !occluded && s->emitters[ds.emitter].type == 2) {
                     /* emitter_val = lookup(uv) / pdf_single * emitter count (envmap.cpp:186-189, scene.cpp:160-163) */
                     float g = mo_rcp(ds.pdf_single) * (s->n_emitters > 1 ? (float) s->n_emitters : 1.0f), coeff[3];
@@ -498,6 +545,23 @@ static void path_sample(const mo_scene *s, mo_pcg32 *rng, const mo_ray *ray_in, 
         mo_v2 s2; s2.x = mo_pcg32_next_f32(rng); s2.y = mo_pcg32_next_f32(rng);
         mo_bsample bs; float bsdf_w[3];
         mo_bsdf_sample(bsdf, refl, si.wi, s1, s2, &bs, bsdf_w);
+        if (pg) {
+            float dw[3] = { 0.0f, 0.0f, 0.0f };
+            if (pg_here && !bs.delta && bs.pdf > 0.0f) {
+                float vp[3], vm[3], pp, pm;
+                mo_bsdf_eval_pdf(&b_p, refl_p, si.wi, bs.wo, vp, &pp);
+                mo_bsdf_eval_pdf(&b_m, refl_m, si.wi, bs.wo, vm, &pm);
+                const float ip = mo_rcp(bs.pdf);
+                for (int k = 0; k < 3; ++k) dw[k] = ((vp[k] - vm[k]) * inv_2h) * ip;
+            } else if (pg_here && bs.delta) {
+                mo_bsample bp_, bm_; float wp[3], wm[3];
+                const int okp = mo_bsdf_sample(&b_p, refl_p, si.wi, s1, s2, &bp_, wp), okm = mo_bsdf_sample(&b_m, refl_m, si.wi, s1, s2, &bm_, wm);
+                if (okp && okm && bp_.delta && bm_.delta && bp_.wo.x == bs.wo.x && bp_.wo.y == bs.wo.y && bp_.wo.z == bs.wo.z &&
+                    bm_.wo.x == bs.wo.x && bm_.wo.y == bs.wo.y && bm_.wo.z == bs.wo.z)
+                    for (int k = 0; k < 3; ++k) dw[k] = (wp[k] - wm[k]) * inv_2h;
+            }
+            for (int k = 0; k < 3; ++k) pg->dthr[k] = fmaf(pg->dthr[k], bsdf_w[k], throughput[k] * dw[k]);
+        }
         for (int k = 0; k < 3; ++k) throughput[k] = throughput[k] * bsdf_w[k];
         active = active && (throughput[0] != 0.0f || throughput[1] != 0.0f || throughput[2] != 0.0f);
         if (!active) break;
@@ -976,7 +1040,7 @@ static void render_sample(const mo_scene *s, const mo_render_desc *d, const came
     } else {
     if (d->integrator == 1) direct_sample(s, rng, &ray, d->emitter_samples, d->bsdf_samples, d->hide_emitters, L, &valid, st);
     else if (d->integrator == 2) depth_sample(s, &ray, L, &valid, st);
-    else path_sample(s, rng, &ray, d->max_depth, d->rr_depth, L, &valid, st, NULL);
+    else path_sample(s, rng, &ray, d->max_depth, d->rr_depth, L, &valid, st, NULL, NULL);
     /* ray_weight == 1 in RGB mode (spectrum.h:304-309) */
     srgb_to_xyz(L, xyz);
     }
@@ -1516,8 +1580,32 @@ int mo_render_adjoint_envmap(const mo_scene *s, const mo_render_desc *d, const f
         adjoint_sample(d, &cam, &f, taps, i, dimage, film, &rng, &ray, delta);
         env_grad eg = { delta, grad_env };
         int valid;
-        path_sample(s, &rng, &ray, d->max_depth, d->rr_depth, L, &valid, &st, &eg);
+        path_sample(s, &rng, &ray, d->max_depth, d->rr_depth, L, &valid, &st, &eg, NULL);
     }
+    return 0;
+}
+
+/* the checker of mtsamd_render_adjoint_param: d(loss)/d(one scalar BSDF parameter), summed over every camera sample (double sum) */
+int mo_render_adjoint_param(const mo_scene *s, const mo_render_desc *d, const float *dimage, const float *film, const uint8_t *shape_mask,
+                            int kind, int comp, float h, double *grad) {
+    if (desc_check(d) || !grad || !shape_mask || s->spectral || !(h > 0.0f) || kind < 0 || kind > 5 || comp < 0 || comp > 2) return -1;
+    camera cam; camera_init(d, &cam);
+    rfilter f; rfilter_init(&f, d->rfilter, d->rfilter_param, d->rfilter_param2);
+    uint32_t taps = (uint32_t) ceilf((f.radius - 2.0f * MO_RAY_EPSILON) * 2.0f);
+    uint64_t total = (uint64_t) d->crop_w * d->crop_h * (uint64_t) d->spp;
+    double sum = 0.0;
+#pragma omp parallel for schedule(dynamic, 256) reduction(+ : sum)
+    for (int64_t i = 0; i < (int64_t) total; ++i) {
+        mo_pcg32 rng; mo_ray ray; float delta[3], L[3];
+        ray_stats st = { 0, 0 };
+        adjoint_sample(d, &cam, &f, taps, (uint64_t) i, dimage, film, &rng, &ray, delta);
+        param_grad pg = { shape_mask, kind, comp, h, { 0.0f, 0.0f, 0.0f }, { 0.0f, 0.0f, 0.0f } };
+        int valid;
+        path_sample(s, &rng, &ray, d->max_depth, d->rr_depth, L, &valid, &st, NULL, &pg);
+        const float g = fmaf(delta[2], pg.dres[2], fmaf(delta[1], pg.dres[1], delta[0] * pg.dres[0]));
+        if (isfinite(g)) sum += (double) g;
+    }
+    *grad = sum;
     return 0;
 }
 

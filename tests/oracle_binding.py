@@ -85,6 +85,7 @@ def lib():
         L.mo_render_window.argtypes = [vp, C.POINTER(RenderDesc), C.c_int, C.c_int, C.c_int, C.c_int, vp]
         L.mo_film_develop.argtypes = [vp, C.c_uint64, vp]
         L.mo_libm_eval.argtypes = [C.c_int, C.c_uint64, vp, vp, vp]
+        L.mo_render_adjoint_param.argtypes = [vp, C.POINTER(RenderDesc), vp, vp, vp, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_double)]
         L.mo_libm_eval.restype = None
         L.mo_render_adjoint.argtypes = [vp, C.POINTER(RenderDesc), vp, vp, vp, vp, vp]
         L.mo_scene_set_emitter_radiance.argtypes = [vp, C.c_uint32, vp]
@@ -151,6 +152,7 @@ class OracleScene:
     def __init__(self, scene_dict, naive=False, spectral_path=None):
         L = lib()
         self.h = C.c_void_p(L.mo_scene_new())
+        self.sd = scene_dict
         self.tex_of_bsdf = {}
         self.tex_of_child = {}                                # (bsdf, child) -> texture of a blendbsdf / mask child
         from mitsuba2_amd import bsdfs as B
@@ -327,6 +329,18 @@ class OracleScene:
         if n_emitters is not None:
             return gs, gt[:tex_floats], ge[:n_emitters]
         return gs, gt[:tex_floats]
+
+    def render_adjoint_param(self, desc, dimage, film, shapes, kind, comp, h):
+        """d(loss)/d(one scalar BSDF parameter of the given shapes): forward-mode replay with detached sampling (checker of
+        mtsamd_render_adjoint_param)"""
+        dimage = _f(dimage); film = _f(film)
+        mask = np.zeros(len(self.sd["meshes"]), np.uint8)
+        mask[list(shapes)] = 1
+        g = C.c_double(0.0)
+        rc = lib().mo_render_adjoint_param(self.h, C.byref(desc), _p(dimage), _p(film), mask.ctypes.data_as(C.c_void_p), int(kind), int(comp), float(h), C.byref(g))
+        if rc != 0:
+            raise RuntimeError("oracle parameter adjoint failed (%d)" % rc)
+        return g.value
 
     def render_adjoint_envmap(self, desc, dimage, film, shape):
         """gradient w.r.t. the texels of the envmap emitter (`shape` = (h, w, 3))"""

@@ -215,7 +215,10 @@ def test_envmap_autograd_and_inversion(gpu):
     from mitsuba2_amd import autodiff
     sd, img, p, scene = _envmap_scene(gpu, 48, 40, 8, 4, False, "gaussian")
     params = autodiff.traverse(scene)
-    assert set(params.keys()) == {"my_envmap.data"}               # glossy / glass BSDFs: no reflectance gradients in this scene
+    # the envmap texels + (round 3) the constant parameters of the scene's BSDF models
+    assert "my_envmap.data" in params and all(k.split(".")[-2] in ("reflectance", "diffuse_reflectance", "specular_reflectance", "specular_transmittance",
+                                                                   "eta", "k", "alpha", "my_envmap") for k in params.keys())
+    params.keep(["my_envmap.data"])
     param_ref = params["my_envmap.data"].clone()
     assert param_ref.shape == (6, 10, 3)
     # central differences through the autograd function (distribution held fixed: the image is linear in the texels)
@@ -296,3 +299,115 @@ def test_twosided_diffuse_adjoint_matches_oracle(gpu, oracle):
     with pytest.raises(RuntimeError, match="diffuse BSDFs"):
         L.check(L.lib().mtsamd_render_adjoint(scene2._handle, C.byref(d), C.c_void_p(di.data_ptr()), C.c_void_p(film.data_ptr()),
                                               C.c_void_p(g_bsdf.data_ptr()), None, None, None))
+
+
+def _material_scene(gpu, materials, w=48, h=48, spp=64, max_depth=5, seed=13):
+    """Cornell box whose tall / short boxes carry the given BSDF dictionaries (ids 'tall' / 'small'), floor two-sided diffuse"""
+    sd = scenes.cornell_box()
+    sd["bsdfs"] = list(sd["bsdfs"]) + [dict(materials[0], id="tall"), dict(materials[1], id="small")]
+    sd["meshes"][6] = dict(sd["meshes"][6], bsdf=len(sd["bsdfs"]) - 2)
+    sd["meshes"][7] = dict(sd["meshes"][7], bsdf=len(sd["bsdfs"]) - 1)
+    p = scenes.cornell_box_sensor(w, h, spp, seed=seed, max_depth=max_depth, rfilter="box")
+    scene = gpu.Scene(sd, sensor=gpu.make_sensor(p), integrator=gpu.PathIntegrator(max_depth=max_depth))
+    return sd, p, scene
+
+
+def _loss_and_grad(autodiff, scene, params, key, weights, spp):
+    """loss = <weights, image> of one differentiable render with a FIXED seed (the call counter is reset), d loss / d params[key]"""
+    autodiff._render_counter[id(scene)] = 0
+    params[key].requires_grad_(True)
+    img = autodiff.render(scene, params=params, spp=spp)
+    loss = (img * weights).sum()
+    loss.backward()
+    g = params[key].grad.clone()
+    params[key].grad = None
+    params[key].requires_grad_(False)
+    return float(loss.item()), g
+
+
+def _loss_only(autodiff, scene, params, key, value, weights, spp):
+    autodiff._render_counter[id(scene)] = 0
+    params[key] = value
+    params.update()
+    with torch.no_grad():
+        return float((autodiff.render(scene, params=params, spp=spp) * weights).sum().item())
+
+
+def test_bsdf_parameter_gradients(gpu):
+    """a21 beyond diffuse reflectances (round 3): d(image)/d(parameter) for the parameters the reference's traverse() exposes of the f-2
+    models (roughconductor.cpp:393-404: alpha, eta, k, specular_reflectance; plastic.cpp:299-307: diffuse_reflectance, ...), through
+    mtsamd_render_adjoint_param: a forward-mode derivative carried beside every replayed path, detached sampling.  Checked against central
+    finite differences of the primal render with common random numbers: exact for parameters the sampled directions do not depend on
+    (a smooth conductor's specular_reflectance: the image is a polynomial in it), statistical for the others (the finite difference
+    moves the sampled directions with the parameter -- the reference's attached estimator -- the adjoint holds them fixed; both
+    estimate the same derivative)."""
+    from mitsuba2_amd import autodiff
+    torch.manual_seed(3)
+    mats = ({"type": "roughconductor", "alpha": 0.3, "distribution": "ggx", "eta": [0.2, 0.92, 1.1], "k": [3.9, 2.45, 2.14], "specular_reflectance": [0.9, 0.8, 0.7]},
+            {"type": "plastic", "diffuse_reflectance": [0.2, 0.5, 0.3], "int_ior": 1.6})
+    sd, p, scene = _material_scene(gpu, mats)
+    params = autodiff.traverse(scene)
+    for k in ("tall.alpha.value", "tall.eta.value", "tall.k.value", "tall.specular_reflectance.value", "small.diffuse_reflectance.value",
+              "small.specular_reflectance.value"):
+        assert k in params, (k, list(params.keys()))
+    n_pix = 48 * 48
+    weights = torch.ones(n_pix * 3, device="cuda") / n_pix                      # loss = mean radiance per channel, summed
+    spp = 64
+    for key, steps in (("tall.alpha.value", 0.03), ("small.diffuse_reflectance.value", 0.03), ("tall.k.value", 0.15), ("tall.specular_reflectance.value", 0.03)):
+        params.keep([key]) if False else None
+        base = params[key].detach().clone()
+        _, g = _loss_and_grad(autodiff, scene, params, key, weights, spp)
+        assert torch.isfinite(g).all() and float(g.abs().max()) > 0
+        for c in range(base.numel()):
+            vp, vm = base.clone(), base.clone()
+            vp.view(-1)[c] += steps; vm.view(-1)[c] -= steps
+            fd = (_loss_only(autodiff, scene, params, key, vp, weights, spp) - _loss_only(autodiff, scene, params, key, vm, weights, spp)) / (2 * steps)
+            got = float(g.view(-1)[c])
+            assert abs(got - fd) < 0.2 * abs(fd) + 2e-4, (key, c, got, fd)
+        params[key] = base
+        params.update()
+    # a smooth conductor: sampled directions do not depend on the parameter, the image is a polynomial in it -> tight agreement
+    mats2 = ({"type": "conductor", "eta": [0.2, 0.92, 1.1], "k": [3.9, 2.45, 2.14], "specular_reflectance": [0.8, 0.7, 0.6]}, {"type": "diffuse", "reflectance": [0.5, 0.5, 0.5]})
+    sd2, p2, scene2 = _material_scene(gpu, mats2, spp=16)
+    params2 = autodiff.traverse(scene2)
+    key = "tall.specular_reflectance.value"
+    base = params2[key].detach().clone()
+    _, g = _loss_and_grad(autodiff, scene2, params2, key, weights, 16)
+    for c in range(3):
+        vp, vm = base.clone(), base.clone()
+        vp[c] += 0.02; vm[c] -= 0.02
+        fd = (_loss_only(autodiff, scene2, params2, key, vp, weights, 16) - _loss_only(autodiff, scene2, params2, key, vm, weights, 16)) / 0.04
+        assert abs(float(g[c]) - fd) < 1e-2 * abs(fd) + 1e-5, (c, float(g[c]), fd)
+
+
+@pytest.mark.parametrize("key,kind,step", [("tall.alpha.value", 4, 0.003), ("tall.k.value", 3, 0.03), ("tall.specular_reflectance.value", 1, 0.01),
+                                           ("small.diffuse_reflectance.value", 0, 0.005)])
+def test_bsdf_parameter_adjoint_matches_oracle(gpu, oracle, key, kind, step):
+    """mtsamd_render_adjoint_param against the oracle's restatement of the same forward-mode replay (mo_render_adjoint_param: the same
+    terms in the same order, the same central difference of the model code): every sample takes the same path on both sides
+    (bit-identical primal, section 2), so the two sums agree to the accumulated rounding of 1.5e5 fp32 terms"""
+    import ctypes as C
+    from mitsuba2_amd import autodiff, _lib as L
+    mats = ({"type": "roughconductor", "alpha": 0.3, "distribution": "ggx", "eta": [0.2, 0.92, 1.1], "k": [3.9, 2.45, 2.14], "specular_reflectance": [0.9, 0.8, 0.7]},
+            {"type": "plastic", "diffuse_reflectance": [0.2, 0.5, 0.3], "int_ior": 1.6})
+    sd, p, scene = _material_scene(gpu, mats, w=40, h=32, spp=16, max_depth=5)
+    sensor = gpu.make_sensor(p)
+    d = autodiff._desc(scene, sensor, gpu.PathIntegrator(max_depth=5), 16, 77)
+    film = autodiff._render_film(scene, d)
+    rng = np.random.RandomState(4)
+    dimage = rng.uniform(-1.0, 1.0, (32, 40, 3)).astype(np.float32)
+    di = torch.from_numpy(dimage).cuda()
+    bsdf_index = len(sd["bsdfs"]) - (2 if key.startswith("tall") else 1)
+    shapes = [i for i, m in enumerate(sd["meshes"]) if m["bsdf"] == bsdf_index]
+    S = oracle.OracleScene(sd)
+    desc = oracle.make_desc(dict(p, seed=77), analytic=True, film_rgb=True)
+    _, film_o = S.render_image(desc)
+    assert np.allclose(film.cpu().numpy(), film_o, rtol=2e-5, atol=1e-6)
+    for comp in range(1 if kind == 4 else 3):
+        g = torch.zeros(1, device="cuda")
+        L.check(L.lib().mtsamd_render_adjoint_param(scene._handle, C.byref(d), C.c_void_p(di.data_ptr()), C.c_void_p(film.data_ptr()), bsdf_index, kind, comp,
+                                                    step, C.c_void_p(g.data_ptr()), None))
+        torch.cuda.synchronize()
+        want = S.render_adjoint_param(desc, dimage, film_o, shapes, kind, comp, step)
+        assert abs(want) > 1e-3
+        assert abs(float(g.item()) - want) < 2e-3 * abs(want) + 1e-5, (key, comp, float(g.item()), want)
