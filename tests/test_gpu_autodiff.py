@@ -411,3 +411,27 @@ def test_bsdf_parameter_adjoint_matches_oracle(gpu, oracle, key, kind, step):
         want = S.render_adjoint_param(desc, dimage, film_o, shapes, kind, comp, step)
         assert abs(want) > 1e-3
         assert abs(float(g.item()) - want) < 2e-3 * abs(want) + 1e-5, (key, comp, float(g.item()), want)
+
+
+def test_invert_roughness(gpu):
+    """the loop of invert_cbox.py on a parameter of a microfacet model: the GGX roughness of the tall box is recovered from a wrong start
+    (roughconductor.cpp:393-404 exposes `alpha`)"""
+    from mitsuba2_amd import autodiff
+    mats = ({"type": "roughconductor", "alpha": 0.15, "distribution": "ggx", "eta": [0.2, 0.92, 1.1], "k": [3.9, 2.45, 2.14]},
+            {"type": "diffuse", "reflectance": [0.5, 0.5, 0.5]})
+    sd, p, scene = _material_scene(gpu, mats, w=64, h=64, spp=16, max_depth=4, seed=21)
+    params = autodiff.traverse(scene)
+    key = "tall.alpha.value"
+    params.keep([key])
+    image_ref = autodiff.render(scene, spp=128).detach()
+    params[key] = [0.45]
+    params.update()
+    opt = autodiff.Adam(params, lr=0.02)
+    for it in range(80):
+        image = autodiff.render(scene, optimizer=opt, unbiased=True, spp=16)
+        (((image - image_ref) ** 2).sum() / image.numel()).backward()
+        opt.step()
+        with torch.no_grad():          # the parameter's domain (microfacet.h:187-200 clamps alpha to >= 1e-4 anyway)
+            params[key] = params[key].detach().clamp(0.02, 1.0)
+            params[key].requires_grad_(True)
+    assert abs(float(params[key].item()) - 0.15) < 0.05, float(params[key].item())
