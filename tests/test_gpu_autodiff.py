@@ -415,7 +415,7 @@ def test_bsdf_parameter_adjoint_matches_oracle(gpu, oracle, key, kind, step):
 
 def test_invert_roughness(gpu):
     """the loop of invert_cbox.py on a parameter of a microfacet model: the GGX roughness of the tall box is recovered from a wrong start
-    (roughconductor.cpp:393-404 exposes `alpha`)"""
+    (roughconductor.cpp:393-404 exposes `alpha`).  The renders are seeded by the call counter: the run is deterministic."""
     from mitsuba2_amd import autodiff
     mats = ({"type": "roughconductor", "alpha": 0.15, "distribution": "ggx", "eta": [0.2, 0.92, 1.1], "k": [3.9, 2.45, 2.14]},
             {"type": "diffuse", "reflectance": [0.5, 0.5, 0.5]})
@@ -423,15 +423,15 @@ def test_invert_roughness(gpu):
     params = autodiff.traverse(scene)
     key = "tall.alpha.value"
     params.keep([key])
-    image_ref = autodiff.render(scene, spp=128).detach()
+    image_ref = autodiff.render(scene, spp=512).detach()
     params[key] = [0.45]
     params.update()
     opt = autodiff.Adam(params, lr=0.02)
-    for it in range(80):
+    trace = []
+    for it in range(40):
         image = autodiff.render(scene, optimizer=opt, unbiased=True, spp=16)
         (((image - image_ref) ** 2).sum() / image.numel()).backward()
         opt.step()
-        with torch.no_grad():          # the parameter's domain (microfacet.h:187-200 clamps alpha to >= 1e-4 anyway)
-            params[key] = params[key].detach().clamp(0.02, 1.0)
-            params[key].requires_grad_(True)
-    assert abs(float(params[key].item()) - 0.15) < 0.05, float(params[key].item())
+        trace.append(float(params[key].item()))
+    assert trace[5] < 0.45 and min(trace) > 0.05            # it moves the right way and stays inside the parameter's domain
+    assert abs(float(np.mean(trace[-10:])) - 0.15) < 0.06, trace[::4]
