@@ -194,3 +194,40 @@ def test_oracle_adjoint_twosided_diffuse(oracle):
     gl = scenes.cornell_box(); gl["bsdfs"] = list(gl["bsdfs"]); gl["bsdfs"][1] = {"type": "conductor"}
     with pytest.raises(RuntimeError, match="adjoint failed"):
         oracle.OracleScene(gl, naive=True).render_adjoint(desc, dimage, film, len(gl["meshes"]), 0)
+
+
+def test_oracle_parameter_adjoint_matches_finite_differences(oracle):
+    """mo_render_adjoint_param (the checker of mtsamd_render_adjoint_param: forward-mode derivative carried beside the replayed path,
+    detached sampling) against central differences of the oracle's own render with identical seeds, for parameters the sampled directions
+    do not depend on -- there the detached and the attached estimator coincide sample by sample: the complex IOR and the specular
+    reflectance of a rough conductor, and a diffuse reflectance in the same (general) scene."""
+    sd = scenes.cornell_box()
+    rough = {"type": "roughconductor", "alpha": 0.3, "distribution": "ggx", "eta": [0.2, 0.92, 1.1], "k": [3.9, 2.45, 2.14], "specular_reflectance": [0.9, 0.8, 0.7]}
+    sd["bsdfs"] = list(sd["bsdfs"]) + [rough]
+    sd["meshes"][6] = dict(sd["meshes"][6], bsdf=len(sd["bsdfs"]) - 1)
+    p = scenes.cornell_box_sensor(16, 12, 8, seed=9, max_depth=4, rfilter="box")
+    desc = oracle.make_desc(p, analytic=True, film_rgb=True)
+    rng = np.random.RandomState(3)
+    dimage = rng.uniform(0.2, 1.0, (12, 16, 3)).astype(np.float32)
+    loss = lambda img: float(np.sum(img.astype(np.float64) * dimage))
+
+    def render_loss(bsdfs):
+        S = oracle.OracleScene(dict(sd, bsdfs=bsdfs))
+        return loss(S.render_image(desc)[0])
+
+    S0 = oracle.OracleScene(sd)
+    image, film = S0.render_image(desc)
+    tall = [i for i, m in enumerate(sd["meshes"]) if m["bsdf"] == len(sd["bsdfs"]) - 1]
+    white = [i for i, m in enumerate(sd["meshes"]) if m["bsdf"] == 0]
+    for shapes, bsdf_index, name, kind, comp, eps in ((tall, len(sd["bsdfs"]) - 1, "k", 3, 1, 0.05), (tall, len(sd["bsdfs"]) - 1, "eta", 2, 0, 0.02),
+                                                      (tall, len(sd["bsdfs"]) - 1, "specular_reflectance", 1, 2, 0.02), (white, 0, "reflectance", 0, 1, 0.01)):
+        g = S0.render_adjoint_param(desc, dimage, film, shapes, kind, comp, 0.01 * max(abs(sd["bsdfs"][bsdf_index][name][comp]), 0.05))
+        lp_lm = []
+        for sign in (+1.0, -1.0):
+            bs = [dict(b) for b in sd["bsdfs"]]
+            v = np.array(bs[bsdf_index][name], np.float32).copy()
+            v[comp] += sign * eps
+            bs[bsdf_index][name] = v
+            lp_lm.append(render_loss(bs))
+        fd = (lp_lm[0] - lp_lm[1]) / (2 * eps)
+        assert abs(fd) > 1e-4 and abs(g - fd) <= 1e-2 * abs(fd) + 1e-5, (name, comp, g, fd)
