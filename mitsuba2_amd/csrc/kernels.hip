@@ -2023,9 +2023,26 @@ MTS_DEV float2 film_load(const float2 *p) {
 }
 #define MTS_FILM_LOAD(p) film_load(p)
 constexpr int kFilmPrefetch = MTS_FILM_PREFETCH;     // samples in flight per thread (x 24 B)
+// DMA (round 3): the stream is staged through LDS by wave-cooperative loads.  Per-lane loads of the pixel-major stream touch one 128-byte
+// line per lane and use 16 bytes of it at a time; the rest has to survive in a 32 KB L1 that 512 lanes share until the lane comes back
+// for it, and the bytes a thread can keep in flight are bounded by its registers (125 accumulators leave room for two samples).  Now
+// eight adjacent lanes fetch the 8 x 16 bytes of one pixel's line (rgba: 8 samples; positions: 4 lanes x 16 bytes) with
+// global_load_lds_dwordx4 -- the data lands in LDS without passing through registers, every line is requested once, by one instruction,
+// and used whole -- and after a barrier every thread consumes the 8 samples of its own pixel from LDS (rotated start: conflict-free
+// ds_read_b128).  Taken when the runs are whole groups of 8 samples; the per-lane loop stays for the rest.
+#ifndef MTS_FILM_DMA
+#define MTS_FILM_DMA 1
+#endif
+constexpr int kFilmRound = 8;                        // samples of a pixel per staging round: one 128-byte line of rgba
+typedef __attribute__((address_space(3))) void film_lds_void;
+typedef __attribute__((address_space(1))) const void film_glb_void;
+template <bool DMA>
 __global__ __launch_bounds__(kBlock) void k_film_accum(const FilmParams F) {
     __shared__ float table[32];
-    __shared__ float E[kFilmTile * kFilmTile * (kFilmTaps * 5 + 1)];      // one tap row of every source pixel: [pixel][kx][channel], padded
+    // staging: rgba [pixel][8] float4 (32 KB) + positions [pixel][8] float2 (16 KB); the exchange buffer E of the epilogue aliases it
+    __shared__ float4 stage[DMA ? kBlock * kFilmRound * 3 / 2 : (kFilmTile * kFilmTile * (kFilmTaps * 5 + 1) + 3) / 4];
+    float *E = reinterpret_cast<float *>(stage);         // one tap row of every source pixel: [pixel][kx][channel], padded
+    static_assert(kBlock * kFilmRound * 3 / 2 * 16 >= kFilmTile * kFilmTile * (kFilmTaps * 5 + 1) * 4, "the exchange buffer fits the staging area");
     const FilterView &f = F.filter;
     const int b = f.border, R = (int) ceilf(f.radius), DW = kFilmTile + 2 * R;
     if (threadIdx.x < 32) table[threadIdx.x] = f.table[threadIdx.x];
@@ -2048,9 +2065,67 @@ __global__ __launch_bounds__(kBlock) void k_film_accum(const FilmParams F) {
 #pragma unroll
             for (int c = 0; c < 5; ++c) acc[ky][kx][c] = 0.0f;
     float4 pv[kFilmPrefetch]; float2 pq[kFilmPrefetch];
-    // blockIdx.y: which run of the pixel's samples (runs start on multiples of 4: whole 64-byte sectors)
-    const int run = ((F.spp + F.slices - 1) / F.slices + 3) & ~3;
+    // blockIdx.y: which run of the pixel's samples (runs start on multiples of 8: whole 128-byte lines)
+    const int run = ((F.spp + F.slices - 1) / F.slices + 7) & ~7;
     const int s_begin = min((int) blockIdx.y * run, F.spp), n_spp = have ? min(s_begin + run, F.spp) : s_begin;
+    auto accumulate = [&](const float4 rec, const float2 rp) {
+        if (!(rec.w >= 0.0f)) return;                        // (X, Y, Z, alpha); alpha < 0: invalid or absent sample
+        float wxs[kFilmTaps], wys[kFilmTaps];
+        axis_taps(f, table, rp.x - offx, sx, tap_x0, R, wxs);
+        axis_taps(f, table, rp.y - offy, sy, tap_y0, R, wys);
+        // a zero weight adds (signed) zeros, which leaves the sums as they are: the film equals the one of a loop over the non-zero
+        // taps only (imageblock.cpp:148-161)
+#pragma unroll
+        for (int ky = 0; ky < kFilmTaps; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < kFilmTaps; ++kx) {
+                const float w = wys[ky] * wxs[kx];
+                acc[ky][kx][0] += rec.x * w; acc[ky][kx][1] += rec.y * w; acc[ky][kx][2] += rec.z * w; acc[ky][kx][3] += rec.w * w;
+                acc[ky][kx][4] += 1.0f * w;
+            }
+    };
+    if (DMA) {
+        // (host: DMA only if F.spp % 8 == 0, so every run is a whole number of rounds and the stream offsets are 16-byte aligned)
+        float4 *s_rgba = stage;
+        float2 *s_pos = reinterpret_cast<float2 *>(stage + kBlock * kFilmRound);
+        const int wv = sp >> 6, ln = sp & 63;
+        const int n_end = min(s_begin + run, F.spp);         // workgroup-uniform
+        const int last_lr = F.pass_lr0 + F.pass_rows;
+        auto slot_of = [&](int q, bool &ok) -> size_t {      // first stream slot of tile pixel q (any lane computes any pixel's)
+            const int qlx = q % kFilmTile, qly = q / kFilmTile;
+            const int qqx = tcx * kFilmTile + qlx, qlr = F.pass_lr0 + tcy * F.tile_h + qly;
+            ok = qqx < F.crop_w && qly < F.tile_h && qlr < last_lr;
+            return ok ? (size_t) (((uint64_t) qlr * (uint64_t) F.crop_w + (uint64_t) qqx) * (uint64_t) F.spp - F.first_ordinal) : 0;
+        };
+        for (int s0 = s_begin; s0 < n_end; s0 += kFilmRound) {
+            // rgba: 8 instructions per wave, lanes 8 g .. 8 g + 7 fetch the line of pixel 64 wv + 8 i + g
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int q = 64 * wv + 8 * i + (ln >> 3);
+                bool ok; const size_t q0 = slot_of(q, ok);
+                if (ok) __builtin_amdgcn_global_load_lds((film_glb_void *) (F.out_rgba + q0 + (size_t) (s0 + (ln & 7))),
+                                                         (film_lds_void *) (s_rgba + (64 * wv + 8 * i) * kFilmRound), 16, 0, 0);
+            }
+            // positions: 4 instructions per wave, lanes 4 g .. 4 g + 3 fetch the 64 bytes (8 x float2) of pixel 64 wv + 16 i + g
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = 64 * wv + 16 * i + (ln >> 2);
+                bool ok; const size_t q0 = slot_of(q, ok);
+                if (ok) __builtin_amdgcn_global_load_lds((film_glb_void *) (F.out_pos + q0 + (size_t) (s0 + 2 * (ln & 3))),
+                                                         (film_lds_void *) (s_pos + (64 * wv + 16 * i) * kFilmRound), 16, 0, 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0);                   // vmcnt(0): the wave's DMA has landed
+            __syncthreads();
+            if (have) {
+#pragma unroll 2
+                for (int kk = 0; kk < kFilmRound; ++kk) {
+                    const int j = (kk + (sp >> 1)) & (kFilmRound - 1);      // rotated start: the 16 lanes of a ds_read_b128 group hit 16 different banks
+                    accumulate(s_rgba[sp * kFilmRound + j], s_pos[sp * kFilmRound + j]);
+                }
+            }
+            __syncthreads();
+        }
+    } else {
 #pragma unroll
     for (int k = 0; k < kFilmPrefetch; ++k) {
         pv[k] = make_float4(0.0f, 0.0f, 0.0f, -1.0f); pq[k] = make_float2(0.0f, 0.0f);
@@ -2065,21 +2140,9 @@ __global__ __launch_bounds__(kBlock) void k_film_accum(const FilmParams F) {
                 pv[k] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
                 if (j < n_spp) { pv[k] = MTS_FILM_LOAD(F.out_rgba + slot0 + (size_t) j); pq[k] = MTS_FILM_LOAD(F.out_pos + slot0 + (size_t) j); }
             }
-            if (!(rec.w >= 0.0f)) continue;                  // (X, Y, Z, alpha); alpha < 0: invalid or absent sample
-            float wxs[kFilmTaps], wys[kFilmTaps];
-            axis_taps(f, table, rp.x - offx, sx, tap_x0, R, wxs);
-            axis_taps(f, table, rp.y - offy, sy, tap_y0, R, wys);
-            // a zero weight adds (signed) zeros, which leaves the sums as they are: the film equals the one of a loop over the non-zero
-            // taps only (imageblock.cpp:148-161)
-#pragma unroll
-            for (int ky = 0; ky < kFilmTaps; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < kFilmTaps; ++kx) {
-                    const float w = wys[ky] * wxs[kx];
-                    acc[ky][kx][0] += rec.x * w; acc[ky][kx][1] += rec.y * w; acc[ky][kx][2] += rec.z * w; acc[ky][kx][3] += rec.w * w;
-                    acc[ky][kx][4] += 1.0f * w;
-                }
+            accumulate(rec, rp);
         }
+    }
     }
     // ---- exchange: film pixel (dx, dy) of the region <- tap (dx - sxl, dy - syl) of the source pixel at block position (sxl, syl),
     // in ascending (ky, kx) order
@@ -2167,7 +2230,9 @@ void film_tile_grid(FilmParams &p) {
 
 hipError_t launch_film_tiles(const FilmParams &p, hipStream_t s) {
     if (p.row1 <= p.row0 || p.pass_rows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_film_accum, dim3((uint32_t) (p.tiles_x * p.tiles_y), (uint32_t) p.slices), dim3(kBlock), 0, s, p);
+    // LDS-staged loads when every run of a pixel's samples is a whole number of 8-sample rounds (and the stream offsets 16-byte aligned)
+    if (MTS_FILM_DMA && p.spp % kFilmRound == 0) hipLaunchKernelGGL(k_film_accum<true>, dim3((uint32_t) (p.tiles_x * p.tiles_y), (uint32_t) p.slices), dim3(kBlock), 0, s, p);
+    else hipLaunchKernelGGL(k_film_accum<false>, dim3((uint32_t) (p.tiles_x * p.tiles_y), (uint32_t) p.slices), dim3(kBlock), 0, s, p);
     const uint64_t n = (uint64_t) (p.row1 - p.row0) * (uint64_t) p.crop_w;
     hipLaunchKernelGGL(k_film_merge, dim3((uint32_t) ((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, p);
     return hipGetLastError();
