@@ -712,7 +712,12 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     // ---- accelerator -------------------------------------------------------------------------
     uint32_t max_leaf = 4;
     if (const char *e = exp_env("MTSAMD_BVH_LEAF")) max_leaf = (uint32_t) std::min(15, std::max(1, atoi(e)));      // experiment switch
-    if (s->n_prims > 0) build_bvh(tri_pos.data(), s->n_prims, max_leaf, s->bvh);
+    BvhOptions bopt;
+    if (const char *e = exp_env("MTSAMD_BVH_BINS")) bopt.bins = atoi(e);                      // experiment switches
+    if (const char *e = exp_env("MTSAMD_BVH_ICOST")) bopt.intersect_cost = atof(e);
+    if (const char *e = exp_env("MTSAMD_BVH_SWEEP")) bopt.sweep_below = (uint32_t) std::max(0, atoi(e));
+    if (const char *e = exp_env("MTSAMD_BVH_ORDER")) bopt.dfs_order = e[0] == 'd';
+    if (s->n_prims > 0) build_bvh(tri_pos.data(), s->n_prims, max_leaf, s->bvh, &bopt);
     else { s->bvh = BvhOutput{}; s->bvh.root = s->bvh.wroot = 0x80000000u; s->bvh.wdepth = 1; }       // a leaf with no triangles (BVH2 and BVH4 root: without wroot the walks of the split pipeline started at node 0 of an empty node array)
     if (s->environment >= 0) {       // ConstantBackgroundEmitter::set_scene (constant.cpp:47-51): bounding sphere of Scene::bbox()
         DevEmitter &e = s->emitters[s->environment];

@@ -13,8 +13,8 @@ namespace {
 
 constexpr uint32_t kLeafFlag = 0x80000000u;
 constexpr uint32_t kLeafCountShift = 27;
-constexpr int kBins = 16;
-constexpr double kTraversalCost = 1.0, kIntersectCost = 1.5;
+constexpr int kMaxBins = 64;
+constexpr double kTraversalCost = 1.0;
 
 struct Box {
     double lo[3], hi[3];
@@ -43,6 +43,11 @@ struct Builder {
     std::vector<uint32_t> perm;
     std::vector<TmpNode> nodes;
     uint32_t max_depth = 0;
+    int kBins = 16;                   // BvhOptions
+    double kIntersectCost = 1.5;
+    uint32_t sweep_below = 0;
+    std::vector<uint32_t> scratch;
+    std::vector<double> suffix_area;
 
     int32_t build(uint32_t first, uint32_t count, uint32_t depth) {
         int32_t idx = (int32_t) nodes.size();
@@ -66,7 +71,7 @@ struct Builder {
         for (int axis = 0; axis < 3; ++axis) {
             double lo = cb.lo[axis], ext = cb.hi[axis] - cb.lo[axis];
             if (!(ext > 0.0)) continue;
-            Box bin_box[kBins]; uint32_t bin_cnt[kBins];
+            Box bin_box[kMaxBins]; uint32_t bin_cnt[kMaxBins];
             for (int b = 0; b < kBins; ++b) { bin_box[b].reset(); bin_cnt[b] = 0; }
             double scale = kBins / ext;
             for (uint32_t i = 0; i < count; ++i) {
@@ -74,7 +79,7 @@ struct Builder {
                 int b = std::min(kBins - 1, std::max(0, (int) ((centroid[3 * p + axis] - lo) * scale)));
                 bin_box[b].grow(prim_box[p]); bin_cnt[b]++;
             }
-            double right_area[kBins]; uint32_t right_cnt[kBins];
+            double right_area[kMaxBins]; uint32_t right_cnt[kMaxBins];
             Box acc; acc.reset(); uint32_t cnt = 0;
             for (int b = kBins - 1; b > 0; --b) {
                 if (bin_cnt[b]) acc.grow(bin_box[b]);
@@ -90,6 +95,28 @@ struct Builder {
                               kIntersectCost * (acc.area() * cnt + right_area[b + 1] * right_cnt[b + 1]) / parent_area;
                 if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
             }
+        }
+        // small nodes: the exact SAH sweep over every split position of every axis (centroid order) instead of the bins
+        int sweep_axis = -1; uint32_t sweep_left = 0;
+        if (count <= sweep_below) {
+            best_cost = DBL_MAX;
+            scratch.resize(count); suffix_area.resize(count + 1);
+            for (int axis = 0; axis < 3; ++axis) {
+                for (uint32_t i = 0; i < count; ++i) scratch[i] = perm[first + i];
+                std::sort(scratch.begin(), scratch.end(), [&](uint32_t a, uint32_t b) {
+                    const double ca = centroid[3 * a + axis], cbb = centroid[3 * b + axis];
+                    return ca < cbb || (ca == cbb && a < b);
+                });
+                Box acc; acc.reset();
+                for (uint32_t i = count; i-- > 0;) { acc.grow(prim_box[scratch[i]]); suffix_area[i] = acc.area(); }
+                acc.reset();
+                for (uint32_t i = 0; i + 1 < count; ++i) {
+                    acc.grow(prim_box[scratch[i]]);
+                    const double cost = kTraversalCost + kIntersectCost * (acc.area() * (i + 1) + suffix_area[i + 1] * (count - i - 1)) / parent_area;
+                    if (cost < best_cost) { best_cost = cost; sweep_axis = axis; sweep_left = i + 1; }
+                }
+            }
+            if (sweep_axis >= 0) best_axis = 3;                 // marks "sweep split chosen"
         }
         double leaf_cost = kIntersectCost * count;
         if (count <= max_leaf && (best_axis < 0 || leaf_cost <= best_cost)) return make_leaf();
@@ -107,6 +134,12 @@ struct Builder {
         uint32_t mid;
         if (best_axis == -2) {
             mid = first + count / 2;
+        } else if (best_axis == 3) {
+            std::sort(perm.begin() + first, perm.begin() + first + count, [&](uint32_t a, uint32_t b) {
+                const double ca = centroid[3 * a + sweep_axis], cbb = centroid[3 * b + sweep_axis];
+                return ca < cbb || (ca == cbb && a < b);
+            });
+            mid = first + sweep_left;
         } else if (best_axis >= 0) {
             double lo = cb.lo[best_axis], ext = cb.hi[best_axis] - cb.lo[best_axis];
             double scale = kBins / ext;
@@ -144,9 +177,12 @@ inline float bits(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 
 } // namespace
 
-void build_bvh(const float *tri_pos, uint32_t n_prims, uint32_t max_leaf, BvhOutput &out) {
+void build_bvh(const float *tri_pos, uint32_t n_prims, uint32_t max_leaf, BvhOutput &out, const BvhOptions *opt) {
     Builder b;
     b.tri_pos = tri_pos; b.n_prims = n_prims; b.max_leaf = std::min<uint32_t>(std::max<uint32_t>(max_leaf, 1), 15);
+    const BvhOptions defaults;
+    if (!opt) opt = &defaults;
+    b.kBins = std::min(std::max(opt->bins, 2), kMaxBins); b.kIntersectCost = opt->intersect_cost; b.sweep_below = opt->sweep_below;
     b.prim_box.resize(n_prims); b.centroid.resize(3 * (size_t) n_prims); b.perm.resize(n_prims);
     Box scene; scene.reset();
     for (uint32_t p = 0; p < n_prims; ++p) {
@@ -172,8 +208,7 @@ void build_bvh(const float *tri_pos, uint32_t n_prims, uint32_t max_leaf, BvhOut
     // array is what gets staged in LDS), triangle slots in the order their leaves are reached.
     std::vector<int32_t> inner_index(b.nodes.size(), -1);
     std::vector<int32_t> bfs;
-    const char *order_env = std::getenv("MTSAMD_BVH_ORDER");      // experiment switch: "dfs" = pre-order layout
-    if (order_env && order_env[0] == 'd') {
+    if (opt->dfs_order) {                                          // experiment: pre-order layout
         std::vector<int32_t> st;
         if (b.nodes[root].left >= 0) st.push_back(root);
         while (!st.empty()) {

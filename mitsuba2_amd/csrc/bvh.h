@@ -28,7 +28,15 @@ struct BvhOutput {
     float bbox[6] = { 0, 0, 0, 0, 0, 0 };
 };
 
+// builder knobs (defaults = the shipped configuration; experiment builds read others from the environment, api.cpp)
+struct BvhOptions {
+    int bins = 16;                 // SAH bins per axis
+    double intersect_cost = 1.5;   // cost of a triangle test relative to a traversal step
+    uint32_t sweep_below = 0;      // nodes of at most this many primitives: exact SAH sweep instead of the bins (0: never)
+    bool dfs_order = false;        // pre-order instead of BFS node layout
+};
+
 // positions: 9 floats per primitive (p0, p1, p2), n_prims >= 1
-void build_bvh(const float *tri_pos, uint32_t n_prims, uint32_t max_leaf, BvhOutput &out);
+void build_bvh(const float *tri_pos, uint32_t n_prims, uint32_t max_leaf, BvhOutput &out, const BvhOptions *opt = nullptr);
 
 } // namespace mtsamd
