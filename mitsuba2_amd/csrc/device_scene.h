@@ -300,6 +300,36 @@ MTS_DEV StackEntry stack_pop(const WalkStack &st, uint32_t sp) {
     return e;
 }
 
+// Experiment builds (-DMTS_TRACE_PROF): where the lanes of the k_trace waves go.  Wave-level event counts and lane sums per phase,
+// added by the first active lane to one of 64 copies of the counter row (scripts/debug/trace_prof.py reads them).
+#ifndef MTS_TRACE_PROF
+#define MTS_TRACE_PROF 0
+#endif
+#if MTS_TRACE_PROF
+static __device__ unsigned long long g_trace_prof[64 * 64];
+template <bool ANY> MTS_DEV void prof_add(int i) {      // placed inside a (divergent) region: +1 event, +active lanes
+    const uint64_t exec = __ballot(true);
+    if (lane_id() == (uint32_t) __ffsll((long long) exec) - 1u) {
+        unsigned long long *row = g_trace_prof + 64u * (blockIdx.x & 63u) + (ANY ? 32 : 0);
+        atomicAdd(row + i, 1ull);
+        atomicAdd(row + i + 1, (unsigned long long) __popcll(exec));
+    }
+}
+template <bool ANY> MTS_DEV void prof_mask(int i, uint64_t mask) {      // +1 event, +lanes of a (wave-uniform) mask
+    const uint64_t exec = __ballot(true);
+    if (lane_id() == (uint32_t) __ffsll((long long) exec) - 1u) {
+        unsigned long long *row = g_trace_prof + 64u * (blockIdx.x & 63u) + (ANY ? 32 : 0);
+        atomicAdd(row + i, 1ull);
+        atomicAdd(row + i + 1, (unsigned long long) __popcll(mask));
+    }
+}
+#define MTS_PROF(ANY, i) prof_add<ANY>(i)
+#define MTS_PROF_MASK(ANY, i, mask) prof_mask<ANY>(i, mask)
+#else
+#define MTS_PROF(ANY, i) ((void) 0)
+#define MTS_PROF_MASK(ANY, i, mask) ((void) 0)
+#endif
+
 #if MTS_BVH4
 // Triangle tests of the leaf a lane holds (all lanes of the wave together), then the next subtree from the stack.
 #ifndef MTS_LEAF_STEP
@@ -332,8 +362,11 @@ MTS_DEV void walk_leaf(BvhWalk &w, const SceneView &sv, uint32_t &cur, uint32_t 
     test_one(start);
 #else
     cur = kNoNode;
-    for (uint32_t i = 0; i < total; ++i)
+    MTS_PROF(ANY, 4);                                   // leaf phases
+    for (uint32_t i = 0; i < total; ++i) {
+        MTS_PROF(ANY, 6);                               // triangle-test iterations
         if (test_one(start + i)) return;
+    }
 #endif
 }
 
@@ -353,18 +386,26 @@ MTS_DEV void walk_round(BvhWalk &w, const SceneView &sv, const WalkStack &st, ui
     auto pop_next = [&]() {
         cur = kNoNode;
         while (sp) {
+            MTS_PROF(ANY, 8);                           // stack pops
             --sp;
             const StackEntry e = stack_pop(st, sp);
             if (__uint_as_float(e.y) <= w.best) { cur = e.x; break; }
         }
     };
+    MTS_PROF(ANY, 0);                                   // rounds
     while (true) {
         const bool inner = (int32_t) cur >= 0 && cur != kNoNode;
         const uint64_t mi = __ballot(inner);
+#if MTS_TRACE_PROF
+        const uint64_t ml = __ballot((cur & kLeafFlag) && cur != kNoNode), mn = __ballot(cur == kNoNode);
+#endif
         if (mi == 0ull) break;
         constexpr int kT = ANY ? MTS_WALK_T_ANY : MTS_WALK_T;
         if (kT > 0 && __popcll(mi) < kT && __ballot((int32_t) cur < 0) != 0ull) break;
         if (!inner) continue;
+        MTS_PROF(ANY, 2);                               // node steps
+        MTS_PROF_MASK(ANY, 16, ml);        // ... lanes waiting at a leaf meanwhile
+        MTS_PROF_MASK(ANY, 18, mn);                     // ... lanes without a ray meanwhile
         const f3 oq = w.o_q;
         const f3 noi = FAR ? mk3(fminf(2.4e-7f * fabsf(oq.x * inv.x), 1.0e30f), fminf(2.4e-7f * fabsf(oq.y * inv.y), 1.0e30f),
                                  fminf(2.4e-7f * fabsf(oq.z * inv.z), 1.0e30f)) : w.noi;

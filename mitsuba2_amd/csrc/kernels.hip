@@ -1530,7 +1530,9 @@ void k_trace(const RenderParams P) {
         bool exhausted = false;
         while (true) {
             const bool need = w.cur == kNoNode;
+            MTS_PROF(ANY, 12);                               // iterations of the work loop
             if (need && busy) {                              // retire the finished item
+                MTS_PROF(ANY, 14);
                 if (ANY) { if (!w.found) retire_any(k); }
                 else st_stream<kNT>(pool.hit + k, w.found ? make_float4(w.best, __uint_as_float(w.best_prim), w.hit.u, w.hit.v)
                                                           : make_float4(__builtin_inff(), __uint_as_float(kNoPrim), 0.0f, 0.0f));
@@ -1544,6 +1546,7 @@ void k_trace(const RenderParams P) {
                 base = __shfl(base, (int) first);
                 exhausted = base + want >= total;
                 if (need) {
+                    MTS_PROF(ANY, 10);                       // fetches
                     const uint32_t idx = base + mask_rank(m);
                     if (idx < total) {
                         k = locate(idx);
@@ -1563,6 +1566,7 @@ void k_trace(const RenderParams P) {
                 if (exhausted) break;
                 continue;                                    // only zombies were fetched: try again
             }
+            MTS_PROF_MASK(ANY, exhausted ? 22 : 20, __ballot(w.cur != kNoNode));      // rounds before / after the list ran out: lanes with a ray
             if (__ballot(w.cur != kNoNode && w.far) != 0ull) {      // wave-uniform choice of the slab-test form
                 if (w.cur != kNoNode) walk_round<ANY, true, kTraceTopNodes != 0u>(w, P.sv, st, tri_tests);
             } else {
@@ -1575,6 +1579,17 @@ void k_trace(const RenderParams P) {
         atomicAdd(reinterpret_cast<unsigned long long *>(P.wave_stats + 4u * (size_t) w0 + 3u),
                   (unsigned long long) tri_tests);
 }
+
+#if MTS_TRACE_PROF
+// experiment builds: the phase counters of device_scene.h (scripts/debug/trace_prof.py)
+extern "C" __attribute__((visibility("default"))) int mtsamd_debug_trace_prof(unsigned long long *out, int reset) {
+    static unsigned long long host[64 * 64];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace_prof), sizeof(host)) != hipSuccess) return -1;
+    for (int i = 0; i < 64; ++i) { out[i] = 0; for (int c = 0; c < 64; ++c) out[i] += host[64 * c + i]; }
+    if (reset) { for (auto &h : host) h = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(g_trace_prof), host, sizeof(host)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 
 uint32_t trace_top_nodes(const SceneView &sv) { return std::min(sv.n_wnodes, kTraceTopNodes); }
 uint32_t trace_group() { return kShadowGroup; }
