@@ -880,7 +880,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     }
     SceneView &v = s->view;
     v.nodes = s->d_nodes; v.qnodes = s->d_qnodes; v.wnodes = s->d_wnodes; v.wroot = s->bvh.wroot; v.n_wnodes = s->bvh.n_wnodes; v.tris = s->d_tris; v.root = s->bvh.root;
-    for (int k = 0; k < 3; ++k) { v.q_lo[k] = s->bvh.q_lo[k]; v.q_step[k] = s->bvh.q_step[k]; }
+    for (int k = 0; k < 3; ++k) { v.q_lo[k] = s->bvh.q_lo[k]; v.q_step[k] = s->bvh.q_step[k]; v.q_inv_step[k] = 1.0f / s->bvh.q_step[k]; }
     v.n_nodes = s->bvh.n_nodes; v.n_slots = s->bvh.n_slots; v.n_prims = s->n_prims;
     // LDS residency: flat scenes keep everything in LDS (see flat_recs below).  For hierarchy scenes staging the
     // top of the tree (nodes are stored in BFS order) was measured to LOSE: 384 staged nodes 2.5-3.2 Gray/s vs none

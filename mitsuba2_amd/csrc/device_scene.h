@@ -72,7 +72,7 @@ struct SceneView {
     const uint4 *wnodes;       // BVH4 collapsed from the BVH2, 4 per node: per child (x, y, z) = lo | hi << 16 on the same grid, w = child
                                // reference (kNoNode: no child, its box is inverted); wroot = reference of the root
     uint32_t wroot, n_wnodes;
-    float q_lo[3], q_step[3];
+    float q_lo[3], q_step[3], q_inv_step[3];      // q_inv_step = 1 / q_step
     const float4 *tris;        // 3 per slot (leaf order)
     uint32_t root;             // child ref of the root
     uint32_t n_nodes, n_slots, n_prims;
@@ -236,23 +236,29 @@ struct BvhWalk {
     Hit hit;
 };
 MTS_DEV void walk_begin(BvhWalk &w, const SceneView &sv, f3 o, f3 d, float mint, float maxt) {
-    w.o = o; w.d = d; w.inv = mk3(clamp_inv(d.x), clamp_inv(d.y), clamp_inv(d.z));
+    w.o = o; w.d = d;
 #if MTS_QNODES
     // box coordinate x = q_lo + q * q_step  =>  t = (q - o_q) * inv_q with o_q = (o - q_lo) / q_step, inv_q = q_step / d
-    // |inv| <= 1e33 keeps q * inv finite for q <= 65535 (a direction component that small is parallel to the slab either way)
-    w.o_q = mk3((o.x - sv.q_lo[0]) / sv.q_step[0], (o.y - sv.q_lo[1]) / sv.q_step[1], (o.z - sv.q_lo[2]) / sv.q_step[2]);
+    // |inv| <= 1e33 keeps q * inv finite for q <= 65535 (a direction component that small is parallel to the slab either way).
+    // The slab test only culls, against boxes padded by 1/8 cell or more, so the walk's own frame is set up with the cheap forms:
+    // v_rcp_f32 (1 ulp) instead of a division, a multiplication by 1 / q_step -- a walk starts every ~8 steps and the exact
+    // divisions were a tenth of k_trace's VALU time.  Error budget: see `far` below.
+    w.inv = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    w.o_q = mk3((o.x - sv.q_lo[0]) * sv.q_inv_step[0], (o.y - sv.q_lo[1]) * sv.q_inv_step[1], (o.z - sv.q_lo[2]) * sv.q_inv_step[2]);
 #if MTS_NODE_F16 && MTS_BVH4
     w.o_q = mk3(w.o_q.x - 32768.0f, w.o_q.y - 32768.0f, w.o_q.z - 32768.0f);      // the fp16 planes are centred on the middle of the grid
 #endif
     w.inv = mk3(clamp_mag33(w.inv.x * sv.q_step[0]), clamp_mag33(w.inv.y * sv.q_step[1]), clamp_mag33(w.inv.z * sv.q_step[2]));
     w.noi = mk3(-(w.o_q.x * w.inv.x), -(w.o_q.y * w.inv.y), -(w.o_q.z * w.inv.z));
-    // fma(q, inv, noi) is off by at most eps * |o_q| grid cells (0.06 cells at |o_q| = 1e6, i.e. an origin ~15 scene extents away);
-    // the boxes are padded by 1/8 cell or more.  Farther origins use (q - o_q) * inv, which is exact in q and consistent in o_q.
-    w.far = !(hmax_abs(w.o_q) <= 1.0e6f);
+    // fma(q, inv, noi) is off by at most eps * |o_q| grid cells, o_q itself by another half of that (the multiplication by 1 / q_step)
+    // and inv by 1 ulp, which moves t * |d_q| by up to eps * (|o_q| + 65535) cells: 0.015 + 0.008 + 0.04 cells at |o_q| = 2.5e5 (an origin
+    // ~4 scene extents away); the boxes are padded by 1/8 cell or more.  Farther origins use (q - o_q) * inv with an explicit pad.
+    w.far = !(hmax_abs(w.o_q) <= 2.5e5f);
     w.sel[0] = w.inv.x >= 0.0f ? 0x03020100u : 0x01000302u;
     w.sel[1] = w.inv.y >= 0.0f ? 0x03020100u : 0x01000302u;
     w.sel[2] = w.inv.z >= 0.0f ? 0x03020100u : 0x01000302u;
 #else
+    w.inv = mk3(clamp_inv(d.x), clamp_inv(d.y), clamp_inv(d.z));
     w.o_q = o; w.noi = o; w.far = true; w.sel[0] = w.sel[1] = w.sel[2] = 0u;
 #endif
     w.mint = mint; w.maxt = maxt; w.best = maxt;
@@ -407,8 +413,8 @@ MTS_DEV void walk_round(BvhWalk &w, const SceneView &sv, const WalkStack &st, ui
         MTS_PROF_MASK(ANY, 16, ml);        // ... lanes waiting at a leaf meanwhile
         MTS_PROF_MASK(ANY, 18, mn);                     // ... lanes without a ray meanwhile
         const f3 oq = w.o_q;
-        const f3 noi = FAR ? mk3(fminf(2.4e-7f * fabsf(oq.x * inv.x), 1.0e30f), fminf(2.4e-7f * fabsf(oq.y * inv.y), 1.0e30f),
-                                 fminf(2.4e-7f * fabsf(oq.z * inv.z), 1.0e30f)) : w.noi;
+        const f3 noi = FAR ? mk3(fminf(4.8e-7f * fabsf(oq.x * inv.x), 1.0e30f), fminf(4.8e-7f * fabsf(oq.y * inv.y), 1.0e30f),
+                                 fminf(4.8e-7f * fabsf(oq.z * inv.z), 1.0e30f)) : w.noi;
         uint4 c0, c1, c2, c3;
         if (TOP && cur < st.n_top) {
             const LdsNodeWord *node = reinterpret_cast<LdsNodeWord *>((uint32_t) reinterpret_cast<uintptr_t>(st.top_nodes)) + 4u * cur;
@@ -499,8 +505,8 @@ MTS_DEV void walk_round(BvhWalk &w, const SceneView &sv, const WalkStack &st, ui
         // instead -- an axis the ray is parallel to then stops culling, nothing is ever culled wrongly.  The pad is recomputed
         // per step (a wave walks in one form, chosen by its farthest origin, so every lane needs it and a register is dearer).
         const f3 oq = w.o_q;
-        const f3 noi = FAR ? mk3(fminf(2.4e-7f * fabsf(oq.x * inv.x), 1.0e30f), fminf(2.4e-7f * fabsf(oq.y * inv.y), 1.0e30f),
-                                 fminf(2.4e-7f * fabsf(oq.z * inv.z), 1.0e30f)) : w.noi;
+        const f3 noi = FAR ? mk3(fminf(4.8e-7f * fabsf(oq.x * inv.x), 1.0e30f), fminf(4.8e-7f * fabsf(oq.y * inv.y), 1.0e30f),
+                                 fminf(4.8e-7f * fabsf(oq.z * inv.z), 1.0e30f)) : w.noi;
         const uint4 a = sv.qnodes[2u * cur], bq = sv.qnodes[2u * cur + 1u];
         // near plane (low half after the permute) / far plane (high half).  FAR: noi holds the error pad e >= 0 of the axis
         auto slab_n = [&](uint32_t q, float o1, float i1, float n1) -> float {
