@@ -216,6 +216,9 @@ struct Workspace {
     hipEvent_t ev[4] = {};               // 0 / 1: count read-back checkpoints, 2: k_shade done, 3: k_trace<any> done
     hipStream_t stream2 = nullptr;       // split pipeline: k_trace<any> of one iteration overlaps k_trace<closest> of the next
     hipStream_t part_stream[3] = {}; hipEvent_t part_ev[3] = {};      // flat scenes: further parts of the scheduling waves
+    // hierarchy scenes: launch chain k runs k_trace<closest> + k_shade on chain_main[k] (chain 0: the job's stream) and k_trace<any> on
+    // chain_any[k]; chain_ev[2k] = its k_shade is done, chain_ev[2k + 1] = its k_trace<any> is done
+    hipStream_t chain_main[kMaxChains] = {}, chain_any[kMaxChains] = {}; hipEvent_t chain_ev[2 * kMaxChains] = {};
     hipEvent_t tev[3] = {};              // timing: bounce loop begin / end, film end
     bool have_events = false;
     std::vector<hipEvent_t> prof_ev;     // desc->profile: begin / end events of the split pipeline's launches, reused pass after pass
@@ -248,6 +251,9 @@ struct Workspace {
         if (stream2) (void) hipStreamDestroy(stream2);
         stream2 = nullptr;
         for (auto &ps : part_stream) { if (ps) (void) hipStreamDestroy(ps); ps = nullptr; }
+        for (auto &ps : chain_main) { if (ps) (void) hipStreamDestroy(ps); ps = nullptr; }
+        for (auto &ps : chain_any) { if (ps) (void) hipStreamDestroy(ps); ps = nullptr; }
+        for (auto &pe : chain_ev) { if (pe) (void) hipEventDestroy(pe); pe = nullptr; }
         for (auto &pe : part_ev) { if (pe) (void) hipEventDestroy(pe); pe = nullptr; }
         if (have_events) for (auto &e : ev) (void) hipEventDestroy(e);
         have_events = false;
@@ -1092,6 +1098,11 @@ static int ensure_workspace(mtsamd_scene *s, uint32_t n_waves, uint32_t seg_cap,
     if (!w.stream2) HIP_TRY(hipStreamCreateWithFlags(&w.stream2, hipStreamNonBlocking));
     for (auto &ps : w.part_stream) if (!ps) HIP_TRY(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
     for (auto &pe : w.part_ev) if (!pe) HIP_TRY(hipEventCreateWithFlags(&pe, hipEventDisableTiming));
+    for (uint32_t k = 0; k < kMaxChains; ++k) {
+        if (k > 0 && !w.chain_main[k]) HIP_TRY(hipStreamCreateWithFlags(&w.chain_main[k], hipStreamNonBlocking));
+        if (!w.chain_any[k]) HIP_TRY(hipStreamCreateWithFlags(&w.chain_any[k], hipStreamNonBlocking));
+    }
+    for (auto &pe : w.chain_ev) if (!pe) HIP_TRY(hipEventCreateWithFlags(&pe, hipEventDisableTiming));
     for (auto &e : w.tev) HIP_TRY(hipEventCreate(&e));
     w.have_events = true;
     w.n_waves = n_waves; w.seg_cap = seg_cap; w.pass_cap = pass_cap; w.spectral = s->spectral; w.split = split;
@@ -1135,11 +1146,14 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     if (const char *e = exp_env("MTSAMD_CHUNKS_PER_WAVE")) cpw = (uint64_t) std::min(64, std::max(1, atoi(e)));      // experiment switch
     const uint64_t chunk = j.s->view.flat ? 64u : std::max<uint64_t>({ (n + nw * cpw - 1) / (nw * cpw), std::min<uint64_t>(256u, (n + nw - 1) / nw), 1u });
     const uint64_t n_chunks = (n + chunk - 1u) / chunk, last_size = n - (n_chunks - 1u) * chunk;
-    // hierarchy scenes run two launch chains over the halves of the scheduling waves: their chunks alternate (kernels.h, chunk_owner)
-    uint32_t chain_split = 0;
-    if (!j.s->view.flat && j.split && nw >= 256u && !exp_env("MTSAMD_ONE_CHAIN") && !exp_env("MTSAMD_NO_CHAIN_INTERLEAVE")) chain_split = (nw / 2u + trace_group() - 1u) & ~(trace_group() - 1u);
+    // hierarchy scenes run several launch chains over parts of the scheduling waves: their chunks alternate (kernels.h, chunk_owner)
+    uint32_t n_chains = 1;
+    if (!j.s->view.flat && j.split && nw >= 256u) n_chains = kTraceChains;
+    if (const char *e = exp_env("MTSAMD_CHAINS")) n_chains = (uint32_t) std::min<int>(kMaxChains, std::max(1, atoi(e)));      // experiment switch
+    if (exp_env("MTSAMD_ONE_CHAIN")) n_chains = 1;
+    while (n_chains > 1 && nw / n_chains < 64u) --n_chains;
     for (uint32_t k = 0; k < nw; ++k) {
-        const uint64_t c0 = chunk_owner(k, nw, chain_split);      // this wave owns the chunks c0, c0 + nw, ...
+        const uint64_t c0 = chunk_owner(k, nw, n_chains);      // this wave owns the chunks c0, c0 + nw, ...
         const uint64_t mine = c0 < n_chunks ? (n_chunks - 1u - c0) / nw + 1u : 0u;
         uint64_t samples = mine * chunk;
         if (mine && (n_chunks - 1u) % nw == c0) samples -= chunk - last_size;       // the last, partial chunk of the pass
@@ -1159,7 +1173,7 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     p.count_shadow = w.count_shadow;
     p.first_ordinal = first; p.first_pix = (uint32_t) (first / spp); p.first_rem = (uint32_t) (first % spp);
     p.chunk = (uint32_t) chunk; p.base_seed = j.d->seed;
-    p.chain_split = chain_split;
+    p.n_chains = n_chains;
     p.rows = j.rows; p.store_xyz = j.store_xyz;
     p.plane_pix0 = j.plane_pix0; p.plane_pixels = j.plane_pixels;
     p.n_waves = nw; p.seg_cap = w.seg_cap; p.target = j.target;
@@ -1238,14 +1252,21 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
         gather_max = 1024u;
         for (uint32_t k = 0; k <= n_parts; ++k) while (gather_max > 4u && part_lo[k] % gather_max) gather_max >>= 2;
     }
-    uint32_t split_parts = p.split == 1 && nw >= 256u ? 2u : 1u;
-    if (exp_env("MTSAMD_ONE_CHAIN")) split_parts = 1;      // experiment switch
-    uint32_t split_lo[3] = { 0, nw, nw };
-    if (split_parts == 2) split_lo[1] = (nw / 2u + trace_group() - 1u) & ~(trace_group() - 1u);      // multiple of the k_trace group size
-    if (split_parts == 2) {      // the second chain starts after the cursors and counts are in place
+    const uint32_t split_parts = p.split == 1 ? n_chains : 1u;
+    uint32_t split_lo[kMaxChains + 1];
+    for (uint32_t k = 0; k <= kMaxChains; ++k) split_lo[k] = chain_first(k, nw, split_parts);      // multiples of the k_trace group size
+    auto chain_main = [&](uint32_t k) { return k == 0 ? j.stream : w.chain_main[k]; };
+    if (split_parts > 1) {       // the other chains start after the cursors and counts are in place
         HIP_TRY(hipEventRecord(w.part_ev[2], j.stream));
-        HIP_TRY(hipStreamWaitEvent(w.part_stream[0], w.part_ev[2], 0));
+        for (uint32_t k = 1; k < split_parts; ++k) HIP_TRY(hipStreamWaitEvent(chain_main(k), w.part_ev[2], 0));
     }
+    auto join_chains = [&]() -> int {        // j.stream waits for what the other chains' main streams hold (their k_shade writes their counts)
+        for (uint32_t k = 1; k < split_parts; ++k) {
+            HIP_TRY(hipEventRecord(w.chain_ev[2 * k], chain_main(k)));
+            HIP_TRY(hipStreamWaitEvent(j.stream, w.chain_ev[2 * k], 0));
+        }
+        return 0;
+    };
     // desc->profile: begin / end timing events around the launches of the split pipeline, each on the stream of its launch
     const bool prof = j.d->profile != 0 && p.split == 1;
     struct ProfRec { int stage; size_t e0; };
@@ -1268,6 +1289,8 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
         if (w.film_stream) (void) hipStreamSynchronize(w.film_stream);
         if (w.stream2) (void) hipStreamSynchronize(w.stream2);
         for (auto &ps : w.part_stream) if (ps) (void) hipStreamSynchronize(ps);
+        for (auto &ps : w.chain_main) if (ps) (void) hipStreamSynchronize(ps);
+        for (auto &ps : w.chain_any) if (ps) (void) hipStreamSynchronize(ps);
     };
     auto join_parts = [&]() -> int {         // j.stream waits for the other parts' streams
         for (uint32_t k = 1; k < n_parts; ++k) {
@@ -1299,8 +1322,8 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
             for (uint32_t k = 0; k < split_parts; ++k) {
                 RenderParams h = p;
                 h.wave_first = split_lo[k]; h.wave_last = split_lo[k + 1];
-                hipStream_t s_main = k == 0 ? j.stream : w.part_stream[0], s_any = k == 0 ? w.stream2 : w.part_stream[1];
-                hipEvent_t e_shade = k == 0 ? w.ev[2] : w.part_ev[0], e_any = k == 0 ? w.ev[3] : w.part_ev[1];
+                hipStream_t s_main = chain_main(k), s_any = w.chain_any[k];
+                hipEvent_t e_shade = w.chain_ev[2 * k], e_any = w.chain_ev[2 * k + 1];
                 size_t pe = 0;
                 if (prof) pe = prof_mark(s_main);
                 HIP_TRY(launch_split_stage(h, 0, s_main));
@@ -1375,10 +1398,7 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
                 }
             }
             if (n_parts > 1) { if (int rc = join_parts()) return rc; }
-            if (split_parts == 2) {       // the counts of the second chain are written by its k_shade
-                HIP_TRY(hipEventRecord(w.part_ev[2], w.part_stream[0]));
-                HIP_TRY(hipStreamWaitEvent(j.stream, w.part_ev[2], 0));
-            }
+            if (split_parts > 1) { if (int rc = join_chains()) return rc; }      // the counts of the other chains are written by their k_shade
             HIP_TRY(hipMemcpyAsync(w.h_counts + (size_t) slot * nw, w.count[cur], nw * sizeof(uint32_t), hipMemcpyDeviceToHost, j.stream));
             if (gather_w < gather_max || finish_at) HIP_TRY(hipMemcpyAsync(w.h_cursor_rb + (size_t) slot * nw, w.cursor, nw * sizeof(uint64_t), hipMemcpyDeviceToHost, j.stream));
             HIP_TRY(hipEventRecord(w.ev[slot], j.stream));
@@ -1387,12 +1407,8 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
         if (it > (1ull << 24)) return fail(MTSAMD_ERR_DEVICE, "wavefront scheduler did not converge");
     }
     if (p.split == 1 && it > 0) {
-        HIP_TRY(hipStreamWaitEvent(j.stream, w.ev[3], 0));
-        if (split_parts == 2) {
-            HIP_TRY(hipStreamWaitEvent(j.stream, w.part_ev[1], 0));
-            HIP_TRY(hipEventRecord(w.part_ev[2], w.part_stream[0]));
-            HIP_TRY(hipStreamWaitEvent(j.stream, w.part_ev[2], 0));
-        }
+        for (uint32_t k = 0; k < split_parts; ++k) HIP_TRY(hipStreamWaitEvent(j.stream, w.chain_ev[2 * k + 1], 0));      // the last k_trace<any> of every chain
+        if (int rc = join_chains()) return rc;
     }
     if (n_parts > 1) { if (int rc = join_parts()) return rc; }
     if (finish) {          // every stream of the loop has been joined into j.stream

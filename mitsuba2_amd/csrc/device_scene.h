@@ -341,6 +341,9 @@ template <bool ANY> MTS_DEV void prof_mask(int i, uint64_t mask) {      // +1 ev
 #ifndef MTS_LEAF_STEP
 #define MTS_LEAF_STEP 0
 #endif
+#ifndef MTS_ANY_SORT
+#define MTS_ANY_SORT 1      // 2: full sort for any-hit walks as well, 1: nearest first only, 0: none
+#endif
 template <bool ANY>
 MTS_DEV void walk_leaf(BvhWalk &w, const SceneView &sv, uint32_t &cur, uint32_t &tri_tests) {
     const uint32_t start = cur & kLeafStartMask, total = (cur >> kLeafCountShift) & 0xfu;
@@ -472,7 +475,14 @@ MTS_DEV void walk_round(BvhWalk &w, const SceneView &sv, const WalkStack &st, ui
             const uint32_t rlo = s ? rb : ra, rhi = s ? ra : rb;
             ta = tlo; tb = thi; ra = rlo; rb = rhi;
         };
-        cswap(t0, r0, t1, r1); cswap(t2, r2, t3, r3); cswap(t0, r0, t2, r2); cswap(t1, r1, t3, r3); cswap(t1, r1, t2, r2);
+#if MTS_ANY_SORT == 0
+        // any-hit walks need no front-to-back order: the hit children are taken as they come (a quarter of the step's cost is the sort)
+        if (!ANY)
+#elif MTS_ANY_SORT == 1
+        if (ANY) { cswap(t0, r0, t1, r1); cswap(t2, r2, t3, r3); cswap(t0, r0, t2, r2); }      // nearest first, the rest as they come
+        else
+#endif
+        { cswap(t0, r0, t1, r1); cswap(t2, r2, t3, r3); cswap(t0, r0, t2, r2); cswap(t1, r1, t3, r3); cswap(t1, r1, t2, r2); }
         stack_push_if(st, sp, t3 < kInf, make_uint2(r3, __float_as_uint(t3)));
         stack_push_if(st, sp, t2 < kInf, make_uint2(r2, __float_as_uint(t2)));
         stack_push_if(st, sp, t1 < kInf, make_uint2(r1, __float_as_uint(t1)));

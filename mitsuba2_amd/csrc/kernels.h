@@ -57,8 +57,8 @@ struct RenderParams {
     float4 *out_rgba;           // per sample ordinal: radiance rgb + valid_ray
     float2 *out_pos;            // per sample ordinal: film position sample
     uint32_t chunk;             // samples per chunk dealt to a scheduling wave (kernels.hip, cursor_sample)
-    uint32_t chain_split;       // 0, or the first scheduling wave of the second launch chain (hierarchy scenes): the chunks are dealt to the
-                                // two chains alternately (chunk_owner), so that both halves of the waves see the same mix of pixels
+    uint32_t n_chains;          // 0 / 1, or the number of launch chains the scheduling waves are cut into (hierarchy scenes): the chunks are dealt
+                                // to the chains in turn (chunk_owner), so that every chain sees the same mix of pixels
     uint32_t first_pix, first_rem;       // first_ordinal = first_pix * spp + first_rem (film renders: passes start on a pixel, first_rem == 0)
     uint64_t first_ordinal;     // local sample ordinal of slot 0 of out_rgba / out_pos
     uint64_t base_seed;
@@ -84,13 +84,30 @@ struct RenderParams {
     uint32_t *trace_spill;      // k_trace: [workgroup][entry][thread]
 };
 
-// Index of the (first) chunk owned by scheduling wave `wave`: the identity, or -- two launch chains [0, h) and [h, n), h >= n - h --
-// even chunks to the first chain and odd ones to the second as long as the second has waves left.  A bijection of [0, n).
-__host__ __device__ inline uint32_t chunk_owner(uint32_t wave, uint32_t n, uint32_t h) {
-    if (h == 0u || h >= n) return wave;
-    const uint32_t m = n - h;                      // waves of the second chain
-    if (wave >= h) return 2u * (wave - h) + 1u;
-    return wave < m ? 2u * wave : m + wave;
+// Launch chains of the split pipeline: chain k covers the scheduling waves [chain_first(k), chain_first(k + 1)); the boundaries are
+// multiples of 8 (the k_trace group size).
+constexpr uint32_t kMaxChains = 8u;
+constexpr uint32_t kTraceChains = 2u;       // chains a render runs
+__host__ __device__ inline uint32_t chain_first(uint32_t k, uint32_t n, uint32_t chains) {
+    if (k >= chains) return n;
+    const uint32_t lo = ((uint32_t) ((uint64_t) n * k / chains) + 7u) & ~7u;
+    return lo < n ? lo : n;
+}
+// Index of the (first) chunk owned by scheduling wave `wave`: the identity, or -- `chains` launch chains -- chunk i * chains + k for
+// the i-th wave of chain k as long as every chain has an i-th wave; the few waves beyond that take the remaining chunks in order.
+// A bijection of [0, n).
+__host__ __device__ inline uint32_t chunk_owner(uint32_t wave, uint32_t n, uint32_t chains) {
+    if (chains <= 1u) return wave;
+    uint32_t s_min = n, k = 0u, lo_k = 0u, extra_before = 0u;
+    for (uint32_t c = 0; c < chains; ++c) {
+        const uint32_t lo = chain_first(c, n, chains), hi = chain_first(c + 1u, n, chains);
+        s_min = hi - lo < s_min ? hi - lo : s_min;
+        if (wave >= lo && wave < hi) { k = c; lo_k = lo; }
+    }
+    const uint32_t i = wave - lo_k;
+    if (i < s_min) return i * chains + k;
+    for (uint32_t c = 0; c < k; ++c) extra_before += chain_first(c + 1u, n, chains) - chain_first(c, n, chains) - s_min;
+    return s_min * chains + extra_before + (i - s_min);
 }
 
 struct FilmParams {

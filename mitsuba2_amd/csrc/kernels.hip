@@ -381,7 +381,7 @@ MTS_DEV void store_result(const RenderParams &P, const PathState &s) {
 // sample has no influence on the result: its RNG stream and its slot in the sample stream depend on the ordinal alone.
 MTS_DEV void cursor_sample(const RenderParams &P, uint32_t wave, uint64_t v, uint64_t &ordinal, uint32_t &lp, uint32_t &j) {
     const uint32_t t = (uint32_t) v / P.chunk, within = (uint32_t) v - t * P.chunk;
-    const uint32_t in_pass = (t * P.n_waves + chunk_owner(wave, P.n_waves, P.chain_split)) * P.chunk + within;      // < 2^31
+    const uint32_t in_pass = (t * P.n_waves + chunk_owner(wave, P.n_waves, P.n_chains)) * P.chunk + within;      // < 2^31
     ordinal = P.first_ordinal + in_pass;
     const uint32_t r = in_pass + P.first_rem, q = r / (uint32_t) P.spp;
     lp = P.first_pix + q; j = r - q * (uint32_t) P.spp;

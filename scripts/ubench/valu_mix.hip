@@ -1,5 +1,8 @@
 // Micro-benchmark: issue cost of the instruction classes the BVH4 step is made of (wave64, gfx950), 8 waves per SIMD, eight independent
-// dependency chains per wave.  Reports SIMD-cycles per wave-instruction against the shader clock the chip really held (s_memtime).
+// dependency chains per wave.  Reports SIMD-cycles per wave-instruction = kernel time (HIP events) x the shader clock the chip really
+// held (s_memtime / s_memrealtime) / wave-instructions per SIMD.  (The workgroups' own s_memtime spans are shorter than the kernel --
+// they do not all run at once -- so they must not be used as the time base: that was the 1.36-vs-2.26 discrepancy of
+// profiles/r02_valu_rate.txt.)
 // Build: hipcc --offload-arch=gfx950 -O3 -o valu_mix valu_mix.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -80,7 +83,9 @@ template <int OP> void run(float *out, unsigned long long *stamps, unsigned long
     for (int b = 0; b < blocks; ++b) { clk += (double) h[2 * b] / (double) h[2 * b + 1] * 100e6; in_kernel += (double) h[2 * b]; }
     clk /= blocks; in_kernel /= blocks;
     const double per_iter = (OP == 30 || OP == 33) ? 128.0 : 64.0;
-    printf("%-58s %6.2f SIMD-cycles per wave-instruction (clock %.2f GHz, %.2f ms)\n", kNames[OP], in_kernel / (iters * per_iter) / blocks_per_cu, clk * 1e-9, ms);
+    const double per_simd = (double) blocks * 4.0 * iters * per_iter / 1024.0;      // wave-instructions per SIMD (256 CUs x 4)
+    (void) in_kernel;
+    printf("%-58s %6.2f SIMD-cycles per wave-instruction (clock %.2f GHz, %.2f ms, %.2f ns)\n", kNames[OP], ms * 1e-3 * clk / per_simd, clk * 1e-9, ms, ms * 1e6 / per_simd);
     if constexpr (OP + 1 < kOps) run<OP + 1>(out, stamps, h);
 }
 int main() {
