@@ -1151,7 +1151,7 @@ int trace_pass(Job &j, uint64_t first, uint64_t n) {
     if (!j.s->view.flat && j.split && nw >= 256u) n_chains = kTraceChains;
     if (const char *e = exp_env("MTSAMD_CHAINS")) n_chains = (uint32_t) std::min<int>(kMaxChains, std::max(1, atoi(e)));      // experiment switch
     if (exp_env("MTSAMD_ONE_CHAIN")) n_chains = 1;
-    while (n_chains > 1 && nw / n_chains < 64u) --n_chains;
+    while (n_chains > 1 && nw / n_chains < 2u * kChainAlign) --n_chains;
     for (uint32_t k = 0; k < nw; ++k) {
         const uint64_t c0 = chunk_owner(k, nw, n_chains);      // this wave owns the chunks c0, c0 + nw, ...
         const uint64_t mine = c0 < n_chunks ? (n_chunks - 1u - c0) / nw + 1u : 0u;

@@ -341,6 +341,9 @@ template <bool ANY> MTS_DEV void prof_mask(int i, uint64_t mask) {      // +1 ev
 #ifndef MTS_LEAF_STEP
 #define MTS_LEAF_STEP 0
 #endif
+#ifndef MTS_CLOSEST_SORT
+#define MTS_CLOSEST_SORT 5  // compare-exchanges of the closest-hit walk's child sort: 5 = full order, 4 / 3 = nearest first, the rest partly ordered
+#endif
 #ifndef MTS_ANY_SORT
 #define MTS_ANY_SORT 1      // 2: full sort for any-hit walks as well, 1: nearest first only, 0: none
 #endif
@@ -482,7 +485,13 @@ MTS_DEV void walk_round(BvhWalk &w, const SceneView &sv, const WalkStack &st, ui
         if (ANY) { cswap(t0, r0, t1, r1); cswap(t2, r2, t3, r3); cswap(t0, r0, t2, r2); }      // nearest first, the rest as they come
         else
 #endif
+#if MTS_CLOSEST_SORT == 3
+        { cswap(t0, r0, t1, r1); cswap(t2, r2, t3, r3); cswap(t0, r0, t2, r2); }
+#elif MTS_CLOSEST_SORT == 4
+        { cswap(t0, r0, t1, r1); cswap(t2, r2, t3, r3); cswap(t0, r0, t2, r2); cswap(t1, r1, t3, r3); }
+#else
         { cswap(t0, r0, t1, r1); cswap(t2, r2, t3, r3); cswap(t0, r0, t2, r2); cswap(t1, r1, t3, r3); cswap(t1, r1, t2, r2); }
+#endif
         stack_push_if(st, sp, t3 < kInf, make_uint2(r3, __float_as_uint(t3)));
         stack_push_if(st, sp, t2 < kInf, make_uint2(r2, __float_as_uint(t2)));
         stack_push_if(st, sp, t1 < kInf, make_uint2(r1, __float_as_uint(t1)));

@@ -85,12 +85,12 @@ struct RenderParams {
 };
 
 // Launch chains of the split pipeline: chain k covers the scheduling waves [chain_first(k), chain_first(k + 1)); the boundaries are
-// multiples of 8 (the k_trace group size).
-constexpr uint32_t kMaxChains = 8u;
+// multiples of kChainAlign (itself a multiple of the k_trace group size: a group never straddles two launches).
+constexpr uint32_t kMaxChains = 8u, kChainAlign = 64u;
 constexpr uint32_t kTraceChains = 2u;       // chains a render runs
 __host__ __device__ inline uint32_t chain_first(uint32_t k, uint32_t n, uint32_t chains) {
     if (k >= chains) return n;
-    const uint32_t lo = ((uint32_t) ((uint64_t) n * k / chains) + 7u) & ~7u;
+    const uint32_t lo = ((uint32_t) ((uint64_t) n * k / chains) + kChainAlign - 1u) & ~(kChainAlign - 1u);
     return lo < n ? lo : n;
 }
 // Index of the (first) chunk owned by scheduling wave `wave`: the identity, or -- `chains` launch chains -- chunk i * chains + k for

@@ -1404,22 +1404,27 @@ hipError_t launch_finish(const RenderParams &p, uint64_t alive, hipStream_t s) {
     return hipGetLastError();
 }
 
-// k_trace<false>: closest hit of every path's ray (input pool), one workgroup per scheduling wave, one thread per slot.
+// k_trace<false>: closest hit of every path's ray (input pool).
 // k_trace<true>: visibility of the queued shadow rays (output pool of k_shade), radiance[slot] += nee if unoccluded.
-// Only about a third of the paths queue a shadow ray, so one workgroup drains the queues of kShadowGroup scheduling
-// waves back to back to keep its lanes filled.  (64-thread workgroups sized to the queues were measured slower.)
-// Workgroup shape of k_trace on hierarchy scenes.  kTraceBlock threads drain the rays of kShadowGroup scheduling waves (16 rays per
-// lane).  1024 threads = two workgroups per CU: each has 80 KB of LDS, enough for the first kTraceLdsDepth stack entries of every lane
-// AND a copy of the top of the BVH (round 3; with 256-thread workgroups eight copies would have to share the same 160 KB).
+// A workgroup drains the rays of a GROUP of consecutive scheduling waves back to back (dynamic fetch, see the kernel body): kTraceGroup
+// waves on hierarchy scenes, kFlatGroup on LDS-resident scenes (shadow queues only: about a third of the paths queue a shadow ray;
+// 64-thread workgroups sized to the queues were measured slower).
+// kTraceBlock: threads per workgroup on hierarchy scenes.  256; MTS_TRACE_BLOCK=1024 (two workgroups per CU, each with a copy of the
+// top of the BVH in LDS next to its stack rows) was built and measured slower.
 #ifndef MTS_TRACE_BLOCK
 #define MTS_TRACE_BLOCK 256
 #endif
+// Scheduling waves per workgroup: the longer a workgroup's ray list, the smaller the share of its rounds that run in the tail of the
+// list (a few lanes finishing the longest walks, profiles/r03_trace_phases.txt), the fewer workgroups a launch has to balance:
+// 4 / 8 / 16 / 32 / 64 waves per 256 threads -> mesh render 55.1 / 51.5 / 49.9 / 51.0 / 58.8 ms (profiles/r03_ab_trace_group.txt).
 #ifndef MTS_TRACE_GROUP
-#define MTS_TRACE_GROUP (MTS_TRACE_BLOCK / 32)
+#define MTS_TRACE_GROUP (MTS_TRACE_BLOCK / 16)
 #endif
 constexpr uint32_t kTraceBlock = MTS_TRACE_BLOCK;      // threads per k_trace workgroup (hierarchy scenes)
-constexpr uint32_t kShadowGroup = MTS_TRACE_GROUP;     // scheduling waves per workgroup (a power of two)
-static_assert((kShadowGroup & (kShadowGroup - 1u)) == 0u, "locate() searches a power-of-two table");
+constexpr uint32_t kTraceGroup = MTS_TRACE_GROUP;      // hierarchy scenes: scheduling waves per workgroup (a power of two)
+constexpr uint32_t kFlatGroup = 8u;                    // LDS-resident scenes (shadow queues only)
+static_assert((kTraceGroup & (kTraceGroup - 1u)) == 0u, "locate() searches a power-of-two table");
+static_assert(kChainAlign % kTraceGroup == 0u, "a k_trace group must not straddle two launch chains");
 // LDS part of k_trace's per-lane stack: entries of 8 bytes (BVH4: reference + entry distance); the full 41-entry stack of the
 // 261 k-triangle mesh would cap the CU at a fraction of a workgroup.  Deeper entries go to a global spill area (rare).
 #ifndef MTS_TRACE_LDS_DEPTH
@@ -1444,6 +1449,7 @@ __global__ __launch_bounds__(FLAT ? kBlock : kTraceBlock)
 __attribute__((amdgpu_waves_per_eu(MTS_TRACE_WAVES, MTS_TRACE_WAVES)))
 #endif
 void k_trace(const RenderParams P) {
+    constexpr uint32_t kShadowGroup = FLAT ? kFlatGroup : kTraceGroup;
     extern __shared__ float4 smem[];
     __shared__ uint32_t s_pre[kShadowGroup + 1u];            // s_pre[g] = work items of the group's scheduling waves before the g-th
     LdsView lds = {};
@@ -1592,7 +1598,7 @@ extern "C" __attribute__((visibility("default"))) int mtsamd_debug_trace_prof(un
 #endif
 
 uint32_t trace_top_nodes(const SceneView &sv) { return std::min(sv.n_wnodes, kTraceTopNodes); }
-uint32_t trace_group() { return kShadowGroup; }
+uint32_t trace_group() { return kTraceGroup; }
 size_t trace_lds_bytes(const SceneView &sv) {      // top of the tree + the stack rows (+ the scratch row of stack_row())
     return (size_t) 64 * trace_top_nodes(sv) + sizeof(StackEntry) * (std::min(sv.stack_depth, kTraceLdsDepth) + 1u) * kTraceBlock;
 }
@@ -1602,7 +1608,7 @@ uint32_t trace_lds_depth(const SceneView &sv) { return std::min(sv.stack_depth, 
 size_t trace_spill_words(const SceneView &sv, uint32_t n_waves) {
     const uint32_t spill = sv.stack_depth > kTraceLdsDepth ? sv.stack_depth - kTraceLdsDepth : 0u;
     const uint32_t spill_f = sv.stack_depth > kFinishLdsDepth ? sv.stack_depth - kFinishLdsDepth : 0u;
-    const size_t trace = (size_t) 2 * ((n_waves + kShadowGroup - 1) / kShadowGroup) * spill * kTraceBlock;
+    const size_t trace = (size_t) 2 * ((n_waves + kTraceGroup - 1) / kTraceGroup) * spill * kTraceBlock;
     const size_t finish = (size_t) n_waves * spill_f * 64u;      // at most one k_finish workgroup per scheduling wave
     return (sizeof(StackEntry) / 4) * std::max(trace, finish);
 }
@@ -1614,7 +1620,7 @@ static hipError_t allow_lds(const void *fn, size_t bytes) {
 // iteration and stage 0 of the next touch disjoint arrays, so the host runs them on two streams (api.cpp).
 hipError_t launch_split_stage(const RenderParams &p, int stage, hipStream_t s) {
     const uint32_t n_launch = (p.wave_last ? p.wave_last : p.n_waves) - p.wave_first;
-    const uint32_t shade_blocks = (n_launch * 64u + kBlock - 1) / kBlock, trace_blocks = (n_launch + kShadowGroup - 1) / kShadowGroup;
+    const uint32_t shade_blocks = (n_launch * 64u + kBlock - 1) / kBlock, trace_blocks = (n_launch + kTraceGroup - 1) / kTraceGroup;
     if (stage == 0) {
         if (hipError_t e = allow_lds(reinterpret_cast<const void *>(&k_trace<false, false>), trace_lds_bytes(p.sv))) return e;
         hipLaunchKernelGGL((k_trace<false, false>), dim3(trace_blocks), dim3(kTraceBlock), trace_lds_bytes(p.sv), s, p);
@@ -1651,7 +1657,7 @@ hipError_t launch_bounce(const RenderParams &p_, hipStream_t s) {
         else if (p.spectral) hipLaunchKernelGGL((k_shade<PathStateS, false, true>), dim3(shade_blocks), dim3(kBlock), lds, s, p);
         else if (p.sv.general) hipLaunchKernelGGL((k_shade<PathState, true, true>), dim3(shade_blocks), dim3(kBlock), lds, s, p);
         else hipLaunchKernelGGL((k_shade<PathState, false, true>), dim3(shade_blocks), dim3(kBlock), lds, s, p);
-        hipLaunchKernelGGL((k_trace<true, true>), dim3((p.n_waves + kShadowGroup - 1) / kShadowGroup), dim3(kBlock), lds, s, p);
+        hipLaunchKernelGGL((k_trace<true, true>), dim3((p.n_waves + kFlatGroup - 1) / kFlatGroup), dim3(kBlock), lds, s, p);
         return hipGetLastError();
     }
     if (p.split) {
