@@ -35,6 +35,17 @@ def test_full_size_cbox_properties():
     small = R.PathIntegrator(paths_per_wave=128)
     assert small.render(scene, sensor)
     assert torch.allclose(sensor.film().bitmap(raw=True), full, rtol=2e-5, atol=1e-4)
+    # the headline configuration itself against the oracle (round 3): the oracle renders, with the same per-sample seeds, the window of
+    # film rows 506..517 (all 1024 columns, 3.1e6 samples); the film pixels of rows 508..515, columns 2..1021 receive splats from
+    # exactly that window (gaussian radius 2), so there both films hold the same sums of the same samples
+    win = ob.OracleScene(cb).render_window(ob.make_desc(sp), 506, 518, 0, 1024)[508:516, 2:1022]
+    got_w = full[508:516, 2:1022].cpu().numpy()
+    assert win[..., 4].min() > 0
+    assert np.allclose(got_w[..., 3:], win[..., 3:], rtol=2e-5, atol=1e-3)          # alpha and weight
+    rgb_g, rgb_r = ob.film_develop(got_w)[..., :3], ob.film_develop(win)[..., :3]
+    relmse = float(np.mean((rgb_g - rgb_r) ** 2 / (rgb_r ** 2 + 1e-2)))
+    assert relmse < 1e-3                                                           # north_star tolerance
+    assert relmse < 1e-9, relmse                                                   # bit-identical samples: only the order of the fp32 sums differs
     # against the oracle on a 64 x 64 @ 256 spp render of the same scene: mean radiance and per-channel balance
     lo = scenes.cornell_box_sensor(64, 64, spp=256, seed=0)
     ref, _ = ob.OracleScene(cb).render(ob.make_desc(lo), mode=1)
