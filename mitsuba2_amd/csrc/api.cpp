@@ -754,7 +754,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
     std::vector<uint4> qnodes(2 * (size_t) s->bvh.n_nodes);
     std::memcpy(qnodes.data(), s->bvh.qnodes.data(), s->bvh.qnodes.size() * sizeof(uint32_t));
     std::vector<uint4> wnodes(4 * (size_t) s->bvh.n_wnodes);
-    std::memcpy(wnodes.data(), (MTS_NODE_F16 ? s->bvh.wnodes_h : s->bvh.wnodes).data(), s->bvh.wnodes.size() * sizeof(uint32_t));
+    std::memcpy(wnodes.data(), (MTS_NODE_P15 ? s->bvh.wnodes_p : (MTS_NODE_F16 ? s->bvh.wnodes_h : s->bvh.wnodes)).data(), s->bvh.wnodes.size() * sizeof(uint32_t));
     std::memcpy(tris.data(), s->bvh.tris.data(), s->bvh.tris.size() * sizeof(float));
     // flat scenes: 64-byte records in primitive order (device_scene.h)
     uint32_t flat_max = kFlatMaxPrims;

@@ -272,7 +272,9 @@ void build_bvh(const float *tri_pos, uint32_t n_prims, uint32_t max_leaf, BvhOut
         for (int k = 0; k < 3; ++k) {
             const double pad = (scene.hi[k] - scene.lo[k] + extent + 1.0) * 1e-5;
             glo[k] = scene.lo[k] - pad;
-            gstep[k] = std::max((scene.hi[k] + pad - glo[k]) / 65535.0, 1e-30);
+            // the padded scene box ends at cell 65532: every snapped plane stays below 65534, so that the 15-bit variant of the BVH4
+            // nodes (even cells only) can round a far plane up without leaving the grid
+            gstep[k] = std::max((scene.hi[k] + pad - glo[k]) / 65532.0, 1e-30);
             out.q_lo[k] = (float) glo[k]; out.q_step[k] = (float) gstep[k];
             // the device decodes with the float values: make them the reference for the snapping below
             glo[k] = (double) out.q_lo[k]; gstep[k] = (double) out.q_step[k];
@@ -302,7 +304,7 @@ void build_bvh(const float *tri_pos, uint32_t n_prims, uint32_t max_leaf, BvhOut
     if (bfs.empty()) out.root = emit_leaf(b.nodes[root]);   // whole scene is one leaf
     else out.root = 0;
     // ---- BVH4: collapse (open the child of largest surface area until four children), BFS order, same grid
-    out.wnodes.clear(); out.wnodes_h.clear(); out.wroot = out.root; out.n_wnodes = 0; out.wdepth = 1;
+    out.wnodes.clear(); out.wnodes_h.clear(); out.wnodes_p.clear(); out.wroot = out.root; out.n_wnodes = 0; out.wdepth = 1;
     if (!bfs.empty()) {
         double glo[3], gstep[3];
         for (int k = 0; k < 3; ++k) { glo[k] = (double) out.q_lo[k]; gstep[k] = (double) out.q_step[k]; }
@@ -357,6 +359,23 @@ void build_bvh(const float *tri_pos, uint32_t n_prims, uint32_t max_leaf, BvhOut
                 for (int k = 0; k < 3; ++k) {
                     const float vlo = (float) qlo(lo[k], k) - 32768.0f, vhi = (float) qhi(hi[k], k) - 32768.0f;
                     w[4 * c + k] = half_of(vlo, false) | (half_of(vhi, true) << 16);
+                }
+                w[4 * c + 3] = b.nodes[t].left >= 0 ? (uint32_t) wide_of[t] : leaf_ref[t];
+            }
+        }
+        // 15-bit planes on the even cells of the same grid, stored as 0x8000 | q15: the two bytes are the upper mantissa (and the lowest
+        // exponent bit) of the float 65536 + 2 q15, which the walk assembles with one v_perm_b32 per plane -- no integer-to-float convert
+        out.wnodes_p.assign(16 * wide.size(), 0u);
+        for (size_t i = 0; i < wide.size(); ++i) {
+            uint32_t *w = out.wnodes_p.data() + 16 * i;
+            for (int c = 0; c < 4; ++c) {
+                if (c >= wide[i].n) { w[4 * c] = w[4 * c + 1] = w[4 * c + 2] = 0xffffu | (0x8000u << 16); w[4 * c + 3] = 0x7fffffffu; continue; }      // lo = 65534, hi = 0
+                const int32_t t = wide[i].child[c];
+                float lo[3], hi[3];
+                padded(b.nodes[t].box, extent, lo, hi);
+                for (int k = 0; k < 3; ++k) {
+                    const uint32_t l15 = qlo(lo[k], k) >> 1, h15 = std::min(32767u, (qhi(hi[k], k) + 1u) >> 1);      // qhi <= 65534 (grid above)
+                    w[4 * c + k] = (0x8000u | l15) | ((0x8000u | h15) << 16);
                 }
                 w[4 * c + 3] = b.nodes[t].left >= 0 ? (uint32_t) wide_of[t] : leaf_ref[t];
             }

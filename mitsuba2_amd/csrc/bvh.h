@@ -21,6 +21,7 @@ struct BvhOutput {
     // the same BVH4 with the planes as fp16 values of (grid coordinate - 32768), rounded outward (lo down, hi up): the walk reads them
     // straight into v_fma_mix_f32 (no integer -> float conversion); an absent child has lo = +32768, hi = -32768
     std::vector<uint32_t> wnodes_h;
+    std::vector<uint32_t> wnodes_p;      // same layout, 15-bit planes stored as 0x8000 | q15 (even cells of the grid): see bvh.cpp
     uint32_t wroot = 0, n_wnodes = 0, wdepth = 0;
     std::vector<float> tris;       // 12 floats per triangle slot
     uint32_t root = 0;             // child reference of the root

@@ -224,17 +224,35 @@ constexpr uint32_t kNoNode = 0x7fffffffu;       // "nothing left": not a leaf, n
 #ifndef MTS_WALK_T
 #define MTS_WALK_T 24
 #endif
+#ifndef MTS_NODE_P15
+#define MTS_NODE_P15 0      // 1: BVH4 planes as 15-bit values the walk turns into floats with v_perm_b32 (measured equal); 0: 16-bit planes + v_cvt
+#endif
 #ifndef MTS_WALK_T_ANY
 #define MTS_WALK_T_ANY MTS_WALK_T
 #endif
 struct BvhWalk {
     f3 o, d, inv; float mint, maxt, best;      // MTS_QNODES: o / inv of the slab test are in grid units (o_q, inv_q)
-    f3 o_q, noi;                               // noi = -(o_q * inv): t = fma(q, inv, noi)
+    f3 noi;                                    // noi = -(o_q * inv): t = fma(q, inv, noi); o_q itself is not kept (walk_origin_q)
     bool far;                                  // origin too far from the scene box for the fma form (cancellation)
     uint32_t sel[3];                           // v_perm_b32 selectors: (lo | hi << 16) -> (near | far << 16) per axis
     uint32_t sp, cur, best_prim; bool found;
     Hit hit;
 };
+// Ray origin in grid units (plus the offset of the node format).  Only the FAR form of the slab test needs it per step, and walks
+// from that far away are rare: it is recomputed there instead of occupying three registers of every walk.
+MTS_DEV f3 walk_origin_q(const SceneView &sv, f3 o) {
+#if MTS_QNODES
+    f3 o_q = mk3((o.x - sv.q_lo[0]) * sv.q_inv_step[0], (o.y - sv.q_lo[1]) * sv.q_inv_step[1], (o.z - sv.q_lo[2]) * sv.q_inv_step[2]);
+#if MTS_NODE_F16 && MTS_BVH4
+    o_q = mk3(o_q.x - 32768.0f, o_q.y - 32768.0f, o_q.z - 32768.0f);      // the fp16 planes are centred on the middle of the grid
+#elif MTS_NODE_P15 && MTS_BVH4
+    o_q = mk3(o_q.x + 65536.0f, o_q.y + 65536.0f, o_q.z + 65536.0f);      // a plane is decoded as 65536 + grid coordinate
+#endif
+    return o_q;
+#else
+    return o;
+#endif
+}
 MTS_DEV void walk_begin(BvhWalk &w, const SceneView &sv, f3 o, f3 d, float mint, float maxt) {
     w.o = o; w.d = d;
 #if MTS_QNODES
@@ -244,22 +262,27 @@ MTS_DEV void walk_begin(BvhWalk &w, const SceneView &sv, f3 o, f3 d, float mint,
     // v_rcp_f32 (1 ulp) instead of a division, a multiplication by 1 / q_step -- a walk starts every ~8 steps and the exact
     // divisions were a tenth of k_trace's VALU time.  Error budget: see `far` below.
     w.inv = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-    w.o_q = mk3((o.x - sv.q_lo[0]) * sv.q_inv_step[0], (o.y - sv.q_lo[1]) * sv.q_inv_step[1], (o.z - sv.q_lo[2]) * sv.q_inv_step[2]);
-#if MTS_NODE_F16 && MTS_BVH4
-    w.o_q = mk3(w.o_q.x - 32768.0f, w.o_q.y - 32768.0f, w.o_q.z - 32768.0f);      // the fp16 planes are centred on the middle of the grid
-#endif
+    const f3 o_q = walk_origin_q(sv, o);
     w.inv = mk3(clamp_mag33(w.inv.x * sv.q_step[0]), clamp_mag33(w.inv.y * sv.q_step[1]), clamp_mag33(w.inv.z * sv.q_step[2]));
-    w.noi = mk3(-(w.o_q.x * w.inv.x), -(w.o_q.y * w.inv.y), -(w.o_q.z * w.inv.z));
+    w.noi = mk3(-(o_q.x * w.inv.x), -(o_q.y * w.inv.y), -(o_q.z * w.inv.z));
     // fma(q, inv, noi) is off by at most eps * |o_q| grid cells, o_q itself by another half of that (the multiplication by 1 / q_step)
     // and inv by 1 ulp, which moves t * |d_q| by up to eps * (|o_q| + 65535) cells: 0.015 + 0.008 + 0.04 cells at |o_q| = 2.5e5 (an origin
     // ~4 scene extents away); the boxes are padded by 1/8 cell or more.  Farther origins use (q - o_q) * inv with an explicit pad.
-    w.far = !(hmax_abs(w.o_q) <= 2.5e5f);
+    w.far = !(hmax_abs(o_q) <= 2.5e5f);
+#if MTS_NODE_P15 && MTS_BVH4
+    // selector of the NEAR plane: (0x47 from the constant, the plane's two bytes, 0x00) -- low half of the word if the ray runs up
+    // the axis, high half otherwise; the far plane's selector is this one ^ kP15Flip
+    w.sel[0] = w.inv.x >= 0.0f ? 0x0305040cu : 0x0307060cu;
+    w.sel[1] = w.inv.y >= 0.0f ? 0x0305040cu : 0x0307060cu;
+    w.sel[2] = w.inv.z >= 0.0f ? 0x0305040cu : 0x0307060cu;
+#else
     w.sel[0] = w.inv.x >= 0.0f ? 0x03020100u : 0x01000302u;
     w.sel[1] = w.inv.y >= 0.0f ? 0x03020100u : 0x01000302u;
     w.sel[2] = w.inv.z >= 0.0f ? 0x03020100u : 0x01000302u;
+#endif
 #else
     w.inv = mk3(clamp_inv(d.x), clamp_inv(d.y), clamp_inv(d.z));
-    w.o_q = o; w.noi = o; w.far = true; w.sel[0] = w.sel[1] = w.sel[2] = 0u;
+    w.noi = o; w.far = true; w.sel[0] = w.sel[1] = w.sel[2] = 0u;
 #endif
     w.mint = mint; w.maxt = maxt; w.best = maxt;
     w.sp = 0; w.cur = MTS_BVH4 ? sv.wroot : sv.root; w.best_prim = kNoPrim; w.found = false;
@@ -418,7 +441,7 @@ MTS_DEV void walk_round(BvhWalk &w, const SceneView &sv, const WalkStack &st, ui
         MTS_PROF(ANY, 2);                               // node steps
         MTS_PROF_MASK(ANY, 16, ml);        // ... lanes waiting at a leaf meanwhile
         MTS_PROF_MASK(ANY, 18, mn);                     // ... lanes without a ray meanwhile
-        const f3 oq = w.o_q;
+        const f3 oq = FAR ? walk_origin_q(sv, w.o) : w.noi;      // (unused in the near form)
         const f3 noi = FAR ? mk3(fminf(4.8e-7f * fabsf(oq.x * inv.x), 1.0e30f), fminf(4.8e-7f * fabsf(oq.y * inv.y), 1.0e30f),
                                  fminf(4.8e-7f * fabsf(oq.z * inv.z), 1.0e30f)) : w.noi;
         uint4 c0, c1, c2, c3;
@@ -456,6 +479,23 @@ MTS_DEV void walk_round(BvhWalk &w, const SceneView &sv, const WalkStack &st, ui
             }
             const float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, w.mint));
             const float tf = fminf(fminf(fx, fy), fminf(fz, w.best));
+            return tn <= tf ? tn : kInf;
+        };
+#elif MTS_NODE_P15
+        // planes are 0x8000 | q15: v_perm_b32 puts the two bytes under the constant's 0x47 and over a zero byte, which IS the float
+        // 65536 + 2 q15 (exponent 2^16, the stored top bit is the exponent's lowest bit): one permute per plane orders near / far
+        // AND converts; t = fma(plane, inv, noi) with the 65536 folded into o_q (walk_begin)
+        constexpr uint32_t kP15Const = 0x47000000u, kP15Flip = 0x00020200u;
+        const uint32_t fsx = w.sel[0] ^ kP15Flip, fsy = w.sel[1] ^ kP15Flip, fsz = w.sel[2] ^ kP15Flip;
+        auto child = [&](const uint4 &c) -> float {
+            const float nx = __uint_as_float(__builtin_amdgcn_perm(c.x, kP15Const, w.sel[0])), ny = __uint_as_float(__builtin_amdgcn_perm(c.y, kP15Const, w.sel[1])),
+                        nz = __uint_as_float(__builtin_amdgcn_perm(c.z, kP15Const, w.sel[2]));
+            const float fx = __uint_as_float(__builtin_amdgcn_perm(c.x, kP15Const, fsx)), fy = __uint_as_float(__builtin_amdgcn_perm(c.y, kP15Const, fsy)),
+                        fz = __uint_as_float(__builtin_amdgcn_perm(c.z, kP15Const, fsz));
+            const float tn = fmaxf(fmaxf(FAR ? fmaf(nx - oq.x, inv.x, -noi.x) : fmaf(nx, inv.x, noi.x), FAR ? fmaf(ny - oq.y, inv.y, -noi.y) : fmaf(ny, inv.y, noi.y)),
+                                   fmaxf(FAR ? fmaf(nz - oq.z, inv.z, -noi.z) : fmaf(nz, inv.z, noi.z), w.mint));
+            const float tf = fminf(fminf(FAR ? fmaf(fx - oq.x, inv.x, noi.x) : fmaf(fx, inv.x, noi.x), FAR ? fmaf(fy - oq.y, inv.y, noi.y) : fmaf(fy, inv.y, noi.y)),
+                                   fminf(FAR ? fmaf(fz - oq.z, inv.z, noi.z) : fmaf(fz, inv.z, noi.z), w.best));
             return tn <= tf ? tn : kInf;
         };
 #else
@@ -523,7 +563,7 @@ MTS_DEV void walk_round(BvhWalk &w, const SceneView &sv, const WalkStack &st, ui
         // FAR: (q - o_q) is only good to eps * |o_q| cells out there, so that form widens every slab interval by that much (in t)
         // instead -- an axis the ray is parallel to then stops culling, nothing is ever culled wrongly.  The pad is recomputed
         // per step (a wave walks in one form, chosen by its farthest origin, so every lane needs it and a register is dearer).
-        const f3 oq = w.o_q;
+        const f3 oq = FAR ? walk_origin_q(sv, w.o) : w.noi;      // (unused in the near form)
         const f3 noi = FAR ? mk3(fminf(4.8e-7f * fabsf(oq.x * inv.x), 1.0e30f), fminf(4.8e-7f * fabsf(oq.y * inv.y), 1.0e30f),
                                  fminf(4.8e-7f * fabsf(oq.z * inv.z), 1.0e30f)) : w.noi;
         const uint4 a = sv.qnodes[2u * cur], bq = sv.qnodes[2u * cur + 1u];

@@ -1531,18 +1531,18 @@ void k_trace(const RenderParams P) {
                                reinterpret_cast<const uint4 *>(smem), n_top };
         BvhWalk w;
         w.cur = kNoNode; w.sp = 0u; w.found = false;
-        bool busy = false;                                   // the lane holds a work item
-        size_t k = 0;
+        constexpr uint32_t kNoItem = 0xffffffffu;
+        uint32_t k = kNoItem;                                // pool index of the work item the lane holds (the pools have fewer than 2^32 slots)
         bool exhausted = false;
         while (true) {
             const bool need = w.cur == kNoNode;
             MTS_PROF(ANY, 12);                               // iterations of the work loop
-            if (need && busy) {                              // retire the finished item
+            if (need && k != kNoItem) {                      // retire the finished item
                 MTS_PROF(ANY, 14);
                 if (ANY) { if (!w.found) retire_any(k); }
                 else st_stream<kNT>(pool.hit + k, w.found ? make_float4(w.best, __uint_as_float(w.best_prim), w.hit.u, w.hit.v)
                                                           : make_float4(__builtin_inff(), __uint_as_float(kNoPrim), 0.0f, 0.0f));
-                busy = false;
+                k = kNoItem;
             }
             const uint64_t m = __ballot(need);
             if (m && !exhausted) {
@@ -1555,15 +1555,15 @@ void k_trace(const RenderParams P) {
                     MTS_PROF(ANY, 10);                       // fetches
                     const uint32_t idx = base + mask_rank(m);
                     if (idx < total) {
-                        k = locate(idx);
+                        const uint32_t item = (uint32_t) locate(idx);
                         if (ANY) {
-                            const float4 o = ld_stream<kNT>(pool.sh_o + k), d = ld_stream<kNT>(pool.sh_d + k);
+                            const float4 o = ld_stream<kNT>(pool.sh_o + item), d = ld_stream<kNT>(pool.sh_d + item);
                             walk_begin(w, P.sv, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), o.w, d.w);
-                            busy = true;
-                        } else if (!((pool.misc[k].y >> 16) & kFlagZombie)) {      // zombies only wait for their shadow ray
-                            const float4 o = ld_stream<kNT>(pool.ray_o + k), d = ld_stream<kNT>(pool.ray_d + k);
+                            k = item;
+                        } else if (!((pool.misc[item].y >> 16) & kFlagZombie)) {      // zombies only wait for their shadow ray
+                            const float4 o = ld_stream<kNT>(pool.ray_o + item), d = ld_stream<kNT>(pool.ray_d + item);
                             walk_begin(w, P.sv, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), o.w, d.w);
-                            busy = true;
+                            k = item;
                         }
                     }
                 }
