@@ -2014,6 +2014,21 @@ MTS_DEV void axis_taps(const FilterView &f, const float *table, float pos, int s
     }
 }
 
+// The same weights for the common case -- a tabulated filter of radius exactly 2 (gaussian, mitchell, catmullrom) and a source pixel
+// whose five taps t0 .. t0 + 4 all lie on the film -- without the per-tap window tests: a tap outside [lo, hi] is more than the radius
+// away from the sample, (int) (|x| * 31 / 2) is then >= 31 and the table (extended with zeros to 64 entries) returns the 0 the window
+// test would have set; x itself is formed exactly as above, (lo - pos) + i with i = k - (lo - t0), so the weights inside the window
+// are the same bits.  (|x| < 4 and radius = 2 exactly: the product with the scale factor cannot round across 31.)  Per tap: three
+// cheap VALU ops, one convert, one LDS read -- the window tests, selects and clamps above were 45 % of k_film_accum's VALU time.
+MTS_DEV void axis_taps_r2(const float *table64, float scale_factor, float pos, float t0f, float w[kFilmTaps]) {
+    const float lo = ceilf(pos - 2.0f), base = lo - pos, dk = lo - t0f;      // lo - t0 is 0 or 1
+#pragma unroll
+    for (int k = 0; k < kFilmTaps; ++k) {
+        const float xx = base + ((float) k - dk);
+        w[k] = table64[(int) fabsf(xx * scale_factor)];
+    }
+}
+
 // One thread per source pixel.  The 5 x 5 x 5 partial sums of its own samples -- for every tap (kx, ky) of the pixel's
 // neighbourhood the sum over the samples of w_y[ky] w_x[kx] (X, Y, Z, A, 1) -- stay in registers for the whole pass: the main loop
 // touches neither LDS (beyond the 32-entry filter table) nor a barrier.  At the end the block exchanges the sums through LDS, one tap
@@ -2059,14 +2074,14 @@ typedef __attribute__((address_space(3))) void film_lds_void;
 typedef __attribute__((address_space(1))) const void film_glb_void;
 template <bool DMA>
 __global__ __launch_bounds__(kBlock) void k_film_accum(const FilmParams F) {
-    __shared__ float table[32];
+    __shared__ float table[64];                          // the filter's 32 entries + zeros (axis_taps_r2)
     // staging: rgba [pixel][8] float4 (32 KB) + positions [pixel][8] float2 (16 KB); the exchange buffer E of the epilogue aliases it
     __shared__ float4 stage[DMA ? kBlock * kFilmRound * 3 / 2 : (kFilmTile * kFilmTile * (kFilmTaps * 5 + 1) + 3) / 4];
     float *E = reinterpret_cast<float *>(stage);         // one tap row of every source pixel: [pixel][kx][channel], padded
     static_assert(kBlock * kFilmRound * 3 / 2 * 16 >= kFilmTile * kFilmTile * (kFilmTaps * 5 + 1) * 4, "the exchange buffer fits the staging area");
     const FilterView &f = F.filter;
     const int b = f.border, R = (int) ceilf(f.radius), DW = kFilmTile + 2 * R;
-    if (threadIdx.x < 32) table[threadIdx.x] = f.table[threadIdx.x];
+    if (threadIdx.x < 64) table[threadIdx.x] = threadIdx.x < 32 ? f.table[threadIdx.x] : 0.0f;
     const int tcx = (int) (blockIdx.x % (uint32_t) F.tiles_x), tcy = (int) (blockIdx.x / (uint32_t) F.tiles_x);
     const int sp = (int) threadIdx.x, lx = sp % kFilmTile, ly = sp / kFilmTile;
     // this thread's source pixel: column qx, local row lr (the pass holds whole local rows; a tile's rows are contiguous on the film)
@@ -2076,6 +2091,9 @@ __global__ __launch_bounds__(kBlock) void k_film_accum(const FilmParams F) {
     const int sx = F.crop_w + 2 * b, sy = F.crop_h + 2 * b;
     const float offx = (float) (F.crop_x - b) + 0.5f, offy = (float) (F.crop_y - b) + 0.5f;
     const int tap_x0 = qx + b - R, tap_y0 = qy + b - R;
+    // radius-2 table filter, every tap of this pixel on the film: the short form of the weights (axis_taps_r2)
+    const bool fast_taps = !f.analytic && f.radius == 2.0f && f.table[31] == 0.0f && tap_x0 >= 0 && tap_x0 + 4 <= sx - 1 && tap_y0 >= 0 && tap_y0 + 4 <= sy - 1;
+    const float tap_x0f = (float) tap_x0, tap_y0f = (float) tap_y0;
     const size_t slot0 = have ? (size_t) (((uint64_t) lr * (uint64_t) F.crop_w + (uint64_t) qx) * (uint64_t) F.spp - F.first_ordinal) : 0;
     __syncthreads();
     float acc[kFilmTaps][kFilmTaps][5];
@@ -2092,8 +2110,13 @@ __global__ __launch_bounds__(kBlock) void k_film_accum(const FilmParams F) {
     auto accumulate = [&](const float4 rec, const float2 rp) {
         if (!(rec.w >= 0.0f)) return;                        // (X, Y, Z, alpha); alpha < 0: invalid or absent sample
         float wxs[kFilmTaps], wys[kFilmTaps];
-        axis_taps(f, table, rp.x - offx, sx, tap_x0, R, wxs);
-        axis_taps(f, table, rp.y - offy, sy, tap_y0, R, wys);
+        if (fast_taps) {
+            axis_taps_r2(table, f.scale_factor, rp.x - offx, tap_x0f, wxs);
+            axis_taps_r2(table, f.scale_factor, rp.y - offy, tap_y0f, wys);
+        } else {
+            axis_taps(f, table, rp.x - offx, sx, tap_x0, R, wxs);
+            axis_taps(f, table, rp.y - offy, sy, tap_y0, R, wys);
+        }
         // a zero weight adds (signed) zeros, which leaves the sums as they are: the film equals the one of a loop over the non-zero
         // taps only (imageblock.cpp:148-161)
 #pragma unroll
