@@ -546,7 +546,7 @@ MTS_DEV void walk_round(BvhWalk &w, const SceneView &sv, const WalkStack &st, ui
     w.cur = cur; w.sp = sp;
 }
 #else
-template <bool ANY, bool FAR = true>
+template <bool ANY, bool FAR = true, bool TOP = false>       // TOP: BVH4 only (ignored here)
 MTS_DEV void walk_round(BvhWalk &w, const SceneView &sv, const WalkStack &st, uint32_t &tri_tests) {
     uint32_t cur = w.cur, sp = w.sp;
     const f3 o = w.o, inv = w.inv;
