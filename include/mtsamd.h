@@ -151,7 +151,10 @@ MTSAMD_API int mtsamd_scene_bbox(const mtsamd_scene *scene, float *out6);
  * [4]=emitter count, [5]=nodes resident in LDS. */
 MTSAMD_API int mtsamd_scene_info(const mtsamd_scene *scene, uint32_t *out6);
 /* parameters_changed() for constant reflectance / radiance / texture data
- * (src/spectra/srgb.cpp:59-61, src/textures/bitmap.cpp:295-299): host data, synchronous. */
+ * (src/spectra/srgb.cpp:59-61, src/textures/bitmap.cpp:295-299): host data, synchronous.
+ * Spectral variant: the colours are `srgb` / `srgb_d65` spectra -- the setters redo the range check and the
+ * coefficient fetch of scene creation (srgb.cpp:31-41, srgb_d65.cpp:31-46); a parameter that was given as a
+ * `uniform` spectrum or a texture is not settable this way (MTSAMD_ERR_UNSUPPORTED). */
 MTSAMD_API int mtsamd_scene_set_bsdf_reflectance(mtsamd_scene *scene, uint32_t bsdf, const float *rgb);
 MTSAMD_API int mtsamd_scene_set_emitter_radiance(mtsamd_scene *scene, uint32_t emitter, const float *rgb);
 /* BitmapTexture `data` parameter (bitmap.cpp:295-299): rgb is a host OR device pointer to height*width*3 floats;
@@ -308,7 +311,8 @@ MTSAMD_API int mtsamd_render_adjoint_envmap(mtsamd_scene *scene, const mtsamd_re
  * ETA / K (conductors), ALPHA (isotropic roughness of roughconductor / roughdielectric; one component). */
 typedef enum { MTSAMD_PARAM_REFLECTANCE = 0, MTSAMD_PARAM_SPECULAR_REFLECTANCE = 1, MTSAMD_PARAM_ETA = 2, MTSAMD_PARAM_K = 3, MTSAMD_PARAM_ALPHA = 4,
                MTSAMD_PARAM_SPECULAR_TRANSMITTANCE = 5 } mtsamd_bsdf_param;
-/* parameters_changed() of a BSDF after one of these parameters was edited (RGB variant; constants): value3 = 3 floats (ALPHA: 1). */
+/* parameters_changed() of a BSDF after one of these parameters was edited (constants): value3 = 3 floats (ALPHA: 1).  Spectral
+ * variant: the three colour kinds become srgb spectra (as above), ETA / K must keep three equal components (uniform spectra). */
 MTSAMD_API int mtsamd_scene_set_bsdf_param(mtsamd_scene *scene, uint32_t bsdf, int32_t param, const float *value3);
 /* d(loss)/d(component of one such parameter) ADDED to *grad1_dev, for the image of mtsamd_render(film_rgb = 1) normalised as
  * mitsuba.python.autodiff.render does (src/python/python/autodiff.py:6-91): every camera sample is replayed with its PCG32 stream through

@@ -364,6 +364,8 @@ struct mtsamd_scene {
     float4 *d_flat = nullptr, *d_pairs = nullptr;
     std::vector<DevTexture> textures;       // device data pointers, owned
     std::vector<float> spec_mean;           // per BSDF: mean of specular_reflectance
+    std::vector<float> diff_mean;           // spectral variant, per BSDF: Texture::mean() of a constant reflectance
+    Rgb2Spec rgb2spec;                      // spectral variant: the upsampling model, kept for parameter updates
     DevTexture *d_textures = nullptr;
     SceneView view{};
     bool spectral = false;
@@ -559,7 +561,7 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
         }
     }
     // spectral variant: RGB -> spectrum coefficients on the host (srgb.cpp:31-41, srgb_d65.cpp:31-46)
-    Rgb2Spec model;
+    Rgb2Spec &model = s->rgb2spec;
     if (desc->spectral) {
         if (!desc->rgb2spec_path || !rgb2spec_load(desc->rgb2spec_path, model)) {
             delete s;
@@ -642,6 +644,8 @@ int mtsamd_scene_create(const mtsamd_scene_desc *desc, int device, mtsamd_scene 
             }
             if (d.type == kBsdfPlastic || d.type == kBsdfRoughPlastic) d.kr = means[1] / (means[0] + means[1]);
             spec_mean[b] = means[1];
+            s->diff_mean.resize(desc->bsdf_count, 0.0f);
+            s->diff_mean[b] = means[0];
         }
     }
 
@@ -934,9 +938,34 @@ int mtsamd_scene_info(const mtsamd_scene *s, uint32_t *out6) {
     return MTSAMD_OK;
 }
 
+// Spectral variant: a colour-valued BSDF parameter (p = 0 reflectance, 1 specular_reflectance, 2 specular_transmittance) is an `srgb`
+// spectrum -- range check, model coefficients, mean for the plastic lobe weights, exactly as mtsamd_scene_create does it
+// (srgb.cpp:31-41, plastic.cpp:170-175).  Parameters given as `uniform` spectra and textured reflectances are not settable this way.
+static int spectral_set_colour(mtsamd_scene *s, uint32_t bsdf, int p, const float *rgb) {
+    DevBsdf &d = s->bsdfs[bsdf];
+    const uint32_t uniform_flag = p == 0 ? kBsdfUniformRefl : (p == 1 ? kBsdfUniformSpec : kBsdfUniformTrans);
+    if (d.type == kBsdfBlend || d.type == kBsdfMask || (d.flags & uniform_flag) || (p == 0 && d.texture >= 0))
+        return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u: this parameter is a uniform spectrum, a texture or a nesting weight; only srgb colours can be set in the spectral variant", bsdf);
+    if (rgb[0] < 0 || rgb[1] < 0 || rgb[2] < 0 || rgb[0] > 1 || rgb[1] > 1 || rgb[2] > 1)
+        return fail(MTSAMD_ERR_INVALID, "Invalid RGB reflectance value [%g, %g, %g], must be in the range [0, 1]!", rgb[0], rgb[1], rgb[2]);
+    float coeff[3];
+    srgb_model_fetch(s->rgb2spec, rgb, coeff);
+    float *dst = p == 0 ? &d.c0 : (p == 1 ? &d.sc0 : &d.tc0);
+    dst[0] = coeff[0]; dst[1] = coeff[1]; dst[2] = coeff[2];
+    if (p == 0) { d.r = rgb[0]; d.g = rgb[1]; d.b = rgb[2]; s->diff_mean[bsdf] = srgb_model_mean(coeff); }
+    if (p == 1) { d.sr = rgb[0]; d.sg = rgb[1]; d.sb = rgb[2]; s->spec_mean[bsdf] = srgb_model_mean(coeff); }
+    if (d.type == kBsdfPlastic || d.type == kBsdfRoughPlastic) {
+        const float d_mean = d.texture >= 0 ? s->textures[d.texture].mean : s->diff_mean[bsdf];
+        d.kr = s->spec_mean[bsdf] / (d_mean + s->spec_mean[bsdf]);
+    }
+    HIP_TRY(hipMemcpy(s->d_bsdfs + bsdf, &d, sizeof(DevBsdf), hipMemcpyHostToDevice));
+    return MTSAMD_OK;
+}
+
 int mtsamd_scene_set_bsdf_reflectance(mtsamd_scene *s, uint32_t bsdf, const float *rgb) {
     if (!s || !rgb || bsdf >= s->bsdfs.size()) return fail(MTSAMD_ERR_INVALID, "invalid bsdf index");
     HIP_TRY(hipSetDevice(s->device));
+    if (s->spectral) return spectral_set_colour(s, bsdf, 0, rgb);
     s->bsdfs[bsdf].r = rgb[0]; s->bsdfs[bsdf].g = rgb[1]; s->bsdfs[bsdf].b = rgb[2];
     if (s->bsdfs[bsdf].type == kBsdfPlastic || s->bsdfs[bsdf].type == kBsdfRoughPlastic) {       // parameters_changed(): specular sampling weight (plastic.cpp:170-175)
         DevBsdf &d = s->bsdfs[bsdf];
@@ -988,6 +1017,16 @@ int mtsamd_scene_set_emitter_radiance(mtsamd_scene *s, uint32_t emitter, const f
     if (!s || !rgb || emitter >= s->emitters.size()) return fail(MTSAMD_ERR_INVALID, "invalid emitter index");
     HIP_TRY(hipSetDevice(s->device));
     s->emitters[emitter].r = rgb[0]; s->emitters[emitter].g = rgb[1]; s->emitters[emitter].b = rgb[2];
+    if (s->spectral) {       // srgb_d65 spectrum: normalised colour -> coefficients, the scale rides on the D65 curve (srgb_d65.cpp:31-46)
+        float color[3] = { rgb[0], rgb[1], rgb[2] }, coeff[3];
+        const float scale = std::max(std::max(color[0], color[1]), color[2]) * 2.0f;
+        if (scale != 0.0f) { const float r = 1.0f / scale; for (float &v : color) v *= r; }
+        srgb_model_fetch(s->rgb2spec, color, coeff);
+        float d65_scale = 1.0f * scale;
+        d65_scale *= 1.0f / 10568.0f;                      // d65.cpp:44-50
+        DevEmitter &d = s->emitters[emitter];
+        d.c0 = coeff[0]; d.c1 = coeff[1]; d.c2 = coeff[2]; d.d65_scale = d65_scale;
+    }
     HIP_TRY(hipMemcpy(s->d_emitters + emitter, &s->emitters[emitter], sizeof(DevEmitter), hipMemcpyHostToDevice));
     return MTSAMD_OK;
 }
@@ -1746,8 +1785,16 @@ static bool bsdf_param_fields(const DevBsdf &b, int32_t kind, int32_t comp, floa
 
 int mtsamd_scene_set_bsdf_param(mtsamd_scene *s, uint32_t bsdf, int32_t kind, const float *value3) {
     if (!s || !value3 || bsdf >= s->bsdfs.size()) return fail(MTSAMD_ERR_INVALID, "invalid bsdf index");
-    if (s->spectral) return fail(MTSAMD_ERR_UNSUPPORTED, "BSDF parameter updates are implemented for the RGB variant (the spectral records hold model coefficients)");
     HIP_TRY(hipSetDevice(s->device));
+    if (s->spectral) {       // colours become srgb spectra; eta / k must stay uniform spectra (one value); alpha is a plain number
+        if (kind == MTSAMD_PARAM_REFLECTANCE || kind == MTSAMD_PARAM_SPECULAR_REFLECTANCE || kind == MTSAMD_PARAM_SPECULAR_TRANSMITTANCE) {
+            float DevBsdf::*f0, DevBsdf::*f1;
+            if (!bsdf_param_fields(s->bsdfs[bsdf], kind, 0, f0, f1)) return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u (type %d) has no settable parameter of kind %d", bsdf, s->bsdfs[bsdf].type, kind);
+            return spectral_set_colour(s, bsdf, kind == MTSAMD_PARAM_REFLECTANCE ? 0 : (kind == MTSAMD_PARAM_SPECULAR_REFLECTANCE ? 1 : 2), value3);
+        }
+        if ((kind == MTSAMD_PARAM_ETA || kind == MTSAMD_PARAM_K) && !(value3[0] == value3[1] && value3[1] == value3[2]))
+            return fail(MTSAMD_ERR_UNSUPPORTED, "bsdf %u: the spectral variant needs uniform (constant) eta and k spectra", bsdf);
+    }
     DevBsdf &d = s->bsdfs[bsdf];
     for (int c = 0; c < (kind == MTSAMD_PARAM_ALPHA ? 1 : 3); ++c) {
         float DevBsdf::*f0, DevBsdf::*f1;
@@ -1755,7 +1802,7 @@ int mtsamd_scene_set_bsdf_param(mtsamd_scene *s, uint32_t bsdf, int32_t kind, co
         d.*f0 = value3[c];
         if (f1) d.*f1 = value3[c];
     }
-    if (d.type == kBsdfPlastic || d.type == kBsdfRoughPlastic) {       // parameters_changed(): specular sampling weight (plastic.cpp:170-175)
+    if (!s->spectral && (d.type == kBsdfPlastic || d.type == kBsdfRoughPlastic)) {       // parameters_changed(): specular sampling weight (plastic.cpp:170-175; spectral: spectral_set_colour)
         const float d_mean = d.texture >= 0 ? s->textures[d.texture].mean : (d.r + d.g + d.b) * (1.0f / 3.0f), s_mean = (d.sr + d.sg + d.sb) * (1.0f / 3.0f);
         d.kr = s_mean / (d_mean + s_mean);
     }

@@ -187,3 +187,40 @@ def test_spectral_textures_match_oracle(gpu, oracle, kind):
     # every operation of the path is shared bit for bit with the oracle (round 3: explicit elementary functions on both sides):
     # all samples identical -- rounds 1-2 accepted 99-99.9 % "close" here
     parity_util.check("per-sample radiance", rgb.cpu().numpy(), want[:, :3])
+
+
+def test_spectral_parameter_updates_equal_a_fresh_scene(gpu):
+    """parameters_changed() in the spectral variant: colours set on a live scene go through the same srgb -> coefficient conversion as at
+    scene creation (round 3; until then the setters wrote the RGB fields the spectral kernels never read).  The film after the updates
+    is the film of a scene built with the new values, bit for bit."""
+    import copy
+    sd = scenes.cornell_box()
+    sd["bsdfs"].append({"type": "plastic", "diffuse_reflectance": np.array([0.1, 0.27, 0.36], np.float32), "specular_reflectance": np.array([0.9, 0.8, 0.7], np.float32)})
+    plastic = len(sd["bsdfs"]) - 1
+    sd["meshes"][6]["bsdf"] = plastic                       # one of the boxes
+    p = scenes.cornell_box_sensor(48, 40, 8, seed=4)
+    scene, sensor = gpu.Scene(sd, variant="spectral"), gpu.make_sensor(p)
+    integ = gpu.PathIntegrator()
+    assert integ.render(scene, sensor)
+    before = sensor.film().bitmap(raw=True).clone()
+    new = copy.deepcopy(sd)
+    new["bsdfs"][1]["reflectance"] = np.array([0.2, 0.5, 0.3], np.float32)
+    new["bsdfs"][plastic]["diffuse_reflectance"] = np.array([0.3, 0.1, 0.05], np.float32)
+    new["bsdfs"][plastic]["specular_reflectance"] = np.array([0.5, 0.6, 0.9], np.float32)
+    new["emitters"][0]["radiance"] = np.array([10.0, 12.0, 15.0], np.float32)
+    scene.set_bsdf_reflectance(1, new["bsdfs"][1]["reflectance"])
+    scene.set_bsdf_param(plastic, 0, new["bsdfs"][plastic]["diffuse_reflectance"])
+    scene.set_bsdf_param(plastic, 1, new["bsdfs"][plastic]["specular_reflectance"])
+    scene.set_emitter_radiance(0, new["emitters"][0]["radiance"])
+    assert integ.render(scene, sensor)
+    after = sensor.film().bitmap(raw=True).clone()
+    assert not np.allclose(before.cpu().numpy(), after.cpu().numpy(), rtol=1e-2)
+    fresh, sensor2 = gpu.Scene(new, variant="spectral"), gpu.make_sensor(p)
+    assert gpu.PathIntegrator().render(fresh, sensor2)
+    assert (sensor2.film().bitmap(raw=True) == after).all()
+    with pytest.raises(RuntimeError, match="Invalid RGB reflectance"):
+        scene.set_bsdf_reflectance(1, [1.2, 0.1, 0.1])
+    uni = scenes.cornell_box()
+    uni["bsdfs"][0] = {"type": "diffuse", "reflectance": 0.4}             # a `uniform` spectrum: not an srgb colour
+    with pytest.raises(RuntimeError, match="uniform spectrum"):
+        gpu.Scene(uni, variant="spectral").set_bsdf_reflectance(0, [0.3, 0.3, 0.3])
