@@ -62,6 +62,8 @@ class ParameterMap:
             refl = b["reflectance"]
             if isinstance(refl, dict) and refl.get("type") != "bitmap":
                 continue                  # procedural textures have no differentiable texels
+            if _is_spectral(scene) and (isinstance(refl, dict) or b.get("uniform_mask", 0) & 1):
+                continue                  # spectral variant: constants that are srgb colours only (_spectral_gradient)
             if isinstance(refl, dict):
                 key = name + ".reflectance.data"
                 self.properties[key] = torch.as_tensor(refl["data"], dtype=torch.float32, device=dev).clone()
@@ -71,8 +73,9 @@ class ParameterMap:
                 self.properties[key] = torch.as_tensor([float(x) for x in refl], dtype=torch.float32, device=dev)
                 self._kind[key] = ("bsdf", i, i)
         # parameters of the BSDF models beyond `diffuse` (what their traverse() exposes, e.g. roughconductor.cpp:393-404, plastic.cpp:299-307):
-        # differentiated by mtsamd_render_adjoint_param in ANY scene (any emitter, any depth): constants only, RGB variant
-        for i, b in enumerate(scene._bsdf_records if not diffuse_scene and not _is_spectral(scene) else []):
+        # differentiated by mtsamd_render_adjoint_param in ANY scene (any emitter, any depth): constants only.  Spectral variant: the same
+        # keys, differentiated by central differences of whole renders (_spectral_gradient); `uniform` spectra are not exposed
+        for i, b in enumerate(scene._bsdf_records if not diffuse_scene else []):
             name = b.get("id", "bsdf_%d" % i) + (".brdf_0" if b.get("twosided") and b["type"] != B.DIFFUSE else "")
             flat_index = i                # top-level records keep their place in the table (bsdfs.flatten)
             for pname, kind, types in (("reflectance", 0, (B.DIFFUSE,)), ("diffuse_reflectance", 0, (B.PLASTIC, B.ROUGHPLASTIC)),
@@ -84,6 +87,8 @@ class ParameterMap:
                 src = b["reflectance"] if kind == 0 else b[pname]
                 if isinstance(src, dict):
                     continue              # textured: no constant parameter
+                if _is_spectral(scene) and (kind in (2, 3) or (b.get("uniform_mask", 0) >> {0: 0, 1: 1, 5: 2}[kind]) & 1):
+                    continue              # spectral variant: eta / k and `uniform` spectra are not srgb colours
                 key = "%s.%s.value" % (name, pname)
                 self.properties[key] = torch.as_tensor([float(x) for x in src], dtype=torch.float32, device=dev)
                 self._kind[key] = ("bsdf_param", flat_index, kind)
@@ -132,8 +137,13 @@ class ParameterMap:
             last = seen.get(k)
             if last is not None and last[0] is v and last[1] == v._version:      # (the tensor itself is kept: an id can be reused)
                 continue
-            seen[k] = (v, v._version)
             kind, idx, _ = self._kind[k]
+            if _is_spectral(self._scene) and (kind == "bsdf" or (kind == "bsdf_param" and self._kind[k][2] != 4)):
+                # spectral variant: an srgb colour lives in [0, 1]^3 (srgb.cpp:34-35); an optimiser step that leaves the box is projected
+                # back onto it (the parameter tensor itself, so that the optimiser's state and the scene agree)
+                with torch.no_grad():
+                    v.clamp_(0.0, 1.0)
+            seen[k] = (v, v._version)
             if kind == "texture":
                 self._scene.update_texture(idx, v)
             elif kind == "emitter":
@@ -174,6 +184,42 @@ def _image_of(film):
     return (film[..., :3] / (film[..., 4:5] + 1e-8)).reshape(-1)
 
 
+def _spectral_gradient(scene, d, pmap, key, gi):
+    """Spectral variant: d(loss)/d(parameter) of a constant colour, radiance or roughness by central differences of the rendered
+    image at fixed random numbers (the derivative pass's seed): two renders per scalar component.  The reference differentiates its
+    spectral variants with Enoki's autodiff like the others; this backend has no spectral path replay, so the
+    spectral ParameterMap is limited to a handful of constants -- texels and envmaps raise."""
+    kind, idx, extra = pmap._kind[key]
+    if kind in ("texture", "envmap"):
+        raise RuntimeError("the spectral variant differentiates constant colours, radiances and roughnesses only (%s is a %s)" % (key, kind))
+    value = [float(x) for x in pmap[key].detach().cpu().reshape(-1).tolist()]
+
+    def push(vals):
+        if kind == "emitter":
+            scene.set_emitter_radiance(idx, vals)
+        elif kind == "bsdf_param":
+            scene.set_bsdf_param(idx, extra, vals)
+        else:
+            scene.set_bsdf_reflectance(idx, vals)
+
+    grad = torch.zeros(len(value), dtype=torch.float32, device=gi.device)
+    colour = kind != "emitter" and not (kind == "bsdf_param" and extra == 4)
+    for c in range(len(value)):
+        h = float(pmap.fd_step) if pmap.fd_step > 0 else 0.01 * max(abs(value[c]), 0.05)
+        hi, lo = value[c] + h, value[c] - h
+        if colour:
+            hi, lo = min(hi, 1.0), max(lo, 0.0)                       # srgb colours live in [0, 1] (srgb.cpp:34-35)
+        elif kind == "bsdf_param":
+            lo = max(lo, 1e-4)                                        # roughness
+        images = []
+        for x in (hi, lo):
+            push(value[:c] + [x] + value[c + 1:])
+            images.append(_image_of(_render_film(scene, d)))
+        grad[c] = torch.dot(gi, images[0] - images[1]) / (hi - lo)
+    push(value)
+    return grad.reshape(pmap[key].shape)
+
+
 class _Render(torch.autograd.Function):
     @staticmethod
     def forward(ctx, scene, d, pmap, keys, *values):
@@ -194,6 +240,8 @@ class _Render(torch.autograd.Function):
         g_tex = torch.zeros(max(tex_floats, 1), dtype=torch.float32, device=dev)
         g_em = torch.zeros((max(len(scene._dict.get("emitters", [])), 1), 3), dtype=torch.float32, device=dev)
         gi = grad_image.to(dev, torch.float32).contiguous()
+        if _is_spectral(scene):
+            return (None, None, None, None) + tuple(_spectral_gradient(scene, d, pmap, k, gi.reshape(-1)) for k in keys)
         kinds = {pmap._kind[k][0] for k in keys}
         if kinds - {"envmap", "bsdf_param"}:
             L.check(L.lib().mtsamd_render_adjoint(scene._handle, C.byref(d), _ptr(gi), _ptr(film), _ptr(g_bsdf), _ptr(g_tex), _ptr(g_em), _stream()))
