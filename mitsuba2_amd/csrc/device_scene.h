@@ -681,6 +681,30 @@ MTS_DEV v2f rcp_nr2(v2f x) {
     return vfma(e, r, r);
 }
 
+// Barycentrics of primitive `prim` for the ray (o, d), by the very operations of the packed loops below on that element (the packed
+// instructions are element-wise IEEE operations, so the bits are the same).  With MTS_FLAT_LATE_UV the closest-hit loops carry only
+// (t, primitive) through their 36 tests -- two conditional moves per triangle less -- and the winner's (u, v) are formed once here.
+MTS_DEV void flat_hit_uv(const LdsView &lds, f3 o, f3 d, uint32_t prim, float &u, float &v) {
+    const float4 *rec = lds.pairs + 5u * (prim >> 1);
+    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4];
+    const bool hi = (prim & 1u) != 0u;
+    const f3 p0 = hi ? mk3(q0.y, q0.w, q1.y) : mk3(q0.x, q0.z, q1.x);
+    const f3 e1 = hi ? mk3(q1.w, q2.y, q2.w) : mk3(q1.z, q2.x, q2.z);
+    const f3 e2 = hi ? mk3(q3.y, q3.w, q4.y) : mk3(q3.x, q3.z, q4.x);
+    const float pvx = fmaf(d.y, e2.z, -(d.z * e2.y)), pvy = fmaf(d.z, e2.x, -(d.x * e2.z)), pvz = fmaf(d.x, e2.y, -(d.y * e2.x));
+    const float det = fmaf(e1.z, pvz, fmaf(e1.y, pvy, e1.x * pvx));
+    float r = __builtin_amdgcn_rcpf(det);
+    float e = fmaf(-det, r, 1.0f); r = fmaf(e, r, r);
+    e = fmaf(-det, r, 1.0f); r = fmaf(e, r, r);
+    const float tx = o.x - p0.x, ty = o.y - p0.y, tz = o.z - p0.z;
+    u = fmaf(tz, pvz, fmaf(ty, pvy, tx * pvx)) * r;
+    const float qx = fmaf(ty, e1.z, -(tz * e1.y)), qy = fmaf(tz, e1.x, -(tx * e1.z)), qz = fmaf(tx, e1.y, -(ty * e1.x));
+    v = fmaf(d.z, qz, fmaf(d.y, qy, d.x * qx)) * r;
+}
+#ifndef MTS_FLAT_LATE_UV
+#define MTS_FLAT_LATE_UV 1
+#endif
+
 // Flat scenes: a wave-uniform loop over every primitive, two per iteration on the packed-fp32 pipe
 // (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32), operands broadcast from LDS (no stack, no divergence).
 // Primitive order + "t <= best" reproduces the brute-force loop of ray_intersect_naive
@@ -732,12 +756,15 @@ MTS_DEV bool traverse_flat(const SceneView &sv, const LdsView &lds, f3 o, f3 d, 
             any = any || ok_a || ok_b;
         } else {
             bool ok_a = (u.x >= 0.0f) && (v.x >= 0.0f) && (uv.x <= 1.0f) && (t.x >= mint) && (t.x <= best);
-            best = ok_a ? t.x : best; best_prim = ok_a ? 2u * k : best_prim; bu = ok_a ? u.x : bu; bv = ok_a ? v.x : bv;
+            best = ok_a ? t.x : best; best_prim = ok_a ? 2u * k : best_prim;
+            if (!MTS_FLAT_LATE_UV) { bu = ok_a ? u.x : bu; bv = ok_a ? v.x : bv; }
             bool ok_b = (u.y >= 0.0f) && (v.y >= 0.0f) && (uv.y <= 1.0f) && (t.y >= mint) && (t.y <= best);
-            best = ok_b ? t.y : best; best_prim = ok_b ? 2u * k + 1u : best_prim; bu = ok_b ? u.y : bu; bv = ok_b ? v.y : bv;
+            best = ok_b ? t.y : best; best_prim = ok_b ? 2u * k + 1u : best_prim;
+            if (!MTS_FLAT_LATE_UV) { bu = ok_b ? u.y : bu; bv = ok_b ? v.y : bv; }
         }
     }
     if (ANY) return any;
+    if (MTS_FLAT_LATE_UV && best_prim != kNoPrim) flat_hit_uv(lds, o, d, best_prim, bu, bv);
     hit.t = best; hit.prim = best_prim; hit.u = bu; hit.v = bv;
     return best_prim != kNoPrim;
 }
@@ -789,11 +816,14 @@ MTS_DEV bool traverse_flat_clustered(const SceneView &sv, const LdsView &lds, f3
             const v2f t = vfma(e2z, qz, vfma(e2y, qy, e2x * qx)) * ivd;
             const v2f uv = u + v;
             bool ok_a = (u.x >= 0.0f) && (v.x >= 0.0f) && (uv.x <= 1.0f) && (t.x >= mint) && (t.x <= best);
-            best = ok_a ? t.x : best; best_prim = ok_a ? 2u * k : best_prim; bu = ok_a ? u.x : bu; bv = ok_a ? v.x : bv;
+            best = ok_a ? t.x : best; best_prim = ok_a ? 2u * k : best_prim;
+            if (!MTS_FLAT_LATE_UV) { bu = ok_a ? u.x : bu; bv = ok_a ? v.x : bv; }
             bool ok_b = (u.y >= 0.0f) && (v.y >= 0.0f) && (uv.y <= 1.0f) && (t.y >= mint) && (t.y <= best);
-            best = ok_b ? t.y : best; best_prim = ok_b ? 2u * k + 1u : best_prim; bu = ok_b ? u.y : bu; bv = ok_b ? v.y : bv;
+            best = ok_b ? t.y : best; best_prim = ok_b ? 2u * k + 1u : best_prim;
+            if (!MTS_FLAT_LATE_UV) { bu = ok_b ? u.y : bu; bv = ok_b ? v.y : bv; }
         }
     }
+    if (MTS_FLAT_LATE_UV && best_prim != kNoPrim) flat_hit_uv(lds, o, d, best_prim, bu, bv);
     hit.t = best; hit.prim = best_prim; hit.u = bu; hit.v = bv;
     return best_prim != kNoPrim;
 }
